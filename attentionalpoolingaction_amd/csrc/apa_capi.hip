@@ -1,0 +1,188 @@
+// apa_capi.hip -- the extern "C" surface of libapa_hip.so (see include/apa.h): argument
+// validation, dispatch between the factorised (M == 1) and dense (M == K) paths, error text.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "apa_internal.h"
+
+namespace apa {
+
+static thread_local char g_err[512] = "no error";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what) {
+  set_error("HIP error %d (%s) at %s", (int)e, hipGetErrorString(e), what);
+  return APA_ERR_HIP;
+}
+
+static thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
+void prof_kernel_events(hipEvent_t* start, hipEvent_t* stop) {
+  *start = g_prof_start;
+  *stop = g_prof_stop;
+}
+
+}  // namespace apa
+
+using namespace apa;
+
+extern "C" int apa_prof_event_create(void** event) {
+  if (!event) { set_error("apa_prof_event_create: null"); return APA_ERR_INVALID_ARG; }
+  hipEvent_t e;
+  APA_HIP_CHECK(hipEventCreate(&e));
+  *event = e;
+  return APA_OK;
+}
+extern "C" int apa_prof_event_destroy(void* event) {
+  if (event) APA_HIP_CHECK(hipEventDestroy(static_cast<hipEvent_t>(event)));
+  return APA_OK;
+}
+extern "C" int apa_prof_event_record(void* event, void* stream) {
+  if (!event) { set_error("apa_prof_event_record: null"); return APA_ERR_INVALID_ARG; }
+  APA_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(event), static_cast<hipStream_t>(stream)));
+  return APA_OK;
+}
+extern "C" int apa_prof_event_elapsed_ms(void* start, void* stop, float* ms) {
+  if (!start || !stop || !ms) { set_error("apa_prof_event_elapsed_ms: null"); return APA_ERR_INVALID_ARG; }
+  APA_HIP_CHECK(hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)));
+  return APA_OK;
+}
+extern "C" int apa_prof_set_kernel_events(void* start, void* stop) {
+  g_prof_start = static_cast<hipEvent_t>(start);
+  g_prof_stop = static_cast<hipEvent_t>(stop);
+  return APA_OK;
+}
+
+extern "C" int apa_version(void) { return APA_VERSION; }
+
+extern "C" const char* apa_last_error(void) { return g_err; }
+
+extern "C" const char* apa_status_string(int status) {
+  switch (status) {
+    case APA_OK: return "APA_OK";
+    case APA_ERR_INVALID_ARG: return "APA_ERR_INVALID_ARG";
+    case APA_ERR_UNSUPPORTED: return "APA_ERR_UNSUPPORTED";
+    case APA_ERR_WORKSPACE: return "APA_ERR_WORKSPACE";
+    case APA_ERR_HIP: return "APA_ERR_HIP";
+    default: return "APA_ERR_UNKNOWN";
+  }
+}
+
+static int check_common(const char* fn, int N, int P, int C, int Ca, int K, int M, int dtype) {
+  if (N <= 0 || P <= 0 || C <= 0 || Ca <= 0 || K <= 0) {
+    set_error("%s: non-positive dimension N=%d P=%d C=%d Ca=%d K=%d", fn, N, P, C, Ca, K);
+    return APA_ERR_INVALID_ARG;
+  }
+  if (M != 1 && M != K) {
+    set_error("%s: M must be 1 (class-agnostic) or K (per-class), got M=%d K=%d", fn, M, K);
+    return APA_ERR_INVALID_ARG;
+  }
+  if (dtype != APA_DTYPE_F32 && dtype != APA_DTYPE_BF16) {
+    set_error("%s: unknown dtype %d", fn, dtype);
+    return APA_ERR_INVALID_ARG;
+  }
+  return APA_OK;
+}
+
+extern "C" size_t apa_attn_pool_workspace_bytes(int N, int P, int C, int Ca, int K, int M,
+                                                unsigned flags) {
+  (void)flags;
+  if (N <= 0 || P <= 0 || C <= 0 || Ca <= 0 || K <= 0) return 0;
+  if (M == 1) return m1_plan(N, P, C, Ca, K).total;
+  return 0;
+}
+
+extern "C" int apa_attn_pool_fwd(const void* X, const void* Xatt, const float* Wa, const float* ba,
+                                 const float* Wt, const float* bt, float* logits, float* att,
+                                 float* zsave, float* abar, void* topdown, void* ws,
+                                 size_t ws_bytes, int N, int P, int C, int Ca, int K, int M,
+                                 unsigned flags, float keep_prob, uint64_t seed, uint64_t offset,
+                                 int dtype, void* stream) {
+  int rc = check_common("apa_attn_pool_fwd", N, P, C, Ca, K, M, dtype);
+  if (rc != APA_OK) return rc;
+  if (!X || !Xatt || !Wa || !ba || !Wt || !bt || !logits || !att) {
+    set_error("apa_attn_pool_fwd: null tensor pointer");
+    return APA_ERR_INVALID_ARG;
+  }
+  if ((flags & APA_FLAG_TRAIN) && !(keep_prob > 0.f && keep_prob <= 1.f)) {
+    set_error("apa_attn_pool_fwd: keep_prob=%g outside (0,1]", (double)keep_prob);
+    return APA_ERR_INVALID_ARG;
+  }
+  if (Xatt == X && Ca != C) {
+    set_error("apa_attn_pool_fwd: Xatt aliases X but Ca=%d != C=%d", Ca, C);
+    return APA_ERR_INVALID_ARG;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (M == 1) {
+    if (!zsave || !abar) {
+      set_error("apa_attn_pool_fwd: M==1 needs zsave and abar buffers");
+      return APA_ERR_INVALID_ARG;
+    }
+    if (topdown) {
+      set_error("apa_attn_pool_fwd: TopDownAttention materialisation is not built for M==1 yet");
+      return APA_ERR_UNSUPPORTED;
+    }
+    if (!m1_supported(C, Ca, dtype, Xatt == X)) {
+      set_error("apa_attn_pool_fwd: M==1 kernels need C in {256,512,1024,2048} (f32) or "
+                "{512,1024,2048} (bf16); got C=%d Ca=%d dtype=%d", C, Ca, dtype);
+      return APA_ERR_UNSUPPORTED;
+    }
+    const size_t need = m1_plan(N, P, C, Ca, K).total;
+    if (!ws || ws_bytes < need) {
+      set_error("apa_attn_pool_fwd: workspace too small (%zu < %zu)", ws_bytes, need);
+      return APA_ERR_WORKSPACE;
+    }
+    return m1_forward(X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar, ws, N, P, C, Ca, K, flags,
+                      keep_prob, seed, offset, dtype, st);
+  }
+  set_error("apa_attn_pool_fwd: per-class (M==K) dense path not built yet");
+  return APA_ERR_UNSUPPORTED;
+}
+
+extern "C" int apa_attn_pool_bwd(const void* X, const void* Xatt, const float* Wa, const float* ba,
+                                 const float* Wt, const float* bt, const float* att,
+                                 const float* zsave, const float* abar, const float* G, void* dX,
+                                 void* dXatt, float* dWa, float* dba, float* dWt, float* dbt,
+                                 void* ws, size_t ws_bytes, int N, int P, int C, int Ca, int K,
+                                 int M, unsigned flags, float keep_prob, uint64_t seed,
+                                 uint64_t offset, int dtype, void* stream) {
+  int rc = check_common("apa_attn_pool_bwd", N, P, C, Ca, K, M, dtype);
+  if (rc != APA_OK) return rc;
+  if (!X || !Xatt || !Wa || !Wt || !bt || !att || !G || !dX || !dWa || !dba || !dWt || !dbt) {
+    set_error("apa_attn_pool_bwd: null tensor pointer");
+    return APA_ERR_INVALID_ARG;
+  }
+  if (Xatt != X && !dXatt) {
+    set_error("apa_attn_pool_bwd: Xatt is a separate tensor but dXatt is NULL");
+    return APA_ERR_INVALID_ARG;
+  }
+  if ((flags & APA_FLAG_TRAIN) && !(keep_prob > 0.f && keep_prob <= 1.f)) {
+    set_error("apa_attn_pool_bwd: keep_prob=%g outside (0,1]", (double)keep_prob);
+    return APA_ERR_INVALID_ARG;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (M == 1) {
+    if (!zsave || !abar) {
+      set_error("apa_attn_pool_bwd: M==1 needs zsave and abar from the forward call");
+      return APA_ERR_INVALID_ARG;
+    }
+    if (!m1_supported(C, Ca, dtype, Xatt == X)) {
+      set_error("apa_attn_pool_bwd: unsupported C=%d Ca=%d dtype=%d", C, Ca, dtype);
+      return APA_ERR_UNSUPPORTED;
+    }
+    const size_t need = m1_plan(N, P, C, Ca, K).total;
+    if (!ws || ws_bytes < need) {
+      set_error("apa_attn_pool_bwd: workspace too small (%zu < %zu)", ws_bytes, need);
+      return APA_ERR_WORKSPACE;
+    }
+    return m1_backward(X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, dX, dXatt, dWa, dba, dWt, dbt,
+                       ws, N, P, C, Ca, K, flags, keep_prob, seed, offset, dtype, st);
+  }
+  set_error("apa_attn_pool_bwd: per-class (M==K) dense path not built yet");
+  return APA_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,152 @@
+// apa_device.h -- gfx950 device-side helpers shared by the attentional-pooling kernels.
+// Wave64 only (CDNA4): every cross-lane helper assumes 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace apa {
+
+struct bf16_t { uint16_t v; };
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// Cross-lane reductions.  In-row (16 lanes) butterflies run on DPP (no LDS traffic); the four
+// row sums are then fetched with v_readlane and added in a fixed order, so every lane gets the
+// same, deterministic value.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+__device__ __forceinline__ float row_sum16(float v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]  : lane ^ 1
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]  : lane ^ 2
+  v += dpp_mov<0x141>(v);  // row_half_mirror      : joins the two quads of an 8-lane group
+  v += dpp_mov<0x140>(v);  // row_mirror           : joins the two 8-lane groups of a row
+  return v;
+}
+
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// Sum over the 64 lanes of the wave; the result is wave-uniform.
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row_sum16(v);
+  const float r0 = readlane_f(v, 0), r1 = readlane_f(v, 16);
+  const float r2 = readlane_f(v, 32), r3 = readlane_f(v, 48);
+  return (r0 + r1) + (r2 + r3);
+}
+
+__device__ __forceinline__ float row_max16(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+  v = row_max16(v);
+  const float r0 = readlane_f(v, 0), r1 = readlane_f(v, 16);
+  const float r2 = readlane_f(v, 32), r3 = readlane_f(v, 48);
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16 <-> f32 (round-to-nearest-even, NaN preserved) on raw bit patterns.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_lo(uint32_t packed) { return __uint_as_float(packed << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t packed) {
+  return __uint_as_float(packed & 0xffff0000u);
+}
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 16-byte vector access.  EPV = elements per 16-byte vector (4 x f32 or 8 x bf16).
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct Vec;
+template <> struct Vec<float> {
+  static constexpr int EPV = 4;
+  static __device__ __forceinline__ void unpack(const uint4& r, float* o) {
+    o[0] = __uint_as_float(r.x); o[1] = __uint_as_float(r.y);
+    o[2] = __uint_as_float(r.z); o[3] = __uint_as_float(r.w);
+  }
+  static __device__ __forceinline__ uint4 pack(const float* o) {
+    return make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]),
+                      __float_as_uint(o[3]));
+  }
+};
+template <> struct Vec<bf16_t> {
+  static constexpr int EPV = 8;
+  static __device__ __forceinline__ void unpack(const uint4& r, float* o) {
+    o[0] = bf16_lo(r.x); o[1] = bf16_hi(r.x); o[2] = bf16_lo(r.y); o[3] = bf16_hi(r.y);
+    o[4] = bf16_lo(r.z); o[5] = bf16_hi(r.z); o[6] = bf16_lo(r.w); o[7] = bf16_hi(r.w);
+  }
+  static __device__ __forceinline__ uint4 pack(const float* o) {
+    return make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]),
+                      pack_bf16x2(o[6], o[7]));
+  }
+};
+
+__device__ __forceinline__ uint4 ld16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void st16(void* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = v; }
+
+// ---------------------------------------------------------------------------------------------
+// Counter-based dropout RNG.  One 32-bit hash yields the keep decision of TWO consecutive
+// elements (16 bits each, keep <=> bits < thresh, thresh = round(keep_prob * 65536)).
+// Stateless: the backward pass and apa_dropout_mask() regenerate the identical mask from
+// (k0, k1) = splitmix64(seed, offset) (host side) and the flat element index.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t rng_hash(uint32_t idx, uint32_t k0, uint32_t k1) {
+  uint32_t x = idx ^ k0;
+  x *= 0x9E3779B1u;
+  x ^= x >> 15;
+  x = (x ^ k1) * 0x85EBCA6Bu;
+  x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return x;
+}
+// Same splitmix64 key derivation as the host-side rng_key() in apa_internal.h.
+__device__ __forceinline__ void rng_key_dev(uint64_t seed, uint64_t offset, uint32_t& k0, uint32_t& k1) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (offset + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  k0 = (uint32_t)z;
+  k1 = (uint32_t)(z >> 32);
+}
+// keep-mask (1.0f / 0.0f) of elements e and e+1, e even (flat index into [N*P*C]).
+__device__ __forceinline__ void rng_keep2(uint64_t e, uint32_t k0, uint32_t k1, uint32_t thresh,
+                                          float& m0, float& m1) {
+  const uint64_t q = e >> 1;
+  const uint32_t h = rng_hash((uint32_t)q, k0, k1 + (uint32_t)(q >> 32) * 0x9E3779B9u);
+  m0 = (h & 0xffffu) < thresh ? 1.0f : 0.0f;
+  m1 = (h >> 16) < thresh ? 1.0f : 0.0f;
+}
+
+// XCD-aware bijective block remap: consecutive logical blocks land on the same XCD (observed
+// dispatch: hardware block b runs on XCD b % 8), so the S blocks of one image share its dz / z
+// rows in one L2.  Placement only affects speed, never results.
+__device__ __forceinline__ int xcd_remap(int b, int nblk) {
+  constexpr int NXCD = 8;
+  const int q = nblk / NXCD, r = nblk % NXCD;
+  const int xcd = b % NXCD, idx = b / NXCD;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+}  // namespace apa

@@ -1,0 +1,93 @@
+// apa_internal.h -- host-side declarations shared by the translation units of libapa_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/apa.h"
+
+namespace apa {
+
+// Thread-local error text behind apa_last_error().
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define APA_HIP_CHECK(expr)                                   \
+  do {                                                        \
+    hipError_t _e = (expr);                                   \
+    if (_e != hipSuccess) return ::apa::hip_fail(_e, #expr);  \
+  } while (0)
+
+#define APA_LAUNCH_CHECK(name)                                      \
+  do {                                                              \
+    hipError_t _e = hipGetLastError();                              \
+    if (_e != hipSuccess) return ::apa::hip_fail(_e, "launch " name); \
+  } while (0)
+
+// Optional per-thread event pair recorded around the dominant kernel (apa_prof_set_kernel_events).
+void prof_kernel_events(hipEvent_t* start, hipEvent_t* stop);
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// splitmix64-derived 2x32-bit dropout key (shared by fwd, bwd and apa_dropout_mask).
+inline void rng_key(uint64_t seed, uint64_t offset, uint32_t* k0, uint32_t* k1) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (offset + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  *k0 = (uint32_t)z;
+  *k1 = (uint32_t)(z >> 32);
+}
+inline uint32_t keep_thresh(float keep_prob) {
+  double t = (double)keep_prob * 65536.0 + 0.5;
+  if (t < 0) t = 0;
+  if (t > 65536.0) t = 65536.0;
+  return (uint32_t)t;
+}
+
+// ------------------------------------------------------------------------------------------
+// Small fp32 GEMM on the f32 MFMA (exact fp32 FMA chain, deterministic):
+//   D[i][j] = sum_k A(i,k) * B(k,j) (+ rank-1 term u[i]*v[j]),  i < m, j < n, k < kdim
+//   A(i,k) = A[i*a_si + k*a_sk],  B(k,j) = B[k*b_sk + j*b_sj],  D[i*ldd + j]
+// splits > 1 runs split-K into `ws` ([splits][m][n] floats) followed by a fixed-order reduce.
+// ------------------------------------------------------------------------------------------
+size_t sgemm_ws_bytes(int m, int n, int splits);
+int sgemm_small(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj,
+                float* D, long ldd, int m, int n, int kdim, int splits, const float* u,
+                const float* v, float* ws, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------
+// M == 1 factorised path (apa_m1.hip)
+// ------------------------------------------------------------------------------------------
+struct M1Plan {
+  int S;        // pixel splits per image
+  int ppb;      // pixels per block
+  int nblk;     // N * S
+  int lsplits;  // split-K factor of the logits GEMM
+  // workspace carve (byte offsets)
+  size_t off_pacc, off_pstat, off_pdwa, off_pdba, off_dz, off_gemm, off_dzatt, total;
+};
+M1Plan m1_plan(int N, int P, int C, int Ca, int K);
+
+int m1_forward(const void* X, const void* Xatt, const float* Wa, const float* ba, const float* Wt,
+               const float* bt, float* logits, float* att, float* zsave, float* abar, void* ws,
+               int N, int P, int C, int Ca, int K, unsigned flags, float keep_prob, uint64_t seed,
+               uint64_t offset, int dtype, hipStream_t stream);
+int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* ba, const float* Wt,
+                const float* bt, const float* att, const float* zsave, const float* abar,
+                const float* G, void* dX, void* dXatt, float* dWa, float* dba, float* dWt,
+                float* dbt, void* ws, int N, int P, int C, int Ca, int K, unsigned flags,
+                float keep_prob, uint64_t seed, uint64_t offset, int dtype, hipStream_t stream);
+bool m1_supported(int C, int Ca, int dtype, bool fused);
+
+// apa_m1_small.hip: LDS-tiled f32-MFMA kernels for the small products of the M == 1 path
+bool m1_small_supported(int C, int K);
+size_t m1_logits_ws_bytes(int N, int C, int K);
+int m1_logits(const float* z, const float* Wt, const float* abar, const float* bt, float* logits,
+              float* part_ws, int N, int C, int K, hipStream_t st);
+int m1_bwd_small(const float* G, const float* Wt, const float* zsave, const float* abar, float* dz,
+                 float* dWt, float* dbt, int N, int C, int K, hipStream_t st);
+int m1_colsum(const float* pdwa, const float* pdba, float* dwa, float* dba, int nblk, int C,
+              uint64_t* rng_bump, hipStream_t st);
+
+}  // namespace apa

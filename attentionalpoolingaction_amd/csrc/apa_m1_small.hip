@@ -1,0 +1,399 @@
+// apa_m1_small.hip -- the latency-critical small kernels around the two streaming passes of the
+// factorised (M == 1) head:
+//
+//   forward   logits = z . Wt + abar (x) bt            [N,C] x [C,K]      (split over C, 2 launches)
+//   backward  dz  = G . Wt^T  [N,K] x [K,C] ;  dWt = z^T . G  [C,N] x [N,K] ;  dbt = abar^T G
+//             (one launch, three block roles)
+//             dwa = column sums of the per-block partials of the streaming pass
+//
+// All of them are ~50 MFLOP / ~3 MB at the benchmark size: what matters is launch count, enough
+// blocks to cover 256 CUs, coalesced operand staging and a short dependent-latency chain.
+// Operands are staged through LDS with coalesced loads and consumed by v_mfma_f32_16x16x4_f32
+// (fp32 in / fp32 accumulate: an exact fmaf chain, so results are deterministic and the argmax
+// is reproducible bit for bit).  Cross-wave and cross-block sums always run in a fixed order.
+//
+// LDS row strides are chosen per operand so that the MFMA fragment reads are bank-conflict free
+// (ds_read_b32: 32 banks, lane groups {0-31},{32-63}):
+//   fragment element (r = lane&15, kq = lane>>4) at [row = r][col = 4t+kq]  -> stride == 2 (mod 32)
+//   fragment element                              at [row = 4t+kq][col = r] -> stride == 16 (mod 32)
+#include "apa_device.h"
+#include "apa_internal.h"
+
+namespace apa {
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// --------------------------------------------------------------------------------------------
+// L1: partial logits.  grid (ceil(K/32), C/128, ceil(N/32)), 256 threads.
+//   part[cc][n][k] = sum_{c in chunk cc} z[n,c] * Wt[c,k]
+// --------------------------------------------------------------------------------------------
+constexpr int L1_ZS = 130;  // Zs[32][130]: == 2 (mod 32)
+constexpr int L1_WS = 48;   // Ws[128][48]: == 16 (mod 32)
+
+__global__ __launch_bounds__(256) void m1_logits_partial_kernel(const float* __restrict__ z,
+                                                                const float* __restrict__ Wt,
+                                                                float* __restrict__ part, int N,
+                                                                int C, int K) {
+  __shared__ float Zs[32 * L1_ZS];
+  __shared__ float Ws[128 * L1_WS];
+  const int k0 = blockIdx.x * 32, c0 = blockIdx.y * 128, n0 = blockIdx.z * 32;
+  const int tid = threadIdx.x;
+  // Wt tile [128 c][32 k]: one wave-instruction covers 2 rows x 32 consecutive floats
+  {
+    const int col = tid & 31, r0 = tid >> 5;
+    const bool ok = (k0 + col) < K;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = r0 + i * 8;
+      Ws[row * L1_WS + col] = ok ? Wt[(size_t)(c0 + row) * K + k0 + col] : 0.f;
+    }
+  }
+  // z tile [32 n][128 c], float4 (rows are 16-byte aligned: C % 4 == 0)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int v = tid + i * 256;
+    const int row = v >> 5, c4 = (v & 31) * 4;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n0 + row < N) q = *reinterpret_cast<const float4*>(z + (size_t)(n0 + row) * C + c0 + c4);
+    float* d = &Zs[row * L1_ZS + c4];
+    d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  const int ni = wave >> 1, kj = wave & 1;
+  const int r = lane & 15, kq = lane >> 4;
+  const float* za = &Zs[(ni * 16 + r) * L1_ZS + kq];
+  const float* wb = &Ws[kq * L1_WS + kj * 16 + r];
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+  for (int t = 0; t < 32; t += 2) {
+    acc0 = mfma16(za[4 * t], wb[4 * t * L1_WS], acc0);
+    acc1 = mfma16(za[4 * t + 4], wb[(4 * t + 4) * L1_WS], acc1);
+  }
+  const int col = k0 + kj * 16 + r;
+  if (col < K) {
+    float* out = part + ((size_t)blockIdx.y * N) * K;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row = n0 + ni * 16 + kq * 4 + reg;
+      if (row < N) out[(size_t)row * K + col] = acc0[reg] + acc1[reg];
+    }
+  }
+}
+
+// L2: logits[n,k] = sum_cc part[cc][n][k] + abar[n] * bt[k]   (fixed order over cc)
+__global__ __launch_bounds__(256) void m1_logits_reduce_kernel(const float* __restrict__ part,
+                                                               const float* __restrict__ abar,
+                                                               const float* __restrict__ bt,
+                                                               float* __restrict__ logits, int N,
+                                                               int K, int nchunks) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= N * K) return;
+  const int n = idx / K, k = idx - n * K;
+  const size_t stride = (size_t)N * K;
+  float v[16];
+  float acc = 0.f;
+  for (int c = 0; c < nchunks; c += 16) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = (c + u < nchunks) ? part[(size_t)(c + u) * stride + idx] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += v[u];
+  }
+  logits[idx] = fmaf(abar[n], bt[k], acc);
+}
+
+// --------------------------------------------------------------------------------------------
+// B12: the three small products of the backward pass in ONE launch.
+//   blocks [0, nA)        role A: dz[n, c0:c0+16] for all n         (nA = C/16)
+//   blocks [nA, nA + nB)  role B: dWt[c0:c0+64, k0:k0+64] (+ dbt)   (nB = C/64 * ceil(K/64))
+// Role A is listed first: the streaming pass that follows waits for dz, not for dWt.
+// Dynamic LDS: role A needs (16 + 32) * Kp + 2048 floats, role B 2 * 32 * 80 + 32.
+// --------------------------------------------------------------------------------------------
+constexpr int B_ZST = 80;   // Zs[32][80]  (64 c columns): == 16 (mod 32)
+constexpr int B_GST = 144;  // Gs[32][144] (128 k columns): == 16 (mod 32)
+
+__host__ __device__ inline int dz_kp(int K) {  // smallest Kp >= K with Kp == 2 (mod 32)
+  int kp = (K / 32) * 32 + 2;
+  while (kp < K) kp += 32;
+  return kp;
+}
+
+// Copy `nrows` consecutive rows of a row-major [*, K] matrix (one contiguous, 16-byte aligned span
+// of nrows*K floats) into an LDS image dst[row][Kp]; columns K..Kp-1 and rows nrows..rows_total-1
+// are zero-filled.  The span is read with 16-byte loads, all of a thread's loads in flight at once
+// (a row of K = 393 floats is not 16-byte aligned on its own, the span is).
+template <int MAXV>
+__device__ __forceinline__ void fill_rows_flat(float* __restrict__ dst, const float* __restrict__ src,
+                                               int nrows, int rows_total, int K, int Kp, int tid) {
+  const int total = nrows * K;
+  const int nvec = (total + 3) >> 2;
+  const float invK = 1.0f / (float)K;
+  float4 q[MAXV];
+#pragma unroll
+  for (int u = 0; u < MAXV; ++u) {
+    const int v = tid + u * 256;
+    q[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (v < nvec) {
+      if (v * 4 + 3 < total) {
+        q[u] = *reinterpret_cast<const float4*>(src + (size_t)v * 4);
+      } else {  // ragged tail of the span
+        const float* s = src + (size_t)v * 4;
+        q[u].x = s[0];
+        if (v * 4 + 1 < total) q[u].y = s[1];
+        if (v * 4 + 2 < total) q[u].z = s[2];
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < MAXV; ++u) {
+    const int v = tid + u * 256;
+    if (v < nvec) {
+      const int idx = v * 4;
+      int row = (int)((float)idx * invK);
+      int col = idx - row * K;
+      if (col < 0) { --row; col += K; }
+      if (col >= K) { ++row; col -= K; }
+      const float e[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (idx + t < total) dst[row * Kp + col] = e[t];
+        if (++col == K) { col = 0; ++row; }
+      }
+    }
+  }
+  const int padc = Kp - K;
+  for (int i = tid; i < nrows * padc; i += 256) dst[(i / padc) * Kp + K + (i % padc)] = 0.f;
+  for (int i = tid; i < (rows_total - nrows) * Kp; i += 256) dst[nrows * Kp + i] = 0.f;
+}
+
+template <int MAXV>
+__global__ __launch_bounds__(256) void m1_bwd_small_kernel(
+    const float* __restrict__ G, const float* __restrict__ Wt, const float* __restrict__ zsave,
+    const float* __restrict__ abar, float* __restrict__ dz, float* __restrict__ dWt,
+    float* __restrict__ dbt, int N, int C, int K, int nA) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, kq = lane >> 4;
+
+  if ((int)blockIdx.x < nA) {
+    // ---------------- role A: dz[n, c] = sum_k G[n,k] Wt[c,k] ----------------
+    const int Kp = dz_kp(K);
+    float* Ws = smem;             // [16][Kp]
+    float* Gs = smem + 16 * Kp;   // [32][Kp]
+    float* red = Gs + 32 * Kp;    // [4 waves][2 tiles][256]
+    const int c0 = blockIdx.x * 16;
+    fill_rows_flat<(MAXV + 1) / 2>(Ws, Wt + (size_t)c0 * K, 16, 16, K, Kp, tid);
+    const int steps = (K + 3) >> 2;
+    const int spw = (steps + 3) >> 2;
+    const int t_begin = wave * spw, t_end = min(steps, t_begin + spw);
+    for (int n0 = 0; n0 < N; n0 += 32) {
+      __syncthreads();  // previous tile's Gs / red readers are done
+      fill_rows_flat<MAXV>(Gs, G + (size_t)n0 * K, min(32, N - n0), 32, K, Kp, tid);
+      __syncthreads();
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+      const float* g0 = &Gs[r * Kp + kq];
+      const float* g1 = &Gs[(16 + r) * Kp + kq];
+      const float* wb = &Ws[r * Kp + kq];
+#pragma unroll 4
+      for (int t = t_begin; t < t_end; ++t) {
+        const float b = wb[4 * t];
+        a0 = mfma16(g0[4 * t], b, a0);
+        a1 = mfma16(g1[4 * t], b, a1);
+      }
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        red[(wave * 2 + 0) * 256 + (kq * 4 + reg) * 16 + r] = a0[reg];
+        red[(wave * 2 + 1) * 256 + (kq * 4 + reg) * 16 + r] = a1[reg];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int row = tid >> 4, col = tid & 15;
+        const float s = (red[(0 * 2 + ni) * 256 + tid] + red[(1 * 2 + ni) * 256 + tid]) +
+                        (red[(2 * 2 + ni) * 256 + tid] + red[(3 * 2 + ni) * 256 + tid]);
+        const int n = n0 + ni * 16 + row;
+        if (n < N) dz[(size_t)n * C + c0 + col] = s;
+      }
+    }
+    return;
+  }
+
+  // ---------------- role B: dWt[c0:c0+64, k0:k0+128] = sum_n z[n,c] G[n,k]  (+ dbt) ----------------
+  const int b = blockIdx.x - nA;
+  const int nkt = (K + 127) >> 7;
+  const int ct = b / nkt, kt = b - ct * nkt;
+  const int c0 = ct * 64, k0 = kt * 128;
+  float* Zs = smem;                // [32][80]
+  float* Gs = smem + 32 * B_ZST;   // [32][144]
+  float* As = Gs + 32 * B_GST;     // abar chunk [32]
+  f32x4 acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dbt_acc = 0.f;
+  for (int n0 = 0; n0 < N; n0 += 32) {
+    __syncthreads();
+    const int nrows = min(32, N - n0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {  // z tile [32][64] as float4 (rows 16-byte aligned)
+      const int v = tid + i * 256;
+      const int row = v >> 4, c4 = (v & 15) * 4;
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < nrows) q = *reinterpret_cast<const float4*>(zsave + (size_t)(n0 + row) * C + c0 + c4);
+      float* d = &Zs[row * B_ZST + c4];
+      d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+    }
+    {
+      const int col = tid & 127, r0 = tid >> 7;
+      const bool ok = (k0 + col) < K;
+      float g[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {  // G tile [32][128]: 16 independent loads per thread
+        const int row = r0 + i * 2;
+        g[i] = (ok && row < nrows) ? G[(size_t)(n0 + row) * K + k0 + col] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Gs[(r0 + i * 2) * B_GST + col] = g[i];
+    }
+    if (tid < 32) As[tid] = tid < nrows ? abar[n0 + tid] : 0.f;
+    __syncthreads();
+    const float* za = &Zs[kq * B_ZST + wave * 16 + r];
+    const float* gb = &Gs[kq * B_GST + r];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float a = za[4 * t * B_ZST];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = mfma16(a, gb[4 * t * B_GST + j * 16], acc[j]);
+    }
+    if (ct == 0 && tid < 128) {
+#pragma unroll 8
+      for (int n = 0; n < 32; ++n) dbt_acc = fmaf(As[n], Gs[n * B_GST + tid], dbt_acc);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int col = k0 + j * 16 + r;
+    if (col < K) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = c0 + wave * 16 + kq * 4 + reg;
+        dWt[(size_t)row * K + col] = acc[j][reg];
+      }
+    }
+  }
+  if (ct == 0 && tid < 128 && k0 + tid < K) dbt[k0 + tid] = dbt_acc;
+}
+
+// --------------------------------------------------------------------------------------------
+// B4: dwa[c] = sum_b pdwa[b][c] (fixed order), dba = sum_b pdba[b].
+// grid = ceil(C/32) blocks of 1024 threads: 32 row groups x 32 columns, 128-byte row segments.
+// The last kernel of the backward call: optionally advances the HBM dropout counter.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void m1_colsum_kernel(const float* __restrict__ pdwa,
+                                                         const float* __restrict__ pdba,
+                                                         float* __restrict__ dwa,
+                                                         float* __restrict__ dba, int nblk, int C,
+                                                         uint64_t* __restrict__ rng_bump) {
+  __shared__ float red[32][33];
+  const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + col;
+  float acc = 0.f;
+  if (c < C) {
+    int b = rg;
+    for (; b + 224 < nblk; b += 256) {  // 8 independent loads in flight
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = pdwa[(size_t)(b + 32 * u) * C + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; b < nblk; b += 32) acc += pdwa[(size_t)b * C + c];
+  }
+  red[rg][col] = acc;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 32; ++g) s += red[g][col];
+    dwa[c] = s;
+  }
+  if (blockIdx.x == 0) {
+    __syncthreads();
+    float a = 0.f;
+    for (int b = threadIdx.x; b < nblk; b += 1024) a += pdba[b];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float s = 0.f;
+      for (int w = 0; w < 16; ++w) s += red[0][w];
+      dba[0] = s;
+      if (rng_bump) *rng_bump += 1;
+    }
+  }
+}
+
+// ============================================================================================
+// host
+// ============================================================================================
+size_t m1_logits_ws_bytes(int N, int C, int K) { return (size_t)(C / 128) * N * K * sizeof(float); }
+
+bool m1_small_supported(int C, int K) {
+  // role A keeps (16 + 32) rows of Kp floats (+ 8 KB) in LDS and stages a 32-row G tile with at
+  // most 26 16-byte loads per thread
+  return C % 128 == 0 && ((size_t)48 * dz_kp(K) + 2048) * sizeof(float) <= 150 * 1024 &&
+         (8 * K + 255) / 256 <= 26;
+}
+
+int m1_logits(const float* z, const float* Wt, const float* abar, const float* bt, float* logits,
+              float* part_ws, int N, int C, int K, hipStream_t st) {
+  dim3 grid((K + 31) / 32, C / 128, (N + 31) / 32);
+  hipLaunchKernelGGL(m1_logits_partial_kernel, grid, dim3(256), 0, st, z, Wt, part_ws, N, C, K);
+  APA_LAUNCH_CHECK("m1_logits_partial_kernel");
+  hipLaunchKernelGGL(m1_logits_reduce_kernel, dim3((N * K + 255) / 256), dim3(256), 0, st, part_ws,
+                     abar, bt, logits, N, K, C / 128);
+  APA_LAUNCH_CHECK("m1_logits_reduce_kernel");
+  return APA_OK;
+}
+
+int m1_bwd_small(const float* G, const float* Wt, const float* zsave, const float* abar, float* dz,
+                 float* dWt, float* dbt, int N, int C, int K, hipStream_t st) {
+  const int nA = C / 16;
+  const int nB = (C / 64) * ((K + 127) / 128);
+  const size_t shmA = ((size_t)48 * dz_kp(K) + 2048) * sizeof(float);
+  const size_t shmB = ((size_t)32 * (B_ZST + B_GST) + 32) * sizeof(float);
+  const size_t shm = shmA > shmB ? shmA : shmB;
+  // vectors per thread to stage a 32-row G tile: ceil(32*K/4/256)
+  const int maxv = (8 * K + 255) / 256;
+#define APA_BS(MV)                                                                               \
+  do {                                                                                           \
+    if (shm > 64 * 1024) {                                                                       \
+      static thread_local bool attr_set = false;                                                 \
+      if (!attr_set) {                                                                           \
+        APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(m1_bwd_small_kernel<MV>), \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        attr_set = true;                                                                         \
+      }                                                                                          \
+    }                                                                                            \
+    hipLaunchKernelGGL(m1_bwd_small_kernel<MV>, dim3(nA + nB), dim3(256), shm, st, G, Wt, zsave,  \
+                       abar, dz, dWt, dbt, N, C, K, nA);                                         \
+  } while (0)
+  if (maxv <= 4) APA_BS(4);
+  else if (maxv <= 8) APA_BS(8);
+  else if (maxv <= 13) APA_BS(13);
+  else APA_BS(26);
+#undef APA_BS
+  APA_LAUNCH_CHECK("m1_bwd_small_kernel");
+  return APA_OK;
+}
+
+int m1_colsum(const float* pdwa, const float* pdba, float* dwa, float* dba, int nblk, int C,
+              uint64_t* rng_bump, hipStream_t st) {
+  hipLaunchKernelGGL(m1_colsum_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, pdwa, pdba, dwa, dba,
+                     nblk, C, rng_bump);
+  APA_LAUNCH_CHECK("m1_colsum_kernel");
+  return APA_OK;
+}
+
+}  // namespace apa

@@ -1,0 +1,363 @@
+"""Loader + thin python wrappers for libapa_hip.so (the MI355X attentional-pooling library).
+
+Shaped like the reference's plugin layer, /root/reference/src/custom_ops/custom_ops_factory.py:
+the shared object lives next to this file (reference :7-18 resolves `<op>.so` relative to
+`__file__` and calls tf.load_op_library at import time) and every op is exposed as a small python
+wrapper.  Here the library is a plain C-ABI .so (include/apa.h) bound with ctypes; tensors are
+torch tensors used purely as device-memory handles (data_ptr + current stream).
+
+There is NO CPU fallback: if the library is missing, or a tensor is not on the GPU, the wrappers
+raise.  The oracle under /oracle is test infrastructure and is never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import (POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_uint, c_uint8, c_uint64,
+                    c_void_p)
+from typing import Optional, Tuple
+
+import numpy as np
+import torch  # imported BEFORE the CDLL so that libamdhip64.so.7 resolves to torch's runtime
+
+cur_path = os.path.realpath(__file__)
+ROOT_PATH = os.path.dirname(cur_path)
+LIB_NAME = 'libapa_hip.so'
+LIB_PATH = os.path.join(ROOT_PATH, LIB_NAME)
+
+APA_DTYPE_F32 = 0
+APA_DTYPE_BF16 = 1
+APA_FLAG_SOFTMAX_ATT = 1
+APA_FLAG_RELU_ATT = 2
+APA_FLAG_TRAIN = 4
+APA_FLAG_RNG_DEVICE = 8
+
+# every symbol include/apa.h declares: name -> (restype, argtypes)
+_SIGNATURES = {
+    'apa_version': (c_int, []),
+    'apa_last_error': (c_char_p, []),
+    'apa_status_string': (c_char_p, [c_int]),
+    'apa_attn_pool_workspace_bytes': (c_size_t, [c_int] * 6 + [c_uint]),
+    'apa_attn_pool_fwd': (c_int, [c_void_p] * 12 + [c_size_t] + [c_int] * 6 +
+                          [c_uint, c_float, c_uint64, c_uint64, c_int, c_void_p]),
+    'apa_attn_pool_bwd': (c_int, [c_void_p] * 17 + [c_size_t] + [c_int] * 6 +
+                          [c_uint, c_float, c_uint64, c_uint64, c_int, c_void_p]),
+    'apa_dropout_mask': (c_int, [c_void_p, c_size_t, c_float, c_uint64, c_uint64, c_void_p]),
+    'apa_softmax_xent_fwd_bwd': (c_int, [c_void_p] * 6 + [c_int, c_int, c_float, c_float, c_void_p]),
+    'apa_pose_l2_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'apa_pose_l2_loss_fwd_bwd': (c_int, [c_void_p] * 6 + [c_size_t, c_int, c_int, c_int, c_float,
+                                                          c_float, c_void_p]),
+    'apa_pose_to_heatmap_out_ht': (c_int64, [c_int64, c_int64, c_int64]),
+    'apa_pose_to_heatmap': (c_int, [POINTER(c_int64), c_int64, c_int64, c_int64, c_int64, c_int,
+                                    c_float, c_int, POINTER(c_float), POINTER(c_uint8)]),
+    'apa_zero_out_channels': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    'apa_prof_event_create': (c_int, [POINTER(c_void_p)]),
+    'apa_prof_event_destroy': (c_int, [c_void_p]),
+    'apa_prof_event_record': (c_int, [c_void_p, c_void_p]),
+    'apa_prof_event_elapsed_ms': (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
+    'apa_prof_set_kernel_events': (c_int, [c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+class ApaError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    """Names the header declares (used by the CPU-side ABI test)."""
+    return sorted(_SIGNATURES)
+
+
+def load_library(path: Optional[str] = None) -> ctypes.CDLL:
+    """dlopen libapa_hip.so from this directory (like custom_ops_factory.py:11-18) and bind every
+    entry point.  Fails loudly when the library has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ApaError(
+            '{} not found. Build it with `python -c "import __graft_entry__ as g; g.build()"` or '
+            '`make -C attentionalpoolingaction_amd/csrc`. There is no CPU fallback.'.format(p))
+    lib = ctypes.CDLL(p)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == missing export
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        lib = load_library()
+        raise ApaError('{} failed: {} ({})'.format(
+            what, lib.apa_status_string(rc).decode(), lib.apa_last_error().decode()))
+
+
+def _dev_ptr(t: Optional[torch.Tensor], name: str, dtype=None) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ApaError('{} must live in GPU memory (got device {}); the HIP path has no CPU '
+                       'fallback'.format(name, t.device))
+    if not t.is_contiguous():
+        raise ApaError('{} must be contiguous'.format(name))
+    if dtype is not None and t.dtype != dtype:
+        raise ApaError('{} must be {} (got {})'.format(name, dtype, t.dtype))
+    return t.data_ptr()
+
+
+def _stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _feat_dtype(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return APA_DTYPE_F32
+    if t.dtype == torch.bfloat16:
+        return APA_DTYPE_BF16
+    raise ApaError('feature maps must be float32 or bfloat16, got {}'.format(t.dtype))
+
+
+def _rng_offset(offset, flags):
+    """An int is passed by value; a 1-element int64 CUDA tensor is passed by address
+    (APA_FLAG_RNG_DEVICE) so that hipGraph replays read -- and the backward advances -- it."""
+    if isinstance(offset, torch.Tensor):
+        if not (offset.is_cuda and offset.dtype == torch.int64 and offset.numel() == 1):
+            raise ApaError('a device-side dropout counter must be a 1-element int64 CUDA tensor')
+        return offset.data_ptr(), flags | APA_FLAG_RNG_DEVICE
+    return int(offset), flags
+
+
+def attn_flags(softmax_att=False, relu_att=False, is_training=False) -> int:
+    return ((APA_FLAG_SOFTMAX_ATT if softmax_att else 0) | (APA_FLAG_RELU_ATT if relu_att else 0) |
+            (APA_FLAG_TRAIN if is_training else 0))
+
+
+# --------------------------------------------------------------------------------------------
+# attentional pooling
+# --------------------------------------------------------------------------------------------
+def attn_pool_workspace_bytes(N, P, C, Ca, K, M, flags=0) -> int:
+    return int(load_library().apa_attn_pool_workspace_bytes(N, P, C, Ca, K, M, flags))
+
+
+def attn_pool_fwd(X, Xatt, Wa, ba, Wt, bt, *, flags=0, keep_prob=1.0, seed=0, offset=0,
+                  workspace=None, want_topdown=False):
+    """logits, att, zsave, abar, topdown, workspace = attn_pool_fwd(...)
+
+    X [N,P,C] (or [N,H,W,C]) f32/bf16; Xatt same tensor object as X (cfg 002) or [N,P,Ca];
+    Wa [Ca,M], ba [M], Wt [C,K], bt [K] f32.  See include/apa.h: apa_attn_pool_fwd.
+    """
+    lib = load_library()
+    N = X.shape[0]
+    C = X.shape[-1]
+    P = X.numel() // (N * C)
+    Ca = Xatt.shape[-1]
+    M = Wa.shape[1]
+    K = Wt.shape[1]
+    dt = _feat_dtype(X)
+    dev = X.device
+    logits = torch.empty((N, K), dtype=torch.float32, device=dev)
+    att = torch.empty((N, P, M), dtype=torch.float32, device=dev)
+    zsave = torch.empty((N, C), dtype=torch.float32, device=dev) if M == 1 else None
+    abar = torch.empty((N,), dtype=torch.float32, device=dev) if M == 1 else None
+    topdown = torch.empty((N, P, K), dtype=X.dtype, device=dev) if want_topdown else None
+    need = int(lib.apa_attn_pool_workspace_bytes(N, P, C, Ca, K, M, flags))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty((max(need, 16),), dtype=torch.uint8, device=dev)
+    xatt_ptr = _dev_ptr(X, 'X') if Xatt is X else _dev_ptr(Xatt, 'Xatt', X.dtype)
+    offset, flags = _rng_offset(offset, flags)
+    rc = lib.apa_attn_pool_fwd(
+        _dev_ptr(X, 'X'), xatt_ptr, _dev_ptr(Wa, 'Wa', torch.float32),
+        _dev_ptr(ba, 'ba', torch.float32), _dev_ptr(Wt, 'Wt', torch.float32),
+        _dev_ptr(bt, 'bt', torch.float32), logits.data_ptr(), att.data_ptr(),
+        _dev_ptr(zsave, 'zsave'), _dev_ptr(abar, 'abar'), _dev_ptr(topdown, 'topdown'),
+        workspace.data_ptr(), workspace.numel(), N, P, C, Ca, K, M, flags, float(keep_prob),
+        int(seed), offset, dt, _stream_ptr())
+    _check(rc, 'apa_attn_pool_fwd')
+    return logits, att, zsave, abar, topdown, workspace
+
+
+def attn_pool_bwd(X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, *, flags=0, keep_prob=1.0, seed=0,
+                  offset=0, workspace=None, out=None):
+    """dX, dXatt, dWa, dba, dWt, dbt = attn_pool_bwd(...).  `out` may supply preallocated
+    (dX, dXatt, dWa, dba, dWt, dbt) buffers (e.g. views into a flat DP gradient bucket)."""
+    lib = load_library()
+    N = X.shape[0]
+    C = X.shape[-1]
+    P = X.numel() // (N * C)
+    Ca = Xatt.shape[-1]
+    M = Wa.shape[1]
+    K = Wt.shape[1]
+    dt = _feat_dtype(X)
+    dev = X.device
+    fused = Xatt is X
+    if out is None:
+        dX = torch.empty_like(X)
+        dXatt = None if fused else torch.empty_like(Xatt)
+        dWa = torch.empty_like(Wa)
+        dba = torch.empty_like(ba)
+        dWt = torch.empty_like(Wt)
+        dbt = torch.empty_like(bt)
+    else:
+        dX, dXatt, dWa, dba, dWt, dbt = out
+    need = int(lib.apa_attn_pool_workspace_bytes(N, P, C, Ca, K, M, flags))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty((max(need, 16),), dtype=torch.uint8, device=dev)
+    xatt_ptr = _dev_ptr(X, 'X') if fused else _dev_ptr(Xatt, 'Xatt', X.dtype)
+    offset, flags = _rng_offset(offset, flags)
+    rc = lib.apa_attn_pool_bwd(
+        _dev_ptr(X, 'X'), xatt_ptr, _dev_ptr(Wa, 'Wa', torch.float32),
+        _dev_ptr(ba, 'ba', torch.float32), _dev_ptr(Wt, 'Wt', torch.float32),
+        _dev_ptr(bt, 'bt', torch.float32), _dev_ptr(att, 'att', torch.float32),
+        _dev_ptr(zsave, 'zsave'), _dev_ptr(abar, 'abar'), _dev_ptr(G, 'G', torch.float32),
+        _dev_ptr(dX, 'dX'), _dev_ptr(dXatt, 'dXatt'), _dev_ptr(dWa, 'dWa'), _dev_ptr(dba, 'dba'),
+        _dev_ptr(dWt, 'dWt'), _dev_ptr(dbt, 'dbt'), workspace.data_ptr(), workspace.numel(), N, P,
+        C, Ca, K, M, flags, float(keep_prob), int(seed), offset, dt, _stream_ptr())
+    _check(rc, 'apa_attn_pool_bwd')
+    return dX, dXatt, dWa, dba, dWt, dbt
+
+
+def dropout_mask(shape, keep_prob, seed, offset, device='cuda') -> torch.Tensor:
+    """The exact {0,1} mask APA_FLAG_TRAIN applies to X (uint8, `shape` = X.shape)."""
+    lib = load_library()
+    mask = torch.empty(shape, dtype=torch.uint8, device=device)
+    rc = lib.apa_dropout_mask(_dev_ptr(mask, 'mask'), mask.numel(), float(keep_prob), int(seed),
+                              int(offset), _stream_ptr())
+    _check(rc, 'apa_dropout_mask')
+    return mask
+
+
+# --------------------------------------------------------------------------------------------
+# losses
+# --------------------------------------------------------------------------------------------
+def softmax_xent_fwd_bwd(logits, labels, *, wt=1.0, grad_scale=1.0, want_grad=True,
+                         want_probs=False, want_pred=False):
+    """(loss_buf[1+N], G, probs, pred): src/loss.py:74-80 + eval.py:193-197 fused."""
+    lib = load_library()
+    N, K = logits.shape
+    dev = logits.device
+    loss = torch.empty((1 + N,), dtype=torch.float32, device=dev)
+    G = torch.empty_like(logits) if want_grad else None
+    probs = torch.empty_like(logits) if want_probs else None
+    pred = torch.empty((N,), dtype=torch.int64, device=dev) if want_pred else None
+    rc = lib.apa_softmax_xent_fwd_bwd(
+        _dev_ptr(logits, 'logits', torch.float32), _dev_ptr(labels, 'labels', torch.int64),
+        loss.data_ptr(), _dev_ptr(G, 'G'), _dev_ptr(probs, 'probs'), _dev_ptr(pred, 'pred'), N, K,
+        float(wt), float(grad_scale), _stream_ptr())
+    _check(rc, 'apa_softmax_xent_fwd_bwd')
+    return loss, G, probs, pred
+
+
+def pose_l2_loss_fwd_bwd(Pl, lbl, valid, *, wt=1.0, grad_scale=1.0, want_grad=True):
+    """(loss[1], dPl): src/loss.py:29-70.  Pl/lbl [N,P,J] (or [N,H,W,J]) f32, valid [N,J] bool/uint8."""
+    lib = load_library()
+    N = Pl.shape[0]
+    J = Pl.shape[-1]
+    P = Pl.numel() // (N * J)
+    dev = Pl.device
+    v8 = valid.to(torch.uint8).contiguous()
+    loss = torch.empty((1,), dtype=torch.float32, device=dev)
+    dPl = torch.empty_like(Pl) if want_grad else None
+    need = int(lib.apa_pose_l2_workspace_bytes(N, P, J))
+    ws = torch.empty((max(need, 16),), dtype=torch.uint8, device=dev)
+    rc = lib.apa_pose_l2_loss_fwd_bwd(
+        _dev_ptr(Pl, 'Pl', torch.float32), _dev_ptr(lbl, 'lbl', torch.float32),
+        _dev_ptr(v8, 'valid'), loss.data_ptr(), _dev_ptr(dPl, 'dPl'), ws.data_ptr(), ws.numel(),
+        N, P, J, float(wt), float(grad_scale), _stream_ptr())
+    _check(rc, 'apa_pose_l2_loss_fwd_bwd')
+    return loss, dPl
+
+
+# --------------------------------------------------------------------------------------------
+# the reference's own custom ops (src/custom_ops/custom_ops_factory.py:20-47)
+# --------------------------------------------------------------------------------------------
+def pose_to_heatmap(pose_label, im_ht, im_wd, out_wd, out_channels=16, marker_wd_ratio=0.1,
+                    do_gauss_blur=True) -> Tuple[np.ndarray, np.ndarray]:
+    """Same call surface as custom_ops_factory.py:20-28 (`pose_to_heatmap(*args, **kwargs)`):
+    returns (uint8 heatmap [out_ht,out_wd,out_channels] = float heatmap * 255 truncated,
+    bool valid [out_channels]).  Host op, like the reference (DEVICE_CPU)."""
+    lib = load_library()
+    pose = np.ascontiguousarray(np.asarray(pose_label, dtype=np.int64).reshape(-1))
+    out_ht = int(lib.apa_pose_to_heatmap_out_ht(int(im_ht), int(im_wd), int(out_wd)))
+    if out_ht < 0:
+        raise ApaError('apa_pose_to_heatmap_out_ht: bad image size')
+    hm = np.zeros((out_ht, int(out_wd), int(out_channels)), dtype=np.float32)
+    valid = np.zeros((int(out_channels),), dtype=np.uint8)
+    rc = lib.apa_pose_to_heatmap(
+        pose.ctypes.data_as(POINTER(c_int64)), pose.size, int(im_ht), int(im_wd), int(out_wd),
+        int(out_channels), float(marker_wd_ratio), 1 if do_gauss_blur else 0,
+        hm.ctypes.data_as(POINTER(c_float)), valid.ctypes.data_as(POINTER(c_uint8)))
+    _check(rc, 'apa_pose_to_heatmap')
+    return (hm * np.float32(255.0)).astype(np.uint8), valid.astype(bool)
+
+
+def pose_to_heatmap_float(pose_label, im_ht, im_wd, out_wd, out_channels=16, marker_wd_ratio=0.1,
+                          do_gauss_blur=True) -> Tuple[np.ndarray, np.ndarray]:
+    """The raw op outputs (float heatmap in [0,1], bool valid) before the python wrapper's *255."""
+    lib = load_library()
+    pose = np.ascontiguousarray(np.asarray(pose_label, dtype=np.int64).reshape(-1))
+    out_ht = int(lib.apa_pose_to_heatmap_out_ht(int(im_ht), int(im_wd), int(out_wd)))
+    hm = np.zeros((max(out_ht, 0), int(out_wd), int(out_channels)), dtype=np.float32)
+    valid = np.zeros((int(out_channels),), dtype=np.uint8)
+    rc = lib.apa_pose_to_heatmap(
+        pose.ctypes.data_as(POINTER(c_int64)), pose.size, int(im_ht), int(im_wd), int(out_wd),
+        int(out_channels), float(marker_wd_ratio), 1 if do_gauss_blur else 0,
+        hm.ctypes.data_as(POINTER(c_float)), valid.ctypes.data_as(POINTER(c_uint8)))
+    _check(rc, 'apa_pose_to_heatmap')
+    return hm, valid.astype(bool)
+
+
+def zero_out_channels(to_zero: torch.Tensor, channels: torch.Tensor) -> torch.Tensor:
+    """custom_ops_factory.py:30-32 / zero_out_channels.cc: out[...,c] = channels[c] ? in : 0."""
+    lib = load_library()
+    C = to_zero.shape[-1]
+    out = torch.empty_like(to_zero)
+    ch = channels.to(torch.uint8).contiguous()
+    rc = lib.apa_zero_out_channels(_dev_ptr(to_zero, 'to_zero', torch.float32), _dev_ptr(ch, 'channels'),
+                                   out.data_ptr(), to_zero.numel() // C, C, _stream_ptr())
+    _check(rc, 'apa_zero_out_channels')
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# measurement hooks (bench.py)
+# --------------------------------------------------------------------------------------------
+class KernelTimer:
+    """HIP-event pairs recorded by the library around its dominant streaming kernel
+    (m1_bwd_main_kernel) on the launch stream; see apa_prof_set_kernel_events in include/apa.h."""
+
+    def __init__(self, n_pairs: int):
+        lib = load_library()
+        self._lib = lib
+        self.pairs = []
+        for _ in range(n_pairs):
+            a, b = c_void_p(), c_void_p()
+            _check(lib.apa_prof_event_create(ctypes.byref(a)), 'apa_prof_event_create')
+            _check(lib.apa_prof_event_create(ctypes.byref(b)), 'apa_prof_event_create')
+            self.pairs.append((a, b))
+
+    def arm(self, i: int) -> None:
+        a, b = self.pairs[i]
+        self._lib.apa_prof_set_kernel_events(a, b)
+
+    def disarm(self) -> None:
+        self._lib.apa_prof_set_kernel_events(None, None)
+
+    def elapsed_ms(self):
+        out = []
+        for a, b in self.pairs:
+            ms = c_float()
+            _check(self._lib.apa_prof_event_elapsed_ms(a, b, ctypes.byref(ms)), 'apa_prof_event_elapsed_ms')
+            out.append(ms.value)
+        return out
+
+    def close(self) -> None:
+        for a, b in self.pairs:
+            self._lib.apa_prof_event_destroy(a)
+            self._lib.apa_prof_event_destroy(b)
+        self.pairs = []

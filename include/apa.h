@@ -1,0 +1,166 @@
+/*
+ * apa.h -- C ABI of libapa_hip.so, the MI355X (gfx950) attentional-pooling library.
+ *
+ * This is the drop-in boundary for the attentional-pooling hot path of
+ * rohitgirdhar/AttentionalPoolingAction.  The reference has no native implementation of the
+ * head (it is ~10 TF-slim graph ops, models/slim/nets/nets_factory.py:242-328); its only native
+ * plugin mechanism is the set of TF custom ops in src/custom_ops/ (REGISTER_OP + OpKernel::Compute,
+ * loaded by src/custom_ops/custom_ops_factory.py:11-18 via tf.load_op_library).  Each entry point
+ * below names the reference code it replaces.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns 0 (APA_OK) or a negative apa_status.
+ *     Nothing throws across the boundary (the reference signals errors with OP_REQUIRES_OK /
+ *     assert, src/custom_ops/pose_to_heatmap.cc:27-32,49).
+ *   - all tensor pointers are DEVICE pointers (HBM) unless the name ends in _host.
+ *   - the caller owns every buffer, including workspaces; the library is stateless and
+ *     re-entrant (the reference ops run concurrently on TF inter-op threads,
+ *     src/custom_ops/pose_utils.hpp:7-14).
+ *   - every launch goes to the hipStream_t passed as `void* stream`; no implicit
+ *     synchronisation, no allocation -> all entry points are hipGraph-capturable.
+ *   - layouts are the reference's: feature maps NHWC flattened to [N, P=H*W, C]; 1x1-conv
+ *     weights [Cin, Cout] (TF HWIO [1,1,Cin,Cout] squeezed); float32 unless stated.
+ *
+ * Symbols: N batch, P = H*W pixels, C feature channels (2048), Ca channels of the attention
+ * input (C for cfg 002, 768 for cfg 003), K classes, M bottom-up maps (1, or K for per-class),
+ * J pose keypoints (16), Cp pose pre-logit channels (768).
+ */
+#ifndef APA_H_
+#define APA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APA_VERSION 100 /* major*10000 + minor*100 + patch */
+
+typedef enum apa_status {
+  APA_OK = 0,
+  APA_ERR_INVALID_ARG = -1,   /* null pointer, non-positive dimension, bad enum           */
+  APA_ERR_UNSUPPORTED = -2,   /* shape/dtype combination the kernels are not built for    */
+  APA_ERR_WORKSPACE = -3,     /* ws_bytes smaller than apa_*_workspace_bytes()            */
+  APA_ERR_HIP = -4            /* a HIP runtime call / launch failed (see apa_last_error)  */
+} apa_status;
+
+/* dtype of the feature-map tensors (X, Xatt, dX, dXatt, TopDown); parameters are always f32 */
+#define APA_DTYPE_F32 0
+#define APA_DTYPE_BF16 1
+
+/* flags (mirror cfg.NET.USE_POSE_PRELOGITS_BASED_ATTENTION_*, src/config.py:194-203)      */
+#define APA_FLAG_SOFTMAX_ATT 1u /* _SOFTMAX_ATT: spatial softmax of the bottom-up map       */
+#define APA_FLAG_RELU_ATT 2u    /* _RELU_ATT                                                 */
+#define APA_FLAG_TRAIN 4u       /* is_training: dropout on the top-down input is active      */
+#define APA_FLAG_RNG_DEVICE 8u  /* `offset` is the ADDRESS of a uint64 step counter in HBM: the   */
+                                /* kernels read it at run time and apa_attn_pool_bwd adds 1 to it */
+                                /* when it is done, so a captured hipGraph draws a fresh dropout  */
+                                /* mask on every replay                                           */
+
+int apa_version(void);
+/* Thread-local, never NULL; describes the last failure on the calling thread. */
+const char* apa_last_error(void);
+const char* apa_status_string(int status);
+
+/* ------------------------------------------------------------------------------------------
+ * Attentional pooling, forward.   Replaces nets_factory.py:247-328 + the squeeze at :350-351.
+ *
+ *   Z = Xatt . Wa + ba                      [N,P,M]     'Conv2d_PrePose_Attn'   (:259-270)
+ *   A = f(Z), f = id | softmax over P | relu                                     (:276-287)
+ *   Xt = X * mask / keep_prob  (APA_FLAG_TRAIN) else X             slim.dropout  (:296)
+ *   T = Xt . Wt + bt                        [N,P,K]     'Conv'                  (:298-309)
+ *   logits[n,k] = (1/P) sum_p A[n,p,m(k)] * T[n,p,k],  m(k) = 0 if M==1 else k   (:322-325)
+ *
+ * X     [N,P,C]   dtype            Xatt  [N,P,Ca]  dtype; pass Xatt == X (Ca == C) for cfg 002
+ * Wa    [Ca,M] f32, ba [M] f32     Wt    [C,K] f32, bt [K] f32
+ * logits[N,K] f32 (out)            att   [N,P,M] f32 (out) = end_points['PosePrelogitsBasedAttention']
+ * zsave [N,C] f32 (out, M==1 only) = (1/P) sum_p A[n,p] Xt[n,p,:]   -- saved for backward
+ * abar  [N]   f32 (out, M==1 only) = (1/P) sum_p A[n,p]             -- saved for backward
+ * topdown [N,P,K] dtype or NULL    = end_points['TopDownAttention']; only materialised on request
+ *                                    (the reference needs it for eval.py --ept dumps only)
+ * ws / ws_bytes: scratch of at least apa_attn_pool_workspace_bytes(...) bytes.
+ * seed/offset: counter-based dropout RNG key (APA_FLAG_TRAIN); the same pair must be passed to
+ *              the backward call.  apa_dropout_mask() materialises the identical mask.
+ * M == 1 runs the factorised HBM-bound path (T is never formed); M == K the dense MFMA path.
+ */
+size_t apa_attn_pool_workspace_bytes(int N, int P, int C, int Ca, int K, int M, unsigned flags);
+
+int apa_attn_pool_fwd(const void* X, const void* Xatt, const float* Wa, const float* ba,
+                      const float* Wt, const float* bt, float* logits, float* att, float* zsave,
+                      float* abar, void* topdown, void* ws, size_t ws_bytes, int N, int P, int C,
+                      int Ca, int K, int M, unsigned flags, float keep_prob, uint64_t seed,
+                      uint64_t offset, int dtype, void* stream);
+
+/* Attentional pooling, backward (the reference has none: TF autodiff of the ops above,
+ * model_deploy.py:263).  G = dLoss/dlogits [N,K] f32.  Outputs (all written, not accumulated):
+ *   dX [N,P,C] dtype; dXatt [N,P,Ca] dtype or NULL when Xatt == X (its term is folded into dX);
+ *   dWa [Ca,M], dba [M], dWt [C,K], dbt [K]  f32.
+ * att/zsave/abar are the tensors the forward call produced.
+ */
+int apa_attn_pool_bwd(const void* X, const void* Xatt, const float* Wa, const float* ba,
+                      const float* Wt, const float* bt, const float* att, const float* zsave,
+                      const float* abar, const float* G, void* dX, void* dXatt, float* dWa,
+                      float* dba, float* dWt, float* dbt, void* ws, size_t ws_bytes, int N, int P,
+                      int C, int Ca, int K, int M, unsigned flags, float keep_prob, uint64_t seed,
+                      uint64_t offset, int dtype, void* stream);
+
+/* Writes the {0,1} keep-mask that APA_FLAG_TRAIN applies to X (uint8 [N*P*C]); used by the
+ * parity tests to hand the oracle the exact mask (TF's own RNG stream is not reproducible). */
+int apa_dropout_mask(uint8_t* mask, size_t n_elems, float keep_prob, uint64_t seed, uint64_t offset,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Action loss: tf.losses.softmax_cross_entropy(one_hot(labels,K), logits, weights=wt)
+ * (src/loss.py:74-80) fused with its gradient.
+ *   loss[0] = wt/N * sum_n -log_softmax(logits[n])[labels[n]];  G = wt/N * (softmax - onehot)
+ * `grad_scale` multiplies G only (1/num_clones of model_deploy.py:223-225 goes here).
+ * labels int64 [N]; loss f32 [1+N]: loss[0] = weighted batch-mean loss, loss[1+n] = unweighted
+ * per-example cross-entropy; G f32 [N,K] or NULL; probs f32 [N,K] or NULL (eval.py:196);
+ * pred int64 [N] or NULL (argmax, first maximal index -- eval.py:193).
+ */
+int apa_softmax_xent_fwd_bwd(const float* logits, const int64_t* labels, float* loss, float* G,
+                             float* probs, int64_t* pred, int N, int K, float wt, float grad_scale,
+                             void* stream);
+
+/* Pose loss: src/loss.py:29-70 ('l2', LOSS_FN_POSE_SAMPLED off) fused with its gradient.
+ *   loss[0] = wt * sum_j mean_n( valid[n,j] ? 0.5*sum_p (Pl-lbl)^2 / (N*P) : 0 )
+ *   dPl = grad_scale * wt * valid[n,j] * (Pl - lbl) / (N*N*P)
+ * Pl, lbl [N,P,J] f32; valid uint8 [N,J]; dPl [N,P,J] f32 or NULL; loss f32 [1];
+ * ws: at least apa_pose_l2_workspace_bytes(N,P,J) bytes of device scratch. */
+size_t apa_pose_l2_workspace_bytes(int N, int P, int J);
+int apa_pose_l2_loss_fwd_bwd(const float* Pl, const float* lbl, const uint8_t* valid, float* loss,
+                             float* dPl, void* ws, size_t ws_bytes, int N, int P, int J, float wt,
+                             float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Label generator: PoseToHeatmapOp::Compute, src/custom_ops/pose_to_heatmap.cc:35-96.
+ * HOST function (the reference op is DEVICE_CPU and runs inside the input pipeline).
+ * pose_host int64 [n_vals], n_vals % (3*out_channels) == 0, triples (x, y, is_visible);
+ * heatmap_host f32 [out_ht, out_wd, out_channels] with out_ht = (int)(im_ht*out_wd*1.0/im_wd)
+ * (query it with apa_pose_to_heatmap_out_ht); valid_host uint8 [out_channels].
+ */
+int64_t apa_pose_to_heatmap_out_ht(int64_t im_ht, int64_t im_wd, int64_t out_wd);
+int apa_pose_to_heatmap(const int64_t* pose_host, int64_t n_vals, int64_t im_ht, int64_t im_wd,
+                        int64_t out_wd, int out_channels, float marker_wd_ratio, int do_gauss_blur,
+                        float* heatmap_host, uint8_t* valid_host);
+
+/* zero_out_channels.cc:18-51:  out[n,h,w,c] = channels[c] ? in[n,h,w,c] : 0   (f32, device). */
+int apa_zero_out_channels(const float* in, const uint8_t* channels, float* out, size_t n_outer,
+                          int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Measurement hooks (bench.py): HIP events owned by the library's HIP runtime, and a per-thread
+ * pair that the next apa_attn_pool_bwd call records immediately before / after its dominant
+ * streaming kernel (m1_bwd_main_kernel), on the call's stream.  Pass NULL, NULL to clear.
+ */
+int apa_prof_event_create(void** event);
+int apa_prof_event_destroy(void* event);
+int apa_prof_event_record(void* event, void* stream);
+int apa_prof_event_elapsed_ms(void* start, void* stop, float* ms); /* both must have completed */
+int apa_prof_set_kernel_events(void* start, void* stop);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APA_H_ */
