@@ -85,8 +85,9 @@ bool m1_small_supported(int C, int K);
 size_t m1_logits_ws_bytes(int N, int C, int K);
 int m1_logits(const float* z, const float* Wt, const float* abar, const float* bt, float* logits,
               float* part_ws, int N, int C, int K, hipStream_t st);
-int m1_bwd_small(const float* G, const float* Wt, const float* zsave, const float* abar, float* dz,
-                 float* dWt, float* dbt, int N, int C, int K, hipStream_t st);
+int m1_bwd_small(const float* G, const float* Wt, const float* zsave, const float* abar,
+                 const float* bt, float* dz, float* dWt, float* dbt, float* sn, int N, int C, int K,
+                 hipStream_t st);
 int m1_colsum(const float* pdwa, const float* pdba, float* dwa, float* dba, int nblk, int C,
               uint64_t* rng_bump, hipStream_t st);
 

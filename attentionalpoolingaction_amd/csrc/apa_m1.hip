@@ -333,7 +333,8 @@ template <typename T, int VEC, bool FUSED, bool TRAIN>
 __global__ __launch_bounds__(256) void m1_bwd_main_kernel(
     const T* __restrict__ X, const float* __restrict__ Wa, const float* __restrict__ att,
     const float* __restrict__ dz, const float* __restrict__ zsave, const float* __restrict__ abar,
-    const float* __restrict__ G, const float* __restrict__ bt, T* __restrict__ dX,
+    const float* __restrict__ G, const float* __restrict__ bt,
+    const float* __restrict__ sn_pre, T* __restrict__ dX,
     float* __restrict__ dZout, float* __restrict__ pdwa, float* __restrict__ pdba, int P, int S,
     int K, int act, float inv_keep, uint32_t thresh, uint64_t seed, uint64_t offset,
     const uint64_t* __restrict__ offset_dev) {
@@ -388,9 +389,14 @@ __global__ __launch_bounds__(256) void m1_bwd_main_kernel(
       }
     }
   }
-  float sn = 0.f;  // G[n,:] . bt
-  for (int k = lane; k < K; k += 64) sn = fmaf(G[(size_t)n * K + k], bt[k], sn);
-  sn = wave_sum(sn);
+  float sn;  // G[n,:] . bt: precomputed by the dz kernel (one load), else a K-long dot here
+  if (sn_pre) {
+    sn = sn_pre[n];
+  } else {
+    sn = 0.f;
+    for (int k = lane; k < K; k += 64) sn = fmaf(G[(size_t)n * K + k], bt[k], sn);
+    sn = wave_sum(sn);
+  }
   float corr = 0.f;
   if (act == ACT_SOFTMAX) corr = wave_sum(zdz) + sn * abar[n];
 
@@ -618,7 +624,7 @@ M1Plan m1_plan(int N, int P, int C, int Ca, int K) {
   pl.off_pacc = off;  off += align_up((size_t)pl.nblk * C * 4, 256);
   pl.off_pstat = off; off += align_up((size_t)pl.nblk * 4 * 4, 256);
   pl.off_pdwa = off;  off += align_up((size_t)pl.nblk * cmax * 4, 256);
-  pl.off_pdba = off;  off += align_up((size_t)pl.nblk * 4, 256);
+  pl.off_pdba = off;  off += align_up((size_t)(pl.nblk + N) * 4, 256);  // + sn[N]
   pl.off_dz = off;    off += align_up((size_t)N * C * 4, 256);
   pl.off_dzatt = off; off += align_up((size_t)N * P * 4, 256);
   pl.off_gemm = off;  off += align_up(sgemm_ws_bytes(N, K > C ? K : C, 16), 256);
@@ -652,14 +658,15 @@ static int launch_pool_fwd(bool fused, bool train, int nblk, hipStream_t st, con
 template <typename T, int VEC>
 static int launch_bwd_main(bool fused, bool train, int nblk, hipStream_t st, const void* X,
                            const float* Wa, const float* att, const float* dz, const float* zsave,
-                           const float* abar, const float* G, const float* bt, void* dX,
+                           const float* abar, const float* G, const float* bt,
+                           const float* sn_pre, void* dX,
                            float* dZout, float* pdwa, float* pdba, int P, int S, int K, int act,
                            RngArgs r) {
   const T* x = static_cast<const T*>(X);
   T* dx = static_cast<T*>(dX);
 #define APA_GO(F, TR)                                                                            \
   hipLaunchKernelGGL((m1_bwd_main_kernel<T, VEC, F, TR>), dim3(nblk), dim3(256), 0, st, x, Wa,   \
-                     att, dz, zsave, abar, G, bt, dx, dZout, pdwa, pdba, P, S, K, act,           \
+                     att, dz, zsave, abar, G, bt, sn_pre, dx, dZout, pdwa, pdba, P, S, K, act,   \
                      r.inv_keep, r.thresh, r.seed, r.offset, r.offset_dev)
   if (fused) { if (train) APA_GO(true, true); else APA_GO(true, false); }
   else       { if (train) APA_GO(false, true); else APA_GO(false, false); }
@@ -766,6 +773,7 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
   float* dz = reinterpret_cast<float*>(w + pl.off_dz);
   float* dZatt = reinterpret_cast<float*>(w + pl.off_dzatt);
   float* gemm_ws = reinterpret_cast<float*>(w + pl.off_gemm);
+  float* sn_buf = pdba + pl.nblk;   // [N] floats: the pdba region is sized nblk + N
   const RngArgs r = rng_args(train, keep_prob, seed, offset, flags);
 
   // the staged kernels read G / Wt / z with 16-byte loads
@@ -775,7 +783,7 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
   int rc;
   if (small_ok) {
     // dz = G . Wt^T, dWt = z^T . G, dbt = abar^T G in one launch
-    rc = m1_bwd_small(G, Wt, zsave, abar, dz, dWt, dbt, N, C, K, st);
+    rc = m1_bwd_small(G, Wt, zsave, abar, bt, dz, dWt, dbt, sn_buf, N, C, K, st);
     if (rc != APA_OK) return rc;
   } else {
     // generic fallback (very large K): dz[n,c] = sum_k G[n,k] Wt[c,k]; dWt[c,k] = sum_n z[n,c] G[n,k]
@@ -789,7 +797,8 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
   prof_kernel_events(&ev0, &ev1);
   if (ev0) APA_HIP_CHECK(hipEventRecord(ev0, st));
   rc = APA_DISPATCH_VEC(launch_bwd_main, dtype, C, fused, train, pl.nblk, st, X, Wa, att, dz,
-                        zsave, abar, G, bt, dX, dZatt, pdwa, pdba, P, pl.S, K, act, r);
+                        zsave, abar, G, bt, small_ok ? sn_buf : nullptr, dX, dZatt, pdwa, pdba, P,
+                        pl.S, K, act, r);
   if (rc != APA_OK) return rc;
   if (ev1) APA_HIP_CHECK(hipEventRecord(ev1, st));
 

@@ -171,8 +171,9 @@ __device__ __forceinline__ void fill_rows_flat(float* __restrict__ dst, const fl
 template <int MAXV>
 __global__ __launch_bounds__(256) void m1_bwd_small_kernel(
     const float* __restrict__ G, const float* __restrict__ Wt, const float* __restrict__ zsave,
-    const float* __restrict__ abar, float* __restrict__ dz, float* __restrict__ dWt,
-    float* __restrict__ dbt, int N, int C, int K, int nA) {
+    const float* __restrict__ abar, const float* __restrict__ bt, float* __restrict__ dz,
+    float* __restrict__ dWt, float* __restrict__ dbt, float* __restrict__ sn, int N, int C, int K,
+    int nA) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 15, kq = lane >> 4;
@@ -192,6 +193,13 @@ __global__ __launch_bounds__(256) void m1_bwd_small_kernel(
       __syncthreads();  // previous tile's Gs / red readers are done
       fill_rows_flat<MAXV>(Gs, G + (size_t)n0 * K, min(32, N - n0), 32, K, Kp, tid);
       __syncthreads();
+      // sn[n] = G[n,:] . bt for the streaming pass: block b serves row n0 + b of this tile
+      if (wave == 0 && (int)blockIdx.x < 32 && n0 + (int)blockIdx.x < N) {
+        float acc = 0.f;
+        for (int k = lane; k < K; k += 64) acc = fmaf(Gs[blockIdx.x * Kp + k], bt[k], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) sn[n0 + blockIdx.x] = acc;
+      }
       f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
       const float* g0 = &Gs[r * Kp + kq];
       const float* g1 = &Gs[(16 + r) * Kp + kq];
@@ -357,8 +365,9 @@ int m1_logits(const float* z, const float* Wt, const float* abar, const float* b
   return APA_OK;
 }
 
-int m1_bwd_small(const float* G, const float* Wt, const float* zsave, const float* abar, float* dz,
-                 float* dWt, float* dbt, int N, int C, int K, hipStream_t st) {
+int m1_bwd_small(const float* G, const float* Wt, const float* zsave, const float* abar,
+                 const float* bt, float* dz, float* dWt, float* dbt, float* sn, int N, int C, int K,
+                 hipStream_t st) {
   const int nA = C / 16;
   const int nB = (C / 64) * ((K + 127) / 128);
   const size_t shmA = ((size_t)48 * dz_kp(K) + 2048) * sizeof(float);
@@ -377,7 +386,7 @@ int m1_bwd_small(const float* G, const float* Wt, const float* zsave, const floa
       }                                                                                          \
     }                                                                                            \
     hipLaunchKernelGGL(m1_bwd_small_kernel<MV>, dim3(nA + nB), dim3(256), shm, st, G, Wt, zsave,  \
-                       abar, dz, dWt, dbt, N, C, K, nA);                                         \
+                       abar, bt, dz, dWt, dbt, sn, N, C, K, nA);                                 \
   } while (0)
   if (maxv <= 4) APA_BS(4);
   else if (maxv <= 8) APA_BS(8);

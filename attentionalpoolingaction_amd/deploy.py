@@ -1,0 +1,149 @@
+"""Data-parallel deployment of the head: one process per GPU, RCCL all-reduce over xGMI.
+
+Reference semantics (/root/reference/models/slim/deployment/model_deploy.py):
+  * every clone's loss is divided by num_clones          (_gather_clone_loss, :223-225)
+  * per variable, the tower gradients are summed          (_sum_clones_gradients, :421-451)
+  * the regularisation loss is added once (clone 0)       (optimize_clones, :294-309)
+  * with TRAIN.ITER_SIZE > 1 gradients are accumulated locally and applied on the last
+    micro-step                                           (src/train.py:529-566)
+The reference does this in ONE process with towers on /gpu:i and the sum on the CPU device.  Here
+each rank owns one MI355X and the sum is a single `all_reduce(SUM)` of one flat fp32 bucket
+([dWa | dba | dWt | dbt | ...]: 3.2 MB for cfg 002) -- the kernels write their gradients straight
+into views of that bucket, so there is no packing copy.  Backend "nccl" is RCCL on ROCm; the same
+code runs on "gloo" with CPU tensors (tests/test_deploy_gloo.py, world_size 2).
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+class DeploymentConfig:
+    """The subset of slim's DeploymentConfig (model_deploy.py:481-683) that survives the move to
+    one-process-per-GPU: the clone count and this process's clone index."""
+
+    def __init__(self, num_clones: Optional[int] = None, clone_index: Optional[int] = None,
+                 process_group=None):
+        if dist.is_available() and dist.is_initialized():
+            self.num_clones = dist.get_world_size(process_group) if num_clones is None else num_clones
+            self.clone_index = dist.get_rank(process_group) if clone_index is None else clone_index
+        else:
+            self.num_clones = 1 if num_clones is None else num_clones
+            self.clone_index = 0 if clone_index is None else clone_index
+        self.process_group = process_group
+
+    @property
+    def clone_loss_scale(self) -> float:
+        """model_deploy.py:223-225: clone_loss / num_clones (only when num_clones > 1)."""
+        return 1.0 / self.num_clones if self.num_clones > 1 else 1.0
+
+    def is_chief(self) -> bool:
+        return self.clone_index == 0
+
+
+class GradientBucket:
+    """One flat fp32 buffer holding every head gradient; `views[name]` are the per-parameter
+    windows the HIP kernels (or autograd) write into."""
+
+    def __init__(self, shapes: Dict[str, Sequence[int]], device, dtype=torch.float32):
+        self.names = list(shapes)
+        self.shapes = {k: tuple(v) for k, v in shapes.items()}
+        sizes = [int(torch.Size(self.shapes[k]).numel()) for k in self.names]
+        self.flat = torch.zeros(sum(sizes), dtype=dtype, device=device)
+        self.views: Dict[str, torch.Tensor] = {}
+        o = 0
+        for k, s in zip(self.names, sizes):
+            self.views[k] = self.flat[o:o + s].view(self.shapes[k])
+            o += s
+
+    @classmethod
+    def for_parameters(cls, named_params: Iterable[Tuple[str, torch.Tensor]]):
+        named = list(named_params)
+        return cls({n: p.shape for n, p in named}, named[0][1].device)
+
+    def zero_(self):
+        self.flat.zero_()
+
+    def nbytes(self) -> int:
+        return self.flat.numel() * self.flat.element_size()
+
+
+def sum_clone_gradients(bucket: GradientBucket, config: DeploymentConfig, async_op: bool = False):
+    """_sum_clones_gradients: one all-reduce(SUM) of the flat bucket.  The gradients must already
+    carry the 1/num_clones loss scale (pass DeploymentConfig.clone_loss_scale as `grad_scale` to
+    the loss kernel).  Returns the work handle when async_op=True (overlap with the next
+    micro-batch's forward; wait before the optimizer step)."""
+    if config.num_clones == 1:
+        return None
+    return dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM, group=config.process_group,
+                           async_op=async_op)
+
+
+def add_regularization_gradient(bucket: GradientBucket, params: Dict[str, torch.Tensor],
+                                weight_decay: float, regularized: Sequence[str]) -> None:
+    """d/dW [ wd * 0.5 * |W|^2 ] = wd * W, added ONCE after the reduce -- equivalent to the
+    reference adding the regularisation loss to clone 0 only (model_deploy.py:294-309)."""
+    if weight_decay == 0.0:
+        return
+    for name in regularized:
+        bucket.views[name].add_(params[name].detach().to(bucket.flat.dtype), alpha=weight_decay)
+
+
+class GradientAccumulator:
+    """TRAIN.ITER_SIZE semantics (src/train.py:529-566): micro-step gradients are summed into an
+    accumulator, and only the last micro-step triggers reduce + apply; the accumulated gradient
+    is divided by ITER_SIZE like train.py:556-560."""
+
+    def __init__(self, bucket: GradientBucket, iter_size: int):
+        self.bucket = bucket
+        self.iter_size = max(1, int(iter_size))
+        self.acc = torch.zeros_like(bucket.flat) if self.iter_size > 1 else None
+        self.micro = 0
+
+    def step(self) -> bool:
+        """Call after each micro-batch's backward.  Returns True when the bucket now holds the
+        gradient to reduce and apply."""
+        if self.iter_size == 1:
+            return True
+        self.acc.add_(self.bucket.flat)
+        self.micro += 1
+        if self.micro < self.iter_size:
+            return False
+        self.bucket.flat.copy_(self.acc).div_(float(self.iter_size))
+        self.acc.zero_()
+        self.micro = 0
+        return True
+
+
+class MomentumSGD:
+    """tf.train.MomentumOptimizer(lr, momentum) (src/train.py:90-94): acc = m*acc + g;
+    w -= lr*acc (no Nesterov, no dampening) on the flat bucket layout."""
+
+    def __init__(self, params: Dict[str, torch.Tensor], bucket: GradientBucket, lr: float,
+                 momentum: float = 0.9):
+        self.params = params
+        self.bucket = bucket
+        self.lr = lr
+        self.momentum = momentum
+        self.acc = torch.zeros_like(bucket.flat)
+
+    def step(self, lr: Optional[float] = None) -> None:
+        lr = self.lr if lr is None else lr
+        self.acc.mul_(self.momentum).add_(self.bucket.flat)
+        o = 0
+        for name in self.bucket.names:
+            p = self.params[name]
+            n = p.numel()
+            p.data.add_(self.acc[o:o + n].view_as(p), alpha=-lr)
+            o += n
+
+
+def exponential_decay_lr(base_lr: float, global_step: int, decay_steps: int, decay_rate: float,
+                         staircase: bool = True) -> float:
+    """tf.train.exponential_decay (src/train.py:50-56): lr * rate^floor(step/decay_steps)."""
+    e = global_step / float(decay_steps)
+    if staircase:
+        e = float(int(e))
+    return base_lr * (decay_rate ** e)

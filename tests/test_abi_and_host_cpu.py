@@ -1,0 +1,213 @@
+"""CPU-side checks of the C-ABI library and the host logic (no GPU compute calls):
+  * libapa_hip.so loads and exports every symbol include/apa.h declares
+  * argument validation / error reporting of the entry points (returns before any HIP call)
+  * the host label generator (apa_pose_to_heatmap) == the numpy oracle, bit for bit
+  * product mAP / config / head-module plumbing
+"""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from attentionalpoolingaction_amd import config as apa_config
+from attentionalpoolingaction_amd import eval_utils
+from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+from oracle import labels_eval_oracle as leo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+
+# ------------------------------------------------------------------------------------------ ABI
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, 'include', 'apa.h')).read()
+    header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+    declared = sorted(set(re.findall(r'\b(apa_[a-z0-9_]+)\s*\(', header)))
+    assert len(declared) >= 15
+    lib = cof.load_library()
+    for name in declared:
+        assert hasattr(lib, name), 'libapa_hip.so does not export {}'.format(name)
+    # the ctypes table binds exactly the declared set
+    assert sorted(cof.exported_symbols()) == declared
+    assert lib.apa_version() >= 100
+
+
+def test_status_strings_and_error_paths_without_gpu():
+    lib = cof.load_library()
+    assert lib.apa_status_string(0) == b'APA_OK'
+    assert lib.apa_status_string(-2) == b'APA_ERR_UNSUPPORTED'
+    # null pointers / bad dims are rejected before any HIP call is made
+    rc = lib.apa_attn_pool_fwd(None, None, None, None, None, None, None, None, None, None, None, None,
+                               0, 2, 4, 256, 256, 5, 1, 0, 1.0, 0, 0, 0, None)
+    assert rc == -1 and b'null' in lib.apa_last_error()
+    rc = lib.apa_attn_pool_fwd(None, None, None, None, None, None, None, None, None, None, None, None,
+                               0, 0, 4, 256, 256, 5, 1, 0, 1.0, 0, 0, 0, None)
+    assert rc == -1 and b'non-positive' in lib.apa_last_error()
+    rc = lib.apa_attn_pool_fwd(None, None, None, None, None, None, None, None, None, None, None, None,
+                               0, 2, 4, 256, 256, 5, 3, 0, 1.0, 0, 0, 0, None)
+    assert rc == -1 and b'M must be 1' in lib.apa_last_error()
+    assert lib.apa_softmax_xent_fwd_bwd(None, None, None, None, None, None, 4, 4, 1.0, 1.0, None) == -1
+    assert lib.apa_pose_l2_loss_fwd_bwd(None, None, None, None, None, None, 0, 1, 1, 1, 1.0, 1.0, None) == -1
+    assert lib.apa_attn_pool_workspace_bytes(32, 196, 2048, 2048, 393, 1, 0) > 0
+    assert lib.apa_attn_pool_workspace_bytes(0, 196, 2048, 2048, 393, 1, 0) == 0
+
+
+def test_wrappers_refuse_cpu_tensors():
+    x = torch.zeros(2, 4, 256)
+    w = torch.zeros(256, 1)
+    with pytest.raises(cof.ApaError, match='GPU memory'):
+        cof.attn_pool_fwd(x, x, w, torch.zeros(1), torch.zeros(256, 3), torch.zeros(3))
+    with pytest.raises(cof.ApaError, match='GPU memory'):
+        cof.softmax_xent_fwd_bwd(torch.zeros(2, 3), torch.zeros(2, dtype=torch.int64))
+
+
+# ------------------------------------------------------------------------------- label generator
+def test_pose_to_heatmap_reference_vector():
+    """The only input the reference ships (src/custom_ops/test/pose_to_heatmap_op_test.py:10-23):
+    2 people, image 100x200, out_wd 100 -> valid = [T]*5 + [F]*11 ([0,0,1] counts as valid)."""
+    d = np.load(os.path.join(GOLD, 'labels_eval.npz'))
+    hm, valid = cof.pose_to_heatmap_float(d['ref_pose'], 100, 200, 100, out_channels=16)
+    assert valid.tolist() == [True] * 5 + [False] * 11
+    assert hm.shape == (50, 100, 16)
+    np.testing.assert_array_equal(hm, d['ref_hm'])                       # with the 7x7 blur
+    hm_nb, _ = cof.pose_to_heatmap_float(d['ref_pose'], 100, 200, 100, out_channels=16, do_gauss_blur=False)
+    np.testing.assert_array_equal(hm_nb, d['ref_hm_noblur'])
+    assert set(np.unique(hm_nb)) <= {0.0, 1.0}
+    u8, _ = cof.pose_to_heatmap(d['ref_pose'], 100, 200, 100, out_channels=16, do_gauss_blur=False)
+    assert u8.dtype == np.uint8 and set(np.unique(u8)) <= {0, 255}        # wrapper: *255, uint8
+
+
+def test_pose_to_heatmap_training_geometry_golden():
+    d = np.load(os.path.join(GOLD, 'labels_eval.npz'))
+    hm, valid = cof.pose_to_heatmap_float(d['train_pose'], 360, 480, 200, out_channels=16,
+                                          marker_wd_ratio=0.05, do_gauss_blur=False)
+    assert tuple(hm.shape) == tuple(d['train_hm_shape'])
+    np.testing.assert_array_equal(np.packbits(hm > 0), d['train_hm_packed'])
+    np.testing.assert_array_equal(valid, d['train_valid'])
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_pose_to_heatmap_matches_oracle_random(seed):
+    rng = np.random.RandomState(seed)
+    nk = [16, 16, 4, 16, 7, 16][seed]
+    people = rng.randint(1, 4)
+    im_ht, im_wd = int(rng.randint(60, 500)), int(rng.randint(60, 500))
+    out_wd = [200, 100, 15, 64, 200, 33][seed]
+    pose = rng.randint(-30, max(im_ht, im_wd) + 30, size=(people * nk * 3,))
+    pose[rng.rand(pose.size) < 0.2] = -1                                  # missing joints
+    ratio = [0.05, 0.1, 0.1, 0.2, 0.05, 0.3][seed]
+    blur = bool(seed % 2)
+    want_hm, want_valid = leo.pose_to_heatmap(pose, im_ht, im_wd, out_wd, nk, ratio, blur)
+    hm, valid = cof.pose_to_heatmap_float(pose, im_ht, im_wd, out_wd, nk, ratio, blur)
+    np.testing.assert_array_equal(valid, want_valid)
+    if blur:
+        np.testing.assert_allclose(hm, want_hm, rtol=0, atol=2e-7)        # summation order differs
+    else:
+        np.testing.assert_array_equal(hm, want_hm)
+
+
+def test_pose_to_heatmap_rejects_ragged_label():
+    with pytest.raises(cof.ApaError, match='not a multiple'):
+        cof.pose_to_heatmap_float([1, 2, 3, 4], 100, 100, 50, out_channels=16)
+
+
+def test_filled_circle_midpoint_rule_properties():
+    """cv::circle(thickness=-1) is restated as OpenCV's integer midpoint span fill.  Measured here:
+    with that error-term update the filled set coincides with the Euclidean disc dx^2+dy^2 <= r^2
+    for every radius we tried (0..60) -- SURVEY Appendix B expected boundary differences; the
+    restated algorithm shows none -- and it is 4-fold symmetric and clips at the image border."""
+    for r in list(range(0, 25)) + [40, 60]:
+        n = 2 * r + 7
+        c = n // 2
+        img = np.zeros((n, n), dtype=np.float32)
+        leo.cv_filled_circle(img, c, c, r)
+        yy, xx = np.mgrid[:n, :n]
+        eucl = ((yy - c) ** 2 + (xx - c) ** 2 <= r * r).astype(np.float32)
+        np.testing.assert_array_equal(img, eucl)
+        assert np.array_equal(img, img[::-1]) and np.array_equal(img, img[:, ::-1]) and np.array_equal(img, img.T)
+    img = np.zeros((20, 30), dtype=np.float32)
+    leo.cv_filled_circle(img, -3, 5, 10)          # centre left of the image: clipped, no wrap
+    assert img[:, 8:].sum() == 0 and img[5, 0] == 1 and img[5, 7] == 1
+    leo.cv_filled_circle(img, 100, 100, 10)       # entirely outside: no-op
+    assert img[:, 8:].sum() == 0
+
+
+# ------------------------------------------------------------------------------------------ mAP
+def test_compute_map_matches_oracle_and_golden():
+    d = np.load(os.path.join(GOLD, 'labels_eval.npz'))
+    m, aps = eval_utils.compute_map(d['map_scores'], d['map_labels'])
+    assert m == pytest.approx(float(d['map_value']), abs=1e-15)
+    np.testing.assert_allclose(aps, d['map_aps'], rtol=0, atol=1e-15)
+    assert len(aps) == 6                         # class 6 has no positives and is skipped
+    rng = np.random.RandomState(0)
+    for _ in range(5):
+        n, k = rng.randint(5, 60), rng.randint(2, 9)
+        scores = np.round(rng.rand(n, k), 1).astype(np.float32)     # many exact ties
+        labels = rng.randint(0, k, size=(n,))
+        got, want = eval_utils.compute_map(scores, labels), leo.compute_map(scores, labels)
+        assert got[0] == pytest.approx(want[0], abs=1e-15)
+        assert eval_utils.accuracy(scores, labels) == pytest.approx(float(np.mean(scores.argmax(1) == labels)))
+
+
+def test_voc_ap_known_values():
+    # perfect ranking -> 1; one positive ranked last among 4 -> 1/4
+    assert eval_utils.calc_pr_ovr_noref(np.array([1, 1, 0, 0.]), np.array([.9, .8, .2, .1]))[3] == pytest.approx(1.0)
+    assert eval_utils.calc_pr_ovr_noref(np.array([0, 0, 0, 1.]), np.array([.9, .8, .7, .1]))[3] == pytest.approx(0.25)
+
+
+# --------------------------------------------------------------------------------------- config
+CFG_002 = """
+GPUS: '0,1,2,3'
+NUM_READERS: 4
+NUM_PREPROCESSING_THREADS: 12
+MODEL_NAME: 'resnet_v1_101'
+NET:
+  USE_POSE_PRELOGITS_BASED_ATTENTION: True
+  USE_POSE_PRELOGITS_BASED_ATTENTION_SINGLE_LAYER_ATT: True
+TRAIN:
+  ITER_SIZE: 2
+  LEARNING_RATE: 0.001
+  BATCH_SIZE: 16
+  FINAL_POSE_HMAP_SIDE: 15
+  LEARNING_RATE_DECAY_RATE: 0.33
+  NUM_STEPS_PER_DECAY: 5000
+  MAX_NUMBER_OF_STEPS: 12000
+  CHECKPOINT_PATH: data/pretrained_models/resnet_v1_101.ckpt
+  CHECKPOINT_EXCLUDE_SCOPES: resnet_v1_101/logits
+  LOSS_FN_ACTION: 'softmax-xentropy'
+  LOSS_FN_POSE: ''
+TEST:
+  EVAL_METRIC: mAP
+  BATCH_SIZE: 1
+"""
+
+
+def test_config_loads_reference_style_yaml(tmp_path):
+    cfg = apa_config.reset_cfg()
+    p = tmp_path / 'exp.yaml'
+    p.write_text(CFG_002)
+    apa_config.cfg_from_file(str(p))
+    assert cfg.NET.USE_POSE_PRELOGITS_BASED_ATTENTION and cfg.NET.USE_POSE_PRELOGITS_BASED_ATTENTION_SINGLE_LAYER_ATT
+    assert cfg.TRAIN.ITER_SIZE == 2 and cfg.TRAIN.LOSS_FN_POSE == '' and cfg.TEST.EVAL_METRIC == 'mAP'
+    assert cfg.NET.DROPOUT == -1.0 and apa_config.dropout_keep_prob(cfg) == 0.2    # nets_factory.py:145
+    with pytest.raises(KeyError):
+        apa_config.cfg_from_dict({'NET': {'NO_SUCH_FLAG': True}})
+    with pytest.raises(ValueError):
+        apa_config.cfg_from_dict({'TRAIN': {'ITER_SIZE': 'two'}})
+    apa_config.cfg_from_dict({'NET': {'DROPOUT': 0.5}})
+    assert apa_config.dropout_keep_prob(cfg) == 0.5
+    apa_config.reset_cfg()
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/experiments'), reason='reference tree not mounted')
+def test_config_loads_every_shipped_experiment_unchanged():
+    import glob
+    files = sorted(glob.glob('/root/reference/experiments/*.yaml'))
+    assert len(files) >= 7
+    for f in files:
+        cfg = apa_config.reset_cfg()
+        apa_config.cfg_from_file(f)
+        assert cfg.MODEL_NAME == 'resnet_v1_101' and cfg.TRAIN.BATCH_SIZE == 16
+    apa_config.reset_cfg()
