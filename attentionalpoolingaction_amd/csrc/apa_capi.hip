@@ -94,6 +94,9 @@ extern "C" size_t apa_attn_pool_workspace_bytes(int N, int P, int C, int Ca, int
   (void)flags;
   if (N <= 0 || P <= 0 || C <= 0 || Ca <= 0 || K <= 0) return 0;
   if (M == 1) return m1_plan(N, P, C, Ca, K).total;
+  if (M == K) {  // dtype-dependent intermediates: report the larger (fp32) size
+    return pc_workspace_bytes(N, P, C, Ca, K, APA_DTYPE_F32);
+  }
   return 0;
 }
 
@@ -140,8 +143,18 @@ extern "C" int apa_attn_pool_fwd(const void* X, const void* Xatt, const float* W
     return m1_forward(X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar, ws, N, P, C, Ca, K, flags,
                       keep_prob, seed, offset, dtype, st);
   }
-  set_error("apa_attn_pool_fwd: per-class (M==K) dense path not built yet");
-  return APA_ERR_UNSUPPORTED;
+  // M == K: per-class maps, dense MFMA path.  zsave holds the fp32 [N,P,K] top-down map.
+  if (!zsave) {
+    set_error("apa_attn_pool_fwd: M==K needs zsave = fp32 [N,P,K] buffer (top-down map saved for backward)");
+    return APA_ERR_INVALID_ARG;
+  }
+  const size_t need = pc_workspace_bytes(N, P, C, Ca, K, dtype);
+  if (!ws || ws_bytes < need) {
+    set_error("apa_attn_pool_fwd: workspace too small (%zu < %zu)", ws_bytes, need);
+    return APA_ERR_WORKSPACE;
+  }
+  return pc_forward(X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, topdown, ws, N, P, C, Ca, K, flags,
+                    keep_prob, seed, offset, dtype, st);
 }
 
 extern "C" int apa_attn_pool_bwd(const void* X, const void* Xatt, const float* Wa, const float* ba,
@@ -183,6 +196,15 @@ extern "C" int apa_attn_pool_bwd(const void* X, const void* Xatt, const float* W
     return m1_backward(X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, dX, dXatt, dWa, dba, dWt, dbt,
                        ws, N, P, C, Ca, K, flags, keep_prob, seed, offset, dtype, st);
   }
-  set_error("apa_attn_pool_bwd: per-class (M==K) dense path not built yet");
-  return APA_ERR_UNSUPPORTED;
+  if (!zsave) {
+    set_error("apa_attn_pool_bwd: M==K needs zsave (the fp32 [N,P,K] top-down map from forward)");
+    return APA_ERR_INVALID_ARG;
+  }
+  const size_t need = pc_workspace_bytes(N, P, C, Ca, K, dtype);
+  if (!ws || ws_bytes < need) {
+    set_error("apa_attn_pool_bwd: workspace too small (%zu < %zu)", ws_bytes, need);
+    return APA_ERR_WORKSPACE;
+  }
+  return pc_backward(X, Xatt, Wa, Wt, att, zsave, G, dX, dXatt, dWa, dba, dWt, dbt, ws, N, P, C, Ca,
+                     K, flags, keep_prob, seed, offset, dtype, st);
 }

@@ -1,0 +1,536 @@
+// apa_dense.hip -- the dense (MFMA-bound) parts of the head, built on apa_gemm.hip:
+//
+//   A. PoseLogits head, /root/reference/models/slim/nets/nets_factory.py:147-160
+//        Ppre = relu(X.W1 + b1)   [N,P,768]      'PoseLogits/ExtraConv2d_1x1'
+//        Pl   = Ppre.W2 + b2      [N,P,J]        'PoseLogits/Conv2d_1c_1x1'
+//      and its backward (the reference relies on TF autodiff).
+//   B. Per-class bottom-up maps (cfg.NET..._PER_CLASS, nets_factory.py:257): M == K.  Z and T are
+//      two real GEMMs here ([N*P, C] x [C, K]); the activation / spatial mean and their gradients
+//      are small fused elementwise-reduction kernels over the [N,P,K] tensors.
+#include <math.h>
+
+#include "apa_device.h"
+#include "apa_internal.h"
+
+namespace apa {
+
+static int dt_code(int dtype) { return dtype == APA_DTYPE_BF16 ? 1 : 0; }
+static size_t dt_size(int dtype) { return dtype == APA_DTYPE_BF16 ? 2 : 4; }
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p, size_t i);
+template <> __device__ __forceinline__ float ldf<float>(const float* p, size_t i) { return p[i]; }
+template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p, size_t i) {
+  return __uint_as_float((uint32_t)p[i].v << 16);
+}
+template <typename T> __device__ __forceinline__ void stf(T* p, size_t i, float v);
+template <> __device__ __forceinline__ void stf<float>(float* p, size_t i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, size_t i, float v) {
+  p[i].v = (uint16_t)f32_to_bf16_bits(v);
+}
+
+// =============================================================================================
+// A. PoseLogits head
+// =============================================================================================
+constexpr int POSE_RB = 32;  // rows per block of the dPpre kernel
+
+// dPpre[r,j] = (sum_q dPl[r,q] W2[j,q] + ext[r,j]) * [Ppre[r,j] > 0]
+// plus per-block column partials for db1 (= sum_r dPpre) and db2 (= sum_r dPl).
+// block b owns rows [b*32, b*32+32); thread t owns columns t, t+256, ...  (coalesced along j)
+template <typename T, int JMAX, int NCOL>
+__global__ __launch_bounds__(256) void pose_dppre_kernel(const float* __restrict__ dPl,
+                                                         const float* __restrict__ W2,
+                                                         const T* __restrict__ ext,
+                                                         const T* __restrict__ Ppre,
+                                                         T* __restrict__ dPpre,
+                                                         float* __restrict__ partial, long R,
+                                                         int Cp, int J) {
+  __shared__ float s_dpl[POSE_RB * JMAX];
+  const int tid = threadIdx.x;
+  const long r0 = (long)blockIdx.x * POSE_RB;
+  const int nrows = (int)min((long)POSE_RB, R - r0);
+  if (dPl) {
+    for (int i = tid; i < POSE_RB * J; i += 256) {
+      const int rr = i / J;
+      s_dpl[rr * JMAX + (i - rr * J)] = rr < nrows ? dPl[(r0 + rr) * J + (i - rr * J)] : 0.f;
+    }
+  }
+  float w[NCOL][JMAX];
+  float acc[NCOL];
+#pragma unroll
+  for (int c = 0; c < NCOL; ++c) {
+    acc[c] = 0.f;
+    const int j = tid + c * 256;
+#pragma unroll
+    for (int q = 0; q < JMAX; ++q) w[c][q] = (dPl && j < Cp && q < J) ? W2[(size_t)j * J + q] : 0.f;
+  }
+  __syncthreads();
+  for (int rr = 0; rr < nrows; ++rr) {
+    const size_t rowoff = (size_t)(r0 + rr) * Cp;
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) {
+      const int j = tid + c * 256;
+      if (j < Cp) {
+        float s = ext ? ldf<T>(ext, rowoff + j) : 0.f;
+        if (dPl) {
+#pragma unroll
+          for (int q = 0; q < JMAX; ++q) s = fmaf(s_dpl[rr * JMAX + q], w[c][q], s);
+        }
+        s = ldf<T>(Ppre, rowoff + j) > 0.f ? s : 0.f;
+        stf<T>(dPpre, rowoff + j, s);
+        acc[c] += s;
+      }
+    }
+  }
+  float* prow = partial + (size_t)blockIdx.x * (Cp + J);
+#pragma unroll
+  for (int c = 0; c < NCOL; ++c) {
+    const int j = tid + c * 256;
+    if (j < Cp) prow[j] = acc[c];
+  }
+  if (tid < J) {
+    float a = 0.f;
+    if (dPl)
+      for (int rr = 0; rr < nrows; ++rr) a += s_dpl[rr * JMAX + tid];
+    prow[Cp + tid] = a;
+  }
+}
+
+struct PosePlan {
+  long R;
+  int nchunks;
+  size_t off_dppre, off_partial, off_gemm, total;
+};
+static PosePlan pose_plan(int N, int P, int C, int Cp, int J, int dtype) {
+  PosePlan pl;
+  pl.R = (long)N * P;
+  pl.nchunks = (int)((pl.R + POSE_RB - 1) / POSE_RB);
+  size_t off = 0;
+  pl.off_dppre = off;   off += align_up((size_t)pl.R * Cp * dt_size(dtype), 256);
+  pl.off_partial = off; off += align_up((size_t)pl.nchunks * (Cp + J) * 4, 256);
+  size_t g = gemm_ws_bytes((int)pl.R, J, 32);
+  const size_t g2 = gemm_ws_bytes(Cp, J, 32), g3 = gemm_ws_bytes(C, Cp, 32);
+  if (g2 > g) g = g2;
+  if (g3 > g) g = g3;
+  pl.off_gemm = off;    off += align_up(g, 256);
+  pl.total = off;
+  return pl;
+}
+
+}  // namespace apa
+
+using namespace apa;
+
+extern "C" size_t apa_pose_head_workspace_bytes(int N, int P, int C, int Cp, int J, int dtype) {
+  if (N <= 0 || P <= 0 || C <= 0 || Cp <= 0 || J <= 0) return 0;
+  return pose_plan(N, P, C, Cp, J, dtype).total;
+}
+
+extern "C" int apa_pose_head_fwd(const void* X, const float* W1, const float* b1, const float* W2,
+                                 const float* b2, void* Ppre, float* Pl, void* ws, size_t ws_bytes,
+                                 int N, int P, int C, int Cp, int J, int dtype, void* stream) {
+  if (!X || !W1 || !b1 || !W2 || !b2 || !Ppre || !Pl || N <= 0 || P <= 0 || C <= 0 || Cp <= 0 || J <= 0) {
+    set_error("apa_pose_head_fwd: null pointer or non-positive dimension");
+    return APA_ERR_INVALID_ARG;
+  }
+  if (dtype != APA_DTYPE_F32 && dtype != APA_DTYPE_BF16) {
+    set_error("apa_pose_head_fwd: unknown dtype %d", dtype);
+    return APA_ERR_INVALID_ARG;
+  }
+  const PosePlan pl = pose_plan(N, P, C, Cp, J, dtype);
+  if (!ws || ws_bytes < pl.total) {
+    set_error("apa_pose_head_fwd: workspace too small (%zu < %zu)", ws_bytes, pl.total);
+    return APA_ERR_WORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* gws = reinterpret_cast<float*>(static_cast<char*>(ws) + pl.off_gemm);
+  const int R = (int)pl.R;
+  GemmDesc g1;  // Ppre = relu(X.W1 + b1)
+  g1.A = X; g1.lda = C; g1.ta = dt_code(dtype); g1.a_kc = true;
+  g1.B = W1; g1.ldb = Cp; g1.tb = 0; g1.b_kc = false;
+  g1.C = Ppre; g1.ldc = Cp; g1.tc = dt_code(dtype);
+  g1.M = R; g1.N = Cp; g1.K = C; g1.bias = b1; g1.act = 1;
+  int rc = gemm_launch(g1, st);
+  if (rc != APA_OK) return rc;
+  GemmDesc g2;  // Pl = Ppre.W2 + b2
+  g2.A = Ppre; g2.lda = Cp; g2.ta = dt_code(dtype); g2.a_kc = true;
+  g2.B = W2; g2.ldb = J; g2.tb = 0; g2.b_kc = false;
+  g2.C = Pl; g2.ldc = J; g2.tc = 0;
+  g2.M = R; g2.N = J; g2.K = Cp; g2.bias = b2;
+  g2.splits = gemm_pick_splits(R, J, Cp); g2.ws = gws;
+  return gemm_launch(g2, st);
+}
+
+extern "C" int apa_pose_head_bwd(const void* X, const float* W1, const float* W2, const void* Ppre,
+                                 const float* dPl, const void* dPpre_ext, void* dX, int accumulate_dX,
+                                 float* dW1, float* db1, float* dW2, float* db2, void* ws,
+                                 size_t ws_bytes, int N, int P, int C, int Cp, int J, int dtype,
+                                 void* stream) {
+  if (!X || !W1 || !W2 || !Ppre || !dX || !dW1 || !db1 || !dW2 || !db2 || N <= 0 || P <= 0 ||
+      C <= 0 || Cp <= 0 || J <= 0) {
+    set_error("apa_pose_head_bwd: null pointer or non-positive dimension");
+    return APA_ERR_INVALID_ARG;
+  }
+  if (!dPl && !dPpre_ext) {
+    set_error("apa_pose_head_bwd: neither dPl nor dPpre_ext given (no gradient to propagate)");
+    return APA_ERR_INVALID_ARG;
+  }
+  if (J > 32 || Cp > 2048) {
+    set_error("apa_pose_head_bwd: J=%d > 32 or Cp=%d > 2048 not built", J, Cp);
+    return APA_ERR_UNSUPPORTED;
+  }
+  const PosePlan pl = pose_plan(N, P, C, Cp, J, dtype);
+  if (!ws || ws_bytes < pl.total) {
+    set_error("apa_pose_head_bwd: workspace too small (%zu < %zu)", ws_bytes, pl.total);
+    return APA_ERR_WORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* w = static_cast<char*>(ws);
+  void* dPpre = w + pl.off_dppre;
+  float* partial = reinterpret_cast<float*>(w + pl.off_partial);
+  float* gws = reinterpret_cast<float*>(w + pl.off_gemm);
+  const int R = (int)pl.R;
+  const int tdt = dt_code(dtype);
+
+#define APA_DPPRE(T, JM, NC)                                                                       \
+  hipLaunchKernelGGL((pose_dppre_kernel<T, JM, NC>), dim3(pl.nchunks), dim3(256), 0, st, dPl, W2,    \
+                     static_cast<const T*>(dPpre_ext), static_cast<const T*>(Ppre),                 \
+                     static_cast<T*>(dPpre), partial, pl.R, Cp, J)
+  const int ncol = (Cp + 255) / 256;
+  if (dtype == APA_DTYPE_F32) {
+    if (J <= 16 && ncol <= 3) APA_DPPRE(float, 16, 3);
+    else if (ncol <= 4) APA_DPPRE(float, 32, 4);
+    else APA_DPPRE(float, 32, 8);
+  } else {
+    if (J <= 16 && ncol <= 3) APA_DPPRE(bf16_t, 16, 3);
+    else if (ncol <= 4) APA_DPPRE(bf16_t, 32, 4);
+    else APA_DPPRE(bf16_t, 32, 8);
+  }
+#undef APA_DPPRE
+  APA_LAUNCH_CHECK("pose_dppre_kernel");
+  // db1 = column sums of dPpre, db2 = column sums of dPl (fixed-order reduce of the block partials)
+  int rc = m1_colsum(partial, nullptr, db1, nullptr, pl.nchunks, Cp, Cp + J, nullptr, st);
+  if (rc != APA_OK) return rc;
+  rc = m1_colsum(partial + Cp, nullptr, db2, nullptr, pl.nchunks, J, Cp + J, nullptr, st);
+  if (rc != APA_OK) return rc;
+
+  if (dPl) {  // dW2[j,q] = sum_r Ppre[r,j] dPl[r,q]
+    GemmDesc g;
+    g.A = Ppre; g.lda = Cp; g.ta = tdt; g.a_kc = false;
+    g.B = dPl; g.ldb = J; g.tb = 0; g.b_kc = false;
+    g.C = dW2; g.ldc = J; g.tc = 0;
+    g.M = Cp; g.N = J; g.K = R;
+    g.splits = gemm_pick_splits(Cp, J, R); g.ws = gws;
+    rc = gemm_launch(g, st);
+    if (rc != APA_OK) return rc;
+  } else {
+    APA_HIP_CHECK(hipMemsetAsync(dW2, 0, (size_t)Cp * J * sizeof(float), st));
+  }
+  {  // dW1[c,j] = sum_r X[r,c] dPpre[r,j]
+    GemmDesc g;
+    g.A = X; g.lda = C; g.ta = tdt; g.a_kc = false;
+    g.B = dPpre; g.ldb = Cp; g.tb = tdt; g.b_kc = false;
+    g.C = dW1; g.ldc = Cp; g.tc = 0;
+    g.M = C; g.N = Cp; g.K = R;
+    g.splits = gemm_pick_splits(C, Cp, R); g.ws = gws;
+    rc = gemm_launch(g, st);
+    if (rc != APA_OK) return rc;
+  }
+  {  // dX (+)= dPpre . W1^T
+    GemmDesc g;
+    g.A = dPpre; g.lda = Cp; g.ta = tdt; g.a_kc = true;
+    g.B = W1; g.ldb = Cp; g.tb = 0; g.b_kc = true;   // W1 [C][Cp]: n = c rows, k contiguous
+    g.C = dX; g.ldc = C; g.tc = tdt;
+    g.M = R; g.N = C; g.K = Cp; g.beta = accumulate_dX ? 1.f : 0.f;
+    rc = gemm_launch(g, st);
+  }
+  return rc;
+}
+
+// =============================================================================================
+// B. Per-class bottom-up maps (M == K)
+// =============================================================================================
+namespace apa {
+
+__global__ __launch_bounds__(256) void pc_pad_kernel(const float* __restrict__ W, float* __restrict__ Wp,
+                                                     int rows, int K, int Kp) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)rows * Kp) return;
+  const int r = (int)(idx / Kp), k = (int)(idx - (long)r * Kp);
+  Wp[idx] = k < K ? W[(size_t)r * K + k] : 0.f;
+}
+
+// forward activation + spatial mean.  grid (N, ceil(K/64)); 256 threads = 64 classes x 4 pixel groups
+//   A[n,p,k] = f(Z[n,p,k]);  logits[n,k] = (1/P) sum_p A * T;  optional TopDownAttention copy
+template <typename T>
+__global__ __launch_bounds__(256) void pc_fwd_act_kernel(const float* __restrict__ Z, int ldz,
+                                                         const float* __restrict__ Tm,
+                                                         float* __restrict__ att,
+                                                         float* __restrict__ logits,
+                                                         T* __restrict__ topdown, int P, int K,
+                                                         int act) {
+  __shared__ float red[4][64];
+  const int n = blockIdx.x;
+  const int kk = threadIdx.x & 63, pg = threadIdx.x >> 6;
+  const int k = blockIdx.y * 64 + kk;
+  const bool ok = k < K;
+  const size_t rbase = (size_t)n * P;
+  float m = -INFINITY, l = 1.f;
+  if (act == 2) {  // spatial softmax over p (tf.nn.softmax: max-subtracted)
+    if (ok)
+      for (int p = pg; p < P; p += 4) m = fmaxf(m, Z[(rbase + p) * ldz + k]);
+    red[pg][kk] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0][kk], red[1][kk]), fmaxf(red[2][kk], red[3][kk]));
+    __syncthreads();
+    float s = 0.f;
+    if (ok)
+      for (int p = pg; p < P; p += 4) s += expf(Z[(rbase + p) * ldz + k] - m);
+    red[pg][kk] = s;
+    __syncthreads();
+    l = (red[0][kk] + red[1][kk]) + (red[2][kk] + red[3][kk]);
+    __syncthreads();
+  }
+  const float invl = 1.0f / l;
+  float acc = 0.f;
+  if (ok) {
+    for (int p = pg; p < P; p += 4) {
+      const float z = Z[(rbase + p) * ldz + k];
+      float a = z;
+      if (act == 2) a = expf(z - m) * invl;
+      else if (act == 1) a = fmaxf(z, 0.f);
+      const float t = Tm[(rbase + p) * K + k];
+      att[(rbase + p) * K + k] = a;
+      if (topdown) stf<T>(topdown, (rbase + p) * K + k, t);
+      acc = fmaf(a, t, acc);
+    }
+  }
+  red[pg][kk] = acc;
+  __syncthreads();
+  if (pg == 0 && ok)
+    logits[(size_t)n * K + k] = ((red[0][kk] + red[1][kk]) + (red[2][kk] + red[3][kk])) / (float)P;
+}
+
+// backward of the same: dT = G*A/P, dA = G*T/P, dZ = act'(dA); column partials for dbt / dba.
+// dT/dZ are written with leading dimension Kp (pad columns zeroed) in the intermediate dtype.
+template <typename T>
+__global__ __launch_bounds__(256) void pc_bwd_act_kernel(const float* __restrict__ G,
+                                                         const float* __restrict__ att,
+                                                         const float* __restrict__ Tm,
+                                                         T* __restrict__ dT, T* __restrict__ dZ,
+                                                         float* __restrict__ pdbt,
+                                                         float* __restrict__ pdba, int P, int K,
+                                                         int Kp, int act) {
+  __shared__ float red[4][64];
+  __shared__ float red2[4][64];
+  const int n = blockIdx.x;
+  const int kk = threadIdx.x & 63, pg = threadIdx.x >> 6;
+  const int k = blockIdx.y * 64 + kk;
+  const bool ok = k < K;
+  const bool pad = !ok && k < Kp;
+  const size_t rbase = (size_t)n * P;
+  const float invP = 1.0f / (float)P;
+  const float g = ok ? G[(size_t)n * K + k] * invP : 0.f;
+  float corr = 0.f;
+  if (act == 2) {  // sum_p A * dA
+    float s = 0.f;
+    if (ok)
+      for (int p = pg; p < P; p += 4) s = fmaf(att[(rbase + p) * K + k], g * Tm[(rbase + p) * K + k], s);
+    red[pg][kk] = s;
+    __syncthreads();
+    corr = (red[0][kk] + red[1][kk]) + (red[2][kk] + red[3][kk]);
+    __syncthreads();
+  }
+  float sdt = 0.f, sdz = 0.f;
+  for (int p = pg; p < P; p += 4) {
+    if (ok) {
+      const float a = att[(rbase + p) * K + k];
+      const float dA = g * Tm[(rbase + p) * K + k];
+      const float dt = g * a;
+      float dz = dA;
+      if (act == 2) dz = a * (dA - corr);
+      else if (act == 1) dz = a > 0.f ? dA : 0.f;
+      stf<T>(dT, (rbase + p) * Kp + k, dt);
+      stf<T>(dZ, (rbase + p) * Kp + k, dz);
+      sdt += dt;
+      sdz += dz;
+    } else if (pad) {
+      stf<T>(dT, (rbase + p) * Kp + k, 0.f);
+      stf<T>(dZ, (rbase + p) * Kp + k, 0.f);
+    }
+  }
+  red[pg][kk] = sdt;
+  red2[pg][kk] = sdz;
+  __syncthreads();
+  if (pg == 0 && ok) {
+    pdbt[(size_t)n * K + k] = (red[0][kk] + red[1][kk]) + (red[2][kk] + red[3][kk]);
+    pdba[(size_t)n * K + k] = (red2[0][kk] + red2[1][kk]) + (red2[2][kk] + red2[3][kk]);
+  }
+}
+
+struct PcPlan {
+  long R;
+  int Kp;
+  size_t off_wap, off_wtp, off_bap, off_z, off_dt, off_dz, off_pdbt, off_pdba, off_gemm, total;
+};
+static PcPlan pc_plan(int N, int P, int C, int Ca, int K, int dtype) {
+  PcPlan pl;
+  pl.R = (long)N * P;
+  pl.Kp = (K + 7) / 8 * 8;
+  size_t off = 0;
+  pl.off_wap = off;  off += align_up((size_t)Ca * pl.Kp * 4, 256);
+  pl.off_wtp = off;  off += align_up((size_t)C * pl.Kp * 4, 256);
+  pl.off_bap = off;  off += align_up((size_t)pl.Kp * 4, 256);
+  pl.off_z = off;    off += align_up((size_t)pl.R * pl.Kp * 4, 256);
+  pl.off_dt = off;   off += align_up((size_t)pl.R * pl.Kp * dt_size(dtype), 256);
+  pl.off_dz = off;   off += align_up((size_t)pl.R * pl.Kp * dt_size(dtype), 256);
+  pl.off_pdbt = off; off += align_up((size_t)N * K * 4, 256);
+  pl.off_pdba = off; off += align_up((size_t)N * K * 4, 256);
+  const int cm = C > Ca ? C : Ca;
+  pl.off_gemm = off; off += align_up(gemm_ws_bytes(cm, K, 32), 256);
+  pl.total = off;
+  return pl;
+}
+
+size_t pc_workspace_bytes(int N, int P, int C, int Ca, int K, int dtype) {
+  return pc_plan(N, P, C, Ca, K, dtype).total;
+}
+
+static int act_code(unsigned flags) {
+  if (flags & APA_FLAG_SOFTMAX_ATT) return 2;
+  if (flags & APA_FLAG_RELU_ATT) return 1;
+  return 0;
+}
+
+static void set_dropout(GemmDesc& g, bool on_a, bool on_c, float keep_prob, uint64_t seed,
+                        uint64_t offset, unsigned flags) {
+  g.drop_a = on_a; g.drop_c = on_c;
+  g.inv_keep = 1.0f / keep_prob;
+  g.thresh = keep_thresh(keep_prob);
+  g.seed = seed;
+  g.offset = (flags & APA_FLAG_RNG_DEVICE) ? 0 : offset;
+  g.offset_dev = (flags & APA_FLAG_RNG_DEVICE)
+                     ? reinterpret_cast<const uint64_t*>(static_cast<uintptr_t>(offset)) : nullptr;
+}
+
+int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba, const float* Wt,
+               const float* bt, float* logits, float* att, float* Tsave, void* topdown, void* ws,
+               int N, int P, int C, int Ca, int K, unsigned flags, float keep_prob, uint64_t seed,
+               uint64_t offset, int dtype, hipStream_t st) {
+  const PcPlan pl = pc_plan(N, P, C, Ca, K, dtype);
+  char* w = static_cast<char*>(ws);
+  float* WaP = reinterpret_cast<float*>(w + pl.off_wap);
+  float* baP = reinterpret_cast<float*>(w + pl.off_bap);
+  float* Z = reinterpret_cast<float*>(w + pl.off_z);
+  const int Kp = pl.Kp, R = (int)pl.R;
+  const bool train = (flags & APA_FLAG_TRAIN) && keep_prob < 1.0f;
+  const int tdt = dt_code(dtype);
+  hipLaunchKernelGGL(pc_pad_kernel, dim3((unsigned)(((long)Ca * Kp + 255) / 256)), dim3(256), 0, st, Wa, WaP, Ca, K, Kp);
+  hipLaunchKernelGGL(pc_pad_kernel, dim3((unsigned)((Kp + 255) / 256)), dim3(256), 0, st, ba, baP, 1, K, Kp);
+  APA_LAUNCH_CHECK("pc_pad_kernel");
+  GemmDesc gz;  // Z = Xatt . Wa + ba
+  gz.A = Xatt; gz.lda = Ca; gz.ta = tdt; gz.a_kc = true;
+  gz.B = WaP; gz.ldb = Kp; gz.tb = 0; gz.b_kc = false;
+  gz.C = Z; gz.ldc = Kp; gz.tc = 0;
+  gz.M = R; gz.N = Kp; gz.K = Ca; gz.bias = baP;
+  int rc = gemm_launch(gz, st);
+  if (rc != APA_OK) return rc;
+  GemmDesc gt;  // T = dropout(X) . Wt + bt   (Wt rows are K floats: unaligned -> scalar staging)
+  gt.A = X; gt.lda = C; gt.ta = tdt; gt.a_kc = true;
+  gt.B = Wt; gt.ldb = K; gt.tb = 0; gt.b_kc = false;
+  gt.C = Tsave; gt.ldc = K; gt.tc = 0;
+  gt.M = R; gt.N = K; gt.K = C; gt.bias = bt;
+  if (train) set_dropout(gt, true, false, keep_prob, seed, offset, flags);
+  rc = gemm_launch(gt, st);
+  if (rc != APA_OK) return rc;
+  dim3 grid(N, (K + 63) / 64);
+  if (dtype == APA_DTYPE_F32)
+    hipLaunchKernelGGL(pc_fwd_act_kernel<float>, grid, dim3(256), 0, st, Z, Kp, Tsave, att, logits,
+                       static_cast<float*>(topdown), P, K, act_code(flags));
+  else
+    hipLaunchKernelGGL(pc_fwd_act_kernel<bf16_t>, grid, dim3(256), 0, st, Z, Kp, Tsave, att, logits,
+                       static_cast<bf16_t*>(topdown), P, K, act_code(flags));
+  APA_LAUNCH_CHECK("pc_fwd_act_kernel");
+  return APA_OK;
+}
+
+int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* Wt, const float* att,
+                const float* Tsave, const float* G, void* dX, void* dXatt, float* dWa, float* dba,
+                float* dWt, float* dbt, void* ws, int N, int P, int C, int Ca, int K,
+                unsigned flags, float keep_prob, uint64_t seed, uint64_t offset, int dtype,
+                hipStream_t st) {
+  const PcPlan pl = pc_plan(N, P, C, Ca, K, dtype);
+  char* w = static_cast<char*>(ws);
+  float* WaP = reinterpret_cast<float*>(w + pl.off_wap);
+  float* WtP = reinterpret_cast<float*>(w + pl.off_wtp);
+  void* dT = w + pl.off_dt;
+  void* dZ = w + pl.off_dz;
+  float* pdbt = reinterpret_cast<float*>(w + pl.off_pdbt);
+  float* pdba = reinterpret_cast<float*>(w + pl.off_pdba);
+  float* gws = reinterpret_cast<float*>(w + pl.off_gemm);
+  const int Kp = pl.Kp, R = (int)pl.R;
+  const bool train = (flags & APA_FLAG_TRAIN) && keep_prob < 1.0f;
+  const bool fused = (Xatt == X);
+  const int tdt = dt_code(dtype);
+  hipLaunchKernelGGL(pc_pad_kernel, dim3((unsigned)(((long)Ca * Kp + 255) / 256)), dim3(256), 0, st, Wa, WaP, Ca, K, Kp);
+  hipLaunchKernelGGL(pc_pad_kernel, dim3((unsigned)(((long)C * Kp + 255) / 256)), dim3(256), 0, st, Wt, WtP, C, K, Kp);
+  APA_LAUNCH_CHECK("pc_pad_kernel");
+  dim3 grid(N, (Kp + 63) / 64);
+  if (dtype == APA_DTYPE_F32)
+    hipLaunchKernelGGL(pc_bwd_act_kernel<float>, grid, dim3(256), 0, st, G, att, Tsave,
+                       static_cast<float*>(dT), static_cast<float*>(dZ), pdbt, pdba, P, K, Kp,
+                       act_code(flags));
+  else
+    hipLaunchKernelGGL(pc_bwd_act_kernel<bf16_t>, grid, dim3(256), 0, st, G, att, Tsave,
+                       static_cast<bf16_t*>(dT), static_cast<bf16_t*>(dZ), pdbt, pdba, P, K, Kp,
+                       act_code(flags));
+  APA_LAUNCH_CHECK("pc_bwd_act_kernel");
+  int rc = m1_colsum(pdbt, nullptr, dbt, nullptr, N, K, K, nullptr, st);
+  if (rc != APA_OK) return rc;
+  rc = m1_colsum(pdba, nullptr, dba, nullptr, N, K, K, nullptr, st);
+  if (rc != APA_OK) return rc;
+  {  // dWt[c,k] = sum_r Xt[r,c] dT[r,k]
+    GemmDesc g;
+    g.A = X; g.lda = C; g.ta = tdt; g.a_kc = false;
+    g.B = dT; g.ldb = Kp; g.tb = tdt; g.b_kc = false;
+    g.C = dWt; g.ldc = K; g.tc = 0;
+    g.M = C; g.N = K; g.K = R;
+    g.splits = gemm_pick_splits(C, K, R); g.ws = gws;
+    if (train) set_dropout(g, true, false, keep_prob, seed, offset, flags);
+    // dropout index of A(m=c, k=r) is r*C + c: the stager computes row*Ktot + k with row = m, so
+    // the transposed operand needs the swapped form -> handled by drop_a == 2
+    if (train) g.drop_a = 2;
+    rc = gemm_launch(g, st);
+    if (rc != APA_OK) return rc;
+  }
+  {  // dWa[c,k] = sum_r Xatt[r,c] dZ[r,k]
+    GemmDesc g;
+    g.A = Xatt; g.lda = Ca; g.ta = tdt; g.a_kc = false;
+    g.B = dZ; g.ldb = Kp; g.tb = tdt; g.b_kc = false;
+    g.C = dWa; g.ldc = K; g.tc = 0;
+    g.M = Ca; g.N = K; g.K = R;
+    g.splits = gemm_pick_splits(Ca, K, R); g.ws = gws;
+    rc = gemm_launch(g, st);
+    if (rc != APA_OK) return rc;
+  }
+  {  // dX = (dT . Wt^T) * mask/keep
+    GemmDesc g;
+    g.A = dT; g.lda = Kp; g.ta = tdt; g.a_kc = true;
+    g.B = WtP; g.ldb = Kp; g.tb = 0; g.b_kc = true;
+    g.C = dX; g.ldc = C; g.tc = tdt;
+    g.M = R; g.N = C; g.K = Kp;
+    if (train) set_dropout(g, false, true, keep_prob, seed, offset, flags);
+    rc = gemm_launch(g, st);
+    if (rc != APA_OK) return rc;
+  }
+  {  // + dZ . Wa^T  (into dX when the attention input is X itself, else into dXatt)
+    GemmDesc g;
+    g.A = dZ; g.lda = Kp; g.ta = tdt; g.a_kc = true;
+    g.B = WaP; g.ldb = Kp; g.tb = 0; g.b_kc = true;
+    g.C = fused ? dX : dXatt; g.ldc = fused ? C : Ca; g.tc = tdt;
+    g.M = R; g.N = fused ? C : Ca; g.K = Kp; g.beta = fused ? 1.f : 0.f;
+    rc = gemm_launch(g, st);
+  }
+  return rc;
+}
+
+}  // namespace apa

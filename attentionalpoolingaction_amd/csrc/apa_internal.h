@@ -57,6 +57,29 @@ int sgemm_small(const float* A, long a_si, long a_sk, const float* B, long b_sk,
                 const float* v, float* ws, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------
+// Dense MFMA GEMM (apa_gemm.hip): C = act(A.B + bias) [* dropout] + beta*C, 128x128x32 tiles.
+//   a_kc: A stored [M][K] (k contiguous) else [K][M];  b_kc: B stored [N][K] else [K][N].
+//   ta/tb/tc: 0 = f32, 1 = bf16.  f32 x f32 runs on the exact f32 MFMA, anything else on bf16 MFMA.
+// ------------------------------------------------------------------------------------------
+struct GemmDesc {
+  const void* A = nullptr; long lda = 0; int ta = 0; bool a_kc = true;
+  const void* B = nullptr; long ldb = 0; int tb = 0; bool b_kc = false;
+  void* C = nullptr; long ldc = 0; int tc = 0;
+  int M = 0, N = 0, K = 0;
+  const float* bias = nullptr;
+  float beta = 0.f;
+  int act = 0;
+  int splits = 1;
+  float* ws = nullptr;  // split-K partials, gemm_ws_bytes(M, N, splits)
+  int drop_a = 0, drop_c = 0;
+  float inv_keep = 1.f; uint32_t thresh = 0; uint64_t seed = 0, offset = 0;
+  const uint64_t* offset_dev = nullptr;
+};
+size_t gemm_ws_bytes(int M, int N, int splits);
+int gemm_pick_splits(int M, int N, int K);
+int gemm_launch(const GemmDesc& d, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------
 // M == 1 factorised path (apa_m1.hip)
 // ------------------------------------------------------------------------------------------
 struct M1Plan {
@@ -88,7 +111,19 @@ int m1_logits(const float* z, const float* Wt, const float* abar, const float* b
 int m1_bwd_small(const float* G, const float* Wt, const float* zsave, const float* abar,
                  const float* bt, float* dz, float* dWt, float* dbt, float* sn, int N, int C, int K,
                  hipStream_t st);
-int m1_colsum(const float* pdwa, const float* pdba, float* dwa, float* dba, int nblk, int C,
+int m1_colsum(const float* pdwa, const float* pdba, float* dwa, float* dba, int nblk, int C, int ld,
               uint64_t* rng_bump, hipStream_t st);
+
+// apa_dense.hip: per-class bottom-up maps (M == K); Tsave = fp32 [N,P,K] top-down map saved for bwd
+size_t pc_workspace_bytes(int N, int P, int C, int Ca, int K, int dtype);
+int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba, const float* Wt,
+               const float* bt, float* logits, float* att, float* Tsave, void* topdown, void* ws,
+               int N, int P, int C, int Ca, int K, unsigned flags, float keep_prob, uint64_t seed,
+               uint64_t offset, int dtype, hipStream_t st);
+int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* Wt, const float* att,
+                const float* Tsave, const float* G, void* dX, void* dXatt, float* dWa, float* dba,
+                float* dWt, float* dbt, void* ws, int N, int P, int C, int Ca, int K,
+                unsigned flags, float keep_prob, uint64_t seed, uint64_t offset, int dtype,
+                hipStream_t st);
 
 }  // namespace apa

@@ -826,7 +826,7 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
   uint64_t* bump = (train && (flags & APA_FLAG_RNG_DEVICE))
                        ? reinterpret_cast<uint64_t*>(static_cast<uintptr_t>(offset))
                        : nullptr;
-  if (small_ok) return m1_colsum(pdwa, pdba, dWa, dba, nred, cred, bump, st);
+  if (small_ok) return m1_colsum(pdwa, pdba, dWa, dba, nred, cred, cred, bump, st);
   hipLaunchKernelGGL(m1_bwd_reduce_kernel, dim3((cred + 63) / 64 + 1), dim3(256), 0, st, pdwa, pdba,
                      dWa, dba, abar, G, dbt, nred, cred, N, K, 1, bump);
   APA_LAUNCH_CHECK("m1_bwd_reduce_kernel");

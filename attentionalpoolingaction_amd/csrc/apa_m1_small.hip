@@ -302,7 +302,7 @@ __global__ __launch_bounds__(1024) void m1_colsum_kernel(const float* __restrict
                                                          const float* __restrict__ pdba,
                                                          float* __restrict__ dwa,
                                                          float* __restrict__ dba, int nblk, int C,
-                                                         uint64_t* __restrict__ rng_bump) {
+                                                         int ld, uint64_t* __restrict__ rng_bump) {
   __shared__ float red[32][33];
   const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + col;
@@ -312,11 +312,11 @@ __global__ __launch_bounds__(1024) void m1_colsum_kernel(const float* __restrict
     for (; b + 224 < nblk; b += 256) {  // 8 independent loads in flight
       float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = pdwa[(size_t)(b + 32 * u) * C + c];
+      for (int u = 0; u < 8; ++u) v[u] = pdwa[(size_t)(b + 32 * u) * ld + c];
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc += v[u];
     }
-    for (; b < nblk; b += 32) acc += pdwa[(size_t)b * C + c];
+    for (; b < nblk; b += 32) acc += pdwa[(size_t)b * ld + c];
   }
   red[rg][col] = acc;
   __syncthreads();
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(1024) void m1_colsum_kernel(const float* __restrict
     for (int g = 0; g < 32; ++g) s += red[g][col];
     dwa[c] = s;
   }
-  if (blockIdx.x == 0) {
+  if (blockIdx.x == 0 && pdba) {
     __syncthreads();
     float a = 0.f;
     for (int b = threadIdx.x; b < nblk; b += 1024) a += pdba[b];
@@ -397,10 +397,10 @@ int m1_bwd_small(const float* G, const float* Wt, const float* zsave, const floa
   return APA_OK;
 }
 
-int m1_colsum(const float* pdwa, const float* pdba, float* dwa, float* dba, int nblk, int C,
+int m1_colsum(const float* pdwa, const float* pdba, float* dwa, float* dba, int nblk, int C, int ld,
               uint64_t* rng_bump, hipStream_t st) {
   hipLaunchKernelGGL(m1_colsum_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, pdwa, pdba, dwa, dba,
-                     nblk, C, rng_bump);
+                     nblk, C, ld, rng_bump);
   APA_LAUNCH_CHECK("m1_colsum_kernel");
   return APA_OK;
 }

@@ -43,6 +43,10 @@ _SIGNATURES = {
     'apa_attn_pool_bwd': (c_int, [c_void_p] * 17 + [c_size_t] + [c_int] * 6 +
                           [c_uint, c_float, c_uint64, c_uint64, c_int, c_void_p]),
     'apa_dropout_mask': (c_int, [c_void_p, c_size_t, c_float, c_uint64, c_uint64, c_void_p]),
+    'apa_pose_head_workspace_bytes': (c_size_t, [c_int] * 6),
+    'apa_pose_head_fwd': (c_int, [c_void_p] * 8 + [c_size_t] + [c_int] * 6 + [c_void_p]),
+    'apa_pose_head_bwd': (c_int, [c_void_p] * 7 + [c_int] + [c_void_p] * 5 + [c_size_t] + [c_int] * 6 +
+                          [c_void_p]),
     'apa_softmax_xent_fwd_bwd': (c_int, [c_void_p] * 6 + [c_int, c_int, c_float, c_float, c_void_p]),
     'apa_pose_l2_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'apa_pose_l2_loss_fwd_bwd': (c_int, [c_void_p] * 6 + [c_size_t, c_int, c_int, c_int, c_float,
@@ -163,7 +167,8 @@ def attn_pool_fwd(X, Xatt, Wa, ba, Wt, bt, *, flags=0, keep_prob=1.0, seed=0, of
     dev = X.device
     logits = torch.empty((N, K), dtype=torch.float32, device=dev)
     att = torch.empty((N, P, M), dtype=torch.float32, device=dev)
-    zsave = torch.empty((N, C), dtype=torch.float32, device=dev) if M == 1 else None
+    # saved for backward: M == 1 -> z [N,C] + abar [N]; per-class -> the fp32 top-down map [N,P,K]
+    zsave = torch.empty((N, C) if M == 1 else (N, P, K), dtype=torch.float32, device=dev)
     abar = torch.empty((N,), dtype=torch.float32, device=dev) if M == 1 else None
     topdown = torch.empty((N, P, K), dtype=X.dtype, device=dev) if want_topdown else None
     need = int(lib.apa_attn_pool_workspace_bytes(N, P, C, Ca, K, M, flags))
@@ -230,6 +235,57 @@ def dropout_mask(shape, keep_prob, seed, offset, device='cuda') -> torch.Tensor:
                               int(offset), _stream_ptr())
     _check(rc, 'apa_dropout_mask')
     return mask
+
+
+# --------------------------------------------------------------------------------------------
+# PoseLogits head (nets_factory.py:147-160)
+# --------------------------------------------------------------------------------------------
+def pose_head_fwd(X, W1, b1, W2, b2, workspace=None):
+    """Ppre [..,Cp] (dtype of X), Pl [..,J] f32, workspace = pose_head_fwd(X [N,P,C] or [N,H,W,C], ...)."""
+    lib = load_library()
+    N, C = X.shape[0], X.shape[-1]
+    P = X.numel() // (N * C)
+    Cp, J = W1.shape[1], W2.shape[1]
+    dt = _feat_dtype(X)
+    need = int(lib.apa_pose_head_workspace_bytes(N, P, C, Cp, J, dt))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty((max(need, 16),), dtype=torch.uint8, device=X.device)
+    Ppre = torch.empty(tuple(X.shape[:-1]) + (Cp,), dtype=X.dtype, device=X.device)
+    Pl = torch.empty(tuple(X.shape[:-1]) + (J,), dtype=torch.float32, device=X.device)
+    rc = lib.apa_pose_head_fwd(
+        _dev_ptr(X, 'X'), _dev_ptr(W1, 'W1', torch.float32), _dev_ptr(b1, 'b1', torch.float32),
+        _dev_ptr(W2, 'W2', torch.float32), _dev_ptr(b2, 'b2', torch.float32), Ppre.data_ptr(),
+        Pl.data_ptr(), workspace.data_ptr(), workspace.numel(), N, P, C, Cp, J, dt, _stream_ptr())
+    _check(rc, 'apa_pose_head_fwd')
+    return Ppre, Pl, workspace
+
+
+def pose_head_bwd(X, W1, W2, Ppre, dPl, dPpre_ext, *, dX=None, accumulate_dX=False, workspace=None):
+    """dX, dW1, db1, dW2, db2 = pose_head_bwd(...).  dPl: pose-loss gradient [..,J] f32 or None;
+    dPpre_ext: gradient from the attention branch [..,Cp] (dtype of X) or None.  With
+    accumulate_dX the product dPpre.W1^T is ADDED to the given dX buffer."""
+    lib = load_library()
+    N, C = X.shape[0], X.shape[-1]
+    P = X.numel() // (N * C)
+    Cp, J = W1.shape[1], W2.shape[1]
+    dt = _feat_dtype(X)
+    need = int(lib.apa_pose_head_workspace_bytes(N, P, C, Cp, J, dt))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty((max(need, 16),), dtype=torch.uint8, device=X.device)
+    if dX is None:
+        if accumulate_dX:
+            raise ApaError('accumulate_dX needs an existing dX buffer')
+        dX = torch.empty_like(X)
+    dW1, db1 = torch.empty_like(W1), torch.empty((Cp,), dtype=torch.float32, device=X.device)
+    dW2, db2 = torch.empty_like(W2), torch.empty((J,), dtype=torch.float32, device=X.device)
+    rc = lib.apa_pose_head_bwd(
+        _dev_ptr(X, 'X'), _dev_ptr(W1, 'W1', torch.float32), _dev_ptr(W2, 'W2', torch.float32),
+        _dev_ptr(Ppre, 'Ppre', X.dtype), _dev_ptr(dPl, 'dPl', torch.float32),
+        _dev_ptr(dPpre_ext, 'dPpre_ext', X.dtype), _dev_ptr(dX, 'dX', X.dtype),
+        1 if accumulate_dX else 0, dW1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), db2.data_ptr(),
+        workspace.data_ptr(), workspace.numel(), N, P, C, Cp, J, dt, _stream_ptr())
+    _check(rc, 'apa_pose_head_bwd')
+    return dX, dW1, db1, dW2, db2
 
 
 # --------------------------------------------------------------------------------------------

@@ -75,7 +75,8 @@ const char* apa_status_string(int status);
  * X     [N,P,C]   dtype            Xatt  [N,P,Ca]  dtype; pass Xatt == X (Ca == C) for cfg 002
  * Wa    [Ca,M] f32, ba [M] f32     Wt    [C,K] f32, bt [K] f32
  * logits[N,K] f32 (out)            att   [N,P,M] f32 (out) = end_points['PosePrelogitsBasedAttention']
- * zsave [N,C] f32 (out, M==1 only) = (1/P) sum_p A[n,p] Xt[n,p,:]   -- saved for backward
+ * zsave (out, saved for backward)  M==1: [N,C] f32 = (1/P) sum_p A[n,p] Xt[n,p,:]
+ *                                  M==K: [N,P,K] f32 = the top-down map T
  * abar  [N]   f32 (out, M==1 only) = (1/P) sum_p A[n,p]             -- saved for backward
  * topdown [N,P,K] dtype or NULL    = end_points['TopDownAttention']; only materialised on request
  *                                    (the reference needs it for eval.py --ept dumps only)
@@ -109,6 +110,26 @@ int apa_attn_pool_bwd(const void* X, const void* Xatt, const float* Wa, const fl
  * parity tests to hand the oracle the exact mask (TF's own RNG stream is not reproducible). */
 int apa_dropout_mask(uint8_t* mask, size_t n_elems, float keep_prob, uint64_t seed, uint64_t offset,
                      void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * PoseLogits head.  Replaces nets_factory.py:147-160:
+ *   Ppre = relu(X . W1 + b1)   [N,P,Cp]  dtype    'PoseLogits/ExtraConv2d_1x1'  (Cp = 768)
+ *   Pl   = Ppre . W2 + b2      [N,P,J]   f32      'PoseLogits/Conv2d_1c_1x1'    (J = 16)
+ * W1 [C,Cp], b1 [Cp], W2 [Cp,J], b2 [J] f32.  Dense: bf16 features run on the bf16 MFMA with
+ * fp32 accumulation, fp32 features on the exact f32 MFMA.
+ * Backward (TF autodiff in the reference):  dPl [N,P,J] f32 = gradient of the pose loss (or NULL);
+ * dPpre_ext [N,P,Cp] dtype = gradient arriving at Ppre from the attention branch of cfg 003 (the
+ * dXatt of apa_attn_pool_bwd) or NULL.  Outputs dW1 [C,Cp], db1 [Cp], dW2 [Cp,J], db2 [J] f32 and
+ * dX [N,P,C] dtype, overwritten or (accumulate_dX != 0) added to what the buffer already holds.
+ */
+size_t apa_pose_head_workspace_bytes(int N, int P, int C, int Cp, int J, int dtype);
+int apa_pose_head_fwd(const void* X, const float* W1, const float* b1, const float* W2,
+                      const float* b2, void* Ppre, float* Pl, void* ws, size_t ws_bytes, int N, int P,
+                      int C, int Cp, int J, int dtype, void* stream);
+int apa_pose_head_bwd(const void* X, const float* W1, const float* W2, const void* Ppre,
+                      const float* dPl, const void* dPpre_ext, void* dX, int accumulate_dX, float* dW1,
+                      float* db1, float* dW2, float* db2, void* ws, size_t ws_bytes, int N, int P, int C,
+                      int Cp, int J, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Action loss: tf.losses.softmax_cross_entropy(one_hot(labels,K), logits, weights=wt)

@@ -1,0 +1,205 @@
+"""GPU parity of the dense (MFMA) paths through the C ABI:
+  * PoseLogits head forward/backward (nets_factory.py:147-160)
+  * cfg 003 end to end: pose head -> attention from pose_pre_logits -> pose L2 + action loss
+  * per-class bottom-up maps, M == K (nets_factory.py:257), id / relu / softmax, dropout
+fp32 features run on the exact f32 MFMA (tight tolerance); bf16 features on the bf16 MFMA
+(tolerance set by 8-bit significands)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import attn_pool_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a = a.detach().cpu().double().reshape(-1)
+    b = b.detach().cpu().double().reshape(-1)
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
+
+
+def _pose_problem(N, H, C, Cp, J, seed, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    X = torch.relu(torch.randn(N, H, H, C, generator=g)).to(dtype)
+    W1 = torch.randn(C, Cp, generator=g) / C ** 0.5
+    b1 = torch.randn(Cp, generator=g) * 0.1
+    W2 = torch.randn(Cp, J, generator=g) / Cp ** 0.5
+    b2 = torch.randn(J, generator=g) * 0.1
+    return X, W1, b1, W2, b2, g
+
+
+@pytest.mark.parametrize('N,H,C,Cp,J', [(3, 7, 512, 768, 16), (2, 14, 2048, 768, 16), (1, 5, 256, 200, 7)])
+def test_pose_head_fp32_forward_backward(gpu, N, H, C, Cp, J):
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    X, W1, b1, W2, b2, g = _pose_problem(N, H, C, Cp, J, seed=N + H)
+    dPl = torch.randn(N, H, H, J, generator=g)
+    dExt = torch.randn(N, H, H, Cp, generator=g)
+    Xr, W1r, b1r, W2r, b2r = (t.double().requires_grad_(True) for t in (X, W1, b1, W2, b2))
+    pre, pl = orc.pose_logits_head(Xr, W1r, b1r, W2r, b2r)
+    ((pl * dPl.double()).sum() + (pre * dExt.double()).sum()).backward()
+
+    d = lambda t: t.to(gpu).contiguous()
+    Ppre, Pl, ws = cof.pose_head_fwd(d(X), d(W1), d(b1), d(W2), d(b2))
+    assert _rel(Ppre, pre) < 2e-5 and _rel(Pl, pl) < 2e-5
+    dX, dW1, db1, dW2, db2 = cof.pose_head_bwd(d(X), d(W1), d(W2), Ppre, d(dPl), d(dExt), workspace=ws)
+    for name, got, want in (('dX', dX, Xr.grad), ('dW1', dW1, W1r.grad), ('db1', db1, b1r.grad),
+                            ('dW2', dW2, W2r.grad), ('db2', db2, b2r.grad)):
+        assert _rel(got, want) < 5e-5, name
+    # accumulate mode adds onto an existing dX; dPl-only and ext-only calls are both legal
+    base = torch.randn_like(dX)
+    dX2, *_ = cof.pose_head_bwd(d(X), d(W1), d(W2), Ppre, d(dPl), d(dExt), dX=base.clone(), accumulate_dX=True)
+    assert _rel(dX2 - base, Xr.grad) < 1e-4
+    dXa, _, _, dW2a, _ = cof.pose_head_bwd(d(X), d(W1), d(W2), Ppre, None, d(dExt))
+    assert float(dW2a.abs().max()) == 0.0
+    dXb, *_ = cof.pose_head_bwd(d(X), d(W1), d(W2), Ppre, d(dPl), None)
+    assert _rel(dXa + dXb, Xr.grad) < 1e-4
+
+
+def test_pose_head_bf16(gpu):
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    N, H, C, Cp, J = 4, 14, 2048, 768, 16
+    X, W1, b1, W2, b2, g = _pose_problem(N, H, C, Cp, J, seed=9, dtype=torch.bfloat16)
+    dPl = torch.randn(N, H, H, J, generator=g)
+    # reference: same bf16-rounded operands (X, W1 -> bf16 inside the kernel), float64 accumulation
+    W1q = W1.bfloat16().double()
+    Xr = X.double().requires_grad_(True)
+    W1r = W1q.clone().requires_grad_(True)
+    W2r = W2.double().requires_grad_(True)
+    pre, pl = orc.pose_logits_head(Xr, W1r, b1.double(), W2r, b2.double())
+    (pl * dPl.double()).sum().backward()
+    d = lambda t: t.to(gpu).contiguous()
+    Ppre, Pl, ws = cof.pose_head_fwd(d(X), d(W1), d(b1), d(W2), d(b2))
+    assert Ppre.dtype == torch.bfloat16
+    assert _rel(Ppre, pre) < 2 ** -7            # bf16 output rounding
+    assert _rel(Pl, pl) < 1e-2                  # Ppre (bf16) and W2 (bf16) feed the second product
+    dX, dW1, db1, dW2, db2 = cof.pose_head_bwd(d(X), d(W1), d(W2), Ppre, d(dPl), None, workspace=ws)
+    assert _rel(dW2, W2r.grad) < 2e-2 and _rel(dW1, W1r.grad) < 2e-2 and _rel(dX, Xr.grad) < 2e-2
+
+
+def test_cfg003_pose_regularised_attention_end_to_end(gpu):
+    """cfg 003: bottom-up map from pose_pre_logits (768 ch), top-down from conv5, loss = pose L2 +
+    softmax-xent; every parameter/input gradient against autograd of the oracle."""
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    N, H, C, Cp, J, K = 3, 7, 2048, 768, 16, 393
+    X, W1, b1, W2, b2, g = _pose_problem(N, H, C, Cp, J, seed=33)
+    Wa = torch.randn(Cp, 1, generator=g) / Cp ** 0.5
+    ba = torch.randn(1, generator=g) * 0.1
+    Wt = torch.randn(C, K, generator=g) / C ** 0.5
+    bt = torch.randn(K, generator=g) * 0.1
+    labels = torch.randint(0, K, (N,), generator=g)
+    pose_lbl = torch.rand(N, H, H, J, generator=g)
+    valid = torch.rand(N, J, generator=g) > 0.3
+
+    leaf = lambda t: t.double().clone().requires_grad_(True)
+    Xr, W1r, b1r, W2r, b2r, War, bar, Wtr, btr = map(leaf, (X, W1, b1, W2, b2, Wa, ba, Wt, bt))
+    pre, pl = orc.pose_logits_head(Xr, W1r, b1r, W2r, b2r)
+    lg, _ = orc.attentional_pooling(Xr, pre, pl, [War], [bar], [Wtr], [btr],
+                                    orc.AttnFlags(single_layer_att=False))
+    total = sum(orc.gen_losses(labels, lg, 'softmax-xentropy', K, 1.0, pose_lbl.double(), pl, 'l2', valid, 1.0))
+    total.backward()
+
+    d = lambda t: t.to(gpu).contiguous()
+    Xd, W1d, b1d, W2d, b2d, Wad, bad, Wtd, btd = map(d, (X, W1, b1, W2, b2, Wa, ba, Wt, bt))
+    Ppre, Pl, pws = cof.pose_head_fwd(Xd, W1d, b1d, W2d, b2d)
+    logits, att, zs, ab, _, ws = cof.attn_pool_fwd(Xd, Ppre, Wad, bad, Wtd, btd)
+    lossx, G, _, pred = cof.softmax_xent_fwd_bwd(logits, d(labels), want_pred=True)
+    lossp, dPl = cof.pose_l2_loss_fwd_bwd(Pl, d(pose_lbl), d(valid))
+    dX, dXatt, dWa, dba, dWt, dbt = cof.attn_pool_bwd(Xd, Ppre, Wad, bad, Wtd, btd, att, zs, ab, G, workspace=ws)
+    dX, dW1, db1, dW2, db2 = cof.pose_head_bwd(Xd, W1d, W2d, Ppre, dPl, dXatt, dX=dX, accumulate_dX=True,
+                                               workspace=pws)
+    assert abs(float(lossx[0] + lossp[0]) - float(total)) < 2e-5 * float(total)
+    assert torch.equal(pred.cpu(), lg.argmax(1))
+    for name, got, want in (('dX', dX, Xr.grad), ('dW1', dW1, W1r.grad), ('db1', db1, b1r.grad),
+                            ('dW2', dW2, W2r.grad), ('db2', db2, b2r.grad), ('dWa', dWa, War.grad),
+                            ('dba', dba, bar.grad), ('dWt', dWt, Wtr.grad), ('dbt', dbt, btr.grad)):
+        assert _rel(got, want) < 1e-4, name
+
+
+def _pc_problem(N, H, C, K, seed, Ca=None, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    Ca = C if Ca is None else Ca
+    X = torch.relu(torch.randn(N, H, H, C, generator=g)).to(dtype)
+    Xatt = X if Ca == C else torch.relu(torch.randn(N, H, H, Ca, generator=g)).to(dtype)
+    Wa = torch.randn(Ca, K, generator=g) / Ca ** 0.5
+    ba = torch.randn(K, generator=g) * 0.1
+    Wt = torch.randn(C, K, generator=g) / C ** 0.5
+    bt = torch.randn(K, generator=g) * 0.1
+    labels = torch.randint(0, K, (N,), generator=g)
+    return X, Xatt, Wa, ba, Wt, bt, labels
+
+
+def _pc_run(gpu, X, Xatt, Wa, ba, Wt, bt, labels, softmax, relu, train=False, keep=0.5, seed=5, offset=2,
+            want_topdown=False):
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    d = lambda t: t.to(gpu).contiguous()
+    Xd = d(X)
+    Xad = Xd if Xatt is X else d(Xatt)
+    flags = cof.attn_flags(softmax, relu, train)
+    logits, att, Ts, _, td, ws = cof.attn_pool_fwd(Xd, Xad, d(Wa), d(ba), d(Wt), d(bt), flags=flags,
+                                                   keep_prob=keep, seed=seed, offset=offset,
+                                                   want_topdown=want_topdown)
+    loss, G, _, pred = cof.softmax_xent_fwd_bwd(logits, d(labels), want_pred=True)
+    grads = cof.attn_pool_bwd(Xd, Xad, d(Wa), d(ba), d(Wt), d(bt), att, Ts, None, G, flags=flags,
+                              keep_prob=keep, seed=seed, offset=offset, workspace=ws)
+    return logits, att, td, loss, pred, grads
+
+
+@pytest.mark.parametrize('K,softmax,relu', [(51, False, False), (393, False, False), (51, True, False),
+                                            (20, False, True)])
+def test_per_class_maps_fp32(gpu, K, softmax, relu):
+    N, H, C = 3, 6, 512
+    X, Xatt, Wa, ba, Wt, bt, labels = _pc_problem(N, H, C, K, seed=K)
+    leaf = lambda t: t.double().clone().requires_grad_(True)
+    Xr, War, bar, Wtr, btr = map(leaf, (X, Wa, ba, Wt, bt))
+    flags = orc.AttnFlags(per_class=True, softmax_att=softmax, relu_att=relu)
+    lg, ep = orc.attentional_pooling(Xr, None, None, [War], [bar], [Wtr], [btr], flags)
+    orc.action_softmax_xent(lg, labels, K).backward()
+    logits, att, td, loss, pred, (dX, dXatt, dWa, dba, dWt, dbt) = _pc_run(
+        gpu, X, Xatt, Wa, ba, Wt, bt, labels, softmax, relu, want_topdown=True)
+    assert dXatt is None
+    assert _rel(logits, lg) < 2e-5 and float((logits.cpu().double() - lg.detach()).abs().max()) < 1e-3
+    assert torch.equal(pred.cpu(), lg.argmax(1))
+    assert _rel(att.view(N, H, H, K), ep['PosePrelogitsBasedAttention']) < 2e-5
+    assert _rel(td.view(N, H, H, K), ep['TopDownAttention']) < 2e-5          # end-point dump
+    for name, got, want in (('dX', dX, Xr.grad), ('dWa', dWa, War.grad), ('dba', dba, bar.grad),
+                            ('dWt', dWt, Wtr.grad), ('dbt', dbt, btr.grad)):
+        tol = 5e-5 if not (softmax and name == 'dba') else 1e-3                # d(ba) == 0 under softmax
+        err = float((got.cpu().double().reshape(-1) - want.reshape(-1)).abs().max())
+        assert err <= tol * max(float(want.abs().max()), 1e-30) + (1e-8 if name == 'dba' else 0), name
+
+
+def test_per_class_maps_training_dropout_and_separate_attention_input(gpu):
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    N, H, C, K, Ca = 2, 5, 512, 51, 96
+    X, Xatt, Wa, ba, Wt, bt, labels = _pc_problem(N, H, C, K, seed=77, Ca=Ca)
+    keep, seed, offset = 0.5, 21, 4
+    mask = cof.dropout_mask(tuple(X.shape), keep, seed, offset).cpu()
+    leaf = lambda t: t.double().clone().requires_grad_(True)
+    Xr, Xar, War, bar, Wtr, btr = map(leaf, (X, Xatt, Wa, ba, Wt, bt))
+    flags = orc.AttnFlags(single_layer_att=False, per_class=True)
+    lg, _ = orc.attentional_pooling(Xr, Xar, None, [War], [bar], [Wtr], [btr], flags, is_training=True,
+                                    keep_prob=keep, dropout_mask=mask)
+    orc.action_softmax_xent(lg, labels, K).backward()
+    logits, att, _, loss, pred, (dX, dXatt, dWa, dba, dWt, dbt) = _pc_run(
+        gpu, X, Xatt, Wa, ba, Wt, bt, labels, False, False, train=True, keep=keep, seed=seed, offset=offset)
+    assert _rel(logits, lg) < 2e-5
+    for name, got, want in (('dX', dX, Xr.grad), ('dXatt', dXatt, Xar.grad), ('dWa', dWa, War.grad),
+                            ('dba', dba, bar.grad), ('dWt', dWt, Wtr.grad), ('dbt', dbt, btr.grad)):
+        assert _rel(got, want) < 5e-5, name
+
+
+def test_per_class_maps_bf16_hmdb_shape(gpu):
+    """HMDB-51 config of BASELINE.json: 51 classes, bf16 features, per-class maps on the bf16 MFMA."""
+    N, H, C, K = 4, 14, 2048, 51
+    X, Xatt, Wa, ba, Wt, bt, labels = _pc_problem(N, H, C, K, seed=51, dtype=torch.bfloat16)
+    leaf = lambda t: t.double().clone().requires_grad_(True)
+    Xr = leaf(X)
+    War, Wtr = leaf(Wa.bfloat16()), leaf(Wt.bfloat16())       # weights are rounded to bf16 in-kernel
+    lg, _ = orc.attentional_pooling(Xr, None, None, [War], [ba.double()], [Wtr], [bt.double()],
+                                    orc.AttnFlags(per_class=True))
+    orc.action_softmax_xent(lg, labels, K).backward()
+    logits, att, _, loss, pred, (dX, _, dWa, dba, dWt, dbt) = _pc_run(gpu, X, Xatt, Wa, ba, Wt, bt, labels, False, False)
+    assert _rel(logits, lg) < 2e-3
+    assert float((logits.cpu().double() - lg.detach()).abs().max()) < 5e-3
+    assert _rel(dWt, Wtr.grad) < 2e-2 and _rel(dWa, War.grad) < 2e-2 and _rel(dX, Xr.grad) < 3e-2
