@@ -126,10 +126,6 @@ extern "C" int apa_attn_pool_fwd(const void* X, const void* Xatt, const float* W
       set_error("apa_attn_pool_fwd: M==1 needs zsave and abar buffers");
       return APA_ERR_INVALID_ARG;
     }
-    if (topdown) {
-      set_error("apa_attn_pool_fwd: TopDownAttention materialisation is not built for M==1 yet");
-      return APA_ERR_UNSUPPORTED;
-    }
     if (!m1_supported(C, Ca, dtype, Xatt == X)) {
       set_error("apa_attn_pool_fwd: M==1 kernels need C in {256,512,1024,2048} (f32) or "
                 "{512,1024,2048} (bf16); got C=%d Ca=%d dtype=%d", C, Ca, dtype);
@@ -140,8 +136,26 @@ extern "C" int apa_attn_pool_fwd(const void* X, const void* Xatt, const float* W
       set_error("apa_attn_pool_fwd: workspace too small (%zu < %zu)", ws_bytes, need);
       return APA_ERR_WORKSPACE;
     }
-    return m1_forward(X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar, ws, N, P, C, Ca, K, flags,
-                      keep_prob, seed, offset, dtype, st);
+    rc = m1_forward(X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar, ws, N, P, C, Ca, K, flags,
+                    keep_prob, seed, offset, dtype, st);
+    if (rc != APA_OK || !topdown) return rc;
+    // end_points['TopDownAttention'] = dropout(X).Wt + bt  (nets_factory.py:296-309): the factorised
+    // path never needs it; it is materialised only on request (eval.py --ept dumps) by one GEMM.
+    GemmDesc g;
+    g.A = X; g.lda = C; g.ta = dtype == APA_DTYPE_BF16 ? 1 : 0; g.a_kc = true;
+    g.B = Wt; g.ldb = K; g.tb = 0; g.b_kc = false;
+    g.C = topdown; g.ldc = K; g.tc = g.ta;
+    g.M = N * P; g.N = K; g.K = C; g.bias = bt;
+    if ((flags & APA_FLAG_TRAIN) && keep_prob < 1.0f) {
+      g.drop_a = 1;
+      g.inv_keep = 1.0f / keep_prob;
+      g.thresh = keep_thresh(keep_prob);
+      g.seed = seed;
+      g.offset = (flags & APA_FLAG_RNG_DEVICE) ? 0 : offset;
+      g.offset_dev = (flags & APA_FLAG_RNG_DEVICE)
+                         ? reinterpret_cast<const uint64_t*>(static_cast<uintptr_t>(offset)) : nullptr;
+    }
+    return gemm_launch(g, st);
   }
   // M == K: per-class maps, dense MFMA path.  zsave holds the fp32 [N,P,K] top-down map.
   if (!zsave) {

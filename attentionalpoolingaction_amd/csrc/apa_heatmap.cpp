@@ -7,6 +7,7 @@
 //                                                OpenCV hard-codes for ksize 7 / sigma <= 0,
 //                                                BORDER_REFLECT_101
 // Stateless and re-entrant (the reference op runs on TF inter-op threads).
+#include <math.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -120,6 +121,69 @@ extern "C" int apa_pose_to_heatmap(const int64_t* pose, int64_t n_vals, int64_t 
     }
     for (int r = 0; r < out_ht; ++r)
       for (int c = 0; c < W; ++c) heatmap[((size_t)r * W + c) * nk + i] = chan[(size_t)r * W + c];
+  }
+  return APA_OK;
+}
+
+// Label post-processing of /root/reference/src/preprocess_pipeline.py:21-45 (_replay_augmentation)
+// and :195-214: replay the image's crop / flip on the uint8 heat-map, convert to float (x * 1/255),
+// min-max normalise with cfg.EPS, legacy TF1 bilinear resize (src = dst * in/out, no half pixel)
+// to out_side x out_side.  Host function, stateless.
+extern "C" int apa_pose_label_replay_resize(const uint8_t* hm, int h, int w, int J, int orig_h,
+                                            int orig_w, int crop_y, int crop_x, int crop_h,
+                                            int crop_w, int flip, int out_side, float eps,
+                                            float* out) {
+  using apa::set_error;
+  if (!hm || !out || h <= 0 || w <= 0 || J <= 0 || orig_h <= 0 || orig_w <= 0 || out_side <= 0) {
+    set_error("apa_pose_label_replay_resize: null pointer or non-positive size");
+    return APA_ERR_INVALID_ARG;
+  }
+  // :29-36  ratio = H_size / orig_size (float32); start/size = to_int32(crop * ratio) (truncation)
+  const float ratio_x = (float)w / (float)orig_w, ratio_y = (float)h / (float)orig_h;
+  const int y0 = (int)((float)crop_y * ratio_y), x0 = (int)((float)crop_x * ratio_x);
+  const int ch = (int)((float)crop_h * ratio_y), cw = (int)((float)crop_w * ratio_x);
+  if (y0 < 0 || x0 < 0 || ch <= 0 || cw <= 0 || y0 + ch > h || x0 + cw > w) {
+    set_error("apa_pose_label_replay_resize: crop [%d+%d, %d+%d] outside the %dx%d heat-map", y0, ch,
+              x0, cw, h, w);                       // tf.slice would fail the same way
+    return APA_ERR_INVALID_ARG;
+  }
+  std::vector<float> img((size_t)ch * cw * J);
+  const float inv255 = 1.0f / 255.0f;              // tf.image.convert_image_dtype(uint8 -> float32)
+  float mn = 3.4e38f;
+  for (int y = 0; y < ch; ++y)
+    for (int x = 0; x < cw; ++x) {
+      const int sx = flip ? (cw - 1 - x) : x;      // tf.image.flip_left_right after the crop
+      const uint8_t* s = hm + (((size_t)(y0 + y)) * w + (x0 + sx)) * J;
+      float* d = &img[((size_t)y * cw + x) * J];
+      for (int j = 0; j < J; ++j) {
+        d[j] = (float)s[j] * inv255;
+        if (d[j] < mn) mn = d[j];
+      }
+    }
+  float mx = -3.4e38f;                             // :201-202  x -= min ; x /= (max(x) + EPS)
+  for (float& v : img) {
+    v -= mn;
+    if (v > mx) mx = v;
+  }
+  const float denom = mx + eps;
+  for (float& v : img) v /= denom;
+  // :204-207 tf.image.resize_images -> legacy bilinear
+  const float sy = (float)ch / (float)out_side, sx = (float)cw / (float)out_side;
+  for (int oy = 0; oy < out_side; ++oy) {
+    const float fy = (float)oy * sy;
+    const int ylo = (int)floorf(fy), yhi = ylo + 1 < ch ? ylo + 1 : ch - 1;
+    const float wy = fy - (float)ylo;
+    for (int ox = 0; ox < out_side; ++ox) {
+      const float fx = (float)ox * sx;
+      const int xlo = (int)floorf(fx), xhi = xlo + 1 < cw ? xlo + 1 : cw - 1;
+      const float wx = fx - (float)xlo;
+      for (int j = 0; j < J; ++j) {
+        const float tl = img[((size_t)ylo * cw + xlo) * J + j], tr = img[((size_t)ylo * cw + xhi) * J + j];
+        const float bl = img[((size_t)yhi * cw + xlo) * J + j], br = img[((size_t)yhi * cw + xhi) * J + j];
+        const float top = tl + (tr - tl) * wx, bot = bl + (br - bl) * wx;
+        out[((size_t)oy * out_side + ox) * J + j] = top + (bot - top) * wy;
+      }
+    }
   }
   return APA_OK;
 }

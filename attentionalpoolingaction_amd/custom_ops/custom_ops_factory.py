@@ -55,6 +55,9 @@ _SIGNATURES = {
     'apa_pose_to_heatmap': (c_int, [POINTER(c_int64), c_int64, c_int64, c_int64, c_int64, c_int,
                                     c_float, c_int, POINTER(c_float), POINTER(c_uint8)]),
     'apa_zero_out_channels': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    'apa_pose_label_replay_resize': (c_int, [POINTER(c_uint8)] + [c_int] * 11 + [c_float, POINTER(c_float)]),
+    'apa_frame_pool_fwd': (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),
+    'apa_frame_pool_bwd': (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),
     'apa_prof_event_create': (c_int, [POINTER(c_void_p)]),
     'apa_prof_event_destroy': (c_int, [c_void_p]),
     'apa_prof_event_record': (c_int, [c_void_p, c_void_p]),
@@ -378,6 +381,57 @@ def zero_out_channels(to_zero: torch.Tensor, channels: torch.Tensor) -> torch.Te
                                    out.data_ptr(), to_zero.numel() // C, C, _stream_ptr())
     _check(rc, 'apa_zero_out_channels')
     return out
+
+
+def pose_label_replay_resize(hm_u8: np.ndarray, orig_hw, crop_info, whether_flip: bool, out_side: int,
+                             eps: float = 1e-14) -> np.ndarray:
+    """src/preprocess_pipeline.py:21-45 + :195-214 on one heat-map: replay crop
+    (crop_info = [y, x, h, w] in the coordinates of the orig_hw = (H, W) image) and flip, /255,
+    min-max normalise, legacy-bilinear resize to out_side^2.  Host op.  Returns f32 [S,S,J]."""
+    lib = load_library()
+    hm = np.ascontiguousarray(hm_u8, dtype=np.uint8)
+    h, w, J = hm.shape
+    out = np.zeros((out_side, out_side, J), dtype=np.float32)
+    rc = lib.apa_pose_label_replay_resize(
+        hm.ctypes.data_as(POINTER(c_uint8)), h, w, J, int(orig_hw[0]), int(orig_hw[1]),
+        int(crop_info[0]), int(crop_info[1]), int(crop_info[2]), int(crop_info[3]),
+        1 if whether_flip else 0, int(out_side), float(eps), out.ctypes.data_as(POINTER(c_float)))
+    _check(rc, 'apa_pose_label_replay_resize')
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# frame pooling (nets_factory.py:354-374)
+# --------------------------------------------------------------------------------------------
+def frame_pool_fwd(logits, frames_per_video, w=None, b=None):
+    """pooled [B,K], tatt [B*F] or None."""
+    lib = load_library()
+    BF, K = logits.shape
+    B = BF // frames_per_video
+    pooled = torch.empty((B, K), dtype=torch.float32, device=logits.device)
+    tatt = torch.empty((BF,), dtype=torch.float32, device=logits.device) if w is not None else None
+    rc = lib.apa_frame_pool_fwd(_dev_ptr(logits, 'logits', torch.float32), _dev_ptr(w, 'w', torch.float32),
+                                _dev_ptr(b, 'b', torch.float32), pooled.data_ptr(), _dev_ptr(tatt, 'tatt'),
+                                B, frames_per_video, K, _stream_ptr())
+    _check(rc, 'apa_frame_pool_fwd')
+    return pooled, tatt
+
+
+def frame_pool_bwd(logits, frames_per_video, w, tatt, dpooled):
+    """dlogits [B*F,K], dw [K] or None, db [1] or None."""
+    lib = load_library()
+    BF, K = logits.shape
+    B = BF // frames_per_video
+    dlogits = torch.empty_like(logits)
+    dw = torch.empty((K,), dtype=torch.float32, device=logits.device) if w is not None else None
+    db = torch.empty((1,), dtype=torch.float32, device=logits.device) if w is not None else None
+    scratch = torch.empty((BF,), dtype=torch.float32, device=logits.device) if w is not None else None
+    rc = lib.apa_frame_pool_bwd(_dev_ptr(logits, 'logits', torch.float32), _dev_ptr(w, 'w', torch.float32),
+                                _dev_ptr(tatt, 'tatt'), _dev_ptr(dpooled, 'dpooled', torch.float32),
+                                dlogits.data_ptr(), _dev_ptr(dw, 'dw'), _dev_ptr(db, 'db'),
+                                _dev_ptr(scratch, 'scratch'), B, frames_per_video, K, _stream_ptr())
+    _check(rc, 'apa_frame_pool_bwd')
+    return dlogits, dw, db
 
 
 # --------------------------------------------------------------------------------------------

@@ -8,8 +8,9 @@ map `last_conv` [N,H,W,C] (NHWC, float32 or bfloat16, resident in HBM) directly.
 runs in hand-written HIP (libapa_hip.so) through torch.autograd.Function wrappers -- torch only
 carries device memory, the stream and the autograd graph.
 
-End-point names are the reference's: 'PosePrelogitsBasedAttention' (:287), 'Logits' (:352),
-'logits_beforePool' (:357).  Parameter names map 1:1 onto the TF variable names.
+End-point names are the reference's: 'PoseLogits' (:160), 'PosePrelogitsBasedAttention' (:287),
+'TopDownAttention' (:309, on request), 'Logits' (:352), 'logits_beforePool' (:357).
+Parameter names map 1:1 onto the TF variable names.
 """
 from __future__ import annotations
 
@@ -30,34 +31,43 @@ last_conv_map = {  # nets_factory.py:63-67 ; channel counts of the taps
 
 
 class AttentionalPoolingFunction(torch.autograd.Function):
-    """logits, att = f(X, Xatt, Wa, ba, Wt, bt); nets_factory.py:247-328 in two HIP calls.
+    """logits, att[, topdown] = f(X, Xatt, Wa, ba, Wt, bt); nets_factory.py:247-328 in two HIP calls.
 
     `Xatt is None` means the attention map is computed from X itself (cfg 002,
-    ..._SINGLE_LAYER_ATT).  `att` (the 'PosePrelogitsBasedAttention' end point) is returned for
-    inspection and is not differentiable on its own, exactly as nothing in the reference puts a
-    loss on it.
+    ..._SINGLE_LAYER_ATT).  Wa [Cin,1] selects the factorised class-agnostic path, Wa [Cin,K] the
+    dense per-class path.  `att` / `topdown` are end points returned for inspection; nothing in
+    the reference puts a loss on them, so they are marked non-differentiable.
     """
 
     @staticmethod
-    def forward(ctx, X, Xatt, Wa, ba, Wt, bt, flags, keep_prob, seed, offset):
+    def forward(ctx, X, Xatt, Wa, ba, Wt, bt, flags, keep_prob, seed, offset, want_topdown):
         Xc = X.contiguous()
         fused = Xatt is None
         Xa = Xc if fused else Xatt.contiguous()
-        logits, att, zsave, abar, _, ws = cof.attn_pool_fwd(
+        logits, att, zsave, abar, topdown, ws = cof.attn_pool_fwd(
             Xc, Xa, Wa.contiguous(), ba.contiguous(), Wt.contiguous(), bt.contiguous(),
-            flags=flags, keep_prob=keep_prob, seed=seed, offset=offset)
-        ctx.save_for_backward(Xc, Xa if not fused else Xc, Wa, ba, Wt, bt, att, zsave, abar)
+            flags=flags, keep_prob=keep_prob, seed=seed, offset=offset, want_topdown=want_topdown)
+        saved = [Xc, Xa, Wa, ba, Wt, bt, att, zsave]
+        ctx.has_abar = abar is not None
+        if abar is not None:
+            saved.append(abar)
+        ctx.save_for_backward(*saved)
         ctx.fused = fused
         ctx.cfg = (flags, keep_prob, seed, offset)
         ctx.ws = ws
         ctx.xshape = X.shape
         ctx.xatt_shape = None if fused else Xatt.shape
         ctx.mark_non_differentiable(att)
-        return logits, att
+        if topdown is not None:
+            ctx.mark_non_differentiable(topdown)
+            return logits, att, topdown
+        return logits, att, None
 
     @staticmethod
-    def backward(ctx, dlogits, _datt):
-        Xc, Xa, Wa, ba, Wt, bt, att, zsave, abar = ctx.saved_tensors
+    def backward(ctx, dlogits, _datt, _dtd):
+        saved = ctx.saved_tensors
+        Xc, Xa, Wa, ba, Wt, bt, att, zsave = saved[:8]
+        abar = saved[8] if ctx.has_abar else None
         flags, keep_prob, seed, offset = ctx.cfg
         if ctx.fused:
             Xa = Xc
@@ -68,34 +78,68 @@ class AttentionalPoolingFunction(torch.autograd.Function):
         dX = dX.view(ctx.xshape)
         if dXatt is not None:
             dXatt = dXatt.view(ctx.xatt_shape)
-        return dX, dXatt, dWa, dba, dWt, dbt, None, None, None, None
+        return dX, dXatt, dWa, dba, dWt, dbt, None, None, None, None, None
+
+
+class PoseHeadFunction(torch.autograd.Function):
+    """Ppre, Pl = f(X, W1, b1, W2, b2): the PoseLogits head (nets_factory.py:147-160) on MFMA."""
+
+    @staticmethod
+    def forward(ctx, X, W1, b1, W2, b2):
+        Xc = X.contiguous()
+        Ppre, Pl, ws = cof.pose_head_fwd(Xc, W1.contiguous(), b1.contiguous(), W2.contiguous(),
+                                         b2.contiguous())
+        ctx.save_for_backward(Xc, W1, W2, Ppre)
+        ctx.ws = ws
+        ctx.set_materialize_grads(False)   # an unused output arrives as None, not as zeros
+        return Ppre, Pl
+
+    @staticmethod
+    def backward(ctx, dPpre, dPl):
+        if dPpre is None and dPl is None:
+            return None, None, None, None, None
+        Xc, W1, W2, Ppre = ctx.saved_tensors
+        dPl_c = None if dPl is None else dPl.contiguous().float()
+        dPpre_c = None if dPpre is None else dPpre.contiguous().to(Xc.dtype)
+        dX, dW1, db1, dW2, db2 = cof.pose_head_bwd(Xc, W1.contiguous(), W2.contiguous(), Ppre, dPl_c,
+                                                   dPpre_c, workspace=ctx.ws)
+        return dX, dW1, db1, dW2, db2
 
 
 def attentional_pooling(X, Xatt, Wa, ba, Wt, bt, *, softmax_att=False, relu_att=False,
-                        is_training=False, keep_prob=0.2, seed=0, offset=0):
+                        is_training=False, keep_prob=0.2, seed=0, offset=0, want_topdown=False):
     flags = cof.attn_flags(softmax_att, relu_att, is_training)
     return AttentionalPoolingFunction.apply(X, Xatt, Wa, ba, Wt, bt, flags,
-                                            keep_prob if is_training else 1.0, seed, offset)
+                                            keep_prob if is_training else 1.0, seed, offset,
+                                            want_topdown)
 
 
 class AttentionalPoolingHead(nn.Module):
-    """The `USE_POSE_PRELOGITS_BASED_ATTENTION` head (nets_factory.py:242-352) as a module.
+    """PoseLogits head + the `USE_POSE_PRELOGITS_BASED_ATTENTION` head (nets_factory.py:147-160,
+    242-352) as a module.
 
-    Parameters (TF variable name -> attribute):
-      PosePrelogitsBasedAttention/Conv2d_PrePose_Attn/{weights,biases} -> att_weights [Cin,M], att_biases [M]
-      PosePrelogitsBasedAttention/Conv/{weights,biases}                -> td_weights [C,K],   td_biases [K]
-    Initialisation follows the reference: weights ~ N(0, 0.001), biases zero (:141,265-266,301-302).
+    Parameters (attribute -> TF variable name), reference initialisers in brackets:
+      pose_w1 [C,768], pose_b1      PoseLogits/ExtraConv2d_1x1/{weights,biases}   [N(0,1e-3), 0]
+      pose_w2 [768,J], pose_b2      PoseLogits/Conv2d_1c_1x1/{weights,biases}     [variance scaling, 0]
+      att_weights [Cin,M], att_biases   PosePrelogitsBasedAttention/Conv2d_PrePose_Attn/{..}  [N(0,1e-3), 0]
+      td_weights [C,K], td_biases       PosePrelogitsBasedAttention/Conv/{..}                  [N(0,1e-3), 0]
+    The pose head is only *evaluated* when something consumes it (attention from pose_pre_logits,
+    cfg 003, or `with_pose_logits=True` for the pose loss) -- TF prunes it likewise.
     """
 
     TF_NAMES = {
+        'pose_w1': 'PoseLogits/ExtraConv2d_1x1/weights', 'pose_b1': 'PoseLogits/ExtraConv2d_1x1/biases',
+        'pose_w2': 'PoseLogits/Conv2d_1c_1x1/weights', 'pose_b2': 'PoseLogits/Conv2d_1c_1x1/biases',
         'att_weights': 'PosePrelogitsBasedAttention/Conv2d_PrePose_Attn/weights',
         'att_biases': 'PosePrelogitsBasedAttention/Conv2d_PrePose_Attn/biases',
         'td_weights': 'PosePrelogitsBasedAttention/Conv/weights',
         'td_biases': 'PosePrelogitsBasedAttention/Conv/biases',
     }
+    POSE_PRELOGITS = 768
 
-    def __init__(self, num_classes: int, cfg, in_channels: int = 2048, att_in_channels: int = None,
-                 is_training: bool = False, seed: int = 42):
+    def __init__(self, num_classes: int, cfg, in_channels: int = 2048, num_pose_keypoints: int = 16,
+                 is_training: bool = False, seed: int = 42, with_pose_logits: Optional[bool] = None,
+                 want_topdown: bool = False):
         super().__init__()
         net = cfg.NET
         if not net.USE_POSE_PRELOGITS_BASED_ATTENTION:
@@ -114,9 +158,20 @@ class AttentionalPoolingHead(nn.Module):
         self.keep_prob = dropout_keep_prob(cfg)
         self.is_training = is_training
         self.seed = seed
+        self.want_topdown = want_topdown
+        if with_pose_logits is None:  # the pose logits are needed when a pose loss is configured
+            with_pose_logits = bool(is_training and cfg.TRAIN.LOSS_FN_POSE and num_pose_keypoints > 0)
+        self.with_pose_logits = with_pose_logits
         self._step = 0
         n_maps = num_classes if self.per_class else 1
-        cin = in_channels if self.single_layer else (att_in_channels or 768)
+        cp = self.POSE_PRELOGITS
+        cin = in_channels if self.single_layer else cp
+        self.pose_w1 = nn.Parameter(torch.randn(in_channels, cp) * 0.001)
+        self.pose_b1 = nn.Parameter(torch.zeros(cp))
+        # slim.variance_scaling_initializer(): truncated normal, std = sqrt(1.3 * 2 / fan_in)
+        self.pose_w2 = nn.Parameter(torch.randn(cp, max(num_pose_keypoints, 1)).clamp_(-2, 2) *
+                                    (2.6 / cp) ** 0.5)
+        self.pose_b2 = nn.Parameter(torch.zeros(max(num_pose_keypoints, 1)))
         self.att_weights = nn.Parameter(torch.randn(cin, n_maps) * 0.001)
         self.att_biases = nn.Parameter(torch.zeros(n_maps))
         self.td_weights = nn.Parameter(torch.randn(in_channels, num_classes) * 0.001)
@@ -124,40 +179,79 @@ class AttentionalPoolingHead(nn.Module):
 
     def regularized_weights(self):
         """conv weights carry slim.l2_regularizer from the resnet arg-scope (resnet_utils.py:241);
-        biases do not."""
-        return [self.att_weights, self.td_weights]
+        biases do not.  Pose-head weights only count when the pose head is in the graph."""
+        ws = [self.att_weights, self.td_weights]
+        if self.with_pose_logits or not self.single_layer:
+            ws += [self.pose_w1, self.pose_w2]
+        return ws
 
-    def forward(self, last_conv: torch.Tensor, pose_pre_logits: Optional[torch.Tensor] = None
-                ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+    def forward(self, last_conv: torch.Tensor) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
         end_points: Dict[str, torch.Tensor] = {}
-        if not self.single_layer and pose_pre_logits is None:
-            raise ValueError('cfg selects attention from pose_pre_logits (cfg 003) but none given')
-        xatt = None if self.single_layer else pose_pre_logits
+        pose_pre = None
+        if self.with_pose_logits or not self.single_layer:          # :147-160
+            pose_pre, pose_logits = PoseHeadFunction.apply(last_conv, self.pose_w1, self.pose_b1,
+                                                           self.pose_w2, self.pose_b2)
+            end_points['PoseLogits'] = pose_logits
+        xatt = None if self.single_layer else pose_pre               # :247-250
         offset = self._step
         if self.is_training:
             self._step += 1            # a fresh dropout mask per step
-        logits, att = attentional_pooling(
+        logits, att, topdown = attentional_pooling(
             last_conv, xatt, self.att_weights, self.att_biases, self.td_weights, self.td_biases,
             softmax_att=self.softmax_att, relu_att=self.relu_att, is_training=self.is_training,
-            keep_prob=self.keep_prob, seed=self.seed, offset=offset)
+            keep_prob=self.keep_prob, seed=self.seed, offset=offset, want_topdown=self.want_topdown)
         n, h, w = last_conv.shape[0], last_conv.shape[1], last_conv.shape[2]
-        end_points['PosePrelogitsBasedAttention'] = att.view(n, h, w, -1)
-        end_points['Logits'] = logits
+        end_points['PosePrelogitsBasedAttention'] = att.view(n, h, w, -1)        # :287
+        if topdown is not None:
+            end_points['TopDownAttention'] = topdown.view(n, h, w, -1)           # :309
+        end_points['Logits'] = logits                                            # :352
         return logits, end_points
 
 
-def frame_pooling(logits: torch.Tensor, frames_per_video: int, end_points: Dict[str, torch.Tensor]
+class FramePoolFunction(torch.autograd.Function):
+    """[B*F,K] -> [B,K]: mean over frames, optionally weighted by the temporal attention
+    a = logits.w + b (nets_factory.py:354-374), forward and backward in HIP."""
+
+    @staticmethod
+    def forward(ctx, logits, w, b, frames_per_video):
+        lc = logits.contiguous().float()
+        pooled, tatt = cof.frame_pool_fwd(lc, frames_per_video,
+                                          None if w is None else w.contiguous().view(-1),
+                                          None if b is None else b.contiguous().view(-1))
+        ctx.fpv = frames_per_video
+        ctx.has_att = w is not None
+        ctx.save_for_backward(lc, *( [w.contiguous().view(-1), tatt] if w is not None else [] ))
+        if tatt is not None:
+            ctx.mark_non_differentiable(tatt)
+        return pooled, tatt
+
+    @staticmethod
+    def backward(ctx, dpooled, _dtatt):
+        saved = ctx.saved_tensors
+        lc = saved[0]
+        w, tatt = (saved[1], saved[2]) if ctx.has_att else (None, None)
+        dlogits, dw, db = cof.frame_pool_bwd(lc, ctx.fpv, w, tatt, dpooled.contiguous().float())
+        if dw is not None:
+            dw = dw.view(-1, 1)
+        return dlogits, dw, db, None
+
+
+def frame_pooling(logits: torch.Tensor, frames_per_video: int, end_points: Dict[str, torch.Tensor],
+                  temporal_w: Optional[torch.Tensor] = None, temporal_b: Optional[torch.Tensor] = None
                   ) -> torch.Tensor:
-    """nets_factory.py:354-374 without temporal attention: [B*F,K] -> mean over the F frames."""
+    """nets_factory.py:354-374: end_points['logits_beforePool'], optional temporal attention
+    (end_points['TemporalAttention'], [B,F,1,1] like the reference's conv output), mean over F."""
     end_points['logits_beforePool'] = logits
-    bf, k = logits.shape
-    return logits.view(bf // frames_per_video, frames_per_video, k).mean(dim=1)
+    pooled, tatt = FramePoolFunction.apply(logits, temporal_w, temporal_b, frames_per_video)
+    if tatt is not None:
+        end_points['TemporalAttention'] = tatt.view(-1, frames_per_video, 1, 1)
+    return pooled
 
 
 def get_network_fn(name: str, num_classes: int, num_pose_keypoints: int, cfg,
                    weight_decay: float = 0.0, is_training: bool = False,
                    backbone: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
-                   device='cuda'):
+                   device='cuda', **head_kwargs):
     """Same signature as nets_factory.py:94-95 (+ optional backbone/device).
 
     Returns `network_fn(images) -> (logits, end_points)`; `network_fn.head` exposes the module
@@ -169,20 +263,37 @@ def get_network_fn(name: str, num_classes: int, num_pose_keypoints: int, cfg,
         raise ValueError('Name of network unknown %s' % name)
     channels = last_conv_map[name][1]
     head = AttentionalPoolingHead(num_classes, cfg, in_channels=channels,
-                                  is_training=is_training, seed=cfg.RNG_SEED).to(device)
+                                  num_pose_keypoints=num_pose_keypoints, is_training=is_training,
+                                  seed=cfg.RNG_SEED, **head_kwargs).to(device)
+    temporal = None
+    if cfg.NET.USE_TEMPORAL_ATT:
+        # 'TemporalAttention/Conv/{weights,biases}': 1x1 conv K->1, N(0,1e-3) weights; the bias is
+        # initialised to 1/frames_per_video at the first call (:366-368), when F is known
+        temporal = nn.ParameterDict({
+            'weights': nn.Parameter(torch.randn(num_classes, 1) * 0.001),
+            'biases': nn.Parameter(torch.zeros(1))}).to(device)
+        temporal._bias_initialised = False
 
-    def network_fn(images: torch.Tensor, pose_pre_logits: Optional[torch.Tensor] = None):
+    def network_fn(images: torch.Tensor):
         frames_per_video = 1
         if images.dim() == 5:                                   # :121-125
             frames_per_video = images.shape[1]
             images = images.reshape(-1, *images.shape[2:])
         last_conv = backbone(images) if backbone is not None else images
-        logits, end_points = head(last_conv, pose_pre_logits)
+        logits, end_points = head(last_conv)
         if frames_per_video > 1:                                # :354-374
-            logits = frame_pooling(logits, frames_per_video, end_points)
+            tw = tb = None
+            if temporal is not None:
+                if not temporal._bias_initialised:
+                    with torch.no_grad():
+                        temporal['biases'].fill_(1.0 / frames_per_video)
+                    temporal._bias_initialised = True
+                tw, tb = temporal['weights'], temporal['biases']
+            logits = frame_pooling(logits, frames_per_video, end_points, tw, tb)
         return logits, end_points
 
     network_fn.head = head
+    network_fn.temporal = temporal
     network_fn.weight_decay = weight_decay
     network_fn.num_pose_keypoints = num_pose_keypoints
     return network_fn

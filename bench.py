@@ -221,6 +221,19 @@ def main():
     alg_bytes = 2.0 * N * P * C * esz           # bwd main kernel: read X once + write dX once
     achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9
 
+    # HBM traffic of the dominant kernel from the separate rocprofv3 --pmc passes (profiles/):
+    # only valid for the exact workload it was collected on
+    traffic = args.traffic_bytes
+    if traffic is None:
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+            key = 'cfg002_N{}_{}x{}x{}_{}_K{}_{}'.format(N, H, H, C, args.dtype, K,
+                                                        'train' if train else 'eval')
+            if key in pmc and not args.softmax_att:
+                traffic = pmc[key]['hbm_bytes_per_launch']
+        except (OSError, ValueError, KeyError):
+            traffic = None
+
     if rank == 0:
         total_images = N * world * args.steps
         out = {
@@ -253,7 +266,7 @@ def main():
                 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                'traffic': args.traffic_bytes,
+                'traffic': traffic,
                 'alg_bytes_per_launch': alg_bytes,
                 'kernel_avg_us': round(k_avg_ms * 1e3, 3),
                 'kernel_med_us': round(kms[len(kms) // 2] * 1e3, 3),

@@ -166,6 +166,31 @@ int apa_pose_to_heatmap(const int64_t* pose_host, int64_t n_vals, int64_t im_ht,
                         int64_t out_wd, int out_channels, float marker_wd_ratio, int do_gauss_blur,
                         float* heatmap_host, uint8_t* valid_host);
 
+/* Label post-processing: _replay_augmentation (src/preprocess_pipeline.py:21-45) + :195-214.
+ * HOST function.  hm_host uint8 [h,w,J] (the python wrapper's *255 heat-map); the crop
+ * (crop_y, crop_x, crop_h, crop_w) is given in the coordinates of the orig_h x orig_w image it was
+ * recorded on and is rescaled to the heat-map with the reference's float32 ratios and truncation;
+ * flip != 0 mirrors left-right after the crop; values become float (x/255), are min-max
+ * normalised ((x - min) / (max(x - min) + eps), eps = cfg.EPS = 1e-14) and resized with the TF1
+ * legacy bilinear rule to out_side x out_side.  out_host f32 [out_side, out_side, J]. */
+int apa_pose_label_replay_resize(const uint8_t* hm_host, int h, int w, int J, int orig_h, int orig_w,
+                                 int crop_y, int crop_x, int crop_h, int crop_w, int flip,
+                                 int out_side, float eps, float* out_host);
+
+/* ------------------------------------------------------------------------------------------
+ * Video frame pooling of per-frame logits, nets_factory.py:354-374.  logits f32 [B*F, K] (F
+ * consecutive rows per video) -> pooled f32 [B, K].
+ *   w == NULL : pooled = mean over the F frames                                   (:374)
+ *   w != NULL : temporal attention (cfg.NET.USE_TEMPORAL_ATT, :362-372): tatt[b,f] =
+ *               logits[b,f,:] . w + b[0]; pooled = mean_f(logits * tatt); tatt f32 [B*F] is an
+ *               output (end_points['TemporalAttention']) and is needed by the backward call.
+ * Backward: dpooled [B,K] -> dlogits [B*F,K], dw [K], db [1]; dlda_ws: B*F floats of scratch. */
+int apa_frame_pool_fwd(const float* logits, const float* w, const float* b, float* pooled, float* tatt,
+                       int B, int F, int K, void* stream);
+int apa_frame_pool_bwd(const float* logits, const float* w, const float* tatt, const float* dpooled,
+                       float* dlogits, float* dw, float* db, float* dlda_ws, int B, int F, int K,
+                       void* stream);
+
 /* zero_out_channels.cc:18-51:  out[n,h,w,c] = channels[c] ? in[n,h,w,c] : 0   (f32, device). */
 int apa_zero_out_channels(const float* in, const uint8_t* channels, float* out, size_t n_outer,
                           int C, void* stream);

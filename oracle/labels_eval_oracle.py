@@ -131,6 +131,45 @@ def pose_to_heatmap_py_wrapper(*args, **kwargs):
     return (hm * np.float32(255.0)).astype(np.uint8), valid
 
 
+def replay_normalise_resize(hm_u8: np.ndarray, orig_hw, crop_info, whether_flip: bool,
+                            out_side: int, eps: float = 1e-14) -> np.ndarray:
+    """src/preprocess_pipeline.py:21-45 (_replay_augmentation) followed by :195-214.
+
+    hm_u8 uint8 [h,w,J]; crop_info = [offset_y, offset_x, crop_h, crop_w] in the coordinates of
+    the orig_hw image (aug_info['image_shape']).  float32 arithmetic like TF:
+      ratio = H_size / orig_size; start = to_int32(crop[:2]*ratio); size = to_int32(crop[2:]*ratio)
+      slice, optional flip_left_right, convert_image_dtype (x * (1/255)),
+      x -= min(x); x /= (max(x) + EPS); legacy bilinear resize to [out_side, out_side].
+    """
+    h, w, J = hm_u8.shape
+    ratio_x = np.float32(w) / np.float32(orig_hw[1])
+    ratio_y = np.float32(h) / np.float32(orig_hw[0])
+    y0 = int(np.float32(crop_info[0]) * ratio_y)
+    x0 = int(np.float32(crop_info[1]) * ratio_x)
+    ch = int(np.float32(crop_info[2]) * ratio_y)
+    cw = int(np.float32(crop_info[3]) * ratio_x)
+    img = hm_u8[y0:y0 + ch, x0:x0 + cw, :]
+    assert img.shape[:2] == (ch, cw), 'tf.slice out of range'
+    if whether_flip:
+        img = img[:, ::-1, :]
+    img = img.astype(np.float32) * np.float32(1.0 / 255.0)
+    img = img - img.min()
+    img = img / (img.max() + np.float32(eps))
+    out = np.zeros((out_side, out_side, J), dtype=np.float32)
+    sy = np.float32(ch) / np.float32(out_side)
+    sx = np.float32(cw) / np.float32(out_side)
+    for oy in range(out_side):
+        fy = np.float32(oy) * sy
+        ylo = int(np.floor(fy)); yhi = min(ylo + 1, ch - 1); wy = fy - np.float32(ylo)
+        for ox in range(out_side):
+            fx = np.float32(ox) * sx
+            xlo = int(np.floor(fx)); xhi = min(xlo + 1, cw - 1); wx = fx - np.float32(xlo)
+            top = img[ylo, xlo] + (img[ylo, xhi] - img[ylo, xlo]) * wx
+            bot = img[yhi, xlo] + (img[yhi, xhi] - img[yhi, xlo]) * wx
+            out[oy, ox] = top + (bot - top) * wy
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # mAP -- src/eval/utils.py:4-16, src/eval/cap_eval_utils.py:55-109
 # --------------------------------------------------------------------------------------

@@ -134,6 +134,30 @@ def test_filled_circle_midpoint_rule_properties():
     assert img[:, 8:].sum() == 0
 
 
+@pytest.mark.parametrize('seed', range(5))
+def test_label_replay_normalise_resize_matches_oracle(seed):
+    """crop/flip replay + /255 + min-max normalise + TF1 legacy bilinear resize to 15x15
+    (preprocess_pipeline.py:21-45,195-214) on the training-call heat-map geometry."""
+    rng = np.random.RandomState(100 + seed)
+    im_ht, im_wd = int(rng.randint(300, 520)), int(rng.randint(300, 520))
+    pose = rng.randint(0, min(im_ht, im_wd), size=(16 * 3 * 2,))
+    pose[rng.rand(pose.size) < 0.15] = -1
+    hm_u8, _ = cof.pose_to_heatmap(pose, im_ht, im_wd, 200, out_channels=16, marker_wd_ratio=0.05,
+                                   do_gauss_blur=False)
+    # the image was resized (short side 480) and a 450x450 crop taken from it
+    scale = 480.0 / min(im_ht, im_wd)
+    rs_h, rs_w = int(im_ht * scale), int(im_wd * scale)
+    cy, cx = int(rng.randint(0, rs_h - 450 + 1)), int(rng.randint(0, rs_w - 450 + 1))
+    flip = bool(seed % 2)
+    want = leo.replay_normalise_resize(hm_u8, (rs_h, rs_w), [cy, cx, 450, 450], flip, 15)
+    got = cof.pose_label_replay_resize(hm_u8, (rs_h, rs_w), [cy, cx, 450, 450], flip, 15)
+    assert got.shape == (15, 15, 16) and got.dtype == np.float32
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-7)
+    assert got.min() >= 0.0 and got.max() <= 1.0 + 1e-6
+    with pytest.raises(cof.ApaError, match='outside'):
+        cof.pose_label_replay_resize(hm_u8, (rs_h, rs_w), [rs_h, rs_w, 450, 450], flip, 15)
+
+
 # ------------------------------------------------------------------------------------------ mAP
 def test_compute_map_matches_oracle_and_golden():
     d = np.load(os.path.join(GOLD, 'labels_eval.npz'))

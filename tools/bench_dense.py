@@ -1,0 +1,115 @@
+#!/usr/bin/env python
+"""Supplementary measurements for the MFMA-bound rows of SURVEY.md section 8 (NOT the headline
+bench -- that is /bench.py on the cfg 002 workload):
+
+  cfg003    pose-regularised attention, bf16 (BASELINE configs[2]): PoseLogits head fwd (X.W1+relu,
+            Ppre.W2) -> attention from pose_pre_logits -> pose L2 + softmax-xent -> backward of
+            both heads.  Dense work: 1.864 GFLOP/img in the pose head.
+  perclass  per-class bottom-up maps (M == K), HMDB-51 shape (K = 51, bf16) or K = 393:
+            1.893 GFLOP/img at K = 393, 0.246 at K = 51.
+
+Prints one JSON line per workload with images/sec and the achieved TFLOP/s of the whole step
+against the dense bf16 MFMA peak (2.5 PFLOP/s) / the fp32 MFMA peak (157.3 TFLOP/s).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof  # noqa: E402
+
+PEAK = {'bf16': 2500.0, 'f32': 157.3}  # TFLOP/s, dense (MI355X_MICROARCH.md)
+
+
+def timed(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--workload', default='cfg003', choices=['cfg003', 'perclass'])
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--hw', type=int, default=14)
+    ap.add_argument('--classes', type=int, default=None)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    args = ap.parse_args()
+    dev = torch.device('cuda:0')
+    N, H, C, Cp, J = args.batch, args.hw, 2048, 768, 16
+    P = H * H
+    td = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    g = torch.Generator().manual_seed(42)
+    X = torch.relu(torch.randn(N, P, C, generator=g)).to(td).to(dev)
+
+    if args.workload == 'cfg003':
+        K = args.classes or 393
+        W1 = (torch.randn(C, Cp, generator=g) / C ** 0.5).to(dev); b1 = torch.zeros(Cp, device=dev)
+        W2 = (torch.randn(Cp, J, generator=g) / Cp ** 0.5).to(dev); b2 = torch.zeros(J, device=dev)
+        Wa = (torch.randn(Cp, 1, generator=g) / Cp ** 0.5).to(dev); ba = torch.zeros(1, device=dev)
+        Wt = (torch.randn(C, K, generator=g) / C ** 0.5).to(dev); bt = torch.zeros(K, device=dev)
+        labels = torch.randint(0, K, (N,), generator=g).to(dev)
+        lbl = torch.rand(N, P, J, generator=g).to(dev)
+        valid = (torch.rand(N, J, generator=g) > 0.3).to(dev)
+        flags = cof.attn_flags(False, False, True)
+        ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+        pws = aws = None
+
+        def step():
+            nonlocal pws, aws
+            Ppre, Pl, pws = cof.pose_head_fwd(X, W1, b1, W2, b2, workspace=pws)
+            logits, att, zs, ab, _, aws = cof.attn_pool_fwd(X, Ppre, Wa, ba, Wt, bt, flags=flags, keep_prob=0.2,
+                                                           seed=42, offset=ctr, workspace=aws)
+            _, G, _, _ = cof.softmax_xent_fwd_bwd(logits, labels)
+            _, dPl = cof.pose_l2_loss_fwd_bwd(Pl, lbl, valid)
+            dX, dXatt, *_ = cof.attn_pool_bwd(X, Ppre, Wa, ba, Wt, bt, att, zs, ab, G, flags=flags, keep_prob=0.2,
+                                              seed=42, offset=ctr, workspace=aws)
+            cof.pose_head_bwd(X, W1, W2, Ppre, dPl, dXatt, dX=dX, accumulate_dX=True, workspace=pws)
+
+        flops_img = 3 * (2.0 * P * C * Cp + 2.0 * P * Cp * J)          # fwd + 2x bwd
+        name = 'cfg003 pose-regularised attention head fwd+bwd (pose head 2048->768->16 + M=1 pooling)'
+    else:
+        K = args.classes or 51
+        Wa = (torch.randn(C, K, generator=g) / C ** 0.5).to(dev); ba = torch.zeros(K, device=dev)
+        Wt = (torch.randn(C, K, generator=g) / C ** 0.5).to(dev); bt = torch.zeros(K, device=dev)
+        labels = torch.randint(0, K, (N,), generator=g).to(dev)
+        flags = cof.attn_flags(False, False, True)
+        ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+        ws = None
+
+        def step():
+            nonlocal ws
+            logits, att, Ts, _, _, ws = cof.attn_pool_fwd(X, X, Wa, ba, Wt, bt, flags=flags, keep_prob=0.2,
+                                                          seed=42, offset=ctr, workspace=ws)
+            _, G, _, _ = cof.softmax_xent_fwd_bwd(logits, labels)
+            cof.attn_pool_bwd(X, X, Wa, ba, Wt, bt, att, Ts, None, G, flags=flags, keep_prob=0.2,
+                              seed=42, offset=ctr, workspace=ws)
+
+        flops_img = 3 * (2 * 2.0 * P * C * K)                           # Z and T products, fwd + 2x bwd
+        name = 'per-class bottom-up maps (M=K) attention head fwd+bwd'
+
+    sec = timed(step, args.steps, args.warmup)
+    tflops = N * flops_img / sec / 1e12
+    print(json.dumps({
+        'workload': '{}; per-GPU batch {} x {}x{}x{} {}, K={}'.format(name, N, H, H, C, args.dtype, K),
+        'images_per_sec': round(N / sec, 1), 'ms_per_step': round(sec * 1e3, 4),
+        'roofline': {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': PEAK[args.dtype],
+                     'unit': 'TFLOP/s', 'frac': round(tflops / PEAK[args.dtype], 4),
+                     'algorithmic_gflop_per_image': round(flops_img / 1e9, 3),
+                     'note': 'whole step (all kernels) against the dense MFMA peak'}}))
+
+
+if __name__ == '__main__':
+    main()
