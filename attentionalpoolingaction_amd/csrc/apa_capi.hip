@@ -27,9 +27,17 @@ void prof_kernel_events(hipEvent_t* start, hipEvent_t* stop) {
   *stop = g_prof_stop;
 }
 
+#ifdef APA_ABLATION
+int g_dbg_skip = [] { const char* e = getenv("APA_DBG_SKIP"); return e ? atoi(e) : 0; }();
+#endif
+
 }  // namespace apa
 
 using namespace apa;
+
+#ifdef APA_ABLATION
+extern "C" void apa_debug_set_skip(int mask) { apa::g_dbg_skip = mask; }
+#endif
 
 extern "C" int apa_prof_event_create(void** event) {
   if (!event) { set_error("apa_prof_event_create: null"); return APA_ERR_INVALID_ARG; }

@@ -57,6 +57,17 @@ __device__ __forceinline__ float wave_max(float v) {
   return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
+// Minimum of an int over the 64 lanes (wave-uniform result).
+__device__ __forceinline__ int wave_min_i(int v) {
+  v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0xB1, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x4E, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x141, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x140, 0xf, 0xf, false));
+  const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+  const int r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+  return min(min(r0, r1), min(r2, r3));
+}
+
 // ---------------------------------------------------------------------------------------------
 // bf16 <-> f32 (round-to-nearest-even, NaN preserved) on raw bit patterns.
 // ---------------------------------------------------------------------------------------------

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/apa.h"
 
@@ -26,6 +27,15 @@ int hip_fail(hipError_t e, const char* what);
 
 // Optional per-thread event pair recorded around the dominant kernel (apa_prof_set_kernel_events).
 void prof_kernel_events(hipEvent_t* start, hipEvent_t* stop);
+
+// Ablation hook for profiling experiments only (make ABLATE=1): a bit mask of kernels NOT to launch
+// (results are then wrong by construction).  Compiled out of the product build.
+#ifdef APA_ABLATION
+extern int g_dbg_skip;
+inline int dbg_skip() { return g_dbg_skip; }
+#else
+constexpr int dbg_skip() { return 0; }
+#endif
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -102,6 +112,23 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
                 float* dbt, void* ws, int N, int P, int C, int Ca, int K, unsigned flags,
                 float keep_prob, uint64_t seed, uint64_t offset, int dtype, hipStream_t stream);
 bool m1_supported(int C, int Ca, int dtype, bool fused);
+
+// apa_m1_stream.hip: "pixel tile x channel split" streaming passes for wide maps
+struct M1Rng {
+  float inv_keep;
+  uint32_t thresh;
+  uint64_t seed, offset;
+  const uint64_t* offset_dev;
+};
+bool m1s_supported(int C, int dtype);
+int m1s_launch_pool_fwd(int dtype, int C, bool fused, bool train, int nblk, hipStream_t st,
+                        const void* X, const float* Wa, const float* ba, float* att, float* pacc,
+                        float* pstat, int P, int S, int act, const M1Rng& r);
+int m1s_launch_bwd_main(int dtype, int C, bool fused, bool train, int nblk, hipStream_t st,
+                        const void* X, const float* Wa, const float* att, const float* dz,
+                        const float* zsave, const float* abar, const float* G, const float* bt,
+                        const float* sn_pre, void* dX, float* dZout, float* pdwa, float* pdba,
+                        int P, int S, int K, int act, const M1Rng& r);
 
 // apa_m1_small.hip: LDS-tiled f32-MFMA kernels for the small products of the M == 1 path
 bool m1_small_supported(int C, int K);

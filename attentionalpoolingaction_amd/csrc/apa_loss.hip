@@ -10,12 +10,15 @@
 
 namespace apa {
 
-// One wave per row (rows strided over all waves of the grid).  The row lives in registers
-// (NV values per lane, K <= 64*NV): one coalesced read, max / sum-exp by DPP wave reductions, one
-// write of G / probs.  out_loss[1+n] = xent_n (unweighted); out_loss[0] = lscale * sum_n xent_n
-// is written here when the grid is a single block (N <= 64: latency matters more than width) and
-// by sum_scale_kernel otherwise.  NV == 0 selects the streaming variant for very wide rows.
-template <int NV>
+// One wave per row (rows strided over all waves of the grid), R rows per wave per iteration.
+// A global round trip costs ~1.5-2 us on this part and the kernel is a pure latency chain, so
+// every load a wave will need (labels, R whole rows) is issued before anything is consumed; the
+// rows then live in registers (NV values per lane, K <= 64*NV): max / sum-exp by DPP wave
+// reductions, one write of G / probs.  out_loss[1+n] = xent_n (unweighted); out_loss[0] =
+// lscale * sum_n xent_n is written here when the grid is a single block (N <= 64: latency matters
+// more than width) and by sum_scale_kernel otherwise.  NV == 0 selects the streaming variant for
+// very wide rows.
+template <int NV, int R>
 __global__ __launch_bounds__(1024) void softmax_xent_kernel(
     const float* __restrict__ logits, const int64_t* __restrict__ labels,
     float* __restrict__ out_loss, float* __restrict__ G, float* __restrict__ probs,
@@ -26,64 +29,82 @@ __global__ __launch_bounds__(1024) void softmax_xent_kernel(
   const int wid = blockIdx.x * wpb + (threadIdx.x >> 6);
   const int nw = gridDim.x * wpb;
   float wave_loss = 0.f;
-  for (int n = wid; n < N; n += nw) {
-    const float* row = logits + (size_t)n * K;
-    const int lab = (int)labels[n];
-    float v[NV > 0 ? NV : 1];
-    float m = -INFINITY;
-    int arg = 0x7fffffff;
+  for (int n0 = wid; n0 < N; n0 += nw * R) {
+    int lab[R];
+    float v[R][NV > 0 ? NV : 1];
     if (NV > 0) {
 #pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const int k = lane + 64 * i;
-        v[i] = k < K ? row[k] : -INFINITY;
-      }
+      for (int q = 0; q < R; ++q) {
+        const int n = min(n0 + q * nw, N - 1);   // surplus slots re-read the last row
+        lab[q] = (int)labels[n];
+        const float* row = logits + (size_t)n * K;
 #pragma unroll
-      for (int i = 0; i < NV; ++i)
-        if (v[i] > m) { m = v[i]; arg = lane + 64 * i; }   // first maximal index of this lane
-    } else {
-      for (int k = lane; k < K; k += 64) {
-        const float x = row[k];
-        if (x > m) { m = x; arg = k; }
-      }
-    }
-    const float mw = wave_max(m);
-    // argmax: smallest index among the lanes holding the max (np / tf argmax tie rule: first)
-    int cand = (m == mw) ? arg : 0x7fffffff;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) cand = min(cand, __shfl_xor(cand, off));
-    float l = 0.f;
-    if (NV > 0) {
-#pragma unroll
-      for (int i = 0; i < NV; ++i) { v[i] = expf(v[i] - mw); l += v[i]; }   // exp(-inf) = 0 pads
-    } else {
-      for (int k = lane; k < K; k += 64) l += expf(row[k] - mw);
-    }
-    l = wave_sum(l);
-    const float logl = logf(l);
-    const float inv = 1.0f / l;
-    if (NV > 0) {
-#pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const int k = lane + 64 * i;
-        if (k < K) {
-          const float p = v[i] * inv;
-          if (probs) probs[(size_t)n * K + k] = p;
-          if (G) G[(size_t)n * K + k] = (p - (k == lab ? 1.0f : 0.0f)) * gscale;
+        for (int i = 0; i < NV; ++i) {
+          const int k = lane + 64 * i;
+          v[q][i] = k < K ? row[k] : -INFINITY;
         }
       }
-    } else {
-      for (int k = lane; k < K; k += 64) {
-        const float p = expf(row[k] - mw) * inv;
-        if (probs) probs[(size_t)n * K + k] = p;
-        if (G) G[(size_t)n * K + k] = (p - (k == lab ? 1.0f : 0.0f)) * gscale;
-      }
     }
-    const float lv = (lab >= 0 && lab < K) ? -(row[lab] - mw - logl) : 0.f;
-    wave_loss += lv;   // rows of one wave are summed in increasing n
-    if (lane == 0) {
-      out_loss[1 + n] = lv;
-      if (pred) pred[n] = cand;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const int n = n0 + q * nw;
+      if (n >= N) break;
+      const float* row = logits + (size_t)n * K;
+      if (NV == 0) lab[q] = (int)labels[n];
+      float m = -INFINITY;
+      int arg = 0x7fffffff;
+      float xl = 0.f;   // logit of the label (held by exactly one lane)
+      if (NV > 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const int k = lane + 64 * i;
+          if (v[q][i] > m) { m = v[q][i]; arg = k; }   // first maximal index of this lane
+          if (k == lab[q]) xl = v[q][i];
+        }
+      } else {
+        for (int k = lane; k < K; k += 64) {
+          const float x = row[k];
+          if (x > m) { m = x; arg = k; }
+          if (k == lab[q]) xl = x;
+        }
+      }
+      const float mw = wave_max(m);
+      // argmax: smallest index among the lanes holding the max (np / tf argmax tie rule: first)
+      const int cand = wave_min_i((m == mw) ? arg : 0x7fffffff);
+      xl = wave_sum(xl);   // one non-zero term: exact
+      float l = 0.f;
+      if (NV > 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { v[q][i] = expf(v[q][i] - mw); l += v[q][i]; }   // exp(-inf) = 0 pads
+      } else {
+        for (int k = lane; k < K; k += 64) l += expf(row[k] - mw);
+      }
+      l = wave_sum(l);
+      const float logl = logf(l);
+      const float inv = 1.0f / l;
+      if (NV > 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const int k = lane + 64 * i;
+          if (k < K) {
+            const float p = v[q][i] * inv;
+            if (probs) probs[(size_t)n * K + k] = p;
+            if (G) G[(size_t)n * K + k] = (p - (k == lab[q] ? 1.0f : 0.0f)) * gscale;
+          }
+        }
+      } else {
+        for (int k = lane; k < K; k += 64) {
+          const float p = expf(row[k] - mw) * inv;
+          if (probs) probs[(size_t)n * K + k] = p;
+          if (G) G[(size_t)n * K + k] = (p - (k == lab[q] ? 1.0f : 0.0f)) * gscale;
+        }
+      }
+      const float lv = (lab[q] >= 0 && lab[q] < K) ? -(xl - mw - logl) : 0.f;
+      wave_loss += lv;   // rows of one wave are summed in increasing n
+      if (lane == 0) {
+        out_loss[1 + n] = lv;
+        if (pred) pred[n] = cand;
+      }
     }
   }
   if (single_block) {
@@ -172,14 +193,17 @@ extern "C" int apa_softmax_xent_fwd_bwd(const float* logits, const int64_t* labe
   const int single = N <= 64 ? 1 : 0;
   int nb = single ? 1 : (N + 15) / 16;
   if (nb > 1024) nb = 1024;
-#define APA_XENT(NV)                                                                               \
-  hipLaunchKernelGGL(softmax_xent_kernel<NV>, dim3(nb), dim3(1024), 0, st, logits, labels, loss, G, \
-                     probs, pred, N, K, gscale, lscale, single)
-  if (K <= 64) APA_XENT(1);
-  else if (K <= 128) APA_XENT(2);
-  else if (K <= 256) APA_XENT(4);
-  else if (K <= 512) APA_XENT(8);
-  else APA_XENT(0);
+#define APA_XENT(NV, R)                                                                           \
+  hipLaunchKernelGGL((softmax_xent_kernel<NV, R>), dim3(nb), dim3(1024), 0, st, logits, labels,   \
+                     loss, G, probs, pred, N, K, gscale, lscale, single)
+  if (dbg_skip() & 16) return APA_OK;
+  // single block, N in (16, 64]: a wave owns 2..4 rows -- fetch them together (one round trip)
+  const bool multi = single && N > 16;
+  if (K <= 64) { if (multi) APA_XENT(1, 4); else APA_XENT(1, 1); }
+  else if (K <= 128) { if (multi) APA_XENT(2, 4); else APA_XENT(2, 1); }
+  else if (K <= 256) { if (multi) APA_XENT(4, 4); else APA_XENT(4, 1); }
+  else if (K <= 512) { if (multi) APA_XENT(8, 2); else APA_XENT(8, 1); }
+  else APA_XENT(0, 1);
 #undef APA_XENT
   APA_LAUNCH_CHECK("softmax_xent_kernel");
   if (!single) {

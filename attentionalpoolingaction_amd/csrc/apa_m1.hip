@@ -208,6 +208,15 @@ __global__ __launch_bounds__(256) void m1_finalize_fwd_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float invP = 1.0f / (float)P;
   const float* st = pstat + (size_t)n * S * 4;
+  // Latency chain: every load is issued before anything is consumed -- the first 16 partial rows
+  // (all of them at the benchmark batch) and the per-split statistics travel together.
+  constexpr int FB = 16;
+  const int v = blockIdx.y * 256 + threadIdx.x;
+  const float* pa = pacc + (size_t)n * S * C + (v * 4 < C ? v * 4 : 0);
+  float4 first[FB];
+#pragma unroll
+  for (int u = 0; u < FB; ++u)
+    first[u] = *reinterpret_cast<const float4*>(pa + (size_t)min(u, S - 1) * C);
   // one split per thread: no serial dependent-load chain
   float m_s = -INFINITY, l_s = 0.f, a_s = 0.f;
   if ((int)threadIdx.x < S) {
@@ -235,27 +244,27 @@ __global__ __launch_bounds__(256) void m1_finalize_fwd_kernel(
     asum = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
   }
   __syncthreads();
-  const int v = blockIdx.y * 256 + threadIdx.x;
   if (v * 4 < C) {
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* pa = pacc + (size_t)n * S * C + v * 4;
-    int s = 0;
-    for (; s + 4 <= S; s += 4) {   // 4 independent 16-byte loads in flight
-      float4 a[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float4*>(pa + (size_t)(s + u) * C);
+    for (int u = 0; u < FB; ++u) {
+      if (u < S) {
+        const float w = s_w[u];
+        r.x = fmaf(first[u].x, w, r.x); r.y = fmaf(first[u].y, w, r.y);
+        r.z = fmaf(first[u].z, w, r.z); r.w = fmaf(first[u].w, w, r.w);
+      }
+    }
+    for (int s0 = FB; s0 < S; s0 += FB) {   // S > 16 (small batches): further rounds of 16
+      float4 a[FB];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float w = s_w[s + u];
+      for (int u = 0; u < FB; ++u)
+        a[u] = *reinterpret_cast<const float4*>(pa + (size_t)min(s0 + u, S - 1) * C);
+#pragma unroll
+      for (int u = 0; u < FB; ++u) {
+        const float w = s0 + u < S ? s_w[s0 + u] : 0.f;
         r.x = fmaf(a[u].x, w, r.x); r.y = fmaf(a[u].y, w, r.y);
         r.z = fmaf(a[u].z, w, r.z); r.w = fmaf(a[u].w, w, r.w);
       }
-    }
-    for (; s < S; ++s) {
-      const float w = s_w[s];
-      const float4 a = *reinterpret_cast<const float4*>(pa + (size_t)s * C);
-      r.x = fmaf(a.x, w, r.x); r.y = fmaf(a.y, w, r.y);
-      r.z = fmaf(a.z, w, r.z); r.w = fmaf(a.w, w, r.w);
     }
     *reinterpret_cast<float4*>(z + (size_t)n * C + v * 4) = r;
   }
@@ -632,12 +641,14 @@ M1Plan m1_plan(int N, int P, int C, int Ca, int K) {
   return pl;
 }
 
-struct RngArgs {
-  float inv_keep;
-  uint32_t thresh;
-  uint64_t seed, offset;
-  const uint64_t* offset_dev;
-};
+typedef M1Rng RngArgs;
+
+// The channel-split streaming kernels (apa_m1_stream.hip) serve wide maps; APA_M1_STREAM=0 forces
+// the per-pixel kernels of this file (A/B experiments).
+static bool use_stream_kernels(int C, int dtype) {
+  static const int enabled = env_int("APA_M1_STREAM", 1);
+  return enabled && m1s_supported(C, dtype);
+}
 
 template <typename T, int VEC>
 static int launch_pool_fwd(bool fused, bool train, int nblk, hipStream_t st, const void* X,
@@ -744,10 +755,17 @@ int m1_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
     }
     pool_act = ACT_ID;  // att already final
   }
-  int rc = APA_DISPATCH_VEC(launch_pool_fwd, dtype, C, fused, train, pl.nblk, st, X, Wa, ba, att,
-                            pacc, pstat, P, pl.S, pool_act, r);
+  int rc = APA_OK;
+  if (dbg_skip() & 1) {}
+  else if (use_stream_kernels(C, dtype))
+    rc = m1s_launch_pool_fwd(dtype, C, fused, train, pl.nblk, st, X, Wa, ba, att, pacc, pstat, P,
+                             pl.S, pool_act, r);
+  else
+    rc = APA_DISPATCH_VEC(launch_pool_fwd, dtype, C, fused, train, pl.nblk, st, X, Wa, ba, att,
+                          pacc, pstat, P, pl.S, pool_act, r);
   if (rc != APA_OK) return rc;
   const int online = (fused && act == ACT_SOFTMAX) ? 1 : 0;
+  if (!(dbg_skip() & 2))
   hipLaunchKernelGGL(m1_finalize_fwd_kernel, dim3(N, (C + 1023) / 1024), dim3(256), 0, st, pacc,
                      pstat, zsave, abar, att, P, pl.S, C, online);
   APA_LAUNCH_CHECK("m1_finalize_fwd_kernel");
@@ -781,7 +799,8 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
                         ((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(Wt) |
                           reinterpret_cast<uintptr_t>(zsave)) & 15) == 0;
   int rc;
-  if (small_ok) {
+  if (dbg_skip() & 32) { rc = APA_OK; }
+  else if (small_ok) {
     // dz = G . Wt^T, dWt = z^T . G, dbt = abar^T G in one launch
     rc = m1_bwd_small(G, Wt, zsave, abar, bt, dz, dWt, dbt, sn_buf, N, C, K, st);
     if (rc != APA_OK) return rc;
@@ -796,9 +815,15 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   prof_kernel_events(&ev0, &ev1);
   if (ev0) APA_HIP_CHECK(hipEventRecord(ev0, st));
-  rc = APA_DISPATCH_VEC(launch_bwd_main, dtype, C, fused, train, pl.nblk, st, X, Wa, att, dz,
-                        zsave, abar, G, bt, small_ok ? sn_buf : nullptr, dX, dZatt, pdwa, pdba, P,
-                        pl.S, K, act, r);
+  if (dbg_skip() & 64) {}
+  else if (use_stream_kernels(C, dtype))
+    rc = m1s_launch_bwd_main(dtype, C, fused, train, pl.nblk, st, X, Wa, att, dz, zsave, abar, G,
+                             bt, small_ok ? sn_buf : nullptr, dX, dZatt, pdwa, pdba, P, pl.S, K,
+                             act, r);
+  else
+    rc = APA_DISPATCH_VEC(launch_bwd_main, dtype, C, fused, train, pl.nblk, st, X, Wa, att, dz,
+                          zsave, abar, G, bt, small_ok ? sn_buf : nullptr, dX, dZatt, pdwa, pdba,
+                          P, pl.S, K, act, r);
   if (rc != APA_OK) return rc;
   if (ev1) APA_HIP_CHECK(hipEventRecord(ev1, st));
 
@@ -826,6 +851,7 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
   uint64_t* bump = (train && (flags & APA_FLAG_RNG_DEVICE))
                        ? reinterpret_cast<uint64_t*>(static_cast<uintptr_t>(offset))
                        : nullptr;
+  if (dbg_skip() & 128) return APA_OK;
   if (small_ok) return m1_colsum(pdwa, pdba, dWa, dba, nred, cred, cred, bump, st);
   hipLaunchKernelGGL(m1_bwd_reduce_kernel, dim3((cred + 63) / 64 + 1), dim3(256), 0, st, pdwa, pdba,
                      dWa, dba, abar, G, dbt, nred, cred, N, K, 1, bump);

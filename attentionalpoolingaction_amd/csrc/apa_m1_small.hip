@@ -309,7 +309,14 @@ __global__ __launch_bounds__(1024) void m1_colsum_kernel(const float* __restrict
   float acc = 0.f;
   if (c < C) {
     int b = rg;
-    for (; b + 224 < nblk; b += 256) {  // 8 independent loads in flight
+    for (; b + 480 < nblk; b += 512) {  // 16 independent loads in flight (one round trip at 512 rows)
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = pdwa[(size_t)(b + 32 * u) * ld + c];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc += v[u];
+    }
+    for (; b + 224 < nblk; b += 256) {
       float v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) v[u] = pdwa[(size_t)(b + 32 * u) * ld + c];
@@ -357,8 +364,10 @@ bool m1_small_supported(int C, int K) {
 int m1_logits(const float* z, const float* Wt, const float* abar, const float* bt, float* logits,
               float* part_ws, int N, int C, int K, hipStream_t st) {
   dim3 grid((K + 31) / 32, C / 128, (N + 31) / 32);
+  if (!(dbg_skip() & 4))
   hipLaunchKernelGGL(m1_logits_partial_kernel, grid, dim3(256), 0, st, z, Wt, part_ws, N, C, K);
   APA_LAUNCH_CHECK("m1_logits_partial_kernel");
+  if (!(dbg_skip() & 8))
   hipLaunchKernelGGL(m1_logits_reduce_kernel, dim3((N * K + 255) / 256), dim3(256), 0, st, part_ws,
                      abar, bt, logits, N, K, C / 128);
   APA_LAUNCH_CHECK("m1_logits_reduce_kernel");

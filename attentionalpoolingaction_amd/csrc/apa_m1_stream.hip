@@ -1,0 +1,558 @@
+// apa_m1_stream.hip -- the two HBM-bound streaming passes of the factorised (M == 1) head for
+// wide feature maps (C >= 1024 fp32 / 2048 bf16), "pixel tile x channel split" shape.
+//
+// Reference semantics: models/slim/nets/nets_factory.py:247-328 (see include/apa.h and the
+// closed forms at the top of apa_m1.hip).
+//
+// Work decomposition.  Block (n, s) owns a contiguous run of pixels of image n, processed in
+// chunks of at most PIX (<= 16) pixels.  Inside a block the four waves split the CHANNELS, not
+// the pixels: wave w owns channels [w*C/4, (w+1)*C/4) of every pixel of the chunk.
+//   * all loads of a chunk (PIX x VW 16-byte vectors per lane, up to 32 KiB per wave) are issued
+//     back to back before anything is consumed -> every CU has its whole share in flight at once;
+//   * the four waves always do the same amount of work (no 4-vs-3 pixel imbalance);
+//   * the C-long dot products (x.wa, x.dz) are finished with ONE block exchange per chunk:
+//     16-lane DPP row sums -> 1 KiB of LDS -> one barrier -> every lane holds the total of pixel
+//     (lane & 15), bit-identical in all four waves (fixed summation order);
+//   * the channel accumulators (z partials, dwa partials) are private to a wave, so they go from
+//     registers straight to the per-block partial row -- no cross-wave LDS reduction.
+// X is read once per pass and dX written once, exactly like the per-pixel kernels in apa_m1.hip
+// (which stay as the path for narrow maps).
+#include <math.h>
+
+#include "apa_device.h"
+#include "apa_internal.h"
+
+namespace apa {
+
+namespace {
+enum { S_ACT_ID = 0, S_ACT_RELU = 1, S_ACT_SOFTMAX = 2 };
+
+// Every wave passes its PIX per-lane partial dot products d[i] (pixel slot i, this wave's channel
+// share).  Returns, in lane l of every wave, the block total of slot (l & 15).
+//   sm: 256 floats, layout [wave][slot][row]; written conflict-free, read back as one float4.
+template <int PIX>
+__device__ __forceinline__ float block_dots(const float (&d)[PIX], float* sm, int wave, int lane) {
+  const int l16 = lane & 15;
+  float mine = 0.f;
+#pragma unroll
+  for (int i = 0; i < PIX; ++i) {
+    const float r = row_sum16(d[i]);
+    mine = (l16 == i) ? r : mine;
+  }
+  sm[wave * 64 + l16 * 4 + (lane >> 4)] = mine;
+  __syncthreads();
+  const float4 v = *reinterpret_cast<const float4*>(&sm[lane * 4]);
+  float s = (v.x + v.y) + (v.z + v.w);  // wave (lane >> 4)'s total of slot l16
+  s += __shfl_xor(s, 16);               // (w0 + w1) | (w2 + w3)
+  s += __shfl_xor(s, 32);               // (w0 + w1) + (w2 + w3): same bits in every row
+  return s;
+}
+
+// keep decisions of elements e, e+1 (e even) as bits 0 / 1.
+__device__ __forceinline__ uint32_t rng_keep2_bits(uint64_t e, uint32_t k0, uint32_t k1,
+                                                   uint32_t thresh) {
+  const uint64_t q = e >> 1;
+  const uint32_t h = rng_hash((uint32_t)q, k0, k1 + (uint32_t)(q >> 32) * 0x9E3779B9u);
+  return ((h & 0xffffu) < thresh ? 1u : 0u) | ((h >> 16) < thresh ? 2u : 0u);
+}
+}  // namespace
+
+// --------------------------------------------------------------------------------------------
+// Chunk helpers.  A chunk = np (<= PIX) consecutive pixels starting at q0; xr holds this wave's
+// channel share of them.  Chunks are double-buffered: the loads of chunk k+1 are in flight while
+// chunk k is consumed (and, in backward, while its dX rows are stored), so reads, VALU work and
+// writes of different chunks overlap inside one wave.
+// --------------------------------------------------------------------------------------------
+template <typename T, int VW, int PIX>
+__device__ __forceinline__ void load_chunk(uint4 (&xr)[PIX][VW], const T* __restrict__ xim, int q0,
+                                           int p_last, int C, int cbase) {
+  constexpr int EPV = Vec<T>::EPV;
+#pragma unroll
+  for (int i = 0; i < PIX; ++i) {
+    const int p = min(q0 + i, p_last);   // slots past the block's last pixel re-read that pixel
+#pragma unroll
+    for (int j = 0; j < VW; ++j) xr[i][j] = ld16(xim + (size_t)p * C + cbase + j * 64 * EPV);
+  }
+  // keep the prefetch ahead of the current chunk's arithmetic and barrier
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// Chunk ch of a block covers pixel slots q0 .. q0+PIX-1; only the first np are the block's own
+// (np < PIX on the last chunk only).  Every slot is always processed -- straight-line code, so the
+// compiler keeps exact s_waitcnt counts and the next chunk's loads stay in flight -- and the
+// surplus slots repeat the block's last pixel: their weights are zero in every accumulation and
+// their dX stores rewrite the identical bytes.
+struct ChunkRange { int q0, np; };
+template <int PIX>
+__device__ __forceinline__ ChunkRange chunk_range(int p_begin, int p_end, int ch) {
+  ChunkRange r;
+  r.q0 = p_begin + ch * PIX;
+  r.np = min(PIX, p_end - r.q0);
+  return r;
+}
+
+// --------------------------------------------------------------------------------------------
+// Forward pooling pass.  Outputs are those of m1_pool_fwd_kernel (apa_m1.hip):
+//   att (FUSED: id/relu -> final A, softmax -> raw Z, normalised by the finalize kernel),
+//   pacc[blk][C] = sum_p A*Xt over the block's pixels (softmax: relative to pstat m),
+//   pstat[blk][4] = {m, l, asum, -}.
+// --------------------------------------------------------------------------------------------
+template <typename T, int VW, int PIX, bool FUSED, bool TRAIN>
+struct FwdState {
+  static constexpr int EPV = Vec<T>::EPV;
+  static constexpr int EPL = VW * EPV;
+  float wa[FUSED ? EPL : 1];
+  float acc[EPL];
+  float bias, m_run, l_run, a_sum;
+};
+
+template <typename T, int VW, int PIX, bool FUSED, bool TRAIN>
+__device__ __forceinline__ void fwd_chunk(FwdState<T, VW, PIX, FUSED, TRAIN>& st,
+                                          const uint4 (&xr)[PIX][VW], ChunkRange cr, float* sm,
+                                          float* __restrict__ att_im, int n, int P, int C, int cbase,
+                                          int wave, int lane, int act, float inv_keep,
+                                          uint32_t thresh, uint32_t k0, uint32_t k1) {
+  constexpr int EPV = Vec<T>::EPV;
+  constexpr int EPL = VW * EPV;
+  const int l16 = lane & 15;
+  const int q0 = cr.q0, np = cr.np;
+  float av = 0.f;   // lane l16: weight of pixel slot l16
+  if (FUSED) {
+    float d[PIX];
+#pragma unroll
+    for (int i = 0; i < PIX; ++i) {
+      float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < VW; ++j) {
+        float x[EPV];
+        Vec<T>::unpack(xr[i][j], x);
+#pragma unroll
+        for (int e = 0; e < EPV; e += 2) {
+          d0 = fmaf(x[e], st.wa[j * EPV + e], d0);
+          d1 = fmaf(x[e + 1], st.wa[j * EPV + e + 1], d1);
+        }
+      }
+      d[i] = d0 + d1;
+    }
+    const float zt = block_dots<PIX>(d, sm, wave, lane) + st.bias;
+    if (act == S_ACT_SOFTMAX) {
+      const float m_chunk = row_max16(l16 < np ? zt : -INFINITY);
+      const float m_new = fmaxf(st.m_run, m_chunk);
+      const float scale = expf(st.m_run - m_new);   // exp(-inf) = 0 on the first chunk
+      av = l16 < np ? expf(zt - m_new) : 0.f;
+      st.l_run = st.l_run * scale + row_sum16(av);
+      st.m_run = m_new;
+      if (wave == 0 && lane < np) att_im[q0 + lane] = zt;   // raw logit; normalised later
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) st.acc[i] *= scale;
+    } else {
+      av = (act == S_ACT_RELU) ? fmaxf(zt, 0.f) : zt;
+      if (l16 >= np) av = 0.f;
+      if (wave == 0 && lane < np) att_im[q0 + lane] = av;
+    }
+  } else {
+    av = l16 < np ? att_im[q0 + l16] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < PIX; ++i) {
+    const float a = readlane_f(av, i);   // 0 for surplus slots
+    st.a_sum += a;
+    const float ak = TRAIN ? a * inv_keep : a;
+    const uint64_t ebase = ((uint64_t)n * P + (q0 + i)) * C + cbase;
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+      float x[EPV];
+      Vec<T>::unpack(xr[i][j], x);
+      if (TRAIN) {
+#pragma unroll
+        for (int e = 0; e < EPV; e += 2) {
+          float m0, m1;
+          rng_keep2(ebase + j * 64 * EPV + e, k0, k1, thresh, m0, m1);
+          st.acc[j * EPV + e] = fmaf(ak * m0, x[e], st.acc[j * EPV + e]);
+          st.acc[j * EPV + e + 1] = fmaf(ak * m1, x[e + 1], st.acc[j * EPV + e + 1]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) st.acc[j * EPV + e] = fmaf(ak, x[e], st.acc[j * EPV + e]);
+      }
+    }
+  }
+}
+
+template <typename T, int VW, int PIX, bool FUSED, bool TRAIN>
+__global__ __launch_bounds__(256, 2) void m1s_pool_fwd_kernel(
+    const T* __restrict__ X, const float* __restrict__ Wa, const float* __restrict__ ba,
+    float* __restrict__ att, float* __restrict__ pacc, float* __restrict__ pstat, int P, int S,
+    int act, float inv_keep, uint32_t thresh, uint64_t seed, uint64_t offset,
+    const uint64_t* __restrict__ offset_dev) {
+  constexpr int EPV = Vec<T>::EPV;
+  constexpr int EPL = VW * EPV;   // channels per lane
+  constexpr int CW = EPL * 64;    // channels per wave
+  constexpr int C = CW * 4;
+  __shared__ __attribute__((aligned(16))) float sm_x[2][256];
+  uint32_t k0 = 0, k1 = 0;
+  if (TRAIN) rng_key_dev(seed, offset_dev ? *offset_dev : offset, k0, k1);
+
+  const int blk = xcd_remap(blockIdx.x, gridDim.x);
+  const int n = blk / S, s = blk % S;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int p_begin = (int)(((long)s * P) / S);
+  const int p_end = (int)(((long)(s + 1) * P) / S);
+  const int npt = p_end - p_begin;
+  const int nchunk = (npt + PIX - 1) / PIX;
+  const int cbase = wave * CW + lane * EPV;   // + j * 64 * EPV
+
+  const T* xim = X + (size_t)n * P * C;
+  float* att_im = att + (size_t)n * P;
+
+  const int p_last = p_end - 1;
+  uint4 xa[PIX][VW], xb[PIX][VW];
+  load_chunk<T, VW, PIX>(xa, xim, p_begin, p_last, C, cbase);
+  FwdState<T, VW, PIX, FUSED, TRAIN> st;
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) st.acc[i] = 0.f;
+  st.bias = 0.f; st.m_run = -INFINITY; st.l_run = 0.f; st.a_sum = 0.f;
+  if (FUSED) {   // L2 hits, issued in the shadow of the first chunk's HBM loads
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+#pragma unroll
+      for (int e = 0; e < EPV; e += 4) {
+        const float4 w = *reinterpret_cast<const float4*>(Wa + cbase + j * 64 * EPV + e);
+        st.wa[j * EPV + e + 0] = w.x; st.wa[j * EPV + e + 1] = w.y;
+        st.wa[j * EPV + e + 2] = w.z; st.wa[j * EPV + e + 3] = w.w;
+      }
+    }
+    st.bias = ba[0];
+  }
+
+  // chunk k+1 is always fetched (clamped to the block's last pixel past the end: L1/L2 hits)
+  for (int ch = 0; ch < nchunk; ch += 2) {
+    load_chunk<T, VW, PIX>(xb, xim, p_begin + (ch + 1) * PIX, p_last, C, cbase);
+    fwd_chunk<T, VW, PIX, FUSED, TRAIN>(st, xa, chunk_range<PIX>(p_begin, p_end, ch), sm_x[0],
+                                        att_im, n, P, C, cbase, wave, lane, act, inv_keep, thresh,
+                                        k0, k1);
+    if (ch + 1 >= nchunk) break;
+    load_chunk<T, VW, PIX>(xa, xim, p_begin + (ch + 2) * PIX, p_last, C, cbase);
+    fwd_chunk<T, VW, PIX, FUSED, TRAIN>(st, xb, chunk_range<PIX>(p_begin, p_end, ch + 1), sm_x[1],
+                                        att_im, n, P, C, cbase, wave, lane, act, inv_keep, thresh,
+                                        k0, k1);
+  }
+
+  float* pa = pacc + (size_t)blk * C + cbase;
+#pragma unroll
+  for (int j = 0; j < VW; ++j) {
+#pragma unroll
+    for (int e = 0; e < EPV; e += 4) {
+      const int i = j * EPV + e;
+      *reinterpret_cast<float4*>(pa + j * 64 * EPV + e) =
+          make_float4(st.acc[i], st.acc[i + 1], st.acc[i + 2], st.acc[i + 3]);
+    }
+  }
+  if (threadIdx.x == 0) {
+    pstat[blk * 4 + 0] = (FUSED && act == S_ACT_SOFTMAX) ? st.m_run : 0.f;
+    pstat[blk * 4 + 1] = st.l_run;
+    pstat[blk * 4 + 2] = st.a_sum;
+    pstat[blk * 4 + 3] = 0.f;
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// Backward streaming pass (the dominant kernel: reads X once, writes dX once).  Same outputs as
+// m1_bwd_main_kernel (apa_m1.hip): dX, dZout (!FUSED), pdwa[blk][C], pdba[blk] (FUSED).
+// --------------------------------------------------------------------------------------------
+template <typename T, int VW, int PIX, bool FUSED, bool TRAIN>
+struct BwdState {
+  static constexpr int EPV = Vec<T>::EPV;
+  static constexpr int EPL = VW * EPV;
+  float dzr[EPL];
+  float wa[FUSED ? EPL : 1];
+  float dwa[FUSED ? EPL : 1];
+  float dba_acc, sn, corr;
+};
+
+template <typename T, int VW, int PIX, bool FUSED, bool TRAIN>
+__device__ __forceinline__ void bwd_chunk(BwdState<T, VW, PIX, FUSED, TRAIN>& st,
+                                          const uint4 (&xr)[PIX][VW], float a_l, ChunkRange cr,
+                                          float* sm, T* __restrict__ dxim,
+                                          float* __restrict__ dZout_im, int n, int P, int C,
+                                          int cbase, int wave, int lane, int act, float invP,
+                                          float inv_keep, uint32_t thresh, uint32_t k0,
+                                          uint32_t k1) {
+  constexpr int EPV = Vec<T>::EPV;
+  constexpr int EPL = VW * EPV;
+  constexpr int MBW = (PIX * EPL + 31) / 32;   // mask-bit words per lane
+  const int l16 = lane & 15;
+  const int q0 = cr.q0, np = cr.np;
+  uint32_t mb[TRAIN ? MBW : 1];
+  if (TRAIN) {
+#pragma unroll
+    for (int w = 0; w < MBW; ++w) mb[w] = 0u;
+  }
+  float d[PIX];
+#pragma unroll
+  for (int i = 0; i < PIX; ++i) {
+    const int pi = min(q0 + i, q0 + np - 1);   // surplus slots repeat the last pixel
+    const uint64_t ebase = ((uint64_t)n * P + pi) * C + cbase;
+    float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+      float x[EPV];
+      Vec<T>::unpack(xr[i][j], x);
+#pragma unroll
+      for (int e = 0; e < EPV; e += 2) {
+        const int c = j * EPV + e;
+        if (TRAIN) {
+          const uint32_t b = rng_keep2_bits(ebase + j * 64 * EPV + e, k0, k1, thresh);
+          const int bit = i * EPL + c;
+          mb[bit >> 5] |= b << (bit & 31);
+          d0 = fmaf((b & 1u) ? x[e] : 0.f, st.dzr[c], d0);
+          d1 = fmaf((b & 2u) ? x[e + 1] : 0.f, st.dzr[c + 1], d1);
+        } else {
+          d0 = fmaf(x[e], st.dzr[c], d0);
+          d1 = fmaf(x[e + 1], st.dzr[c + 1], d1);
+        }
+      }
+    }
+    d[i] = d0 + d1;
+  }
+  float tot = block_dots<PIX>(d, sm, wave, lane);
+  if (TRAIN) tot *= inv_keep;
+  const float dA = (tot + st.sn) * invP;
+  float dZl;
+  if (act == S_ACT_SOFTMAX) dZl = a_l * (dA - st.corr);
+  else if (act == S_ACT_RELU) dZl = a_l > 0.f ? dA : 0.f;
+  else dZl = dA;
+  if (!FUSED && wave == 0 && lane < np) dZout_im[q0 + lane] = dZl;
+
+#pragma unroll
+  for (int i = 0; i < PIX; ++i) {
+    // slot i >= np duplicates slot np-1: it stores the same dX row again (identical bytes) and
+    // contributes nothing to dwa / dba
+    const int src = min(i, np - 1);
+    const float dZ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dZl), src));
+    const float ap = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a_l), src)) * invP;
+    const float apk = TRAIN ? ap * inv_keep : ap;
+    const float dZa = i < np ? dZ : 0.f;
+    if (FUSED) st.dba_acc += dZa;
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+      float x[EPV], o[EPV];
+      if (FUSED) Vec<T>::unpack(xr[i][j], x);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) {
+        const int c = j * EPV + e;
+        float t = apk;
+        if (TRAIN) {
+          const int bit = i * EPL + c;
+          t = ((mb[bit >> 5] >> (bit & 31)) & 1u) ? apk : 0.f;
+        }
+        if (FUSED) {
+          o[e] = fmaf(t, st.dzr[c], dZ * st.wa[c]);
+          st.dwa[c] = fmaf(dZa, x[e], st.dwa[c]);
+        } else {
+          o[e] = t * st.dzr[c];
+        }
+      }
+      st16(dxim + (size_t)(q0 + src) * C + cbase + j * 64 * EPV, Vec<T>::pack(o));
+    }
+  }
+}
+
+template <typename T, int VW, int PIX, bool FUSED, bool TRAIN>
+__global__ __launch_bounds__(256, 2) void m1s_bwd_main_kernel(
+    const T* __restrict__ X, const float* __restrict__ Wa, const float* __restrict__ att,
+    const float* __restrict__ dz, const float* __restrict__ zsave, const float* __restrict__ abar,
+    const float* __restrict__ G, const float* __restrict__ bt, const float* __restrict__ sn_pre,
+    T* __restrict__ dX, float* __restrict__ dZout, float* __restrict__ pdwa,
+    float* __restrict__ pdba, int P, int S, int K, int act, float inv_keep, uint32_t thresh,
+    uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev) {
+  constexpr int EPV = Vec<T>::EPV;
+  constexpr int EPL = VW * EPV;
+  constexpr int CW = EPL * 64;
+  constexpr int C = CW * 4;
+  __shared__ __attribute__((aligned(16))) float sm_x[2][256];
+  __shared__ float sm_aux[4];
+  uint32_t k0 = 0, k1 = 0;
+  if (TRAIN) rng_key_dev(seed, offset_dev ? *offset_dev : offset, k0, k1);
+
+  const int blk = xcd_remap(blockIdx.x, gridDim.x);
+  const int n = blk / S, s = blk % S;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l16 = lane & 15;
+  const int p_begin = (int)(((long)s * P) / S);
+  const int p_end = (int)(((long)(s + 1) * P) / S);
+  const int npt = p_end - p_begin;
+  const int nchunk = (npt + PIX - 1) / PIX;
+  const int cbase = wave * CW + lane * EPV;
+  const float invP = 1.0f / (float)P;
+
+  const T* xim = X + (size_t)n * P * C;
+  T* dxim = dX + (size_t)n * P * C;
+  const float* att_im = att + (size_t)n * P;
+  float* dZout_im = FUSED ? nullptr : dZout + (size_t)n * P;
+
+  const int p_last = p_end - 1;
+  uint4 xa[PIX][VW], xb[PIX][VW];
+  load_chunk<T, VW, PIX>(xa, xim, p_begin, p_last, C, cbase);
+  float a_a = att_im[min(p_begin + l16, p_last)], a_b = 0.f;
+
+  // per-image constants: L2 hits issued behind the first chunk's HBM loads
+  BwdState<T, VW, PIX, FUSED, TRAIN> st;
+  st.dba_acc = 0.f; st.sn = 0.f; st.corr = 0.f;
+  {
+    float zdz = 0.f;
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+#pragma unroll
+      for (int e = 0; e < EPV; e += 4) {
+        const int i = j * EPV + e;
+        const int c = cbase + j * 64 * EPV + e;
+        const float4 dd = *reinterpret_cast<const float4*>(dz + (size_t)n * C + c);
+        st.dzr[i] = dd.x; st.dzr[i + 1] = dd.y; st.dzr[i + 2] = dd.z; st.dzr[i + 3] = dd.w;
+        if (FUSED) {
+          const float4 w = *reinterpret_cast<const float4*>(Wa + c);
+          st.wa[i] = w.x; st.wa[i + 1] = w.y; st.wa[i + 2] = w.z; st.wa[i + 3] = w.w;
+          st.dwa[i] = 0.f; st.dwa[i + 1] = 0.f; st.dwa[i + 2] = 0.f; st.dwa[i + 3] = 0.f;
+        }
+        if (act == S_ACT_SOFTMAX) {
+          const float4 zz = *reinterpret_cast<const float4*>(zsave + (size_t)n * C + c);
+          zdz = fmaf(zz.x, dd.x, zdz); zdz = fmaf(zz.y, dd.y, zdz);
+          zdz = fmaf(zz.z, dd.z, zdz); zdz = fmaf(zz.w, dd.w, zdz);
+        }
+      }
+    }
+    if (sn_pre) {
+      st.sn = sn_pre[n];
+    } else {   // G[n,:] . bt
+      float sn = 0.f;
+      for (int k = lane; k < K; k += 64) sn = fmaf(G[(size_t)n * K + k], bt[k], sn);
+      st.sn = wave_sum(sn);
+    }
+    if (act == S_ACT_SOFTMAX) {   // corr = z.dz + (G.bt) * abar, z.dz summed over the 4 waves
+      zdz = wave_sum(zdz);
+      if (lane == 0) sm_aux[wave] = zdz;
+      __syncthreads();
+      st.corr = ((sm_aux[0] + sm_aux[1]) + (sm_aux[2] + sm_aux[3])) + st.sn * abar[n];
+    }
+  }
+
+  for (int ch = 0; ch < nchunk; ch += 2) {
+    load_chunk<T, VW, PIX>(xb, xim, p_begin + (ch + 1) * PIX, p_last, C, cbase);
+    a_b = att_im[min(p_begin + (ch + 1) * PIX + l16, p_last)];
+    bwd_chunk<T, VW, PIX, FUSED, TRAIN>(st, xa, a_a, chunk_range<PIX>(p_begin, p_end, ch), sm_x[0],
+                                        dxim, dZout_im, n, P, C, cbase, wave, lane, act, invP,
+                                        inv_keep, thresh, k0, k1);
+    if (ch + 1 >= nchunk) break;
+    load_chunk<T, VW, PIX>(xa, xim, p_begin + (ch + 2) * PIX, p_last, C, cbase);
+    a_a = att_im[min(p_begin + (ch + 2) * PIX + l16, p_last)];
+    bwd_chunk<T, VW, PIX, FUSED, TRAIN>(st, xb, a_b, chunk_range<PIX>(p_begin, p_end, ch + 1),
+                                        sm_x[1], dxim, dZout_im, n, P, C, cbase, wave, lane, act,
+                                        invP, inv_keep, thresh, k0, k1);
+  }
+
+  if (FUSED) {
+    float* pa = pdwa + (size_t)blk * C + cbase;
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+#pragma unroll
+      for (int e = 0; e < EPV; e += 4) {
+        const int i = j * EPV + e;
+        *reinterpret_cast<float4*>(pa + j * 64 * EPV + e) =
+            make_float4(st.dwa[i], st.dwa[i + 1], st.dwa[i + 2], st.dwa[i + 3]);
+      }
+    }
+    if (threadIdx.x == 0) pdba[blk] = st.dba_acc;
+  }
+}
+
+// ============================================================================================
+// host side
+// ============================================================================================
+bool m1s_supported(int C, int dtype) {
+  const int epv = dtype == APA_DTYPE_BF16 ? 8 : 4;
+  if (C % (256 * epv) != 0) return false;
+  const int vw = C / (256 * epv);
+  // bf16 at C >= 4096 would spill (the unpacked chunk does not fit 256 VGPRs): per-pixel kernels
+  if (dtype == APA_DTYPE_BF16) return vw == 1;
+  return vw == 1 || vw == 2 || vw == 4;
+}
+
+static int env_pix() {
+  static const int v = [] { const char* e = getenv("APA_M1S_PIX"); return (e && *e) ? atoi(e) : 2; }();
+  return v;
+}
+
+template <typename T, int VW, int PIX>
+static int launch_fwd_t(bool fused, bool train, int nblk, hipStream_t st, const void* X,
+                        const float* Wa, const float* ba, float* att, float* pacc, float* pstat,
+                        int P, int S, int act, const M1Rng& r) {
+  const T* x = static_cast<const T*>(X);
+#define APA_GO(F, TR)                                                                            \
+  hipLaunchKernelGGL((m1s_pool_fwd_kernel<T, VW, PIX, F, TR>), dim3(nblk), dim3(256), 0, st, x,  \
+                     Wa, ba, att, pacc, pstat, P, S, act, r.inv_keep, r.thresh, r.seed,          \
+                     r.offset, r.offset_dev)
+  if (fused) { if (train) APA_GO(true, true); else APA_GO(true, false); }
+  else       { if (train) APA_GO(false, true); else APA_GO(false, false); }
+#undef APA_GO
+  APA_LAUNCH_CHECK("m1s_pool_fwd_kernel");
+  return APA_OK;
+}
+
+template <typename T, int VW, int PIX>
+static int launch_bwd_t(bool fused, bool train, int nblk, hipStream_t st, const void* X,
+                        const float* Wa, const float* att, const float* dz, const float* zsave,
+                        const float* abar, const float* G, const float* bt, const float* sn_pre,
+                        void* dX, float* dZout, float* pdwa, float* pdba, int P, int S, int K,
+                        int act, const M1Rng& r) {
+  const T* x = static_cast<const T*>(X);
+  T* dx = static_cast<T*>(dX);
+#define APA_GO(F, TR)                                                                            \
+  hipLaunchKernelGGL((m1s_bwd_main_kernel<T, VW, PIX, F, TR>), dim3(nblk), dim3(256), 0, st, x,  \
+                     Wa, att, dz, zsave, abar, G, bt, sn_pre, dx, dZout, pdwa, pdba, P, S, K,    \
+                     act, r.inv_keep, r.thresh, r.seed, r.offset, r.offset_dev)
+  if (fused) { if (train) APA_GO(true, true); else APA_GO(true, false); }
+  else       { if (train) APA_GO(false, true); else APA_GO(false, false); }
+#undef APA_GO
+  APA_LAUNCH_CHECK("m1s_bwd_main_kernel");
+  return APA_OK;
+}
+
+#define APA_S_PIX(FN, T, VW, ...)                                           \
+  switch (pix) {                                                            \
+    case 1: return FN<T, VW, 1>(__VA_ARGS__);                               \
+    case 2: return FN<T, VW, 2>(__VA_ARGS__);                               \
+    case 8: return FN<T, VW, 8>(__VA_ARGS__);                               \
+    default: return FN<T, VW, 4>(__VA_ARGS__);                              \
+  }
+#define APA_S_DISPATCH(FN, dtype, C, ...)                                   \
+  [&]() -> int {                                                            \
+    const int pix = env_pix();                                              \
+    if ((dtype) == APA_DTYPE_F32) {                                         \
+      switch ((C) / 1024) {                                                 \
+        case 1: APA_S_PIX(FN, float, 1, __VA_ARGS__)                        \
+        case 2: APA_S_PIX(FN, float, 2, __VA_ARGS__)                        \
+        case 4: return pix >= 4 ? FN<float, 4, 4>(__VA_ARGS__) : FN<float, 4, 2>(__VA_ARGS__); \
+      }                                                                     \
+    } else {                                                                \
+      if ((C) == 2048) { APA_S_PIX(FN, bf16_t, 1, __VA_ARGS__) }            \
+    }                                                                       \
+    set_error("m1 stream kernels: unsupported C=%d dtype=%d", (C), (dtype)); \
+    return APA_ERR_UNSUPPORTED;                                             \
+  }()
+
+int m1s_launch_pool_fwd(int dtype, int C, bool fused, bool train, int nblk, hipStream_t st,
+                        const void* X, const float* Wa, const float* ba, float* att, float* pacc,
+                        float* pstat, int P, int S, int act, const M1Rng& r) {
+  return APA_S_DISPATCH(launch_fwd_t, dtype, C, fused, train, nblk, st, X, Wa, ba, att, pacc,
+                        pstat, P, S, act, r);
+}
+
+int m1s_launch_bwd_main(int dtype, int C, bool fused, bool train, int nblk, hipStream_t st,
+                        const void* X, const float* Wa, const float* att, const float* dz,
+                        const float* zsave, const float* abar, const float* G, const float* bt,
+                        const float* sn_pre, void* dX, float* dZout, float* pdwa, float* pdba,
+                        int P, int S, int K, int act, const M1Rng& r) {
+  return APA_S_DISPATCH(launch_bwd_t, dtype, C, fused, train, nblk, st, X, Wa, att, dz, zsave,
+                        abar, G, bt, sn_pre, dX, dZout, pdwa, pdba, P, S, K, act, r);
+}
+
+}  // namespace apa

@@ -239,3 +239,30 @@ def test_m1_batch_and_class_tails(gpu, N, K):
     _close(got['loss'], ref['loss'], TIGHT, 'loss')
     assert torch.equal(got['pred'], ref['logits'].argmax(dim=1))
     _grads_close(got, ref, ('dX', 'dWa', 'dba', 'dWt', 'dbt'))
+
+
+@pytest.mark.parametrize('target_blocks', [4, 12, 64])
+@pytest.mark.parametrize('mode', ['id', 'softmax_dropout', 'sep_att', 'bf16', 'c1024'])
+def test_m1_stream_kernels_pixel_chunking(gpu, monkeypatch, target_blocks, mode):
+    """The channel-split streaming kernels process a block's pixels in chunks of <= 16.  Force
+    S = 1 / 3 / 16 splits per image (13 / 5 / 1 chunks per block at 14x14) and check every variant
+    against the oracle; APA_M1_STREAM=0 must give the same answer from the per-pixel kernels."""
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    monkeypatch.setenv('APA_M1_TARGET_BLOCKS', str(target_blocks))
+    C = 1024 if mode == 'c1024' else 2048
+    inp = make_head_inputs(N=4, H=14, W=14, C=C, K=51, Ca=768 if mode == 'sep_att' else None,
+                           seed=77, dtype=torch.bfloat16 if mode == 'bf16' else torch.float32)
+    softmax = mode in ('softmax_dropout', 'c1024')
+    train = mode == 'softmax_dropout'
+    keep, seed, offset = 0.5, 5, 11
+    mask = cof.dropout_mask(tuple(inp['X'].shape), keep, seed, offset).cpu() if train else None
+    flags = orc.AttnFlags(single_layer_att=(mode != 'sep_att'), softmax_att=softmax)
+    ref = _oracle(inp, flags, train=train, keep=keep, mask=mask)
+    got = _run_hip(inp, gpu, softmax=softmax, train=train, keep=keep, seed=seed, offset=offset)
+    _close(got['logits'], ref['logits'], TIGHT, 'logits')
+    _close(got['att'].reshape(ref['att'].shape), ref['att'], TIGHT, 'attention map')
+    keys = ('dWa', 'dba', 'dWt', 'dbt') + (() if mode == 'bf16' else ('dX',))
+    _grads_close(got, ref, keys + (('dXatt',) if mode == 'sep_att' else ()))
+    if mode == 'bf16':
+        err = (got['dX'].double() - ref['dX']).abs()
+        assert float((err - ref['dX'].abs() * 2 ** -8).max()) <= 1e-5 * float(ref['dX'].abs().max())
