@@ -37,6 +37,7 @@ using namespace apa;
 
 #ifdef APA_ABLATION
 extern "C" void apa_debug_set_skip(int mask) { apa::g_dbg_skip = mask; }
+
 #endif
 
 extern "C" int apa_prof_event_create(void** event) {

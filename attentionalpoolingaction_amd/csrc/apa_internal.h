@@ -31,9 +31,13 @@ void prof_kernel_events(hipEvent_t* start, hipEvent_t* stop);
 // Ablation hook for profiling experiments only (make ABLATE=1): a bit mask of kernels NOT to launch
 // (results are then wrong by construction).  Compiled out of the product build.
 #ifdef APA_ABLATION
+// in-kernel timestamps (s_memtime, shader clock): slot[blk * 8 + i]
+// (define `__device__ unsigned long long apa_dbg_ts[4096];` in the TU under test)
+#define APA_TS(i) do { if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == 0 && blockIdx.x < 512) apa_dbg_ts[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
 extern int g_dbg_skip;
 inline int dbg_skip() { return g_dbg_skip; }
 #else
+#define APA_TS(i) do {} while (0)
 constexpr int dbg_skip() { return 0; }
 #endif
 
@@ -138,6 +142,10 @@ int m1_logits(const float* z, const float* Wt, const float* abar, const float* b
 int m1_bwd_small(const float* G, const float* Wt, const float* zsave, const float* abar,
                  const float* bt, float* dz, float* dWt, float* dbt, float* sn, int N, int C, int K,
                  hipStream_t st);
+bool m1_bwd_head_supported(int N, int C, int K);
+int m1_bwd_head(const float* G, const float* Wt, const float* zsave, const float* abar,
+                const float* bt, float* dz, float* dWt, float* dbt, float* sn, int N, int C, int K,
+                hipStream_t st);
 int m1_colsum(const float* pdwa, const float* pdba, float* dwa, float* dba, int nblk, int C, int ld,
               uint64_t* rng_bump, hipStream_t st);
 

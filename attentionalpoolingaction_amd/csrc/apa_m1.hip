@@ -802,7 +802,11 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
   if (dbg_skip() & 32) { rc = APA_OK; }
   else if (small_ok) {
     // dz = G . Wt^T, dWt = z^T . G, dbt = abar^T G in one launch
-    rc = m1_bwd_small(G, Wt, zsave, abar, bt, dz, dWt, dbt, sn_buf, N, C, K, st);
+    static const int use_head = env_int("APA_M1_BWD_HEAD", 1);
+    if (use_head && m1_bwd_head_supported(N, C, K))
+      rc = m1_bwd_head(G, Wt, zsave, abar, bt, dz, dWt, dbt, sn_buf, N, C, K, st);
+    else
+      rc = m1_bwd_small(G, Wt, zsave, abar, bt, dz, dWt, dbt, sn_buf, N, C, K, st);
     if (rc != APA_OK) return rc;
   } else {
     // generic fallback (very large K): dz[n,c] = sum_k G[n,k] Wt[c,k]; dWt[c,k] = sum_n z[n,c] G[n,k]

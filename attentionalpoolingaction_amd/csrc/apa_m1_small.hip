@@ -19,6 +19,13 @@
 #include "apa_device.h"
 #include "apa_internal.h"
 
+#ifdef APA_ABLATION
+namespace apa { __device__ unsigned long long apa_dbg_ts[4096]; }
+extern "C" int apa_debug_read_ts(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(apa::apa_dbg_ts), sizeof(unsigned long long) * n);
+}
+#endif
+
 namespace apa {
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
@@ -294,6 +301,158 @@ __global__ __launch_bounds__(256) void m1_bwd_small_kernel(
 }
 
 // --------------------------------------------------------------------------------------------
+// B12v2: the small products of the backward pass, LDS-free.  Two block roles per 16-channel slab
+// (grid = 2 * C/16, role = blockIdx & 1):
+//   role 0   dz[n, c0:c0+16]  = sum_k G[n,k] Wt[c,k]      (all n)   (+ sn[n] = G[n,:].bt)
+//   role 1   dWt[c0:c0+16, :] = sum_n z[n,c] G[n,k]                  (+ dbt)
+// What these kernels cost is latency, not bytes or flops (measured with in-kernel timestamps:
+// a staged version spent 2.5 us filling LDS, then ran its MFMAs one LDS round trip at a time):
+// a launch is ~2 us, a global round trip ~1 us, the arithmetic < 1 us.  So every MFMA operand is
+// loaded STRAIGHT from global memory into the register it is consumed from, all loads of a
+// block in one batch, no LDS staging and no barrier before the MFMAs:
+//   * role 0 contracts over k.  MFMA k-order is free as long as A and B agree, so lane (r, kq)
+//     takes 4 CONSECUTIVE k of its row as one 16-byte load (rows of K = 393 floats are only
+//     4-byte aligned: gfx950 services unaligned dwordx4 global loads, tools/unaligned_test.hip)
+//     and feeds element e to MFMA step e of that 16-wide k group;
+//   * role 1 contracts over n (8 steps per 32-row tile): B fragments are 64-byte row segments
+//     of G, A fragments 64-byte segments of z.
+// G (50 KB) is re-read by every block from L2; Wt / dWt slabs are touched exactly once.
+// Everything is exact fp32 (v_mfma_f32_16x16x4_f32) with fixed summation order.
+// --------------------------------------------------------------------------------------------
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int UG>   // 16-wide k groups (role 0) / k tiles (role 1) per wave: ceil(ceil(K/16)/4)
+__global__ __launch_bounds__(256) void m1_bwd_head_kernel(
+    const float* __restrict__ G, const float* __restrict__ Wt, const float* __restrict__ zsave,
+    const float* __restrict__ abar, const float* __restrict__ bt, float* __restrict__ dz,
+    float* __restrict__ dWt, float* __restrict__ dbt, float* __restrict__ sn, int N, int C, int K,
+    int kpb) {
+  __shared__ float red[4 * 2 * 256];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, kq = lane >> 4;
+  const int role = blockIdx.x & 1, b = blockIdx.x >> 1, c0 = b * 16;
+  APA_TS(0);
+
+  if (role == 0) {
+    // ------------------------------ dz + sn ------------------------------
+    f4u bq[UG];
+    int colc[UG];
+#pragma unroll
+    for (int j = 0; j < UG; ++j) {
+      const int col0 = 16 * (wave + 4 * j) + 4 * kq;
+      colc[j] = min(col0, K - 4);   // ragged / surplus groups re-read the row's last 4 columns ...
+      f4u v = *reinterpret_cast<const f4u*>(Wt + (size_t)(c0 + r) * K + colc[j]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= (colc[j] + e >= col0) ? 1.f : 0.f;   // ... masked: each k once
+      bq[j] = v;
+    }
+    for (int n0 = 0; n0 < N; n0 += 32) {
+      const float* g0 = G + (size_t)min(n0 + r, N - 1) * K;        // rows >= N: discarded at the store
+      const float* g1 = G + (size_t)min(n0 + 16 + r, N - 1) * K;
+      f4u aq0[UG], aq1[UG];
+#pragma unroll
+      for (int j = 0; j < UG; ++j) {
+        aq0[j] = *reinterpret_cast<const f4u*>(g0 + colc[j]);
+        aq1[j] = *reinterpret_cast<const f4u*>(g1 + colc[j]);
+      }
+      // sn[n] = G[n,:] . bt for the streaming pass: block b serves row n0 + b, on wave 1
+      const bool do_sn = wave == 1 && n0 + b < N && b < 32;
+      float sacc = 0.f;
+      if (do_sn) {
+        const float* grow = G + (size_t)(n0 + b) * K;
+        for (int k = lane; k < K; k += 64) sacc = fmaf(grow[k], bt[k], sacc);
+      }
+      APA_TS(1);
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < UG; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a0 = mfma16(aq0[j][e], bq[j][e], a0);
+          a1 = mfma16(aq1[j][e], bq[j][e], a1);
+        }
+      }
+      APA_TS(2);
+      if (do_sn) {
+        sacc = wave_sum(sacc);
+        if (lane == 0) sn[n0 + b] = sacc;
+      }
+      if (n0 > 0) __syncthreads();   // previous tile's red readers are done
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        red[(wave * 2 + 0) * 256 + (kq * 4 + reg) * 16 + r] = a0[reg];
+        red[(wave * 2 + 1) * 256 + (kq * 4 + reg) * 16 + r] = a1[reg];
+      }
+      __syncthreads();
+      APA_TS(3);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int row = tid >> 4, col = tid & 15;
+        const float s = (red[(0 * 2 + ni) * 256 + tid] + red[(1 * 2 + ni) * 256 + tid]) +
+                        (red[(2 * 2 + ni) * 256 + tid] + red[(3 * 2 + ni) * 256 + tid]);
+        const int n = n0 + ni * 16 + row;
+        if (n < N) dz[(size_t)n * C + c0 + col] = s;
+      }
+    }
+    APA_TS(4);
+    APA_TS(5);
+    return;
+  }
+
+  // ------------------------------ dWt + dbt ------------------------------
+  const int ktiles = (K + 15) >> 4;
+  int gcol[UG];
+#pragma unroll
+  for (int j = 0; j < UG; ++j)   // surplus tiles recompute the last one; columns >= K are clamped
+    gcol[j] = min(min(wave + 4 * j, ktiles - 1) * 16 + r, K - 1);   // (both discarded at the store)
+  f32x4 wacc[UG];
+#pragma unroll
+  for (int j = 0; j < UG; ++j) wacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dbt_acc = 0.f;
+  // dbt[k] = sum_n abar[n] G[n,k]: k slice [b*kpb, (b+1)*kpb) of this block, on wave 3:
+  // 16 lanes per k (two rows each), 4 k per round
+  const bool do_dbt = wave == 3;
+  for (int n0 = 0; n0 < N; n0 += 32) {
+    float az[8], bg[UG][8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int n = n0 + 4 * t + kq;
+      const size_t nc = (size_t)min(n, N - 1);
+      az[t] = zsave[nc * C + c0 + r] * (n < N ? 1.f : 0.f);   // rows >= N contribute nothing
+#pragma unroll
+      for (int j = 0; j < UG; ++j) bg[j][t] = G[nc * K + gcol[j]];
+    }
+    if (do_dbt) {   // kpb <= 4 (checked on the host): lane group kq owns column b*kpb + kq
+      const int kc = min(b * kpb + kq, K - 1);
+      const int na = min(n0 + r, N - 1), nb2 = min(n0 + 16 + r, N - 1);
+      const float wa_ = n0 + r < N ? abar[na] : 0.f, wb_ = n0 + 16 + r < N ? abar[nb2] : 0.f;
+      const float acc = fmaf(wa_, G[(size_t)na * K + kc], wb_ * G[(size_t)nb2 * K + kc]);
+      dbt_acc += row_sum16(acc);
+    }
+    APA_TS(1);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+      for (int j = 0; j < UG; ++j) wacc[j] = mfma16(az[t], bg[j][t], wacc[j]);
+    }
+    APA_TS(2);
+  }
+  APA_TS(3);
+#pragma unroll
+  for (int j = 0; j < UG; ++j) {
+    const int col = (wave + 4 * j) * 16 + r;
+    if (col < K) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+        dWt[(size_t)(c0 + kq * 4 + reg) * K + col] = wacc[j][reg];
+    }
+  }
+  APA_TS(4);
+  if (do_dbt && r == 0 && kq < kpb && b * kpb + kq < K) dbt[b * kpb + kq] = dbt_acc;
+  APA_TS(5);
+}
+
+// --------------------------------------------------------------------------------------------
 // B4: dwa[c] = sum_b pdwa[b][c] (fixed order), dba = sum_b pdba[b].
 // grid = ceil(C/32) blocks of 1024 threads: 32 row groups x 32 columns, 128-byte row segments.
 // The last kernel of the backward call: optionally advances the HBM dropout counter.
@@ -403,6 +562,31 @@ int m1_bwd_small(const float* G, const float* Wt, const float* zsave, const floa
   else APA_BS(26);
 #undef APA_BS
   APA_LAUNCH_CHECK("m1_bwd_small_kernel");
+  return APA_OK;
+}
+
+bool m1_bwd_head_supported(int N, int C, int K) {
+  (void)N;
+  const int kpb = (K + C / 16 - 1) / (C / 16);   // dbt columns per block
+  return C % 16 == 0 && C >= 512 && K >= 4 && K <= 832 && kpb <= 4;
+}
+
+int m1_bwd_head(const float* G, const float* Wt, const float* zsave, const float* abar,
+                const float* bt, float* dz, float* dWt, float* dbt, float* sn, int N, int C, int K,
+                hipStream_t st) {
+  const int nb = C / 16;
+  const int kpb = (K + nb - 1) / nb;
+  const int ug = (((K + 15) / 16) + 3) / 4;
+#define APA_BH(UG)                                                                                \
+  hipLaunchKernelGGL(m1_bwd_head_kernel<UG>, dim3(2 * nb), dim3(256), 0, st, G, Wt, zsave, abar, \
+                     bt, dz, dWt, dbt, sn, N, C, K, kpb)
+  if (ug <= 1) APA_BH(1);
+  else if (ug <= 2) APA_BH(2);
+  else if (ug <= 4) APA_BH(4);
+  else if (ug <= 7) APA_BH(7);
+  else APA_BH(13);
+#undef APA_BH
+  APA_LAUNCH_CHECK("m1_bwd_head_kernel");
   return APA_OK;
 }
 

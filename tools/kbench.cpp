@@ -22,6 +22,7 @@ int main(int argc, char** argv) {
   auto bwd = (decltype(&apa_attn_pool_bwd))dlsym(h, "apa_attn_pool_bwd");
   auto xent = (decltype(&apa_softmax_xent_fwd_bwd))dlsym(h, "apa_softmax_xent_fwd_bwd");
   auto set_skip = (void (*)(int))dlsym(h, "apa_debug_set_skip");
+  auto read_ts = (int (*)(unsigned long long*, int))dlsym(h, "apa_debug_read_ts");
   auto last_error = (decltype(&apa_last_error))dlsym(h, "apa_last_error");
 
   const size_t nx = (size_t)N * P * C;
@@ -91,6 +92,18 @@ int main(int argc, char** argv) {
     time_it("  logits_partial alone", 255 & ~4, 1, IT);
     time_it("  logits_reduce alone", 255 & ~8, 1, IT);
     time_it("  bwd_small alone", 255 & ~32, 4, IT);
+    if (read_ts) {
+      std::vector<unsigned long long> ts(4096);
+      read_ts(ts.data(), 4096);
+      unsigned long long t0min = ~0ull, t5max = 0;
+      for (int b = 0; b < 128; ++b) { if (ts[b * 8] < t0min) t0min = ts[b * 8]; if (ts[b * 8 + 5] > t5max) t5max = ts[b * 8 + 5]; }
+      printf("    bwd_head in-kernel span (min start -> max end): %llu ticks\n", t5max - t0min);
+      for (int b : {0, 1, 63, 127}) {
+        printf("    blk %3d: start+%-6llu loads+lds %-6llu dz %-6llu dWt %-6llu red+store %-6llu tail %-6llu\n", b, ts[b * 8] - t0min,
+               ts[b * 8 + 1] - ts[b * 8], ts[b * 8 + 2] - ts[b * 8 + 1], ts[b * 8 + 3] - ts[b * 8 + 2],
+               ts[b * 8 + 4] - ts[b * 8 + 3], ts[b * 8 + 5] - ts[b * 8 + 4]);
+      }
+    }
     time_it("  bwd_main alone", 255 & ~64, 4, IT);
     time_it("  colsum alone", 255 & ~128, 4, IT);
     time_it("  step w/o pool", 1, 7, IT);
