@@ -2,6 +2,7 @@
 // Wave64 only (CDNA4): every cross-lane helper assumes 64 lanes.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 namespace apa {
@@ -55,6 +56,17 @@ __device__ __forceinline__ float wave_max(float v) {
   const float r0 = readlane_f(v, 0), r1 = readlane_f(v, 16);
   const float r2 = readlane_f(v, 32), r3 = readlane_f(v, 48);
   return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
+// exp(x) for x <= 0-ish softmax arguments: v_exp_f32 (2^t) on t = x*log2(e) with the rounding
+// error of that product (and the low word of log2 e) folded back in -- 6 VALU ops instead of the
+// ~25 of libm expf, relative error < 2^-22.  exp(-inf) = 0.
+__device__ __forceinline__ float exp_fast(float x) {
+  const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.92596299112661746e-8f;
+  const float t = x * L2E_HI;
+  const float lo = fmaf(x, L2E_LO, fmaf(x, L2E_HI, -t));
+  const float r = __builtin_amdgcn_exp2f(t) * fmaf(lo, 0.693147182464599609375f, 1.0f);
+  return x == -INFINITY ? 0.f : r;   // (-inf * c) - (-inf) would be NaN in `lo`
 }
 
 // Minimum of an int over the 64 lanes (wave-uniform result).

@@ -142,6 +142,10 @@ int m1_logits(const float* z, const float* Wt, const float* abar, const float* b
 int m1_bwd_small(const float* G, const float* Wt, const float* zsave, const float* abar,
                  const float* bt, float* dz, float* dWt, float* dbt, float* sn, int N, int C, int K,
                  hipStream_t st);
+bool m1_logits2_supported(int C, int K);
+size_t m1_logits2_ws_bytes(int N, int C, int K);
+int m1_logits2(const float* z, const float* Wt, const float* abar, const float* bt, float* logits,
+               float* part_ws, int N, int C, int K, hipStream_t st);
 bool m1_bwd_head_supported(int N, int C, int K);
 int m1_bwd_head(const float* G, const float* Wt, const float* zsave, const float* abar,
                 const float* bt, float* dz, float* dWt, float* dbt, float* sn, int N, int C, int K,

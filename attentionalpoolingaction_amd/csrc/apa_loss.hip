@@ -8,113 +8,193 @@
 #include "apa_device.h"
 #include "apa_internal.h"
 
+#ifdef APA_ABLATION
+namespace apa { __device__ unsigned long long apa_dbg_ts[4096]; }
+extern "C" int apa_debug_read_ts2(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(apa::apa_dbg_ts), sizeof(unsigned long long) * n);
+}
+#endif
+
 namespace apa {
 
-// One wave per row (rows strided over all waves of the grid), R rows per wave per iteration.
-// A global round trip costs ~1.5-2 us on this part and the kernel is a pure latency chain, so
-// every load a wave will need (labels, R whole rows) is issued before anything is consumed; the
-// rows then live in registers (NV values per lane, K <= 64*NV): max / sum-exp by DPP wave
-// reductions, one write of G / probs.  out_loss[1+n] = xent_n (unweighted); out_loss[0] =
-// lscale * sum_n xent_n is written here when the grid is a single block (N <= 64: latency matters
-// more than width) and by sum_scale_kernel otherwise.  NV == 0 selects the streaming variant for
-// very wide rows.
-template <int NV, int R>
+// Softmax cross-entropy, fused value + gradient (+ probabilities, + first-index argmax).
+// These launches are pure latency chains, and two things dominate them (in-kernel timestamps,
+// tools/kbench.cpp): global round trips and COLD INSTRUCTION FETCH -- a small kernel starts with
+// an empty instruction cache and straight-line code streams in at well under 2 bytes per cycle,
+// so code size is time.  Hence:
+//   * HALF a wave (32 lanes) owns a row, so one copy of the code reduces two rows at once and a
+//     16-wave block covers 32 rows in a single pass (no per-row unrolled copies);
+//   * a row is NV4 (<= 8) 16-byte vectors per lane, not predicated dwords: rows of K = 393 floats
+//     are only 4-byte aligned, gfx950 services unaligned dwordx4 accesses; the ragged last vector
+//     is shifted back to end at K-1 and its already-covered columns are masked out;
+//   * every load is issued before anything is consumed, every store after the last reduction.
+// out_loss[1+n] = xent_n (unweighted); out_loss[0] = lscale * sum_n xent_n.
+//   mode 1: one block does everything (N <= 64, only the loss is wanted);
+//   mode 2: block 0 computes the losses / predictions of ALL rows (the batch mean needs every row
+//           anyway), blocks 1.. write G / probs: one CU moving 2 x 50 KB alone is 3 us of queueing;
+//   mode 0: N > 64, out_loss[0] is summed by sum_scale_kernel.
+__device__ __forceinline__ float half_sum(float v, int lane) {
+  v = row_sum16(v);
+  const float s0 = readlane_f(v, 0) + readlane_f(v, 16), s1 = readlane_f(v, 32) + readlane_f(v, 48);
+  return lane < 32 ? s0 : s1;
+}
+__device__ __forceinline__ float half_max(float v, int lane) {
+  v = row_max16(v);
+  const float s0 = fmaxf(readlane_f(v, 0), readlane_f(v, 16)), s1 = fmaxf(readlane_f(v, 32), readlane_f(v, 48));
+  return lane < 32 ? s0 : s1;
+}
+__device__ __forceinline__ int half_min_i(int v, int lane) {
+  v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0xB1, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x4E, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x141, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x140, 0xf, 0xf, false));
+  const int s0 = min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16));
+  const int s1 = min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48));
+  return lane < 32 ? s0 : s1;
+}
+
+template <int NV4>   // 16-byte vectors per lane: ceil(ceil(K/4)/32)
 __global__ __launch_bounds__(1024) void softmax_xent_kernel(
     const float* __restrict__ logits, const int64_t* __restrict__ labels,
     float* __restrict__ out_loss, float* __restrict__ G, float* __restrict__ probs,
-    int64_t* __restrict__ pred, int N, int K, float gscale, float lscale, int single_block) {
-  __shared__ float red[16];
-  const int lane = threadIdx.x & 63;
+    int64_t* __restrict__ pred, int N, int K, float gscale, float lscale, int mode) {
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  __shared__ float red[32];
+  const int lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
   const int wpb = blockDim.x >> 6;
-  const int wid = blockIdx.x * wpb + (threadIdx.x >> 6);
-  const int nw = gridDim.x * wpb;
-  float wave_loss = 0.f;
-  for (int n0 = wid; n0 < N; n0 += nw * R) {
-    int lab[R];
-    float v[R][NV > 0 ? NV : 1];
-    if (NV > 0) {
+  const bool split = mode == 2;
+  const bool loss_role = !split || blockIdx.x == 0;
+  if (split && blockIdx.x == 0) { G = nullptr; probs = nullptr; }
+  const int wid = (split ? (blockIdx.x == 0 ? 0 : blockIdx.x - 1) : blockIdx.x) * wpb + (threadIdx.x >> 6);
+  const int nw = (split ? (blockIdx.x == 0 ? 1 : gridDim.x - 1) : gridDim.x) * wpb;
+  float slot_loss = 0.f;
+  APA_TS(0);
+#ifdef APA_ABLATION
+  if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) apa_dbg_ts[64 + (threadIdx.x >> 6)] = __builtin_readcyclecounter();
+#endif
+  for (int base = 2 * wid; base < N; base += 2 * nw) {
+    const int n = base + half;
+    const bool active = n < N;
+    const size_t nc = (size_t)min(n, N - 1);   // the idle half of a ragged last pair re-reads row N-1
+    const int lab = (int)labels[nc];
+    f4u v[NV4];
+    int colc[NV4];
 #pragma unroll
-      for (int q = 0; q < R; ++q) {
-        const int n = min(n0 + q * nw, N - 1);   // surplus slots re-read the last row
-        lab[q] = (int)labels[n];
-        const float* row = logits + (size_t)n * K;
+    for (int i = 0; i < NV4; ++i) {
+      colc[i] = min(4 * (hl + 32 * i), K - 4);
+      v[i] = *reinterpret_cast<const f4u*>(logits + nc * K + colc[i]);
+    }
+    const bool lab_ok = lab >= 0 && lab < K;
+    const float xl = logits[nc * K + (lab_ok ? lab : 0)];   // the label's logit: one broadcast load
+    APA_TS(1);
+    // columns already covered by the previous lane (ragged last vector) leave the reductions
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-          const int k = lane + 64 * i;
-          v[q][i] = k < K ? row[k] : -INFINITY;
-        }
+    for (int i = 0; i < NV4; ++i) {
+      const int col0 = 4 * (hl + 32 * i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[i][e] = colc[i] + e >= col0 ? v[i][e] : -INFINITY;
+    }
+    float m = -INFINITY;
+    int arg = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (v[i][e] > m) { m = v[i][e]; arg = colc[i] + e; }   // first maximal index of this lane
+    }
+    const float mw = half_max(m, lane);
+    // argmax: smallest index among the lanes holding the max (np / tf argmax tie rule: first)
+    const int cand = half_min_i((m == mw) ? arg : 0x7fffffff, lane);
+    float l = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[i][e] = exp_fast(v[i][e] - mw);   // 0 for the excluded columns
+        l += v[i][e];
       }
     }
+    l = half_sum(l, lane);
+    const float inv = 1.0f / l;
+    const float lv = lab_ok ? -(xl - mw - logf(l)) : 0.f;
+    APA_TS(2);
+    if (active) {
+      if (G || probs) {
 #pragma unroll
-    for (int q = 0; q < R; ++q) {
-      const int n = n0 + q * nw;
-      if (n >= N) break;
-      const float* row = logits + (size_t)n * K;
-      if (NV == 0) lab[q] = (int)labels[n];
-      float m = -INFINITY;
-      int arg = 0x7fffffff;
-      float xl = 0.f;   // logit of the label (held by exactly one lane)
-      if (NV > 0) {
+        for (int i = 0; i < NV4; ++i) {
+          const int col0 = 4 * (hl + 32 * i);
+          f4u p, g;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-          const int k = lane + 64 * i;
-          if (v[q][i] > m) { m = v[q][i]; arg = k; }   // first maximal index of this lane
-          if (k == lab[q]) xl = v[q][i];
-        }
-      } else {
-        for (int k = lane; k < K; k += 64) {
-          const float x = row[k];
-          if (x > m) { m = x; arg = k; }
-          if (k == lab[q]) xl = x;
-        }
-      }
-      const float mw = wave_max(m);
-      // argmax: smallest index among the lanes holding the max (np / tf argmax tie rule: first)
-      const int cand = wave_min_i((m == mw) ? arg : 0x7fffffff);
-      xl = wave_sum(xl);   // one non-zero term: exact
-      float l = 0.f;
-      if (NV > 0) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) { v[q][i] = expf(v[q][i] - mw); l += v[q][i]; }   // exp(-inf) = 0 pads
-      } else {
-        for (int k = lane; k < K; k += 64) l += expf(row[k] - mw);
-      }
-      l = wave_sum(l);
-      const float logl = logf(l);
-      const float inv = 1.0f / l;
-      if (NV > 0) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-          const int k = lane + 64 * i;
-          if (k < K) {
-            const float p = v[q][i] * inv;
-            if (probs) probs[(size_t)n * K + k] = p;
-            if (G) G[(size_t)n * K + k] = (p - (k == lab[q] ? 1.0f : 0.0f)) * gscale;
+          for (int e = 0; e < 4; ++e) {
+            p[e] = v[i][e] * inv;
+            g[e] = fmaf(p[e], gscale, colc[i] + e == lab ? -gscale : 0.f);
+          }
+          if (colc[i] == col0) {
+            if (probs) *reinterpret_cast<f4u*>(probs + nc * K + colc[i]) = p;
+            if (G) *reinterpret_cast<f4u*>(G + nc * K + colc[i]) = g;
+          } else if (col0 < K) {   // the one ragged lane of the row: its own columns only
+            for (int e = col0 - colc[i]; e < 4; ++e) {
+              if (probs) probs[nc * K + colc[i] + e] = p[e];
+              if (G) G[nc * K + colc[i] + e] = g[e];
+            }
           }
         }
-      } else {
-        for (int k = lane; k < K; k += 64) {
-          const float p = expf(row[k] - mw) * inv;
-          if (probs) probs[(size_t)n * K + k] = p;
-          if (G) G[(size_t)n * K + k] = (p - (k == lab[q] ? 1.0f : 0.0f)) * gscale;
-        }
       }
-      const float lv = (lab[q] >= 0 && lab[q] < K) ? -(xl - mw - logl) : 0.f;
-      wave_loss += lv;   // rows of one wave are summed in increasing n
-      if (lane == 0) {
+      slot_loss += lv;   // a half-wave's rows are summed in increasing n
+      if (hl == 0 && loss_role) {
         out_loss[1 + n] = lv;
         if (pred) pred[n] = cand;
       }
     }
   }
-  if (single_block) {
-    if (lane == 0) red[threadIdx.x >> 6] = wave_loss;
+  APA_TS(3);
+#ifdef APA_ABLATION
+  if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) apa_dbg_ts[96 + (threadIdx.x >> 6)] = __builtin_readcyclecounter();
+#endif
+  if (mode != 0 && loss_role) {
+    if (hl == 0) red[(threadIdx.x >> 6) * 2 + half] = slot_loss;
     __syncthreads();
     if (threadIdx.x == 0) {
       float t = 0.f;
-      for (int w = 0; w < wpb; ++w) t += red[w];
+      for (int w = 0; w < 2 * wpb; ++w) t += red[w];
       out_loss[0] = t * lscale;
     }
+  }
+  APA_TS(4);
+}
+
+// Generic fallback (K < 4 or K > 1024): one wave per row, three passes over the row.
+__global__ __launch_bounds__(256) void softmax_xent_stream_kernel(
+    const float* __restrict__ logits, const int64_t* __restrict__ labels,
+    float* __restrict__ out_loss, float* __restrict__ G, float* __restrict__ probs,
+    int64_t* __restrict__ pred, int N, int K, float gscale) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const float* row = logits + (size_t)n * K;
+  const int lab = (int)labels[n];
+  float m = -INFINITY, xl = 0.f;
+  int arg = 0x7fffffff;
+  for (int k = lane; k < K; k += 64) {
+    const float x = row[k];
+    if (x > m) { m = x; arg = k; }
+    if (k == lab) xl = x;
+  }
+  const float mw = wave_max(m);
+  const int cand = wave_min_i((m == mw) ? arg : 0x7fffffff);
+  xl = wave_sum(xl);
+  float l = 0.f;
+  for (int k = lane; k < K; k += 64) l += expf(row[k] - mw);
+  l = wave_sum(l);
+  const float inv = 1.0f / l;
+  for (int k = lane; k < K; k += 64) {
+    const float p = expf(row[k] - mw) * inv;
+    if (probs) probs[(size_t)n * K + k] = p;
+    if (G) G[(size_t)n * K + k] = (p - (k == lab ? 1.0f : 0.0f)) * gscale;
+  }
+  if (lane == 0) {
+    out_loss[1 + n] = (lab >= 0 && lab < K) ? -(xl - mw - logf(l)) : 0.f;
+    if (pred) pred[n] = cand;
   }
 }
 
@@ -190,23 +270,31 @@ extern "C" int apa_softmax_xent_fwd_bwd(const float* logits, const int64_t* labe
   // tf.losses.softmax_cross_entropy with a scalar weight: sum(w * l) / (#non-zero weights) = w*mean
   const float lscale = wt / (float)N;
   const float gscale = wt * grad_scale / (float)N;
-  const int single = N <= 64 ? 1 : 0;
-  int nb = single ? 1 : (N + 15) / 16;
-  if (nb > 1024) nb = 1024;
-#define APA_XENT(NV, R)                                                                           \
-  hipLaunchKernelGGL((softmax_xent_kernel<NV, R>), dim3(nb), dim3(1024), 0, st, logits, labels,   \
-                     loss, G, probs, pred, N, K, gscale, lscale, single)
   if (dbg_skip() & 16) return APA_OK;
-  // single block, N in (16, 64]: a wave owns 2..4 rows -- fetch them together (one round trip)
-  const bool multi = single && N > 16;
-  if (K <= 64) { if (multi) APA_XENT(1, 4); else APA_XENT(1, 1); }
-  else if (K <= 128) { if (multi) APA_XENT(2, 4); else APA_XENT(2, 1); }
-  else if (K <= 256) { if (multi) APA_XENT(4, 4); else APA_XENT(4, 1); }
-  else if (K <= 512) { if (multi) APA_XENT(8, 2); else APA_XENT(8, 1); }
-  else APA_XENT(0, 1);
+  if (K < 4 || K > 1024) {
+    hipLaunchKernelGGL(softmax_xent_stream_kernel, dim3((N + 3) / 4), dim3(256), 0, st, logits,
+                       labels, loss, G, probs, pred, N, K, gscale);
+    APA_LAUNCH_CHECK("softmax_xent_stream_kernel");
+    hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, st, loss + 1, loss, N, lscale);
+    APA_LAUNCH_CHECK("sum_scale_kernel");
+    return APA_OK;
+  }
+  // N <= 64: one launch; block 0 = losses + batch mean, blocks 1.. = gradients (when any are
+  // wanted).  A 16-wave block covers 32 rows per pass (half a wave per row).
+  const bool wide = G || probs;
+  const int mode = N <= 64 ? (wide ? 2 : 1) : 0;
+  int nb = mode == 1 ? 1 : (N + 31) / 32 + (mode == 2 ? 1 : 0);
+  if (nb > 1024) nb = 1024;
+#define APA_XENT(NV4)                                                                           \
+  hipLaunchKernelGGL(softmax_xent_kernel<NV4>, dim3(nb), dim3(1024), 0, st, logits, labels, loss, \
+                     G, probs, pred, N, K, gscale, lscale, mode)
+  if (K <= 128) APA_XENT(1);
+  else if (K <= 256) APA_XENT(2);
+  else if (K <= 512) APA_XENT(4);
+  else APA_XENT(8);
 #undef APA_XENT
   APA_LAUNCH_CHECK("softmax_xent_kernel");
-  if (!single) {
+  if (mode == 0) {
     hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, st, loss + 1, loss, N, lscale);
     APA_LAUNCH_CHECK("sum_scale_kernel");
   }

@@ -636,7 +636,11 @@ M1Plan m1_plan(int N, int P, int C, int Ca, int K) {
   pl.off_pdba = off;  off += align_up((size_t)(pl.nblk + N) * 4, 256);  // + sn[N]
   pl.off_dz = off;    off += align_up((size_t)N * C * 4, 256);
   pl.off_dzatt = off; off += align_up((size_t)N * P * 4, 256);
-  pl.off_gemm = off;  off += align_up(sgemm_ws_bytes(N, K > C ? K : C, 16), 256);
+  {
+    size_t g = sgemm_ws_bytes(N, K > C ? K : C, 16);
+    if (C % 64 == 0 && m1_logits2_ws_bytes(N, C, K) > g) g = m1_logits2_ws_bytes(N, C, K);
+    pl.off_gemm = off;  off += align_up(g, 256);
+  }
   pl.total = off;
   return pl;
 }
@@ -765,11 +769,15 @@ int m1_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
                           pacc, pstat, P, pl.S, pool_act, r);
   if (rc != APA_OK) return rc;
   const int online = (fused && act == ACT_SOFTMAX) ? 1 : 0;
-  if (!(dbg_skip() & 2))
-  hipLaunchKernelGGL(m1_finalize_fwd_kernel, dim3(N, (C + 1023) / 1024), dim3(256), 0, st, pacc,
-                     pstat, zsave, abar, att, P, pl.S, C, online);
-  APA_LAUNCH_CHECK("m1_finalize_fwd_kernel");
+  if (!(dbg_skip() & 2)) {
+    hipLaunchKernelGGL(m1_finalize_fwd_kernel, dim3(N, (C + 1023) / 1024), dim3(256), 0, st, pacc,
+                       pstat, zsave, abar, att, P, pl.S, C, online);
+    APA_LAUNCH_CHECK("m1_finalize_fwd_kernel");
+  }
   // logits = z . Wt + abar (x) bt
+  static const int use_l2 = env_int("APA_M1_LOGITS2", 1);
+  if (use_l2 && m1_logits2_supported(C, K) && (reinterpret_cast<uintptr_t>(zsave) & 15) == 0)
+    return m1_logits2(zsave, Wt, abar, bt, logits, gemm_ws, N, C, K, st);
   if (m1_small_supported(C, K) && (reinterpret_cast<uintptr_t>(zsave) & 15) == 0)
     return m1_logits(zsave, Wt, abar, bt, logits, gemm_ws, N, C, K, st);
   return sgemm_small(zsave, C, 1, Wt, K, 1, logits, K, N, K, C, pl.lsplits, abar, bt, gemm_ws, st);

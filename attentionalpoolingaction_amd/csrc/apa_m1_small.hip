@@ -100,13 +100,13 @@ __global__ __launch_bounds__(256) void m1_logits_reduce_kernel(const float* __re
   if (idx >= N * K) return;
   const int n = idx / K, k = idx - n * K;
   const size_t stride = (size_t)N * K;
-  float v[16];
+  float v[32];
   float acc = 0.f;
-  for (int c = 0; c < nchunks; c += 16) {
+  for (int c = 0; c < nchunks; c += 32) {   // one round trip for up to 32 partials
 #pragma unroll
-    for (int u = 0; u < 16; ++u) v[u] = (c + u < nchunks) ? part[(size_t)(c + u) * stride + idx] : 0.f;
+    for (int u = 0; u < 32; ++u) v[u] = part[(size_t)min(c + u, nchunks - 1) * stride + idx];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) acc += v[u];
+    for (int u = 0; u < 32; ++u) acc += (c + u < nchunks) ? v[u] : 0.f;
   }
   logits[idx] = fmaf(abar[n], bt[k], acc);
 }
@@ -298,6 +298,79 @@ __global__ __launch_bounds__(256) void m1_bwd_small_kernel(
     }
   }
   if (ct == 0 && tid < 128 && k0 + tid < K) dbt[k0 + tid] = dbt_acc;
+}
+
+// --------------------------------------------------------------------------------------------
+// L1v2: partial logits, LDS-free operands (same latency-first design as B12v2 below).
+//   part[cx][n][k] = sum_{c in 64-channel chunk cx} z[n,c] Wt[c,k]
+// grid (C/64, ceil(ceil(K/16)/KG), ceil(N/32)); block (cx, gx, nz): wave w owns channels
+// cx*64 + 16w .. +16 for the block's KG k-tiles x 2 n-tiles; the four waves' accumulators are
+// summed through LDS in a fixed order, so only C/64 partials reach memory.
+//   A fragment: lane (r = n, kq) loads the 4 consecutive channels 4kq..4kq+3 of its row as one
+//               16-byte vector and feeds element e to MFMA step e (k-order is free);
+//   B fragment: Wt[c = cw + 4kq + e][k0 + r], 64-byte row segments.
+// (Folding the finalize step in -- forming z in the A registers from the S per-block partials of
+// the pooling pass -- was measured slower than the separate, fully coalesced finalize kernel:
+// 32 strided 16-byte loads per lane, 8.4 us vs 3 + 4 us.)
+// --------------------------------------------------------------------------------------------
+template <int KG>
+__global__ __launch_bounds__(256) void m1_logits2_kernel(const float* __restrict__ z,
+                                                         const float* __restrict__ Wt,
+                                                         float* __restrict__ part, int N, int C,
+                                                         int K) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][2*KG tiles][256]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, kq = lane >> 4;
+  const int cx = blockIdx.x, gx = blockIdx.y, n0 = blockIdx.z * 32;
+  const int cw = cx * 64 + wave * 16;
+  const int ktiles = (K + 15) >> 4;
+  const int na = min(n0 + r, N - 1), nb = min(n0 + 16 + r, N - 1);   // rows >= N: discarded at the store
+
+  // ---- one batch of loads: B fragments (Wt), A fragments (z, or the S partial rows) ----
+  float bw[KG][4];
+#pragma unroll
+  for (int j = 0; j < KG; ++j) {
+    const int col = min(min(gx * KG + j, ktiles - 1) * 16 + r, K - 1);   // surplus tiles / columns:
+#pragma unroll                                                            // recomputed, discarded
+    for (int e = 0; e < 4; ++e) bw[j][e] = Wt[(size_t)(cw + 4 * kq + e) * K + col];
+  }
+  const float4 a0 = *reinterpret_cast<const float4*>(z + (size_t)na * C + cw + 4 * kq);
+  const float4 a1 = *reinterpret_cast<const float4*>(z + (size_t)nb * C + cw + 4 * kq);
+
+  f32x4 acc0[KG], acc1[KG];
+#pragma unroll
+  for (int j = 0; j < KG; ++j) { acc0[j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[j] = acc0[j]; }
+  const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+#pragma unroll
+    for (int j = 0; j < KG; ++j) {
+      acc0[j] = mfma16(av0[e], bw[j][e], acc0[j]);
+      acc1[j] = mfma16(av1[e], bw[j][e], acc1[j]);
+    }
+  }
+  // ---- fixed-order sum of the 4 waves' 16-channel shares, then one store per element ----
+#pragma unroll
+  for (int j = 0; j < KG; ++j) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      red[((wave * 2 + 0) * KG + j) * 256 + (kq * 4 + reg) * 16 + r] = acc0[j][reg];
+      red[((wave * 2 + 1) * KG + j) * 256 + (kq * 4 + reg) * 16 + r] = acc1[j][reg];
+    }
+  }
+  __syncthreads();
+  const int row = tid >> 4, colr = tid & 15;
+  float* out = part + (size_t)cx * N * K;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+    for (int j = 0; j < KG; ++j) {
+      const int t = (ni * KG + j) * 256 + tid;
+      const float sm = (red[t] + red[2 * KG * 256 + t]) + (red[4 * KG * 256 + t] + red[6 * KG * 256 + t]);
+      const int n = n0 + ni * 16 + row, kt = gx * KG + j, k = kt * 16 + colr;
+      if (n < N && kt < ktiles && k < K) out[(size_t)n * K + k] = sm;
+    }
+  }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -529,6 +602,26 @@ int m1_logits(const float* z, const float* Wt, const float* abar, const float* b
   if (!(dbg_skip() & 8))
   hipLaunchKernelGGL(m1_logits_reduce_kernel, dim3((N * K + 255) / 256), dim3(256), 0, st, part_ws,
                      abar, bt, logits, N, K, C / 128);
+  APA_LAUNCH_CHECK("m1_logits_reduce_kernel");
+  return APA_OK;
+}
+
+// L1v2 + L2
+bool m1_logits2_supported(int C, int K) { return C % 64 == 0 && K >= 1; }
+size_t m1_logits2_ws_bytes(int N, int C, int K) { return (size_t)(C / 64) * N * K * sizeof(float); }
+
+int m1_logits2(const float* z, const float* Wt, const float* abar, const float* bt, float* logits,
+               float* part_ws, int N, int C, int K, hipStream_t st) {
+  constexpr int KG = 7;
+  const int ktiles = (K + 15) / 16;
+  dim3 grid(C / 64, (ktiles + KG - 1) / KG, (N + 31) / 32);
+  const size_t shm = (size_t)4 * 2 * KG * 256 * sizeof(float);   // 56 KB
+  if (!(dbg_skip() & 4))
+  hipLaunchKernelGGL(m1_logits2_kernel<KG>, grid, dim3(256), shm, st, z, Wt, part_ws, N, C, K);
+  APA_LAUNCH_CHECK("m1_logits2_kernel");
+  if (!(dbg_skip() & 8))
+  hipLaunchKernelGGL(m1_logits_reduce_kernel, dim3((N * K + 255) / 256), dim3(256), 0, st, part_ws,
+                     abar, bt, logits, N, K, C / 64);
   APA_LAUNCH_CHECK("m1_logits_reduce_kernel");
   return APA_OK;
 }

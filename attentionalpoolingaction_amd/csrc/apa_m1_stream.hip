@@ -281,7 +281,6 @@ __device__ __forceinline__ void bwd_chunk(BwdState<T, VW, PIX, FUSED, TRAIN>& st
   constexpr int EPV = Vec<T>::EPV;
   constexpr int EPL = VW * EPV;
   constexpr int MBW = (PIX * EPL + 31) / 32;   // mask-bit words per lane
-  const int l16 = lane & 15;
   const int q0 = cr.q0, np = cr.np;
   uint32_t mb[TRAIN ? MBW : 1];
   if (TRAIN) {

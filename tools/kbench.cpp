@@ -84,6 +84,18 @@ int main(int argc, char** argv) {
   time_it("step (fwd + xent + bwd)", 0, 7, IT);
   time_it("fwd only", 0, 1, IT);
   time_it("xent only", 0, 2, IT);
+  {
+    auto read_ts2 = (int (*)(unsigned long long*, int))dlsym(h, "apa_debug_read_ts2");
+    if (read_ts2) {
+      std::vector<unsigned long long> ts(4096);
+      read_ts2(ts.data(), 4096);
+      printf("    xent blk0 wave0: loads issued %llu  [wait+reduce] %llu  stores %llu  tail %llu\n", ts[1] - ts[0],
+             ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3]);
+      printf("    xent blk0 per-wave start / end offsets vs wave 0 start:");
+      for (int w = 0; w < 16; ++w) printf(" %lld/%lld", (long long)(ts[64 + w] - ts[64]), (long long)(ts[96 + w] - ts[64]));
+      printf("\n");
+    }
+  }
   time_it("bwd only", 0, 4, IT);
   if (set_skip) {
     // kernels alone: skip everything else (bits: 1 pool 2 finalize 4 lpartial 8 lreduce 16 xent 32 bsmall 64 bmain 128 colsum)
