@@ -22,9 +22,14 @@ int hip_fail(hipError_t e, const char* what) {
 }
 
 static thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
+static thread_local hipEvent_t g_null_start = nullptr, g_null_stop = nullptr;
 void prof_kernel_events(hipEvent_t* start, hipEvent_t* stop) {
   *start = g_prof_start;
   *stop = g_prof_stop;
+}
+void prof_null_events(hipEvent_t* start, hipEvent_t* stop) {
+  *start = g_null_start;
+  *stop = g_null_stop;
 }
 
 #ifdef APA_ABLATION
@@ -64,6 +69,12 @@ extern "C" int apa_prof_event_elapsed_ms(void* start, void* stop, float* ms) {
 extern "C" int apa_prof_set_kernel_events(void* start, void* stop) {
   g_prof_start = static_cast<hipEvent_t>(start);
   g_prof_stop = static_cast<hipEvent_t>(stop);
+  return APA_OK;
+}
+
+extern "C" int apa_prof_set_null_events(void* start, void* stop) {
+  g_null_start = static_cast<hipEvent_t>(start);
+  g_null_stop = static_cast<hipEvent_t>(stop);
   return APA_OK;
 }
 

@@ -63,6 +63,7 @@ _SIGNATURES = {
     'apa_prof_event_record': (c_int, [c_void_p, c_void_p]),
     'apa_prof_event_elapsed_ms': (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
     'apa_prof_set_kernel_events': (c_int, [c_void_p, c_void_p]),
+    'apa_prof_set_null_events': (c_int, [c_void_p, c_void_p]),
 }
 
 _lib = None
@@ -445,29 +446,44 @@ class KernelTimer:
         lib = load_library()
         self._lib = lib
         self.pairs = []
+        self.null_pairs = []      # recorded back to back just before the kernel pair (calibration)
         for _ in range(n_pairs):
-            a, b = c_void_p(), c_void_p()
-            _check(lib.apa_prof_event_create(ctypes.byref(a)), 'apa_prof_event_create')
-            _check(lib.apa_prof_event_create(ctypes.byref(b)), 'apa_prof_event_create')
-            self.pairs.append((a, b))
+            self.pairs.append(self._new_pair())
+            self.null_pairs.append(self._new_pair())
+
+    def _new_pair(self):
+        a, b = c_void_p(), c_void_p()
+        _check(self._lib.apa_prof_event_create(ctypes.byref(a)), 'apa_prof_event_create')
+        _check(self._lib.apa_prof_event_create(ctypes.byref(b)), 'apa_prof_event_create')
+        return a, b
 
     def arm(self, i: int) -> None:
         a, b = self.pairs[i]
         self._lib.apa_prof_set_kernel_events(a, b)
+        a, b = self.null_pairs[i]
+        self._lib.apa_prof_set_null_events(a, b)
 
     def disarm(self) -> None:
         self._lib.apa_prof_set_kernel_events(None, None)
+        self._lib.apa_prof_set_null_events(None, None)
 
-    def elapsed_ms(self):
+    def _elapsed(self, pairs):
         out = []
-        for a, b in self.pairs:
+        for a, b in pairs:
             ms = c_float()
             _check(self._lib.apa_prof_event_elapsed_ms(a, b, ctypes.byref(ms)), 'apa_prof_event_elapsed_ms')
             out.append(ms.value)
         return out
 
+    def elapsed_ms(self):
+        return self._elapsed(self.pairs)
+
+    def null_elapsed_ms(self):
+        return self._elapsed(self.null_pairs)
+
     def close(self) -> None:
-        for a, b in self.pairs:
+        for a, b in self.pairs + self.null_pairs:
             self._lib.apa_prof_event_destroy(a)
             self._lib.apa_prof_event_destroy(b)
         self.pairs = []
+        self.null_pairs = []

@@ -205,6 +205,10 @@ int apa_prof_event_destroy(void* event);
 int apa_prof_event_record(void* event, void* stream);
 int apa_prof_event_elapsed_ms(void* start, void* stop, float* ms); /* both must have completed */
 int apa_prof_set_kernel_events(void* start, void* stop);
+/* Calibration: a second per-thread pair that the same call records BACK TO BACK (nothing between
+ * them) right before the first pair, i.e. under the same stream conditions.  Its elapsed time is
+ * what an event pair costs by itself (~3-4 us on MI355X); bench.py subtracts it.  NULL, NULL clears. */
+int apa_prof_set_null_events(void* start, void* stop);
 
 #ifdef __cplusplus
 }
