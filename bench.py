@@ -231,15 +231,23 @@ def main():
     # HBM traffic of the dominant kernel from the separate rocprofv3 --pmc passes (profiles/):
     # only valid for the exact workload it was collected on
     traffic = args.traffic_bytes
-    if traffic is None:
-        try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
-            key = 'cfg002_N{}_{}x{}x{}_{}_K{}_{}'.format(N, H, H, C, args.dtype, K,
-                                                        'train' if train else 'eval')
-            if key in pmc and not args.softmax_att:
-                traffic = pmc[key]['hbm_bytes_per_launch']
-        except (OSError, ValueError, KeyError):
-            traffic = None
+    workload = ('cfg002 attentional-pooling head fwd + softmax-xent + bwd, per-GPU batch {} '
+                'x {}x{}x{} {} features, K={}, M=1 (class-agnostic bottom-up map), '
+                '{}'.format(N, H, H, C, args.dtype, K,
+                            'dropout keep={}'.format(keep) if train else 'eval (no dropout)'))
+    if traffic is None and not args.softmax_att:
+        # newest committed PMC summary whose workload string is exactly this run's
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')), reverse=True):
+            try:
+                pmc = json.load(open(f))
+            except (OSError, ValueError):
+                continue
+            hit = [v for k, v in pmc.items() if 'bwd_main' in k and isinstance(v, dict)
+                   and v.get('workload') == workload]
+            if hit:
+                traffic = hit[0]['hbm_bytes_per_launch']
+                break
 
     if rank == 0:
         total_images = N * world * args.steps
@@ -257,10 +265,7 @@ def main():
             'dtype': args.dtype,
             'data': 'synthetic',
             'config': {
-                'workload': 'cfg002 attentional-pooling head fwd + softmax-xent + bwd, per-GPU batch {} '
-                            'x {}x{}x{} {} features, K={}, M=1 (class-agnostic bottom-up map), '
-                            '{}'.format(N, H, H, C, args.dtype, K,
-                                        'dropout keep={}'.format(keep) if train else 'eval (no dropout)'),
+                'workload': workload,
                 'global_batch': N * world,
                 'parallelism': 'dp{}'.format(world),
                 'softmax_att': bool(args.softmax_att),
