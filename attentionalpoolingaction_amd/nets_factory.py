@@ -144,12 +144,24 @@ class AttentionalPoolingHead(nn.Module):
         net = cfg.NET
         if not net.USE_POSE_PRELOGITS_BASED_ATTENTION:
             raise ValueError('AttentionalPoolingHead needs cfg.NET.USE_POSE_PRELOGITS_BASED_ATTENTION')
-        if net.USE_POSE_PRELOGITS_BASED_ATTENTION_RANK != 1:
-            raise NotImplementedError('rank > 1 (chained attention convs, nets_factory.py:258-274) '
-                                      'is not built; every shipped config uses rank 1')
-        if net.USE_POSE_PRELOGITS_BASED_ATTENTION_WITH_POSE_FEAT:
-            raise NotImplementedError('..._WITH_POSE_FEAT (nets_factory.py:289-295) is off in all '
-                                      'shipped configs and not built')
+        self.rank = int(net.USE_POSE_PRELOGITS_BASED_ATTENTION_RANK)
+        self.with_pose_feat = bool(net.USE_POSE_PRELOGITS_BASED_ATTENTION_WITH_POSE_FEAT)
+        if self.rank < 1:
+            raise ValueError('USE_POSE_PRELOGITS_BASED_ATTENTION_RANK must be >= 1')
+        if self.rank > 1 and (net.USE_POSE_PRELOGITS_BASED_ATTENTION_PER_CLASS or
+                              net.USE_POSE_PRELOGITS_BASED_ATTENTION_SOFTMAX_ATT or
+                              net.USE_POSE_PRELOGITS_BASED_ATTENTION_RELU_ATT or want_topdown):
+            # softmax + rank > 1 does not even build in the reference (a 4-entry transpose perm on a
+            # 5-D tensor, nets_factory.py:278); relu / per-class maps / the TopDownAttention dump break
+            # the affine collapse used below and no shipped config selects them
+            raise NotImplementedError('rank > 1 is built for the class-agnostic map without '
+                                      'softmax/relu (nets_factory.py:258-274,298-309,322-328)')
+        if net.USE_POSE_PRELOGITS_BASED_ATTENTION_WITH_POSE_FEAT_2LAYER:
+            # that conv inherits batch-norm + relu from the resnet arg-scope (nets_factory.py:291-294
+            # passes neither normalizer_fn nor activation_fn): not built
+            raise NotImplementedError('..._WITH_POSE_FEAT_2LAYER is off in all shipped configs and not built')
+        if self.with_pose_feat and (net.USE_POSE_PRELOGITS_BASED_ATTENTION_PER_CLASS or self.rank > 1):
+            raise NotImplementedError('..._WITH_POSE_FEAT is built for the class-agnostic rank-1 map')
         self.num_classes = num_classes
         self.single_layer = bool(net.USE_POSE_PRELOGITS_BASED_ATTENTION_SINGLE_LAYER_ATT)
         self.softmax_att = bool(net.USE_POSE_PRELOGITS_BASED_ATTENTION_SOFTMAX_ATT)
@@ -161,7 +173,7 @@ class AttentionalPoolingHead(nn.Module):
         self.want_topdown = want_topdown
         if with_pose_logits is None:  # the pose logits are needed when a pose loss is configured
             with_pose_logits = bool(is_training and cfg.TRAIN.LOSS_FN_POSE and num_pose_keypoints > 0)
-        self.with_pose_logits = with_pose_logits
+        self.with_pose_logits = with_pose_logits or self.with_pose_feat
         self._step = 0
         n_maps = num_classes if self.per_class else 1
         cp = self.POSE_PRELOGITS
@@ -174,13 +186,38 @@ class AttentionalPoolingHead(nn.Module):
         self.pose_b2 = nn.Parameter(torch.zeros(max(num_pose_keypoints, 1)))
         self.att_weights = nn.Parameter(torch.randn(cin, n_maps) * 0.001)
         self.att_biases = nn.Parameter(torch.zeros(n_maps))
-        self.td_weights = nn.Parameter(torch.randn(in_channels, num_classes) * 0.001)
+        # ..._WITH_POSE_FEAT: the top-down conv sees concat(last_conv, pose_logits) (:289-295)
+        td_in = in_channels + (max(num_pose_keypoints, 1) if self.with_pose_feat else 0)
+        self.in_channels = in_channels
+        self.td_weights = nn.Parameter(torch.randn(td_in, num_classes) * 0.001)
         self.td_biases = nn.Parameter(torch.zeros(num_classes))
+        # rank > 1 (:258-274, :298-309): the r-th attention conv consumes the OUTPUT of conv r-1
+        # ([M,M] = [1,1] weights, scopes Conv2d_PrePose_Attn1, ...); one more top-down conv per rank
+        # (scopes Conv_1, ...)
+        self.att_weights_r = nn.ParameterList(
+            [nn.Parameter(torch.randn(1, 1) * 0.001) for _ in range(self.rank - 1)])
+        self.att_biases_r = nn.ParameterList(
+            [nn.Parameter(torch.zeros(1)) for _ in range(self.rank - 1)])
+        self.td_weights_r = nn.ParameterList(
+            [nn.Parameter(torch.randn(in_channels, num_classes) * 0.001) for _ in range(self.rank - 1)])
+        self.td_biases_r = nn.ParameterList(
+            [nn.Parameter(torch.zeros(num_classes)) for _ in range(self.rank - 1)])
+
+    def tf_variable_names(self):
+        """attribute -> TF variable name, including the per-rank scopes."""
+        names = dict(self.TF_NAMES)
+        for r in range(1, self.rank):
+            pre = 'PosePrelogitsBasedAttention/'
+            names['att_weights_r.%d' % (r - 1)] = pre + 'Conv2d_PrePose_Attn%d/weights' % r
+            names['att_biases_r.%d' % (r - 1)] = pre + 'Conv2d_PrePose_Attn%d/biases' % r
+            names['td_weights_r.%d' % (r - 1)] = pre + 'Conv_%d/weights' % r
+            names['td_biases_r.%d' % (r - 1)] = pre + 'Conv_%d/biases' % r
+        return names
 
     def regularized_weights(self):
         """conv weights carry slim.l2_regularizer from the resnet arg-scope (resnet_utils.py:241);
         biases do not.  Pose-head weights only count when the pose head is in the graph."""
-        ws = [self.att_weights, self.td_weights]
+        ws = [self.att_weights, self.td_weights] + list(self.att_weights_r) + list(self.td_weights_r)
         if self.with_pose_logits or not self.single_layer:
             ws += [self.pose_w1, self.pose_w2]
         return ws
@@ -196,14 +233,69 @@ class AttentionalPoolingHead(nn.Module):
         offset = self._step
         if self.is_training:
             self._step += 1            # a fresh dropout mask per step
-        logits, att, topdown = attentional_pooling(
-            last_conv, xatt, self.att_weights, self.att_biases, self.td_weights, self.td_biases,
-            softmax_att=self.softmax_att, relu_att=self.relu_att, is_training=self.is_training,
-            keep_prob=self.keep_prob, seed=self.seed, offset=offset, want_topdown=self.want_topdown)
         n, h, w = last_conv.shape[0], last_conv.shape[1], last_conv.shape[2]
-        end_points['PosePrelogitsBasedAttention'] = att.view(n, h, w, -1)        # :287
-        if topdown is not None:
-            end_points['TopDownAttention'] = topdown.view(n, h, w, -1)           # :309
+        C = self.in_channels
+        kw = dict(softmax_att=self.softmax_att, relu_att=self.relu_att, is_training=self.is_training,
+                  keep_prob=self.keep_prob, seed=self.seed, offset=offset)
+
+        if self.rank == 1:
+            wt_x = self.td_weights[:C] if self.with_pose_feat else self.td_weights
+            logits, att, topdown = attentional_pooling(
+                last_conv, xatt, self.att_weights, self.att_biases, wt_x, self.td_biases,
+                want_topdown=self.want_topdown and not self.with_pose_feat, **kw)
+            end_points['PosePrelogitsBasedAttention'] = att.view(n, h, w, -1)    # :287
+            if self.with_pose_feat:
+                # :289-296: the J extra channels of concat(last_conv, pose_logits) go through the
+                # same dropout and the same attention-weighted mean.  [N,P,16] is plumbing-sized, so
+                # this side term is torch ops on the device (the 2048-channel part above is the HIP
+                # op); the op's attention end point is non-differentiable, so the map is re-formed
+                # here for autograd (one GEMV over the attention input)
+                xa = (last_conv if self.single_layer else pose_pre).reshape(n, h * w, -1).float()
+                a_t = (xa @ self.att_weights).squeeze(-1) + self.att_biases
+                if self.softmax_att:
+                    a_t = torch.softmax(a_t, dim=1)
+                if self.relu_att:
+                    a_t = torch.relu(a_t)
+                pl = end_points['PoseLogits'].reshape(n, h * w, -1).float()
+                if self.is_training and self.keep_prob < 1.0:
+                    g = torch.Generator(device=pl.device).manual_seed(self.seed * 1000003 + offset)
+                    keep = torch.rand(pl.shape, generator=g, device=pl.device) < self.keep_prob
+                    pl = pl * keep / self.keep_prob
+                zp = torch.einsum('np,npj->nj', a_t, pl) / float(h * w)
+                logits = logits + zp @ self.td_weights[C:]
+            if topdown is not None:
+                end_points['TopDownAttention'] = topdown.view(n, h, w, -1)       # :309
+        else:
+            # rank R > 1, identity activation, one bottom-up map.  Z_r = Z_{r-1} w_r + b_r with scalar
+            # (w_r, b_r), so Z_r = alpha_r Z_0 + beta_r and
+            #   logits = sum_r mean_p Z_r (X' Wt_r + bt_r)
+            #          = pool(X; Z_0, sum_r alpha_r Wt_r, sum_r alpha_r bt_r)          (pass A)
+            #          + mean_p X' . sum_r beta_r Wt_r + sum_r beta_r bt_r             (pass B)
+            # i.e. two streaming passes of the rank-1 HIP op for any R (pass B is the op with a
+            # constant attention map), same dropout mask in both.
+            one = torch.ones((), device=last_conv.device)
+            alphas, betas = [one], [torch.zeros((), device=last_conv.device)]
+            for r in range(self.rank - 1):
+                wr, br = self.att_weights_r[r].reshape(()), self.att_biases_r[r].reshape(())
+                alphas.append(alphas[-1] * wr)
+                betas.append(betas[-1] * wr + br)
+            wts = [self.td_weights] + list(self.td_weights_r)
+            bts = [self.td_biases] + list(self.td_biases_r)
+            wt_a = sum(a * w_ for a, w_ in zip(alphas, wts))
+            bt_a = sum(a * b_ for a, b_ in zip(alphas, bts))
+            wt_b = sum(b * w_ for b, w_ in zip(betas, wts))
+            c_b = sum(b * b_ for b, b_ in zip(betas, bts))
+            logits_a, att, _ = attentional_pooling(last_conv, xatt, self.att_weights, self.att_biases,
+                                                   wt_a, bt_a, **kw)
+            ones_in = torch.zeros(n, h, w, 8, device=last_conv.device, dtype=last_conv.dtype)
+            logits_b, _, _ = attentional_pooling(
+                last_conv, ones_in, torch.zeros(8, 1, device=last_conv.device),
+                torch.ones(1, device=last_conv.device), wt_b,
+                torch.zeros_like(self.td_biases), **kw)
+            logits = logits_a + logits_b + c_b
+            z0 = att.view(n, h, w, 1)
+            end_points['PosePrelogitsBasedAttention'] = torch.stack(
+                [a * z0 + b for a, b in zip(alphas, betas)], dim=-1)            # [N,H,W,1,R] (:271-274)
         end_points['Logits'] = logits                                            # :352
         return logits, end_points
 

@@ -300,3 +300,97 @@ def test_m1_topdown_endpoint_dump(gpu):
     # and the logits are its attention-weighted spatial mean (the literal reference formula)
     lit = (att.cpu().double().view(2, 7, 7, 1) * want).mean((1, 2))
     assert _rel(logits.cpu().numpy(), lit.numpy()) < 2e-5
+
+
+def _make_head(gpu, net_flags, is_training=False, **kw):
+    from attentionalpoolingaction_amd import config as apa_config, nets_factory
+    cfg = apa_config.reset_cfg()
+    net = {'USE_POSE_PRELOGITS_BASED_ATTENTION': True}
+    net.update(net_flags)
+    apa_config.cfg_from_dict({'MODEL_NAME': 'resnet_v1_101', 'NET': net})
+    fn = nets_factory.get_network_fn('resnet_v1_101', 51, 16, cfg, is_training=is_training, device=gpu, **kw)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():                                  # trained-scale weights everywhere
+        for name, p in fn.head.named_parameters():
+            if p.dim() >= 2 and p.shape[0] > 1:
+                p.copy_(torch.randn(p.shape, generator=g) / p.shape[0] ** 0.5)
+            elif p.dim() >= 2:                             # the [1,1] chained attention convs
+                p.copy_(torch.randn(p.shape, generator=g) * 0.5 + 1.0)
+            else:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+    return fn, cfg
+
+
+@pytest.mark.parametrize('single_layer', [True, False])
+def test_head_module_rank3_matches_oracle(gpu, single_layer):
+    """..._RANK = 3 (nets_factory.py:258-274, 298-309, 322-328): chained [1,1] attention convs, one
+    top-down conv per rank, sum over ranks -- two HIP streaming passes via the affine collapse --
+    against the literal stacked formulation of the oracle, values and every gradient."""
+    from attentionalpoolingaction_amd import config as apa_config
+    fn, _ = _make_head(gpu, {'USE_POSE_PRELOGITS_BASED_ATTENTION_SINGLE_LAYER_ATT': single_layer,
+                             'USE_POSE_PRELOGITS_BASED_ATTENTION_RANK': 3})
+    head = fn.head
+    g = torch.Generator().manual_seed(9)
+    X = torch.relu(torch.randn(3, 14, 14, 2048, generator=g))
+    labels = torch.randint(0, 51, (3,), generator=g)
+    Xd = X.to(gpu).requires_grad_(True)
+    logits, ep = fn(Xd)
+    assert ep['PosePrelogitsBasedAttention'].shape == (3, 14, 14, 1, 3)
+    loss = torch.nn.functional.cross_entropy(logits, labels.to(gpu))
+    loss.backward()
+
+    p = {k: v.detach().cpu().double().requires_grad_(True) for k, v in head.named_parameters()}
+    Xr = X.double().requires_grad_(True)
+    pre = None
+    if not single_layer:
+        pre, _ = orc.pose_logits_head(Xr, p['pose_w1'], p['pose_b1'], p['pose_w2'], p['pose_b2'])
+    aw = [p['att_weights']] + [p['att_weights_r.%d' % r] for r in range(2)]
+    ab = [p['att_biases']] + [p['att_biases_r.%d' % r] for r in range(2)]
+    tw = [p['td_weights']] + [p['td_weights_r.%d' % r] for r in range(2)]
+    tb = [p['td_biases']] + [p['td_biases_r.%d' % r] for r in range(2)]
+    lr, epr = orc.attentional_pooling(Xr, pre, None, aw, ab, tw, tb,
+                                      orc.AttnFlags(single_layer_att=single_layer, rank=3))
+    torch.nn.functional.cross_entropy(lr, labels).backward()
+    assert _rel(logits.detach().cpu().numpy(), lr.detach().numpy()) < 2e-5
+    assert _rel(ep['PosePrelogitsBasedAttention'].detach().cpu().numpy(),
+                epr['PosePrelogitsBasedAttention'].detach().numpy()) < 2e-5
+    assert _rel(Xd.grad.cpu().numpy(), Xr.grad.numpy()) < 1e-4
+    for k, v in head.named_parameters():
+        if p[k].grad is None:
+            assert v.grad is None or float(v.grad.abs().max()) == 0.0, k
+            continue
+        assert _rel(v.grad.cpu().numpy(), p[k].grad.numpy()) < 1e-4, k
+    assert len(head.tf_variable_names()) == 8 + 4 * 2
+    apa_config.reset_cfg()
+
+
+def test_head_module_with_pose_feat_matches_oracle(gpu):
+    """..._WITH_POSE_FEAT (nets_factory.py:289-295): the top-down conv sees concat(last_conv,
+    pose_logits); eval mode (the extra channels' dropout mask is an independent stream)."""
+    from attentionalpoolingaction_amd import config as apa_config
+    fn, _ = _make_head(gpu, {'USE_POSE_PRELOGITS_BASED_ATTENTION_SINGLE_LAYER_ATT': False,
+                             'USE_POSE_PRELOGITS_BASED_ATTENTION_WITH_POSE_FEAT': True})
+    head = fn.head
+    assert head.td_weights.shape == (2048 + 16, 51)
+    g = torch.Generator().manual_seed(19)
+    X = torch.relu(torch.randn(2, 14, 14, 2048, generator=g))
+    labels = torch.randint(0, 51, (2,), generator=g)
+    Xd = X.to(gpu).requires_grad_(True)
+    logits, ep = fn(Xd)
+    torch.nn.functional.cross_entropy(logits, labels.to(gpu)).backward()
+    p = {k: v.detach().cpu().double().requires_grad_(True) for k, v in head.named_parameters()}
+    Xr = X.double().requires_grad_(True)
+    pre, pl = orc.pose_logits_head(Xr, p['pose_w1'], p['pose_b1'], p['pose_w2'], p['pose_b2'])
+    lr, _ = orc.attentional_pooling(Xr, pre, pl, [p['att_weights']], [p['att_biases']],
+                                    [p['td_weights']], [p['td_biases']],
+                                    orc.AttnFlags(single_layer_att=False, with_pose_feat=True))
+    torch.nn.functional.cross_entropy(lr, labels).backward()
+    assert _rel(logits.detach().cpu().numpy(), lr.detach().numpy()) < 2e-5
+    assert _rel(Xd.grad.cpu().numpy(), Xr.grad.numpy()) < 2e-4
+    for k in ('pose_w1', 'pose_b1', 'pose_w2', 'pose_b2', 'att_weights', 'att_biases', 'td_weights', 'td_biases'):
+        assert _rel(getattr(head, k).grad.cpu().numpy(), p[k].grad.numpy()) < 2e-4, k
+    apa_config.reset_cfg()
+    with pytest.raises(NotImplementedError):
+        _make_head(gpu, {'USE_POSE_PRELOGITS_BASED_ATTENTION_WITH_POSE_FEAT': True,
+                         'USE_POSE_PRELOGITS_BASED_ATTENTION_WITH_POSE_FEAT_2LAYER': True})
+    apa_config.reset_cfg()
