@@ -343,17 +343,32 @@ def frame_pooling(logits: torch.Tensor, frames_per_video: int, end_points: Dict[
 def get_network_fn(name: str, num_classes: int, num_pose_keypoints: int, cfg,
                    weight_decay: float = 0.0, is_training: bool = False,
                    backbone: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
-                   device='cuda', **head_kwargs):
+                   device='cuda', with_backbone: bool = False, backbone_dtype=None, **head_kwargs):
     """Same signature as nets_factory.py:94-95 (+ optional backbone/device).
 
     Returns `network_fn(images) -> (logits, end_points)`; `network_fn.head` exposes the module
     (its parameters) and `network_fn.weight_decay` the coefficient for the L2 term.
     With `backbone=None`, `images` IS the conv5 map [N,H,W,C] (or [B,F,H,W,C] for video input,
-    nets_factory.py:121-125).
+    nets_factory.py:121-125).  `with_backbone=True` builds the slim ResNet-v1 of `resnet_v1.py`
+    (PyTorch-ROCm, channels-last: its block4 tap is read by the HIP op with no layout change);
+    `backbone_dtype=torch.bfloat16` runs it under autocast so the tap arrives as bf16.
     """
     if name not in last_conv_map:
         raise ValueError('Name of network unknown %s' % name)
     channels = last_conv_map[name][1]
+    if with_backbone and backbone is None:
+        from . import resnet_v1
+        if name not in resnet_v1.BLOCKS:
+            raise ValueError('no built-in backbone for %s (pass backbone=callable)' % name)
+        net = resnet_v1.ResNetV1(name).to(device)
+        net.train(is_training)
+
+        def backbone(images, _net=net, _dt=backbone_dtype):
+            if _dt is None:
+                return _net(images)
+            with torch.autocast('cuda', dtype=_dt):
+                return _net(images)
+        backbone.module = net
     head = AttentionalPoolingHead(num_classes, cfg, in_channels=channels,
                                   num_pose_keypoints=num_pose_keypoints, is_training=is_training,
                                   seed=cfg.RNG_SEED, **head_kwargs).to(device)
@@ -385,6 +400,7 @@ def get_network_fn(name: str, num_classes: int, num_pose_keypoints: int, cfg,
         return logits, end_points
 
     network_fn.head = head
+    network_fn.backbone = getattr(backbone, 'module', backbone)
     network_fn.temporal = temporal
     network_fn.weight_decay = weight_decay
     network_fn.num_pose_keypoints = num_pose_keypoints
