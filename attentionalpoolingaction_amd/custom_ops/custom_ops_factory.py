@@ -58,6 +58,8 @@ _SIGNATURES = {
     'apa_pose_label_replay_resize': (c_int, [POINTER(c_uint8)] + [c_int] * 11 + [c_float, POINTER(c_float)]),
     'apa_frame_pool_fwd': (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),
     'apa_frame_pool_bwd': (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),
+    'apa_momentum_sgd_step': (c_int, [c_int, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_float),
+                                      c_void_p, c_void_p, c_float, c_float, c_float, c_void_p]),
     'apa_prof_event_create': (c_int, [POINTER(c_void_p)]),
     'apa_prof_event_destroy': (c_int, [c_void_p]),
     'apa_prof_event_record': (c_int, [c_void_p, c_void_p]),
@@ -433,6 +435,23 @@ def frame_pool_bwd(logits, frames_per_video, w, tatt, dpooled):
                                 _dev_ptr(scratch, 'scratch'), B, frames_per_video, K, _stream_ptr())
     _check(rc, 'apa_frame_pool_bwd')
     return dlogits, dw, db
+
+
+def momentum_sgd_step(weights, weight_decay, grad_flat, acc_flat, lr, momentum=0.9, grad_scale=1.0):
+    """One fused launch: acc = m*acc + (grad_scale*g + wd_i*w_i); w_i -= lr*acc for every parameter.
+    `weights`: list of fp32 device tensors in bucket order; `weight_decay`: one float per tensor."""
+    lib = load_library()
+    n = len(weights)
+    ptrs = (c_void_p * n)(*[_dev_ptr(w, 'weights[%d]' % i, torch.float32) for i, w in enumerate(weights)])
+    sizes = (c_size_t * n)(*[w.numel() for w in weights])
+    wds = (c_float * n)(*[float(x) for x in weight_decay])
+    total = sum(w.numel() for w in weights)
+    if grad_flat.numel() != total or acc_flat.numel() != total:
+        raise ValueError('flat buffers hold {} / {} elements, parameters {}'.format(
+            grad_flat.numel(), acc_flat.numel(), total))
+    _check(lib.apa_momentum_sgd_step(n, ptrs, sizes, wds, _dev_ptr(grad_flat, 'grad_flat', torch.float32),
+                                     _dev_ptr(acc_flat, 'acc_flat', torch.float32), lr, momentum,
+                                     grad_scale, _stream_ptr()), 'apa_momentum_sgd_step')
 
 
 # --------------------------------------------------------------------------------------------

@@ -119,24 +119,35 @@ class GradientAccumulator:
 
 class MomentumSGD:
     """tf.train.MomentumOptimizer(lr, momentum) (src/train.py:90-94): acc = m*acc + g;
-    w -= lr*acc (no Nesterov, no dampening) on the flat bucket layout."""
+    w -= lr*acc (no Nesterov, no dampening) on the flat bucket layout, with the slim L2
+    regulariser's gradient `wd * w` folded in for the names in `regularized`
+    (resnet_utils.py:241: conv weights only).  On a GPU the whole update is ONE fused HIP launch
+    (`apa_momentum_sgd_step`); CPU tensors (the gloo tests) take the equivalent torch expressions."""
 
     def __init__(self, params: Dict[str, torch.Tensor], bucket: GradientBucket, lr: float,
-                 momentum: float = 0.9):
+                 momentum: float = 0.9, weight_decay: float = 0.0, regularized: Sequence[str] = ()):
         self.params = params
         self.bucket = bucket
         self.lr = lr
         self.momentum = momentum
         self.acc = torch.zeros_like(bucket.flat)
+        reg = set(regularized)
+        self.wd = [weight_decay if n in reg else 0.0 for n in bucket.names]
 
-    def step(self, lr: Optional[float] = None) -> None:
+    def step(self, lr: Optional[float] = None, grad_scale: float = 1.0) -> None:
         lr = self.lr if lr is None else lr
-        self.acc.mul_(self.momentum).add_(self.bucket.flat)
+        ws = [self.params[n].data for n in self.bucket.names]
+        if self.bucket.flat.is_cuda:
+            from .custom_ops import custom_ops_factory as cof
+            cof.momentum_sgd_step(ws, self.wd, self.bucket.flat, self.acc, lr, self.momentum, grad_scale)
+            return
         o = 0
-        for name in self.bucket.names:
-            p = self.params[name]
-            n = p.numel()
-            p.data.add_(self.acc[o:o + n].view_as(p), alpha=-lr)
+        for w, wd in zip(ws, self.wd):
+            n = w.numel()
+            g = self.bucket.flat[o:o + n].view_as(w) * grad_scale + wd * w
+            a = self.acc[o:o + n].view_as(w)
+            a.mul_(self.momentum).add_(g)
+            w.add_(a, alpha=-lr)
             o += n
 
 

@@ -196,6 +196,20 @@ int apa_zero_out_channels(const float* in, const uint8_t* channels, float* out, 
                           int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused optimizer step (src/train.py:90-94 tf.train.MomentumOptimizer + the slim L2 regulariser of
+ * models/slim/nets/resnet_utils.py:241 on conv weights):  for every parameter segment i
+ *     g   = grad_scale * grad_flat[off_i ...] + weight_decay[i] * w_i
+ *     acc = momentum * acc + g ;   w_i -= lr * acc
+ * weights[i]: device pointers (fp32) to the nseg parameter tensors, sizes[i] their element counts
+ * (host arrays); grad_flat / acc_flat: the flat all-reduce bucket and the momentum accumulators in
+ * the same concatenated order.  weight_decay[i] is 0 for biases.  One launch, any alignment.
+ */
+#define APA_SGD_MAX_SEGMENTS 16
+int apa_momentum_sgd_step(int nseg, float* const* weights, const size_t* sizes,
+                          const float* weight_decay, const float* grad_flat, float* acc_flat,
+                          float lr, float momentum, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py): HIP events owned by the library's HIP runtime, and a per-thread
  * pair that the next apa_attn_pool_bwd call records immediately before / after its dominant
  * streaming kernel (m1_bwd_main_kernel), on the call's stream.  Pass NULL, NULL to clear.

@@ -434,3 +434,32 @@ def test_network_fn_with_resnet_backbone_end_to_end(gpu, bdtype):
     assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
     assert images.grad is not None and float(images.grad.abs().max()) > 0
     apa_config.reset_cfg()
+
+
+def test_fused_momentum_sgd_matches_torch_sgd(gpu):
+    """apa_momentum_sgd_step == tf.train.MomentumOptimizer + slim L2 on weights only
+    (src/train.py:90-94, resnet_utils.py:241) == torch.optim.SGD(momentum, per-group weight_decay);
+    three steps, odd sizes (flat offsets are not 16-byte aligned), grad_scale = 1/ITER_SIZE."""
+    from attentionalpoolingaction_amd import deploy
+    g = torch.Generator().manual_seed(4)
+    shapes = {'att_weights': (2048, 1), 'att_biases': (1,), 'td_weights': (2048, 393), 'td_biases': (393,)}
+    params = {k: torch.randn(s, generator=g).to(gpu) for k, s in shapes.items()}
+    ref = {k: v.detach().cpu().double().requires_grad_(True) for k, v in params.items()}
+    opt_ref = torch.optim.SGD([
+        {'params': [ref['att_weights'], ref['td_weights']], 'weight_decay': 5e-4},
+        {'params': [ref['att_biases'], ref['td_biases']], 'weight_decay': 0.0}], lr=1e-3, momentum=0.9)
+    bucket = deploy.GradientBucket(shapes, gpu)
+    opt = deploy.MomentumSGD(params, bucket, lr=1e-3, momentum=0.9, weight_decay=5e-4,
+                             regularized=['att_weights', 'td_weights'])
+    for step in range(3):
+        lr = deploy.exponential_decay_lr(1e-3, step, 2, 0.33)
+        for k in shapes:
+            gk = torch.randn(shapes[k], generator=g)
+            bucket.views[k].copy_(gk.to(gpu) * 2.0)            # accumulated over ITER_SIZE = 2
+            ref[k].grad = gk.double()
+        for grp in opt_ref.param_groups:
+            grp['lr'] = lr
+        opt_ref.step()
+        opt.step(lr=lr, grad_scale=0.5)
+    for k in shapes:
+        assert _rel(params[k].cpu().numpy(), ref[k].detach().numpy()) < 1e-6, k
