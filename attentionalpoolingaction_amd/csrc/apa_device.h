@@ -93,8 +93,13 @@ __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return u >> 16;
 }
+// two floats -> packed bf16 pair, round-to-nearest-even: one v_cvt_pk_bf16_f32 on gfx950
+// (the bit-twiddled f32_to_bf16_bits above costs ~6 VALU ops per element)
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -133,14 +138,21 @@ __device__ __forceinline__ void st16(void* p, const uint4& v) { *reinterpret_cas
 // Stateless: the backward pass and apa_dropout_mask() regenerate the identical mask from
 // (k0, k1) = splitmix64(seed, offset) (host side) and the flat element index.
 // ---------------------------------------------------------------------------------------------
+// Two rounds of (fold, 24-bit multiply, xorshift).  v_mul_u32_u24 issues at full rate where
+// v_mul_lo_u32 is quarter rate, and the three 32-bit multiplies of the previous hash were ~45 % of
+// the VALU time of the streaming kernels.  The fold before each multiply brings the bits the
+// 24-bit multiplier ignores back into range.  Statistics (keep fraction, lag / lo-hi correlations,
+// byte chi-square, key avalanche) are indistinguishable from the 3-multiply version:
+// scratch notes in DESIGN.md section 3.2.
 __device__ __forceinline__ uint32_t rng_hash(uint32_t idx, uint32_t k0, uint32_t k1) {
   uint32_t x = idx ^ k0;
-  x *= 0x9E3779B1u;
-  x ^= x >> 15;
-  x = (x ^ k1) * 0x85EBCA6Bu;
-  x ^= x >> 13;
-  x *= 0xC2B2AE35u;
   x ^= x >> 16;
+  x = __umul24(x, 0xB5297Bu);
+  x ^= x >> 13;
+  x ^= k1;
+  x ^= x >> 17;
+  x = __umul24(x, 0x68E31Du);
+  x ^= x >> 15;
   return x;
 }
 // Same splitmix64 key derivation as the host-side rng_key() in apa_internal.h.
@@ -156,7 +168,7 @@ __device__ __forceinline__ void rng_key_dev(uint64_t seed, uint64_t offset, uint
 __device__ __forceinline__ void rng_keep2(uint64_t e, uint32_t k0, uint32_t k1, uint32_t thresh,
                                           float& m0, float& m1) {
   const uint64_t q = e >> 1;
-  const uint32_t h = rng_hash((uint32_t)q, k0, k1 + (uint32_t)(q >> 32) * 0x9E3779B9u);
+  const uint32_t h = rng_hash((uint32_t)q, k0, k1 ^ __umul24((uint32_t)(q >> 32), 0x9E3779u));
   m0 = (h & 0xffffu) < thresh ? 1.0f : 0.0f;
   m1 = (h >> 16) < thresh ? 1.0f : 0.0f;
 }

@@ -52,7 +52,7 @@ __device__ __forceinline__ float block_dots(const float (&d)[PIX], float* sm, in
 __device__ __forceinline__ uint32_t rng_keep2_bits(uint64_t e, uint32_t k0, uint32_t k1,
                                                    uint32_t thresh) {
   const uint64_t q = e >> 1;
-  const uint32_t h = rng_hash((uint32_t)q, k0, k1 + (uint32_t)(q >> 32) * 0x9E3779B9u);
+  const uint32_t h = rng_hash((uint32_t)q, k0, k1 ^ __umul24((uint32_t)(q >> 32), 0x9E3779u));
   return ((h & 0xffffu) < thresh ? 1u : 0u) | ((h >> 16) < thresh ? 2u : 0u);
 }
 }  // namespace
