@@ -27,6 +27,8 @@ void prof_kernel_events(hipEvent_t* start, hipEvent_t* stop) {
   *start = g_prof_start;
   *stop = g_prof_stop;
 }
+static thread_local hipEvent_t g_grad_ready = nullptr;
+hipEvent_t grad_ready_event() { return g_grad_ready; }
 void prof_null_events(hipEvent_t* start, hipEvent_t* stop) {
   *start = g_null_start;
   *stop = g_null_stop;
@@ -69,6 +71,11 @@ extern "C" int apa_prof_event_elapsed_ms(void* start, void* stop, float* ms) {
 extern "C" int apa_prof_set_kernel_events(void* start, void* stop) {
   g_prof_start = static_cast<hipEvent_t>(start);
   g_prof_stop = static_cast<hipEvent_t>(stop);
+  return APA_OK;
+}
+
+extern "C" int apa_set_grad_ready_event(void* event) {
+  g_grad_ready = static_cast<hipEvent_t>(event);
   return APA_OK;
 }
 
@@ -239,6 +246,8 @@ extern "C" int apa_attn_pool_bwd(const void* X, const void* Xatt, const float* W
     set_error("apa_attn_pool_bwd: workspace too small (%zu < %zu)", ws_bytes, need);
     return APA_ERR_WORKSPACE;
   }
-  return pc_backward(X, Xatt, Wa, Wt, att, zsave, G, dX, dXatt, dWa, dba, dWt, dbt, ws, N, P, C, Ca,
-                     K, flags, keep_prob, seed, offset, dtype, st);
+  rc = pc_backward(X, Xatt, Wa, Wt, att, zsave, G, dX, dXatt, dWa, dba, dWt, dbt, ws, N, P, C, Ca, K,
+                   flags, keep_prob, seed, offset, dtype, st);
+  if (rc == APA_OK && grad_ready_event()) APA_HIP_CHECK(hipEventRecord(grad_ready_event(), st));
+  return rc;
 }

@@ -28,6 +28,8 @@ int hip_fail(hipError_t e, const char* what);
 // Optional per-thread event pair recorded around the dominant kernel (apa_prof_set_kernel_events).
 void prof_kernel_events(hipEvent_t* start, hipEvent_t* stop);
 void prof_null_events(hipEvent_t* start, hipEvent_t* stop);
+// apa_set_grad_ready_event: recorded once dWt / dbt are final (nullptr when unset)
+hipEvent_t grad_ready_event();
 
 // Ablation hook for profiling experiments only (make ABLATE=1): a bit mask of kernels NOT to launch
 // (results are then wrong by construction).  Compiled out of the product build.

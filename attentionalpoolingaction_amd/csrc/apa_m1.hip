@@ -824,6 +824,9 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
     if (rc != APA_OK) return rc;
   }
 
+  // dWt / dbt are final here (fast path): let a data-parallel caller start their all-reduce now
+  if (small_ok && grad_ready_event()) APA_HIP_CHECK(hipEventRecord(grad_ready_event(), st));
+
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   prof_kernel_events(&ev0, &ev1);
   {
@@ -876,6 +879,7 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
   hipLaunchKernelGGL(m1_bwd_reduce_kernel, dim3((cred + 63) / 64 + 1), dim3(256), 0, st, pdwa, pdba,
                      dWa, dba, abar, G, dbt, nred, cred, N, K, 1, bump);
   APA_LAUNCH_CHECK("m1_bwd_reduce_kernel");
+  if (grad_ready_event()) APA_HIP_CHECK(hipEventRecord(grad_ready_event(), st));   // dbt comes last here
   return APA_OK;
 }
 

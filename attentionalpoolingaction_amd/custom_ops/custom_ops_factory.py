@@ -58,6 +58,7 @@ _SIGNATURES = {
     'apa_pose_label_replay_resize': (c_int, [POINTER(c_uint8)] + [c_int] * 11 + [c_float, POINTER(c_float)]),
     'apa_frame_pool_fwd': (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),
     'apa_frame_pool_bwd': (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),
+    'apa_set_grad_ready_event': (c_int, [c_void_p]),
     'apa_momentum_sgd_step': (c_int, [c_int, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_float),
                                       c_void_p, c_void_p, c_float, c_float, c_float, c_void_p]),
     'apa_prof_event_create': (c_int, [POINTER(c_void_p)]),
@@ -435,6 +436,20 @@ def frame_pool_bwd(logits, frames_per_video, w, tatt, dpooled):
                                 _dev_ptr(scratch, 'scratch'), B, frames_per_video, K, _stream_ptr())
     _check(rc, 'apa_frame_pool_bwd')
     return dlogits, dw, db
+
+
+def set_grad_ready_event(event) -> None:
+    """Register (or clear, with None) the event apa_attn_pool_bwd records as soon as dWt / dbt are
+    final.  `event`: a torch.cuda.Event that has been recorded at least once (so its handle
+    exists) or a raw hipEvent_t."""
+    lib = load_library()
+    if event is None:
+        handle = None
+    elif isinstance(event, torch.cuda.Event):
+        handle = c_void_p(event.cuda_event)
+    else:
+        handle = c_void_p(event)
+    _check(lib.apa_set_grad_ready_event(handle), 'apa_set_grad_ready_event')
 
 
 def momentum_sgd_step(weights, weight_decay, grad_flat, acc_flat, lr, momentum=0.9, grad_scale=1.0):

@@ -70,12 +70,18 @@ class GradientBucket:
         return self.flat.numel() * self.flat.element_size()
 
 
-def sum_clone_gradients(bucket: GradientBucket, config: DeploymentConfig, async_op: bool = False):
+def sum_clone_gradients(bucket: GradientBucket, config: DeploymentConfig, async_op: bool = False,
+                        comm=None):
     """_sum_clones_gradients: one all-reduce(SUM) of the flat bucket.  The gradients must already
     carry the 1/num_clones loss scale (pass DeploymentConfig.clone_loss_scale as `grad_scale` to
-    the loss kernel).  Returns the work handle when async_op=True (overlap with the next
-    micro-batch's forward; wait before the optimizer step)."""
+    the loss kernel).  `comm`: an `rccl.RcclCommunicator` -> the collective is one in-stream
+    ncclAllReduce on the current stream (no torch.distributed call on the step path); otherwise
+    torch.distributed (gloo on CPU, "nccl" = RCCL on GPU), which returns the work handle when
+    async_op=True (overlap with the next micro-batch's forward; wait before the optimizer step)."""
     if config.num_clones == 1:
+        return None
+    if comm is not None:
+        comm.all_reduce_(bucket.flat)
         return None
     return dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM, group=config.process_group,
                            async_op=async_op)

@@ -196,6 +196,16 @@ int apa_zero_out_channels(const float* in, const uint8_t* channels, float* out, 
                           int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Gradient-ready hook (communication / compute overlap).  The classifier gradients dWt / dbt --
+ * 99.7 % of the all-reduce payload -- are final after the FIRST kernel of apa_attn_pool_bwd, before
+ * the streaming pass starts.  If an event is registered (per host thread), apa_attn_pool_bwd
+ * records it on its stream at that point, so a data-parallel trainer can start the RCCL
+ * all-reduce of that part of the bucket on a second stream while dX / dWa are still being
+ * produced (bench.py, deploy.py).  NULL clears.  Purely an ordering aid: results are unaffected.
+ */
+int apa_set_grad_ready_event(void* event);
+
+/* ------------------------------------------------------------------------------------------
  * Fused optimizer step (src/train.py:90-94 tf.train.MomentumOptimizer + the slim L2 regulariser of
  * models/slim/nets/resnet_utils.py:241 on conv weights):  for every parameter segment i
  *     g   = grad_scale * grad_flat[off_i ...] + weight_decay[i] * w_i

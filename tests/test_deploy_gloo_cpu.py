@@ -65,6 +65,11 @@ def _worker(rank, world, port, out_dir):
         work.wait()
         deploy.add_regularization_gradient(bucket2, p, 5e-4, ['att_weights', 'td_weights'])
         assert torch.equal(bucket.flat, bucket2.flat)
+        # the RCCL bootstrap: rank 0's 128-byte unique id must reach every rank intact
+        from attentionalpoolingaction_amd import rccl
+        mine = bytes(range(128)) if rank == 0 else bytes(128)
+        got = rccl.exchange_unique_id(mine, rank, world, None, None)
+        assert got == bytes(range(128)) and len(got) == rccl.NCCL_UNIQUE_ID_BYTES
     finally:
         dist.destroy_process_group()
 

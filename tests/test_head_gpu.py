@@ -463,3 +463,24 @@ def test_fused_momentum_sgd_matches_torch_sgd(gpu):
         opt.step(lr=lr, grad_scale=0.5)
     for k in shapes:
         assert _rel(params[k].cpu().numpy(), ref[k].detach().numpy()) < 1e-6, k
+
+
+def test_direct_rccl_allreduce_single_rank(gpu):
+    """rccl.RcclCommunicator: ctypes ncclCommInitRank / ncclAllReduce on the compute stream.  One GPU
+    per box here, so a 1-rank communicator: the sum over ranks is the identity; the N > 1 arithmetic
+    (loss / num_clones, regulariser once) is covered by tests/test_deploy_gloo_cpu.py."""
+    from attentionalpoolingaction_amd import deploy, rccl
+    comm = rccl.RcclCommunicator(0, 1, gpu)
+    bucket = deploy.GradientBucket({'w': (2048, 393), 'b': (393,)}, gpu)
+    bucket.flat.copy_(torch.arange(bucket.flat.numel(), device=gpu, dtype=torch.float32) % 97)
+    want = bucket.flat.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    comm.all_reduce_(bucket.flat, side)
+    side.synchronize()
+    assert torch.equal(bucket.flat, want)
+    cfg2 = deploy.DeploymentConfig(num_clones=2, clone_index=0)
+    assert deploy.sum_clone_gradients(bucket, cfg2, comm=comm) is None      # in-stream path
+    torch.cuda.synchronize()
+    assert torch.equal(bucket.flat, want)
+    comm.close()
