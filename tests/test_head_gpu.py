@@ -484,3 +484,26 @@ def test_direct_rccl_allreduce_single_rank(gpu):
     torch.cuda.synchronize()
     assert torch.equal(bucket.flat, want)
     comm.close()
+
+
+@pytest.mark.parametrize('N,K', [(1, 3), (5, 4), (32, 393), (33, 51), (64, 129), (65, 512), (200, 513),
+                                 (7, 1024), (3, 1500)])
+def test_softmax_xent_shapes_vs_float64(gpu, N, K):
+    """Every code path of apa_softmax_xent_fwd_bwd (src/loss.py:74-80, eval.py:193-197): streaming
+    fallback (K < 4, K > 1024), 1/2/4/8 vectors per lane, ragged last vector (K % 4 != 0), odd row
+    pairs, loss-only single block, loss + gradient block roles (N <= 64), multi-block (N > 64)."""
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    g = torch.Generator().manual_seed(N * 1000 + K)
+    lg = torch.randn(N, K, generator=g) * 3
+    lab = torch.randint(0, K, (N,), generator=g)
+    ref_lp = torch.log_softmax(lg.double(), dim=1)
+    ref_loss = -ref_lp[torch.arange(N), lab].mean()
+    ref_G = (ref_lp.exp() - torch.nn.functional.one_hot(lab, K)) / N
+    lb, G, probs, pred = cof.softmax_xent_fwd_bwd(lg.to(gpu), lab.to(gpu), want_probs=True, want_pred=True)
+    assert abs(float(lb[0]) - float(ref_loss)) < 2e-6 * max(1.0, float(ref_loss))
+    assert _rel(lb[1:].cpu().numpy(), -ref_lp[torch.arange(N), lab].numpy()) < 2e-6
+    assert _rel(G.cpu().numpy(), ref_G.numpy()) < 5e-6
+    assert _rel(probs.cpu().numpy(), ref_lp.exp().numpy()) < 5e-6
+    assert torch.equal(pred.cpu(), lg.argmax(1))
+    lb2, G2, _, _ = cof.softmax_xent_fwd_bwd(lg.to(gpu), lab.to(gpu), want_grad=False)   # loss only
+    assert G2 is None and float(lb2[0]) == float(lb[0])
