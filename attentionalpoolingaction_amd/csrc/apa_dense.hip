@@ -31,13 +31,15 @@ template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, size_t i, flo
 // =============================================================================================
 // A. PoseLogits head
 // =============================================================================================
-constexpr int POSE_RB = 32;  // rows per block of the dPpre kernel
+constexpr int POSE_RB = 8;   // rows per block of the dPpre kernel
 
 // dPpre[r,j] = (sum_q dPl[r,q] W2[j,q] + ext[r,j]) * [Ppre[r,j] > 0]
 // plus per-block column partials for db1 (= sum_r dPpre) and db2 (= sum_r dPl).
-// block b owns rows [b*32, b*32+32); thread t owns columns t, t+256, ...  (coalesced along j)
-template <typename T, int JMAX, int NCOL>
-__global__ __launch_bounds__(256) void pose_dppre_kernel(const float* __restrict__ dPl,
+// Block b owns rows [8b, 8b+8); thread t owns the 4 consecutive columns 4t..4t+3 of all of them
+// (8-byte bf16 / 16-byte fp32 accesses, a wave covers 512 B / 1 KiB of a row), with its 4 x J
+// slice of W2 in registers.  All 16 row loads are issued before the first is used.
+template <typename T, int JMAX>
+__global__ __launch_bounds__(512) void pose_dppre_kernel(const float* __restrict__ dPl,
                                                          const float* __restrict__ W2,
                                                          const T* __restrict__ ext,
                                                          const T* __restrict__ Ppre,
@@ -48,49 +50,82 @@ __global__ __launch_bounds__(256) void pose_dppre_kernel(const float* __restrict
   const int tid = threadIdx.x;
   const long r0 = (long)blockIdx.x * POSE_RB;
   const int nrows = (int)min((long)POSE_RB, R - r0);
-  if (dPl) {
-    for (int i = tid; i < POSE_RB * J; i += 256) {
-      const int rr = i / J;
-      s_dpl[rr * JMAX + (i - rr * J)] = rr < nrows ? dPl[(r0 + rr) * J + (i - rr * J)] : 0.f;
+  for (int i = tid; i < POSE_RB * JMAX; i += blockDim.x) {
+    const int rr = i / JMAX, q = i - rr * JMAX;
+    s_dpl[i] = (dPl && rr < nrows && q < J) ? dPl[(r0 + rr) * J + q] : 0.f;
+  }
+  const int j0 = tid * 4;
+  const bool active = j0 < Cp;          // Cp % 4 == 0 (checked on the host)
+  float x[POSE_RB][4], pp[POSE_RB][4];
+  if (active) {
+#pragma unroll
+    for (int rr = 0; rr < POSE_RB; ++rr) {
+      const size_t off = (size_t)(r0 + min(rr, nrows - 1)) * Cp + j0;   // surplus rows re-read the last
+      if constexpr (sizeof(T) == 2) {
+        const uint2 pv = *reinterpret_cast<const uint2*>(Ppre + off);
+        pp[rr][0] = bf16_lo(pv.x); pp[rr][1] = bf16_hi(pv.x); pp[rr][2] = bf16_lo(pv.y); pp[rr][3] = bf16_hi(pv.y);
+        if (ext) {
+          const uint2 ev = *reinterpret_cast<const uint2*>(ext + off);
+          x[rr][0] = bf16_lo(ev.x); x[rr][1] = bf16_hi(ev.x); x[rr][2] = bf16_lo(ev.y); x[rr][3] = bf16_hi(ev.y);
+        }
+      } else {
+        const float4 pv = *reinterpret_cast<const float4*>(Ppre + off);
+        pp[rr][0] = pv.x; pp[rr][1] = pv.y; pp[rr][2] = pv.z; pp[rr][3] = pv.w;
+        if (ext) {
+          const float4 ev = *reinterpret_cast<const float4*>(ext + off);
+          x[rr][0] = ev.x; x[rr][1] = ev.y; x[rr][2] = ev.z; x[rr][3] = ev.w;
+        }
+      }
+      if (!ext) { x[rr][0] = x[rr][1] = x[rr][2] = x[rr][3] = 0.f; }
     }
   }
-  float w[NCOL][JMAX];
-  float acc[NCOL];
+  float w[4][JMAX];
+  if (dPl && active && J == JMAX) {   // the 4 x J slice of W2 is one contiguous, 16-byte aligned span
+    const float4* wsrc = reinterpret_cast<const float4*>(W2 + (size_t)j0 * J);
 #pragma unroll
-  for (int c = 0; c < NCOL; ++c) {
-    acc[c] = 0.f;
-    const int j = tid + c * 256;
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int q = 0; q < JMAX; ++q) w[c][q] = (dPl && j < Cp && q < J) ? W2[(size_t)j * J + q] : 0.f;
+      for (int q = 0; q < JMAX; q += 4) {
+        const float4 t = wsrc[(c * JMAX + q) >> 2];
+        w[c][q] = t.x; w[c][q + 1] = t.y; w[c][q + 2] = t.z; w[c][q + 3] = t.w;
+      }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int q = 0; q < JMAX; ++q) w[c][q] = (dPl && active && q < J) ? W2[(size_t)(j0 + c) * J + q] : 0.f;
   }
   __syncthreads();
-  for (int rr = 0; rr < nrows; ++rr) {
-    const size_t rowoff = (size_t)(r0 + rr) * Cp;
+  float* prow = partial + (size_t)blockIdx.x * (Cp + J);
+  if (active) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < NCOL; ++c) {
-      const int j = tid + c * 256;
-      if (j < Cp) {
-        float s = ext ? ldf<T>(ext, rowoff + j) : 0.f;
+    for (int rr = 0; rr < POSE_RB; ++rr) {
+      float o[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float sv = x[rr][c];
         if (dPl) {
 #pragma unroll
-          for (int q = 0; q < JMAX; ++q) s = fmaf(s_dpl[rr * JMAX + q], w[c][q], s);
+          for (int q = 0; q < JMAX; ++q) sv = fmaf(s_dpl[rr * JMAX + q], w[c][q], sv);
         }
-        s = ldf<T>(Ppre, rowoff + j) > 0.f ? s : 0.f;
-        stf<T>(dPpre, rowoff + j, s);
-        acc[c] += s;
+        o[c] = pp[rr][c] > 0.f ? sv : 0.f;
+        acc[c] += rr < nrows ? o[c] : 0.f;
+      }
+      if (rr < nrows) {
+        const size_t off = (size_t)(r0 + rr) * Cp + j0;
+        if constexpr (sizeof(T) == 2)
+          *reinterpret_cast<uint2*>(dPpre + off) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+        else
+          *reinterpret_cast<float4*>(dPpre + off) = make_float4(o[0], o[1], o[2], o[3]);
       }
     }
-  }
-  float* prow = partial + (size_t)blockIdx.x * (Cp + J);
 #pragma unroll
-  for (int c = 0; c < NCOL; ++c) {
-    const int j = tid + c * 256;
-    if (j < Cp) prow[j] = acc[c];
+    for (int c = 0; c < 4; ++c) prow[j0 + c] = acc[c];   // (Cp + J need not be a multiple of 4)
   }
   if (tid < J) {
     float a = 0.f;
-    if (dPl)
-      for (int rr = 0; rr < nrows; ++rr) a += s_dpl[rr * JMAX + tid];
+    for (int rr = 0; rr < nrows; ++rr) a += s_dpl[rr * JMAX + tid];
     prow[Cp + tid] = a;
   }
 }
@@ -98,7 +133,7 @@ __global__ __launch_bounds__(256) void pose_dppre_kernel(const float* __restrict
 struct PosePlan {
   long R;
   int nchunks;
-  size_t off_dppre, off_partial, off_gemm, total;
+  size_t off_dppre, off_partial, off_gemm, off_w1b, total;
 };
 static PosePlan pose_plan(int N, int P, int C, int Cp, int J, int dtype) {
   PosePlan pl;
@@ -112,8 +147,35 @@ static PosePlan pose_plan(int N, int P, int C, int Cp, int J, int dtype) {
   if (g2 > g) g = g2;
   if (g3 > g) g = g3;
   pl.off_gemm = off;    off += align_up(g, 256);
+  // bf16 features: a bf16 copy of W1, so the MFMA GEMMs can DMA both operands straight into LDS
+  pl.off_w1b = off;     off += align_up((size_t)C * Cp * 2, 256);
   pl.total = off;
   return pl;
+}
+
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ in,
+                                                          bf16_t* __restrict__ out, size_t n8) {
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n8; v += (size_t)gridDim.x * 256) {
+    const float4 a = *reinterpret_cast<const float4*>(in + v * 8);
+    const float4 b = *reinterpret_cast<const float4*>(in + v * 8 + 4);
+    st16(out + v * 8, make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y),
+                                 pack_bf16x2(b.z, b.w)));
+  }
+}
+
+// W1 as the bf16 operand of the pose-head GEMMs (only when its size allows whole 16-byte vectors)
+static const void* pose_w1_operand(const float* W1, void* ws_w1b, int C, int Cp, int dtype, int* tb,
+                                   hipStream_t st) {
+  *tb = 0;
+  if (dtype != APA_DTYPE_BF16 || ((size_t)C * Cp) % 8 != 0 || (reinterpret_cast<uintptr_t>(W1) & 15))
+    return W1;
+  const size_t n8 = (size_t)C * Cp / 8;
+  size_t nb = (n8 + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, st, W1,
+                     static_cast<bf16_t*>(ws_w1b), n8);
+  *tb = 1;
+  return ws_w1b;
 }
 
 }  // namespace apa
@@ -144,9 +206,11 @@ extern "C" int apa_pose_head_fwd(const void* X, const float* W1, const float* b1
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* gws = reinterpret_cast<float*>(static_cast<char*>(ws) + pl.off_gemm);
   const int R = (int)pl.R;
+  int w1_tb = 0;
+  const void* W1op = pose_w1_operand(W1, static_cast<char*>(ws) + pl.off_w1b, C, Cp, dtype, &w1_tb, st);
   GemmDesc g1;  // Ppre = relu(X.W1 + b1)
   g1.A = X; g1.lda = C; g1.ta = dt_code(dtype); g1.a_kc = true;
-  g1.B = W1; g1.ldb = Cp; g1.tb = 0; g1.b_kc = false;
+  g1.B = W1op; g1.ldb = Cp; g1.tb = w1_tb; g1.b_kc = false;
   g1.C = Ppre; g1.ldc = Cp; g1.tc = dt_code(dtype);
   g1.M = R; g1.N = Cp; g1.K = C; g1.bias = b1; g1.act = 1;
   int rc = gemm_launch(g1, st);
@@ -191,19 +255,19 @@ extern "C" int apa_pose_head_bwd(const void* X, const float* W1, const float* W2
   const int R = (int)pl.R;
   const int tdt = dt_code(dtype);
 
-#define APA_DPPRE(T, JM, NC)                                                                       \
-  hipLaunchKernelGGL((pose_dppre_kernel<T, JM, NC>), dim3(pl.nchunks), dim3(256), 0, st, dPl, W2,    \
+  if (Cp % 4 != 0) {
+    set_error("apa_pose_head_bwd: Cp=%d must be a multiple of 4", Cp);
+    return APA_ERR_UNSUPPORTED;
+  }
+  const int nthr = ((Cp / 4 + 63) / 64) * 64;   // one thread per 4 columns (<= 512: Cp <= 2048)
+#define APA_DPPRE(T, JM)                                                                            \
+  hipLaunchKernelGGL((pose_dppre_kernel<T, JM>), dim3(pl.nchunks), dim3(nthr), 0, st, dPl, W2,        \
                      static_cast<const T*>(dPpre_ext), static_cast<const T*>(Ppre),                 \
                      static_cast<T*>(dPpre), partial, pl.R, Cp, J)
-  const int ncol = (Cp + 255) / 256;
   if (dtype == APA_DTYPE_F32) {
-    if (J <= 16 && ncol <= 3) APA_DPPRE(float, 16, 3);
-    else if (ncol <= 4) APA_DPPRE(float, 32, 4);
-    else APA_DPPRE(float, 32, 8);
+    if (J <= 16) APA_DPPRE(float, 16); else APA_DPPRE(float, 32);
   } else {
-    if (J <= 16 && ncol <= 3) APA_DPPRE(bf16_t, 16, 3);
-    else if (ncol <= 4) APA_DPPRE(bf16_t, 32, 4);
-    else APA_DPPRE(bf16_t, 32, 8);
+    if (J <= 16) APA_DPPRE(bf16_t, 16); else APA_DPPRE(bf16_t, 32);
   }
 #undef APA_DPPRE
   APA_LAUNCH_CHECK("pose_dppre_kernel");
@@ -238,7 +302,9 @@ extern "C" int apa_pose_head_bwd(const void* X, const float* W1, const float* W2
   {  // dX (+)= dPpre . W1^T
     GemmDesc g;
     g.A = dPpre; g.lda = Cp; g.ta = tdt; g.a_kc = true;
-    g.B = W1; g.ldb = Cp; g.tb = 0; g.b_kc = true;   // W1 [C][Cp]: n = c rows, k contiguous
+    int w1_tb = 0;
+    const void* W1op = pose_w1_operand(W1, w + pl.off_w1b, C, Cp, dtype, &w1_tb, st);
+    g.B = W1op; g.ldb = Cp; g.tb = w1_tb; g.b_kc = true;   // W1 [C][Cp]: n = c rows, k contiguous
     g.C = dX; g.ldc = C; g.tc = tdt;
     g.M = R; g.N = C; g.K = Cp; g.beta = accumulate_dX ? 1.f : 0.f;
     rc = gemm_launch(g, st);

@@ -283,21 +283,46 @@ __global__ __launch_bounds__(256) void gemm128_kernel(GemmParams p) {
     }
 }
 
-template <typename TC>
+// C = act(sum_s partial[s] + bias) + beta*C, fixed order over s.  One thread per 4 consecutive
+// elements when rows allow it (VEC): all `splits` 16-byte loads of a thread in flight at once.
+template <typename TC, bool VEC>
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ partial,
                                                                  TC* __restrict__ C, long ldc,
                                                                  int M, int N, int splits,
                                                                  const float* __restrict__ bias,
                                                                  float beta, int act) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  constexpr int W = VEC ? 4 : 1;
+  const long idx = ((long)blockIdx.x * 256 + threadIdx.x) * W;
   if (idx >= (long)M * N) return;
   const int row = (int)(idx / N), col = (int)(idx % N);
-  float v = 0.f;
-  for (int s = 0; s < splits; ++s) v += partial[(size_t)s * M * N + idx];
-  if (bias) v += bias[col];
-  if (act == 1) v = fmaxf(v, 0.f);
-  if (beta != 0.f) v += Elem<TC>::get(C, (long)row * ldc + col);
-  Elem<TC>::put(C, (long)row * ldc + col, v);
+  float v[W];
+#pragma unroll
+  for (int e = 0; e < W; ++e) v[e] = 0.f;
+  const size_t stride = (size_t)M * N;
+  for (int s0 = 0; s0 < splits; s0 += 8) {
+    float t[8][W];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float* src = partial + (size_t)min(s0 + u, splits - 1) * stride + idx;
+      if constexpr (VEC) {
+        const float4 q = *reinterpret_cast<const float4*>(src);
+        t[u][0] = q.x; t[u][1] = q.y; t[u][2] = q.z; t[u][3] = q.w;
+      } else {
+        t[u][0] = *src;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int e = 0; e < W; ++e) v[e] += (s0 + u < splits) ? t[u][e] : 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < W; ++e) {
+    if (bias) v[e] += bias[col + e];
+    if (act == 1) v[e] = fmaxf(v[e], 0.f);
+    if (beta != 0.f) v[e] += Elem<TC>::get(C, (long)row * ldc + col + e);
+    Elem<TC>::put(C, (long)row * ldc + col + e, v[e]);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -345,13 +370,29 @@ static int gemm_launch_t(const GemmDesc& d, hipStream_t st) {
     return APA_ERR_UNSUPPORTED;
   }
   const int tiles = ((d.M + GM - 1) / GM) * ((d.N + GN - 1) / GN);
+  if (gemm_bf16_eligible(d)) {
+    // 64-deep K tiles: re-derive the split so every chunk is a multiple of 64
+    int kps64 = (d.K + splits - 1) / splits;
+    kps64 = (kps64 + 63) / 64 * 64;
+    splits = (d.K + kps64 - 1) / kps64;
+    const int rc = gemm_bf16_launch(d, splits, kps64, st);
+    if (rc != APA_OK) return rc;
+  } else {
   hipLaunchKernelGGL((gemm128_kernel<TA, TB, TC, A_KC, B_KC, BF16>), dim3(tiles, 1, splits), dim3(256),
                      0, st, p);
   APA_LAUNCH_CHECK("gemm128_kernel");
+  }
   if (splits > 1) {
     const long tot = (long)d.M * d.N;
-    hipLaunchKernelGGL(gemm_splitk_reduce_kernel<TC>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
-                       st, d.ws, static_cast<TC*>(d.C), d.ldc, d.M, d.N, splits, d.bias, d.beta, d.act);
+    if (d.N % 4 == 0 && aligned16(d.ws)) {
+      hipLaunchKernelGGL((gemm_splitk_reduce_kernel<TC, true>), dim3((unsigned)((tot / 4 + 255) / 256)),
+                         dim3(256), 0, st, d.ws, static_cast<TC*>(d.C), d.ldc, d.M, d.N, splits, d.bias,
+                         d.beta, d.act);
+    } else {
+      hipLaunchKernelGGL((gemm_splitk_reduce_kernel<TC, false>), dim3((unsigned)((tot + 255) / 256)),
+                         dim3(256), 0, st, d.ws, static_cast<TC*>(d.C), d.ldc, d.M, d.N, splits, d.bias,
+                         d.beta, d.act);
+    }
     APA_LAUNCH_CHECK("gemm_splitk_reduce_kernel");
   }
   return APA_OK;

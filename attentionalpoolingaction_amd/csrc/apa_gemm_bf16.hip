@@ -1,0 +1,480 @@
+// apa_gemm_bf16.hip -- the bf16 MFMA GEMM behind the dense rows of the head (PoseLogits head
+// nets_factory.py:147-160 and its backward products; per-class attention maps, _PER_CLASS):
+//
+//   C[m,n] = act( sum_k A(m,k) B(k,n) + bias[n] ) + beta * C[m,n]        fp32 accumulation
+//
+// 128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 4x4 v_mfma_f32_16x16x32_bf16 tiles,
+// two LDS buffers (global loads of K-tile t+1 in flight while tile t is consumed), two blocks
+// per CU.  The point of this kernel over the generic one in apa_gemm.hip (which unpacks to fp32
+// and scatters 2-byte LDS stores to transpose k-major operands) is that NOTHING is transposed or
+// converted element-wise:
+//   * k-contiguous operands ([rows][K]) land in a [row][k] LDS image by 16-byte copies and are
+//     read back as 16-byte MFMA fragments (row stride 144 B: conflict-free ds_read_b128);
+//   * k-major operands ([K][rows] -- W1 in the forward product, X and dPpre in dW1 = X^T dPpre)
+//     land in a [k][row] image by the same 16-byte copies and are read with
+//     ds_read_b64_tr_b16, the gfx950 transposing LDS read.  Its semantics, probed on the device
+//     (scratch/tr_probe.hip): inside each 16-lane group, lane s SUPPLIES the address of 4
+//     consecutive b16 elements and lane t RECEIVES element (t & 3) of the suppliers
+//     4e + (t >> 2), e = 0..3.  So if supplier s points at (k = kb + (s >> 2), row = r0 + 4 (s & 3))
+//     then lane t receives rows r0 + t at k = kb..kb+3: a 4x16 -> 16x4 transpose, exactly the
+//     k-run an MFMA A/B fragment wants (two reads per 8-k fragment).
+//   * an fp32 operand (the weights) is converted to bf16 once, 8 elements at a time, on its way
+//     into LDS (v_cvt_pk_bf16_f32).
+// Split-K (grid.z) writes fp32 partials recombined in fixed order by gemm_splitk_reduce_kernel.
+#include "apa_device.h"
+#include "apa_internal.h"
+
+namespace apa {
+
+namespace {
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TM = 128, TN = 128, TK = 64;
+constexpr int LD_KC = TK + 8;    // [row][k] image, 144-byte rows
+constexpr int LD_KM = TM + 8;    // [k][row] image, 272-byte rows
+constexpr int OP_ELEMS = TM * LD_KC;   // 9216 >= TK * LD_KM = 8704
+static_assert(OP_ELEMS >= TK * LD_KM, "operand image size");
+
+// One operand tile (128 rows x 64 k) on its way from global memory to LDS: 4 x 16 bytes per thread.
+template <typename T, bool KM>
+struct Stage {
+  uint4 v[4];
+
+  static __device__ __forceinline__ uint4 load8(const T* p) {
+    if constexpr (sizeof(T) == 2) {
+      return ld16(p);
+    } else {
+      const float4 a = *reinterpret_cast<const float4*>(p);
+      const float4 b = *reinterpret_cast<const float4*>(p + 4);
+      return make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y),
+                        pack_bf16x2(b.z, b.w));
+    }
+  }
+
+  // rows r0.. (< rlim), k in [k0, klim).  KM: element (row, k) at base[k*ld + row]; else base[row*ld + k].
+  // Rows past rlim are clamped (their results are never stored); k past klim reads zero.
+  __device__ __forceinline__ void load(const T* __restrict__ base, long ld, int r0, int rlim, int k0,
+                                       int klim, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int vi = tid + i * 256;
+      if (!KM) {
+        const int row = min(r0 + (vi >> 3), rlim - 1), k = k0 + (vi & 7) * 8;
+        const uint4 x = load8(base + (long)row * ld + min(k, klim - 8));
+        v[i] = k < klim ? x : make_uint4(0u, 0u, 0u, 0u);
+      } else {
+        const int k = k0 + (vi >> 4), row = min(r0 + (vi & 15) * 8, rlim - 8);
+        const uint4 x = load8(base + (long)min(k, klim - 1) * ld + row);
+        v[i] = k < klim ? x : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(short* img, int tid) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int vi = tid + i * 256;
+      short* d = KM ? img + (vi >> 4) * LD_KM + (vi & 15) * 8 : img + (vi >> 3) * LD_KC + (vi & 7) * 8;
+      *reinterpret_cast<uint4*>(d) = v[i];
+    }
+  }
+};
+
+// MFMA fragment (16 rows x 32 k, k-step ks) of the 16-row strip starting at `rbase`.
+template <bool KM>
+__device__ __forceinline__ bf16x8 fragment(const short* img, int rbase, int ks, int lane) {
+  const int l16 = lane & 15, kb = lane >> 4;
+  if (!KM) {
+    return *reinterpret_cast<const bf16x8*>(img + (rbase + l16) * LD_KC + ks * 32 + kb * 8);
+  } else {
+    typedef bf16x4 __attribute__((address_space(3))) * lds_v4;
+    const short* s0 = img + (ks * 32 + kb * 8 + (l16 >> 2)) * LD_KM + rbase + 4 * (l16 & 3);
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(s0));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(s0 + 4 * LD_KM));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  }
+}
+
+template <typename T> __device__ __forceinline__ float c_get(const T* p, long i);
+template <> __device__ __forceinline__ float c_get<float>(const float* p, long i) { return p[i]; }
+template <> __device__ __forceinline__ float c_get<bf16_t>(const bf16_t* p, long i) {
+  return __uint_as_float((uint32_t)p[i].v << 16);
+}
+template <typename T> __device__ __forceinline__ void c_put(T* p, long i, float v);
+template <> __device__ __forceinline__ void c_put<float>(float* p, long i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void c_put<bf16_t>(bf16_t* p, long i, float v) {
+  p[i].v = (uint16_t)(pack_bf16x2(v, 0.f) & 0xffffu);
+}
+
+struct FastParams {
+  const void* A; long lda; const void* B; long ldb; void* C; long ldc;
+  int M, N, K;
+  const float* bias; float beta; int act;
+  int k_per_split; float* partial;
+  int vec_epi;   // N % 8 == 0 and C / bias / partial rows 16-byte addressable
+};
+
+template <typename TC>
+__device__ __forceinline__ void epilogue(f32x4 (&acc)[4][4], const FastParams& p, short* smem, int m0,
+                                         int n0, int tid) {
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  // ---- epilogue.  D layout of the 16x16 MFMA: row = 4 * (lane >> 4) + reg, col = lane & 15.
+  // Fast form (N % 8 == 0, 16-byte addressable C rows): the tile goes through LDS as fp32
+  // [128][132] (conflict-free 4-byte writes) and leaves as full 16-byte row segments -- bias, relu,
+  // the `+ beta * C` read and the bf16 pack happen on 8 consecutive columns at a time.  The direct
+  // form writes one element per lane (32-byte runs): 2-byte accesses made it dominate K = 768.
+  TC* C = static_cast<TC*>(p.C);
+  const int l16 = lane & 15, kb = lane >> 4;
+  if (p.vec_epi) {
+    float* stage = reinterpret_cast<float*>(smem);   // 128 * 132 * 4 = 67 584 B <= 73 728 B
+    constexpr int LDS_C = TN + 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          stage[(wm * 64 + i * 16 + 4 * kb + r) * LDS_C + wn * 64 + j * 16 + l16] = acc[i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int v = tid + it * 256;
+      const int row = v >> 4, c8 = (v & 15) * 8;
+      const int grow = m0 + row, gcol = n0 + c8;
+      if (grow >= p.M || gcol >= p.N) continue;
+      const float4 x0 = *reinterpret_cast<const float4*>(stage + row * LDS_C + c8);
+      const float4 x1 = *reinterpret_cast<const float4*>(stage + row * LDS_C + c8 + 4);
+      float o[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+      if (p.partial) {
+        float* dst = p.partial + ((size_t)blockIdx.z * p.M + grow) * p.N + gcol;
+        *reinterpret_cast<float4*>(dst) = x0;
+        *reinterpret_cast<float4*>(dst + 4) = x1;
+        continue;
+      }
+      if (p.bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + gcol);
+        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + gcol + 4);
+        o[0] += b0.x; o[1] += b0.y; o[2] += b0.z; o[3] += b0.w;
+        o[4] += b1.x; o[5] += b1.y; o[6] += b1.z; o[7] += b1.w;
+      }
+      if (p.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = fmaxf(o[e], 0.f);
+      }
+      TC* dst = C + (long)grow * p.ldc + gcol;
+      if constexpr (sizeof(TC) == 2) {
+        if (p.beta != 0.f) {
+          float c[8];
+          Vec<bf16_t>::unpack(ld16(dst), c);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += c[e];
+        }
+        st16(dst, Vec<bf16_t>::pack(o));
+      } else {
+        float* d = reinterpret_cast<float*>(dst);
+        if (p.beta != 0.f) {
+          const float4 c0 = *reinterpret_cast<const float4*>(d), c1 = *reinterpret_cast<const float4*>(d + 4);
+          o[0] += c0.x; o[1] += c0.y; o[2] += c0.z; o[3] += c0.w;
+          o[4] += c1.x; o[5] += c1.y; o[6] += c1.z; o[7] += c1.w;
+        }
+        *reinterpret_cast<float4*>(d) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(d + 4) = make_float4(o[4], o[5], o[6], o[7]);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = n0 + wn * 64 + j * 16 + l16;
+    if (col >= p.N) continue;
+    const float bv = (p.bias && !p.partial) ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 64 + i * 16 + 4 * kb + r;
+        if (row >= p.M) continue;
+        float v = acc[i][j][r];
+        if (p.partial) {
+          p.partial[((size_t)blockIdx.z * p.M + row) * p.N + col] = v;
+        } else {
+          v += bv;
+          if (p.act == 1) v = fmaxf(v, 0.f);
+          if (p.beta != 0.f) v += c_get<TC>(C, (long)row * p.ldc + col);
+          c_put<TC>(C, (long)row * p.ldc + col, v);
+        }
+      }
+    }
+  }
+}
+
+template <typename TA, typename TB, typename TC, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(FastParams p) {
+  extern __shared__ __attribute__((aligned(16))) short smem[];   // [2 buffers][A image | B image]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntm = (p.M + TM - 1) / TM, ntn = (p.N + TN - 1) / TN;
+  const int tile = xcd_remap(blockIdx.x, ntm * ntn);   // neighbouring tiles (same A panel) share an XCD
+  const int m0 = (tile / ntn) * TM, n0 = (tile % ntn) * TN;
+  const int kbeg = blockIdx.z * p.k_per_split, kend = min(p.K, kbeg + p.k_per_split);
+  const int nk = (kend - kbeg + TK - 1) / TK;
+
+  const TA* A = static_cast<const TA*>(p.A);
+  const TB* B = static_cast<const TB*>(p.B);
+  Stage<TA, A_KM> sa;
+  Stage<TB, B_KM> sb;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) {
+    sa.load(A, p.lda, m0, p.M, kbeg, kend, tid);
+    sb.load(B, p.ldb, n0, p.N, kbeg, kend, tid);
+    sa.store(smem, tid);
+    sb.store(smem + OP_ELEMS, tid);
+  }
+  __syncthreads();
+  for (int t = 0; t < nk; ++t) {
+    const short* a_img = smem + (t & 1) * 2 * OP_ELEMS;
+    const short* b_img = a_img + OP_ELEMS;
+    const bool more = t + 1 < nk;
+    if (more) {   // next tile's global loads fly underneath this tile's MFMAs
+      sa.load(A, p.lda, m0, p.M, kbeg + (t + 1) * TK, kend, tid);
+      sb.load(B, p.ldb, n0, p.N, kbeg + (t + 1) * TK, kend, tid);
+    }
+#pragma unroll
+    for (int ks = 0; ks < TK / 32; ++ks) {
+      bf16x8 af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = fragment<A_KM>(a_img, wm * 64 + i * 16, ks, lane);
+        bf[i] = fragment<B_KM>(b_img, wn * 64 + i * 16, ks, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      short* nxt = smem + ((t + 1) & 1) * 2 * OP_ELEMS;
+      sa.store(nxt, tid);
+      sb.store(nxt + OP_ELEMS, tid);
+    }
+    __syncthreads();
+  }
+
+  epilogue<TC>(acc, p, smem, m0, n0, tid);
+}
+
+// ---------------------------------------------------------------------------------------------
+// All-bf16 variant: operands go global -> LDS by global_load_lds_dwordx4 (no VGPR round trip, no
+// ds_write pass -- 8 x ds_write_b128 per thread per K-tile cost as much as the tile's MFMAs).
+// The DMA writes 64 lanes x 16 B = 1 KiB of CONTIGUOUS LDS per wave-instruction, so the images are
+// unpadded and bank conflicts are removed by XOR-swizzling which 16-byte chunk of a row each lane
+// fetches (the swizzle lives in the per-lane SOURCE address; the fragment readers apply it again):
+//   [row][k]  image, 128-byte rows: chunk' = chunk ^ ((row >> 1) & 7)    -> ds_read_b128 conflict-free
+//   [k][row]  image, 256-byte rows: chunk' = chunk ^ 2*(k & 3) ^ 8*((k >> 3) & 1)
+//                                                          -> ds_read_b64_tr_b16 conflict-free
+// Requires K (per split) to be a multiple of 64 (the DMA cannot zero-fill).
+// ---------------------------------------------------------------------------------------------
+constexpr int IMG = TM * TK;   // 8192 elements = 16 KiB per operand image
+
+template <bool KM>
+__device__ __forceinline__ long glds_src_offset(int g, int lane, long ld, int r0, int rlim) {
+  if (!KM) {
+    const int row = 8 * g + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    return (long)min(r0 + row, rlim - 1) * ld + chunk * 8;
+  } else {
+    const int k = 4 * g + (lane >> 4);
+    const int chunk = (lane & 15) ^ (2 * (k & 3)) ^ (8 * ((k >> 3) & 1));
+    return (long)k * ld + min(r0 + chunk * 8, rlim - 8);
+  }
+}
+
+template <bool KM>
+__device__ __forceinline__ bf16x8 fragment_sw(const short* img, int rbase, int ks, int lane) {
+  const int l16 = lane & 15, kb = lane >> 4;
+  if (!KM) {
+    const int row = rbase + l16;
+    const int chunk = (ks * 4 + kb) ^ ((row >> 1) & 7);
+    return *reinterpret_cast<const bf16x8*>(img + row * TK + chunk * 8);
+  } else {
+    typedef bf16x4 __attribute__((address_space(3))) * lds_v4;
+    const int k = ks * 32 + kb * 8 + (l16 >> 2);          // second read: k + 4 (same k & 3 ... no: +4)
+    const int r = rbase + 4 * (l16 & 3);
+    const int sw = (8 * (kb & 1));
+    const short* s0 = img + k * TM + (((r >> 3) ^ (2 * (k & 3)) ^ sw) * 8) + (r & 7);
+    const short* s1 = img + (k + 4) * TM + (((r >> 3) ^ (2 * ((k + 4) & 3)) ^ sw) * 8) + (r & 7);
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(s0));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(s1));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  }
+}
+
+template <typename TC, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(FastParams p) {
+  extern __shared__ __attribute__((aligned(16))) short smem[];   // [2 buffers][A image | B image], + epilogue
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntm = (p.M + TM - 1) / TM, ntn = (p.N + TN - 1) / TN;
+  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (tile / ntn) * TM, n0 = (tile % ntn) * TN;
+  const int kbeg = blockIdx.z * p.k_per_split, kend = min(p.K, kbeg + p.k_per_split);
+  const int nk = (kend - kbeg) / TK;
+
+  // per-lane DMA source pointers: wave w issues LDS KiB-blocks g = 4w .. 4w+3 of both images
+  const bf16_t* asrc[4];
+  const bf16_t* bsrc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int g = wave * 4 + j;
+    asrc[j] = static_cast<const bf16_t*>(p.A) + glds_src_offset<A_KM>(g, lane, p.lda, m0, p.M) +
+              (A_KM ? (long)kbeg * p.lda : (long)kbeg);
+    bsrc[j] = static_cast<const bf16_t*>(p.B) + glds_src_offset<B_KM>(g, lane, p.ldb, n0, p.N) +
+              (B_KM ? (long)kbeg * p.ldb : (long)kbeg);
+  }
+  const long a_step = A_KM ? (long)TK * p.lda : (long)TK;
+  const long b_step = B_KM ? (long)TK * p.ldb : (long)TK;
+  typedef __attribute__((address_space(1))) const void* gptr;
+  typedef __attribute__((address_space(3))) void* lptr;
+  auto issue = [&](int buf) {
+    short* a_img = smem + buf * 2 * IMG;
+    short* b_img = a_img + IMG;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_global_load_lds((gptr)asrc[j], (lptr)(a_img + (wave * 4 + j) * 512), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr)bsrc[j], (lptr)(b_img + (wave * 4 + j) * 512), 16, 0, 0);
+      asrc[j] += a_step;
+      bsrc[j] += b_step;
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) issue(0);
+  __syncthreads();
+  for (int t = 0; t < nk; ++t) {
+    const short* a_img = smem + (t & 1) * 2 * IMG;
+    const short* b_img = a_img + IMG;
+    if (t + 1 < nk) issue((t + 1) & 1);
+#pragma unroll
+    for (int ks = 0; ks < TK / 32; ++ks) {
+      bf16x8 af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = fragment_sw<A_KM>(a_img, wm * 64 + i * 16, ks, lane);
+        bf[i] = fragment_sw<B_KM>(b_img, wn * 64 + i * 16, ks, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  epilogue<TC>(acc, p, smem, m0, n0, tid);
+}
+
+template <typename TC, bool A_KM, bool B_KM>
+int launch_glds(const FastParams& p, int splits, hipStream_t st) {
+  const size_t shm = (size_t)2 * 2 * OP_ELEMS * sizeof(short);   // epilogue stage needs 67 584 B
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_glds_kernel<TC, A_KM, B_KM>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    attr_set = true;
+  }
+  const int tiles = ((p.M + TM - 1) / TM) * ((p.N + TN - 1) / TN);
+  hipLaunchKernelGGL((gemm_bf16_glds_kernel<TC, A_KM, B_KM>), dim3(tiles, 1, splits), dim3(256), shm, st, p);
+  APA_LAUNCH_CHECK("gemm_bf16_glds_kernel");
+  return APA_OK;
+}
+
+template <typename TC>
+int launch_glds_layout(const FastParams& p, bool a_km, bool b_km, int splits, hipStream_t st) {
+  if (a_km) {
+    if (b_km) return launch_glds<TC, true, true>(p, splits, st);
+    return launch_glds<TC, true, false>(p, splits, st);
+  }
+  if (b_km) return launch_glds<TC, false, true>(p, splits, st);
+  return launch_glds<TC, false, false>(p, splits, st);
+}
+
+template <typename TA, typename TB, typename TC, bool A_KM, bool B_KM>
+int launch(const FastParams& p, int splits, hipStream_t st) {
+  const size_t shm = (size_t)2 * 2 * OP_ELEMS * sizeof(short);   // 73 728 B
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    APA_HIP_CHECK(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(gemm_bf16_kernel<TA, TB, TC, A_KM, B_KM>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    attr_set = true;
+  }
+  const int tiles = ((p.M + TM - 1) / TM) * ((p.N + TN - 1) / TN);
+  hipLaunchKernelGGL((gemm_bf16_kernel<TA, TB, TC, A_KM, B_KM>), dim3(tiles, 1, splits), dim3(256), shm,
+                     st, p);
+  APA_LAUNCH_CHECK("gemm_bf16_kernel");
+  return APA_OK;
+}
+
+template <typename TB, typename TC>
+int launch_layout(const FastParams& p, bool a_km, bool b_km, int splits, hipStream_t st) {
+  if (a_km) {
+    if (b_km) return launch<bf16_t, TB, TC, true, true>(p, splits, st);
+    return launch<bf16_t, TB, TC, true, false>(p, splits, st);
+  }
+  if (b_km) return launch<bf16_t, TB, TC, false, true>(p, splits, st);
+  return launch<bf16_t, TB, TC, false, false>(p, splits, st);
+}
+}  // namespace
+
+// Eligibility: bf16 A, bf16 or fp32 B, no fused dropout, 16-byte addressable rows, K a multiple of 8,
+// at least one full vector of rows for k-major operands.
+bool gemm_bf16_eligible(const GemmDesc& d) {
+  if (getenv("APA_GEMM_FAST") && atoi(getenv("APA_GEMM_FAST")) == 0) return false;
+  if (d.ta != 1 || d.drop_a || d.drop_c) return false;
+  if (d.K % 8 != 0 || d.K < 8 || d.M < 8 || d.N < 8) return false;
+  const int ea = 2, eb = d.tb == 1 ? 2 : 4;
+  if ((reinterpret_cast<uintptr_t>(d.A) & 15) || (d.lda * ea) % 16) return false;
+  if ((reinterpret_cast<uintptr_t>(d.B) & 15) || (d.ldb * eb) % 16) return false;
+  if (!d.a_kc && d.M % 8 != 0) return false;
+  if (!d.b_kc && d.N % 8 != 0) return false;
+  return true;
+}
+
+// splits / k_per_split as chosen by the caller (k_per_split a multiple of 64)
+int gemm_bf16_launch(const GemmDesc& d, int splits, int k_per_split, hipStream_t st) {
+  FastParams p;
+  p.A = d.A; p.lda = d.lda; p.B = d.B; p.ldb = d.ldb; p.C = d.C; p.ldc = d.ldc;
+  p.M = d.M; p.N = d.N; p.K = d.K; p.bias = d.bias; p.beta = d.beta; p.act = d.act;
+  p.k_per_split = k_per_split;
+  p.partial = splits > 1 ? d.ws : nullptr;
+  const int ec = d.tc == 1 ? 2 : 4;
+  p.vec_epi = d.N % 8 == 0 && (reinterpret_cast<uintptr_t>(d.C) & 15) == 0 && (d.ldc * ec) % 16 == 0 &&
+              (!d.bias || (reinterpret_cast<uintptr_t>(d.bias) & 15) == 0) &&
+              (!p.partial || (reinterpret_cast<uintptr_t>(p.partial) & 15) == 0);
+  static const int use_glds = [] { const char* e = getenv("APA_GEMM_GLDS"); return e ? atoi(e) : 1; }();
+  if (use_glds && d.tb == 1 && k_per_split % TK == 0 && d.K % TK == 0) {   // all-bf16, whole K tiles: DMA staging
+    if (d.tc == 1) return launch_glds_layout<bf16_t>(p, !d.a_kc, !d.b_kc, splits, st);
+    return launch_glds_layout<float>(p, !d.a_kc, !d.b_kc, splits, st);
+  }
+  if (d.tb == 1) {
+    if (d.tc == 1) return launch_layout<bf16_t, bf16_t>(p, !d.a_kc, !d.b_kc, splits, st);
+    return launch_layout<bf16_t, float>(p, !d.a_kc, !d.b_kc, splits, st);
+  }
+  if (d.tc == 1) return launch_layout<float, bf16_t>(p, !d.a_kc, !d.b_kc, splits, st);
+  return launch_layout<float, float>(p, !d.a_kc, !d.b_kc, splits, st);
+}
+
+}  // namespace apa

@@ -95,6 +95,9 @@ struct GemmDesc {
 size_t gemm_ws_bytes(int M, int N, int splits);
 int gemm_pick_splits(int M, int N, int K);
 int gemm_launch(const GemmDesc& d, hipStream_t st);
+// apa_gemm_bf16.hip: the fast bf16 path (128x128x64, transposing LDS reads for k-major operands)
+bool gemm_bf16_eligible(const GemmDesc& d);
+int gemm_bf16_launch(const GemmDesc& d, int splits, int k_per_split, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------
 // M == 1 factorised path (apa_m1.hip)
