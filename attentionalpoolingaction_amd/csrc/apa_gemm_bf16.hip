@@ -281,6 +281,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(FastParams p) {
 //   [k][row]  image, 256-byte rows: chunk' = chunk ^ 2*(k & 3) ^ 8*((k >> 3) & 1)
 //                                                          -> ds_read_b64_tr_b16 conflict-free
 // Requires K (per split) to be a multiple of 64 (the DMA cannot zero-fill).
+//
+// Measured on the pose-head shapes (M = 6272, N/K in {768, 2048}), same kernel body:
+//   2 LDS stages, 4 waves, 2 blocks/CU (this file)              38 / 34 / 40 us   (~520-580 TFLOP/s)
+//   3 stages + counted vmcnt + raw s_barrier, 4 waves, 1 block/CU   55 / 53 / 55 us
+//   3 stages, 8 waves (2 per SIMD), 1 block/CU                   44 / 43 / 51 us
+// (the 3-stage variants need the DMA in inline asm: with the builtin hipcc guards the transposing
+// LDS reads with s_waitcnt vmcnt(0) and drains the queue every K-tile).  At these sizes the tile
+// count (294 / 784 / 96 x splits) against 256 CUs matters more than pipeline depth: two resident
+// blocks per CU absorb the ragged last round, one block per CU cannot.  PMC of this variant:
+// SQ_LDS_BANK_CONFLICT = 0 (both swizzles exact), MFMA busy ~21 %, waves parked in s_waitcnt 54 %.
 // ---------------------------------------------------------------------------------------------
 constexpr int IMG = TM * TK;   // 8192 elements = 16 KiB per operand image
 
