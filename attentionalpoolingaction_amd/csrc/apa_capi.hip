@@ -121,8 +121,10 @@ extern "C" size_t apa_attn_pool_workspace_bytes(int N, int P, int C, int Ca, int
   (void)flags;
   if (N <= 0 || P <= 0 || C <= 0 || Ca <= 0 || K <= 0) return 0;
   if (M == 1) return m1_plan(N, P, C, Ca, K).total;
-  if (M == K) {  // dtype-dependent intermediates: report the larger (fp32) size
-    return pc_workspace_bytes(N, P, C, Ca, K, APA_DTYPE_F32);
+  if (M == K) {  // dtype-dependent intermediates: report the larger of the two plans
+    const size_t a = pc_workspace_bytes(N, P, C, Ca, K, APA_DTYPE_F32);
+    const size_t b = pc_workspace_bytes(N, P, C, Ca, K, APA_DTYPE_BF16);
+    return a > b ? a : b;
   }
   return 0;
 }

@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void pc_bwd_act_kernel(const float* __restrict
 struct PcPlan {
   long R;
   int Kp;
-  size_t off_wap, off_wtp, off_bap, off_z, off_dt, off_dz, off_pdbt, off_pdba, off_gemm, total;
+  size_t off_wap, off_wtp, off_bap, off_z, off_dt, off_dz, off_pdbt, off_pdba, off_gemm, off_xd, total;
 };
 static PcPlan pc_plan(int N, int P, int C, int Ca, int K, int dtype) {
   PcPlan pl;
@@ -452,9 +452,51 @@ static PcPlan pc_plan(int N, int P, int C, int Ca, int K, int dtype) {
   pl.off_pdbt = off; off += align_up((size_t)N * K * 4, 256);
   pl.off_pdba = off; off += align_up((size_t)N * K * 4, 256);
   const int cm = C > Ca ? C : Ca;
-  pl.off_gemm = off; off += align_up(gemm_ws_bytes(cm, K, 32), 256);
+  {
+    size_t g = gemm_ws_bytes(cm, K, 32);
+    const size_t g2 = gemm_ws_bytes((int)pl.R, pl.Kp, 8);   // split-K of the skinny forward products
+    if (g2 > g) g = g2;
+    pl.off_gemm = off; off += align_up(g, 256);
+  }
+  // bf16 training: dropout(X) materialised once per call, so the MFMA GEMMs that consume it can DMA
+  // their operands (the generic kernel applies the mask while staging through registers)
+  pl.off_xd = off;   off += dtype == APA_DTYPE_BF16 ? align_up((size_t)pl.R * C * 2, 256) : 0;
   pl.total = off;
   return pl;
+}
+
+// Xd = X * mask / keep (bf16), the same counter-based mask as everywhere else (flat index r*C + c)
+__global__ __launch_bounds__(256) void pc_dropout_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Xd,
+                                                         size_t n8, float inv_keep, uint32_t thresh,
+                                                         uint64_t seed, uint64_t offset,
+                                                         const uint64_t* __restrict__ offset_dev) {
+  uint32_t k0, k1;
+  rng_key_dev(seed, offset_dev ? *offset_dev : offset, k0, k1);
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n8; v += (size_t)gridDim.x * 256) {
+    float x[8];
+    Vec<bf16_t>::unpack(ld16(X + v * 8), x);
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      float m0, m1;
+      rng_keep2(v * 8 + e, k0, k1, thresh, m0, m1);
+      x[e] *= m0 * inv_keep;
+      x[e + 1] *= m1 * inv_keep;
+    }
+    st16(Xd + v * 8, Vec<bf16_t>::pack(x));
+  }
+}
+
+static const void* pc_dropped_features(const void* X, void* Xd, long R, int C, float keep_prob,
+                                       uint64_t seed, uint64_t offset, unsigned flags, hipStream_t st) {
+  const size_t n8 = (size_t)R * C / 8;
+  size_t nb = (n8 + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  const bool devctr = flags & APA_FLAG_RNG_DEVICE;
+  hipLaunchKernelGGL(pc_dropout_kernel, dim3((unsigned)nb), dim3(256), 0, st, static_cast<const bf16_t*>(X),
+                     static_cast<bf16_t*>(Xd), n8, 1.0f / keep_prob, keep_thresh(keep_prob), seed,
+                     devctr ? 0 : offset,
+                     devctr ? reinterpret_cast<const uint64_t*>(static_cast<uintptr_t>(offset)) : nullptr);
+  return Xd;
 }
 
 size_t pc_workspace_bytes(int N, int P, int C, int Ca, int K, int dtype) {
@@ -498,14 +540,31 @@ int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
   gz.B = WaP; gz.ldb = Kp; gz.tb = 0; gz.b_kc = false;
   gz.C = Z; gz.ldc = Kp; gz.tc = 0;
   gz.M = R; gz.N = Kp; gz.K = Ca; gz.bias = baP;
+  // N = Kp is one tile column: R/128 blocks cannot fill 256 CUs, so split the contraction
+  float* gws = reinterpret_cast<float*>(w + pl.off_gemm);
+  gz.splits = gemm_pick_splits(R, Kp, Ca); if (gz.splits > 8) gz.splits = 8;
+  gz.ws = gws;
   int rc = gemm_launch(gz, st);
   if (rc != APA_OK) return rc;
-  GemmDesc gt;  // T = dropout(X) . Wt + bt   (Wt rows are K floats: unaligned -> scalar staging)
+  GemmDesc gt;  // T = dropout(X) . Wt + bt
   gt.A = X; gt.lda = C; gt.ta = tdt; gt.a_kc = true;
-  gt.B = Wt; gt.ldb = K; gt.tb = 0; gt.b_kc = false;
   gt.C = Tsave; gt.ldc = K; gt.tc = 0;
-  gt.M = R; gt.N = K; gt.K = C; gt.bias = bt;
-  if (train) set_dropout(gt, true, false, keep_prob, seed, offset, flags);
+  gt.M = R; gt.K = C; gt.bias = bt;
+  const bool fast = dtype == APA_DTYPE_BF16 && C % 8 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+  if (fast) {   // zero-padded weights (16-byte rows) + materialised dropout: the DMA-staged MFMA GEMM
+    float* WtP = reinterpret_cast<float*>(w + pl.off_wtp);
+    hipLaunchKernelGGL(pc_pad_kernel, dim3((unsigned)(((long)C * Kp + 255) / 256)), dim3(256), 0, st, Wt, WtP, C, K, Kp);
+    APA_LAUNCH_CHECK("pc_pad_kernel");
+    gt.B = WtP; gt.ldb = Kp; gt.tb = 0; gt.b_kc = false;
+    gt.N = Kp; gt.n_valid = K;
+    if (train) gt.A = pc_dropped_features(X, w + pl.off_xd, pl.R, C, keep_prob, seed, offset, flags, st);
+  } else {      // Wt rows are K floats: unaligned -> scalar staging, mask applied while staging
+    gt.B = Wt; gt.ldb = K; gt.tb = 0; gt.b_kc = false;
+    gt.N = K;
+    if (train) set_dropout(gt, true, false, keep_prob, seed, offset, flags);
+  }
+  gt.splits = gemm_pick_splits(R, Kp, C); if (gt.splits > 8) gt.splits = 8;
+  gt.ws = gws;
   rc = gemm_launch(gt, st);
   if (rc != APA_OK) return rc;
   dim3 grid(N, (K + 63) / 64);
@@ -561,10 +620,16 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
     g.C = dWt; g.ldc = K; g.tc = 0;
     g.M = C; g.N = K; g.K = R;
     g.splits = gemm_pick_splits(C, K, R); g.ws = gws;
-    if (train) set_dropout(g, true, false, keep_prob, seed, offset, flags);
-    // dropout index of A(m=c, k=r) is r*C + c: the stager computes row*Ktot + k with row = m, so
-    // the transposed operand needs the swapped form -> handled by drop_a == 2
-    if (train) g.drop_a = 2;
+    const bool fast = dtype == APA_DTYPE_BF16 && C % 8 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+    if (fast) {
+      g.N = Kp; g.n_valid = K;   // dT is [R][Kp] with zero pad columns
+      if (train) g.A = pc_dropped_features(X, w + pl.off_xd, pl.R, C, keep_prob, seed, offset, flags, st);
+    } else if (train) {
+      set_dropout(g, true, false, keep_prob, seed, offset, flags);
+      // dropout index of A(m=c, k=r) is r*C + c: the stager computes row*Ktot + k with row = m, so
+      // the transposed operand needs the swapped form -> handled by drop_a == 2
+      g.drop_a = 2;
+    }
     rc = gemm_launch(g, st);
     if (rc != APA_OK) return rc;
   }
@@ -575,6 +640,7 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
     g.C = dWa; g.ldc = K; g.tc = 0;
     g.M = Ca; g.N = K; g.K = R;
     g.splits = gemm_pick_splits(Ca, K, R); g.ws = gws;
+    if (dtype == APA_DTYPE_BF16) { g.N = Kp; g.n_valid = K; }   // dZ is [R][Kp] with zero pad columns
     rc = gemm_launch(g, st);
     if (rc != APA_OK) return rc;
   }

@@ -349,7 +349,8 @@ static int gemm_launch_t(const GemmDesc& d, hipStream_t st) {
   constexpr bool BF16 = !(std::is_same<TA, float>::value && std::is_same<TB, float>::value);
   GemmParams p;
   p.A = d.A; p.lda = d.lda; p.B = d.B; p.ldb = d.ldb; p.C = d.C; p.ldc = d.ldc;
-  p.M = d.M; p.N = d.N; p.K = d.K; p.bias = d.bias; p.beta = d.beta; p.act = d.act;
+  const int Nst = d.n_valid > 0 ? d.n_valid : d.N;   // columns that exist in C
+  p.M = d.M; p.N = Nst; p.K = d.K; p.bias = d.bias; p.beta = d.beta; p.act = d.act;
   constexpr int VLA = Elem<TA>::VL, VLB = Elem<TB>::VL;
   p.a_vec = aligned16(d.A) && (d.lda % VLA == 0);
   p.b_vec = aligned16(d.B) && (d.ldb % VLB == 0);
@@ -369,7 +370,7 @@ static int gemm_launch_t(const GemmDesc& d, hipStream_t st) {
     set_error("gemm: output dropout is not supported together with split-K");
     return APA_ERR_UNSUPPORTED;
   }
-  const int tiles = ((d.M + GM - 1) / GM) * ((d.N + GN - 1) / GN);
+  const int tiles = ((d.M + GM - 1) / GM) * ((Nst + GN - 1) / GN);
   if (gemm_bf16_eligible(d)) {
     // 64-deep K tiles: re-derive the split so every chunk is a multiple of 64
     int kps64 = (d.K + splits - 1) / splits;
@@ -383,14 +384,14 @@ static int gemm_launch_t(const GemmDesc& d, hipStream_t st) {
   APA_LAUNCH_CHECK("gemm128_kernel");
   }
   if (splits > 1) {
-    const long tot = (long)d.M * d.N;
-    if (d.N % 4 == 0 && aligned16(d.ws)) {
+    const long tot = (long)d.M * Nst;
+    if (Nst % 4 == 0 && aligned16(d.ws)) {
       hipLaunchKernelGGL((gemm_splitk_reduce_kernel<TC, true>), dim3((unsigned)((tot / 4 + 255) / 256)),
-                         dim3(256), 0, st, d.ws, static_cast<TC*>(d.C), d.ldc, d.M, d.N, splits, d.bias,
+                         dim3(256), 0, st, d.ws, static_cast<TC*>(d.C), d.ldc, d.M, Nst, splits, d.bias,
                          d.beta, d.act);
     } else {
       hipLaunchKernelGGL((gemm_splitk_reduce_kernel<TC, false>), dim3((unsigned)((tot + 255) / 256)),
-                         dim3(256), 0, st, d.ws, static_cast<TC*>(d.C), d.ldc, d.M, d.N, splits, d.bias,
+                         dim3(256), 0, st, d.ws, static_cast<TC*>(d.C), d.ldc, d.M, Nst, splits, d.bias,
                          d.beta, d.act);
     }
     APA_LAUNCH_CHECK("gemm_splitk_reduce_kernel");

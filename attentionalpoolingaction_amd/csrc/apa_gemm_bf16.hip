@@ -111,6 +111,8 @@ struct FastParams {
   int M, N, K;
   const float* bias; float beta; int act;
   int k_per_split; float* partial;
+  int Nout;      // columns that exist in C / partial (N may cover zero-padded columns of B)
+  int drop_c; float inv_keep; uint32_t thresh; uint64_t seed, offset; const uint64_t* offset_dev;
   int vec_epi;   // N % 8 == 0 and C / bias / partial rows 16-byte addressable
 };
 
@@ -119,6 +121,8 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][4], const FastParams& p
                                          int n0, int tid) {
   const int wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
+  uint32_t h0 = 0, h1 = 0;   // output dropout (dX = (dT.Wt^T) * mask/keep of the per-class path)
+  if (p.drop_c) rng_key_dev(p.seed, p.offset_dev ? *p.offset_dev : p.offset, h0, h1);
   // ---- epilogue.  D layout of the 16x16 MFMA: row = 4 * (lane >> 4) + reg, col = lane & 15.
   // Fast form (N % 8 == 0, 16-byte addressable C rows): the tile goes through LDS as fp32
   // [128][132] (conflict-free 4-byte writes) and leaves as full 16-byte row segments -- bias, relu,
@@ -142,12 +146,12 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][4], const FastParams& p
       const int v = tid + it * 256;
       const int row = v >> 4, c8 = (v & 15) * 8;
       const int grow = m0 + row, gcol = n0 + c8;
-      if (grow >= p.M || gcol >= p.N) continue;
-      const float4 x0 = *reinterpret_cast<const float4*>(stage + row * LDS_C + c8);
-      const float4 x1 = *reinterpret_cast<const float4*>(stage + row * LDS_C + c8 + 4);
+      if (grow >= p.M || gcol >= p.Nout) continue;
+      float4 x0 = *reinterpret_cast<const float4*>(stage + row * LDS_C + c8);
+      float4 x1 = *reinterpret_cast<const float4*>(stage + row * LDS_C + c8 + 4);
       float o[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
       if (p.partial) {
-        float* dst = p.partial + ((size_t)blockIdx.z * p.M + grow) * p.N + gcol;
+        float* dst = p.partial + ((size_t)blockIdx.z * p.M + grow) * p.Nout + gcol;
         *reinterpret_cast<float4*>(dst) = x0;
         *reinterpret_cast<float4*>(dst + 4) = x1;
         continue;
@@ -161,6 +165,15 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][4], const FastParams& p
       if (p.act == 1) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = fmaxf(o[e], 0.f);
+      }
+      if (p.drop_c) {
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          float k0, k1;
+          rng_keep2((uint64_t)grow * p.Nout + gcol + e, h0, h1, p.thresh, k0, k1);
+          o[e] *= k0 * p.inv_keep;
+          o[e + 1] *= k1 * p.inv_keep;
+        }
       }
       TC* dst = C + (long)grow * p.ldc + gcol;
       if constexpr (sizeof(TC) == 2) {
@@ -187,7 +200,7 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][4], const FastParams& p
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int col = n0 + wn * 64 + j * 16 + l16;
-    if (col >= p.N) continue;
+    if (col >= p.Nout) continue;
     const float bv = (p.bias && !p.partial) ? p.bias[col] : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -197,10 +210,16 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][4], const FastParams& p
         if (row >= p.M) continue;
         float v = acc[i][j][r];
         if (p.partial) {
-          p.partial[((size_t)blockIdx.z * p.M + row) * p.N + col] = v;
+          p.partial[((size_t)blockIdx.z * p.M + row) * p.Nout + col] = v;
         } else {
           v += bv;
           if (p.act == 1) v = fmaxf(v, 0.f);
+          if (p.drop_c) {
+            const uint64_t e = (uint64_t)row * p.Nout + col;
+            float k0, k1;
+            rng_keep2(e & ~1ull, h0, h1, p.thresh, k0, k1);
+            v *= ((e & 1) ? k1 : k0) * p.inv_keep;
+          }
           if (p.beta != 0.f) v += c_get<TC>(C, (long)row * p.ldc + col);
           c_put<TC>(C, (long)row * p.ldc + col, v);
         }
@@ -453,7 +472,8 @@ int launch_layout(const FastParams& p, bool a_km, bool b_km, int splits, hipStre
 // at least one full vector of rows for k-major operands.
 bool gemm_bf16_eligible(const GemmDesc& d) {
   if (getenv("APA_GEMM_FAST") && atoi(getenv("APA_GEMM_FAST")) == 0) return false;
-  if (d.ta != 1 || d.drop_a || d.drop_c) return false;
+  if (d.ta != 1 || d.drop_a) return false;
+  if (d.drop_c && (d.n_valid > 0 && d.n_valid != d.N)) return false;   // mask index uses the row length
   if (d.K % 8 != 0 || d.K < 8 || d.M < 8 || d.N < 8) return false;
   const int ea = 2, eb = d.tb == 1 ? 2 : 4;
   if ((reinterpret_cast<uintptr_t>(d.A) & 15) || (d.lda * ea) % 16) return false;
@@ -470,8 +490,11 @@ int gemm_bf16_launch(const GemmDesc& d, int splits, int k_per_split, hipStream_t
   p.M = d.M; p.N = d.N; p.K = d.K; p.bias = d.bias; p.beta = d.beta; p.act = d.act;
   p.k_per_split = k_per_split;
   p.partial = splits > 1 ? d.ws : nullptr;
+  p.Nout = d.n_valid > 0 ? d.n_valid : d.N;
+  p.drop_c = d.drop_c; p.inv_keep = d.inv_keep; p.thresh = d.thresh; p.seed = d.seed; p.offset = d.offset;
+  p.offset_dev = d.offset_dev;
   const int ec = d.tc == 1 ? 2 : 4;
-  p.vec_epi = d.N % 8 == 0 && (reinterpret_cast<uintptr_t>(d.C) & 15) == 0 && (d.ldc * ec) % 16 == 0 &&
+  p.vec_epi = p.Nout % 8 == 0 && (!d.drop_c || p.Nout % 2 == 0) && (reinterpret_cast<uintptr_t>(d.C) & 15) == 0 && (d.ldc * ec) % 16 == 0 &&
               (!d.bias || (reinterpret_cast<uintptr_t>(d.bias) & 15) == 0) &&
               (!p.partial || (reinterpret_cast<uintptr_t>(p.partial) & 15) == 0);
   static const int use_glds = [] { const char* e = getenv("APA_GEMM_GLDS"); return e ? atoi(e) : 1; }();

@@ -83,6 +83,7 @@ struct GemmDesc {
   const void* B = nullptr; long ldb = 0; int tb = 0; bool b_kc = false;
   void* C = nullptr; long ldc = 0; int tc = 0;
   int M = 0, N = 0, K = 0;
+  int n_valid = 0;   // > 0: B (and ldb) cover N zero-padded columns, only the first n_valid are stored
   const float* bias = nullptr;
   float beta = 0.f;
   int act = 0;
