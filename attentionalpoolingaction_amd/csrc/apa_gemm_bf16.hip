@@ -13,7 +13,7 @@
 //   * k-major operands ([K][rows] -- W1 in the forward product, X and dPpre in dW1 = X^T dPpre)
 //     land in a [k][row] image by the same 16-byte copies and are read with
 //     ds_read_b64_tr_b16, the gfx950 transposing LDS read.  Its semantics, probed on the device
-//     (scratch/tr_probe.hip): inside each 16-lane group, lane s SUPPLIES the address of 4
+//     (tools/tr_probe.hip): inside each 16-lane group, lane s SUPPLIES the address of 4
 //     consecutive b16 elements and lane t RECEIVES element (t & 3) of the suppliers
 //     4e + (t >> 2), e = 0..3.  So if supplier s points at (k = kb + (s >> 2), row = r0 + 4 (s & 3))
 //     then lane t receives rows r0 + t at k = kb..kb+3: a 4x16 -> 16x4 transpose, exactly the

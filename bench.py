@@ -219,9 +219,23 @@ def main():
     comm = None
     if dist is not None and args.comm == 'rccl':
         from attentionalpoolingaction_amd import rccl
-        comm = rccl.RcclCommunicator(rank, max(world, 1), dev, group=None)
-        comm.all_reduce_(torch.zeros(8, device=dev))          # first call builds the rings
-        torch.cuda.synchronize()
+        ok = 1
+        try:
+            comm = rccl.RcclCommunicator(rank, max(world, 1), dev, group=None)
+            comm.all_reduce_(torch.zeros(8, device=dev))      # first call builds the rings
+            torch.cuda.synchronize()
+        except Exception as e:                                 # noqa: BLE001 -- any failure -> fallback
+            print('direct RCCL unavailable on rank {}: {}'.format(rank, e), file=sys.stderr)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)            # every rank takes the same branch
+        if int(flag.item()) == 0:                              # fall back to torch.distributed's RCCL
+            if comm is not None:
+                comm.close()
+            comm = None
+            args.comm = 'torch'
+            dist.destroy_process_group()
+            dist.init_process_group('nccl', device_id=dev)
 
     def allreduce(t, stream=None, async_op=False):
         if comm is not None:
