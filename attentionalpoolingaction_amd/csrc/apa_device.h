@@ -131,6 +131,16 @@ template <> struct Vec<bf16_t> {
 
 __device__ __forceinline__ uint4 ld16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
 __device__ __forceinline__ void st16(void* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = v; }
+__device__ __forceinline__ uint4 ld16_nt(const void* p) {
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  const u4 v = __builtin_nontemporal_load(reinterpret_cast<const u4*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+// streaming store: the line is not needed again by this kernel (dX rows)
+__device__ __forceinline__ void st16_nt(void* p, const uint4& v) {
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(u4{v.x, v.y, v.z, v.w}, reinterpret_cast<u4*>(p));
+}
 
 // ---------------------------------------------------------------------------------------------
 // Counter-based dropout RNG.  One 32-bit hash yields the keep decision of TWO consecutive

@@ -22,6 +22,14 @@
 #include "apa_device.h"
 #include "apa_internal.h"
 
+// Cache policy, measured (bench.py, fp32): dX goes out with NON-TEMPORAL stores -- 307 -> 271 us at
+// N = 512 (5.35 -> 6.07 TB/s), 66 -> 61 us at N = 128, neutral at N = 32.  Non-temporal LOADS of X in
+// the backward pass lose everywhere (271 -> 293 us at N = 512, 16.0 -> 17.0 us at N = 32, where X is
+// still resident in the 256 MiB Infinity Cache from the forward pass), so X uses plain loads.
+#ifndef APA_BWD_NT_LOAD
+#define APA_BWD_NT_LOAD false
+#endif
+
 namespace apa {
 
 namespace {
@@ -63,7 +71,7 @@ __device__ __forceinline__ uint32_t rng_keep2_bits(uint64_t e, uint32_t k0, uint
 // chunk k is consumed (and, in backward, while its dX rows are stored), so reads, VALU work and
 // writes of different chunks overlap inside one wave.
 // --------------------------------------------------------------------------------------------
-template <typename T, int VW, int PIX>
+template <typename T, int VW, int PIX, bool NT = false>
 __device__ __forceinline__ void load_chunk(uint4 (&xr)[PIX][VW], const T* __restrict__ xim, int q0,
                                            int p_last, int C, int cbase) {
   constexpr int EPV = Vec<T>::EPV;
@@ -71,7 +79,10 @@ __device__ __forceinline__ void load_chunk(uint4 (&xr)[PIX][VW], const T* __rest
   for (int i = 0; i < PIX; ++i) {
     const int p = min(q0 + i, p_last);   // slots past the block's last pixel re-read that pixel
 #pragma unroll
-    for (int j = 0; j < VW; ++j) xr[i][j] = ld16(xim + (size_t)p * C + cbase + j * 64 * EPV);
+    for (int j = 0; j < VW; ++j) {
+      const T* src = xim + (size_t)p * C + cbase + j * 64 * EPV;
+      xr[i][j] = NT ? ld16_nt(src) : ld16(src);
+    }
   }
   // keep the prefetch ahead of the current chunk's arithmetic and barrier
   __builtin_amdgcn_sched_barrier(0);
@@ -352,7 +363,7 @@ __device__ __forceinline__ void bwd_chunk(BwdState<T, VW, PIX, FUSED, TRAIN>& st
           o[e] = t * st.dzr[c];
         }
       }
-      st16(dxim + (size_t)(q0 + src) * C + cbase + j * 64 * EPV, Vec<T>::pack(o));
+      st16_nt(dxim + (size_t)(q0 + src) * C + cbase + j * 64 * EPV, Vec<T>::pack(o));
     }
   }
 }
@@ -391,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void m1s_bwd_main_kernel(
 
   const int p_last = p_end - 1;
   uint4 xa[PIX][VW], xb[PIX][VW];
-  load_chunk<T, VW, PIX>(xa, xim, p_begin, p_last, C, cbase);
+  load_chunk<T, VW, PIX, APA_BWD_NT_LOAD>(xa, xim, p_begin, p_last, C, cbase);
   float a_a = att_im[min(p_begin + l16, p_last)], a_b = 0.f;
 
   // per-image constants: L2 hits issued behind the first chunk's HBM loads
@@ -435,13 +446,13 @@ __global__ __launch_bounds__(256, 2) void m1s_bwd_main_kernel(
   }
 
   for (int ch = 0; ch < nchunk; ch += 2) {
-    load_chunk<T, VW, PIX>(xb, xim, p_begin + (ch + 1) * PIX, p_last, C, cbase);
+    load_chunk<T, VW, PIX, APA_BWD_NT_LOAD>(xb, xim, p_begin + (ch + 1) * PIX, p_last, C, cbase);
     a_b = att_im[min(p_begin + (ch + 1) * PIX + l16, p_last)];
     bwd_chunk<T, VW, PIX, FUSED, TRAIN>(st, xa, a_a, chunk_range<PIX>(p_begin, p_end, ch), sm_x[0],
                                         dxim, dZout_im, n, P, C, cbase, wave, lane, act, invP,
                                         inv_keep, thresh, k0, k1);
     if (ch + 1 >= nchunk) break;
-    load_chunk<T, VW, PIX>(xa, xim, p_begin + (ch + 2) * PIX, p_last, C, cbase);
+    load_chunk<T, VW, PIX, APA_BWD_NT_LOAD>(xa, xim, p_begin + (ch + 2) * PIX, p_last, C, cbase);
     a_a = att_im[min(p_begin + (ch + 2) * PIX + l16, p_last)];
     bwd_chunk<T, VW, PIX, FUSED, TRAIN>(st, xb, a_b, chunk_range<PIX>(p_begin, p_end, ch + 1),
                                         sm_x[1], dxim, dZout_im, n, P, C, cbase, wave, lane, act,
