@@ -56,6 +56,8 @@ _SIGNATURES = {
                                     c_float, c_int, POINTER(c_float), POINTER(c_uint8)]),
     'apa_zero_out_channels': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     'apa_pose_label_replay_resize': (c_int, [POINTER(c_uint8)] + [c_int] * 11 + [c_float, POINTER(c_float)]),
+    'apa_pose_labels_device': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int,
+                                       c_void_p, c_void_p, c_void_p, c_void_p]),
     'apa_frame_pool_fwd': (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),
     'apa_frame_pool_bwd': (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),
     'apa_set_grad_ready_event': (c_int, [c_void_p]),
@@ -407,6 +409,32 @@ def pose_label_replay_resize(hm_u8: np.ndarray, orig_hw, crop_info, whether_flip
 # --------------------------------------------------------------------------------------------
 # frame pooling (nets_factory.py:354-374)
 # --------------------------------------------------------------------------------------------
+def pose_labels_device(poses, geoms, out_wd=200, J=16, marker_wd_ratio=0.1, out_side=15, device='cuda'):
+    """The whole label path of src/preprocess_pipeline.py:150-214 for a batch on the device.
+    poses: list of int64 arrays (x, y, vis triples, n_people*J of them); geoms: list of
+    (im_ht, im_wd, crop_y, crop_x, crop_h, crop_w, flip).  Returns (labels f32 [N,S,S,J] device,
+    valid bool [N,J] device, status int32 [N] device)."""
+    lib = load_library()
+    N = len(poses)
+    flat = [np.asarray(p, dtype=np.int64).reshape(-1) for p in poses]
+    max_vals = max(max(f.size for f in flat), 3 * J)
+    pose_h = np.full((N, max_vals), -1, dtype=np.int64)
+    for i, f in enumerate(flat):
+        pose_h[i, :f.size] = f
+    dev = torch.device(device)
+    pose_d = torch.from_numpy(pose_h).to(dev)
+    nv_d = torch.tensor([f.size for f in flat], dtype=torch.int32, device=dev)
+    geom_d = torch.tensor([[int(v) for v in g] for g in geoms], dtype=torch.int32, device=dev)
+    labels = torch.empty((N, out_side, out_side, J), dtype=torch.float32, device=dev)
+    valid = torch.empty((N, J), dtype=torch.uint8, device=dev)
+    status = torch.empty((N,), dtype=torch.int32, device=dev)
+    _check(lib.apa_pose_labels_device(pose_d.data_ptr(), nv_d.data_ptr(), geom_d.data_ptr(), N, max_vals,
+                                      int(out_wd), int(J), float(marker_wd_ratio), int(out_side),
+                                      labels.data_ptr(), valid.data_ptr(), status.data_ptr(), _stream_ptr()),
+           'apa_pose_labels_device')
+    return labels, valid.bool(), status
+
+
 def frame_pool_fwd(logits, frames_per_video, w=None, b=None):
     """pooled [B,K], tatt [B*F] or None."""
     lib = load_library()

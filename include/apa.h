@@ -177,6 +177,20 @@ int apa_pose_label_replay_resize(const uint8_t* hm_host, int h, int w, int J, in
                                  int crop_y, int crop_x, int crop_h, int crop_w, int flip,
                                  int out_side, float eps, float* out_host);
 
+/* The same label path on the DEVICE for a whole batch, canvas-free (training call: no blur,
+ * src/preprocess_pipeline.py:162): apa_pose_to_heatmap -> *255 -> apa_pose_label_replay_resize fused,
+ * one block per image; bit-identical to the two host functions above (eps: any value << 1, e.g.
+ * cfg.EPS = 1e-14, gives the same result on a binary canvas).
+ *   pose    int64 [N][max_vals]  (x, y, is_visible) triples, n_vals[n] of them used (multiple of 3*J,
+ *           at most 32 people)
+ *   geom    int32 [N][7] = im_ht, im_wd, crop_y, crop_x, crop_h, crop_w, flip   (crop in the
+ *           coordinates of the im_ht x im_wd image, like the host function's orig_h x orig_w)
+ *   labels  f32 [N, out_side, out_side, J];  valid uint8 [N, J];  status int32 [N]: 0 = ok, 1 = the
+ *           host path would have failed for this image (bad crop / sizes): its label is all zero. */
+int apa_pose_labels_device(const int64_t* pose, const int32_t* n_vals, const int32_t* geom, int N,
+                           int max_vals, int out_wd, int J, float marker_wd_ratio, int out_side,
+                           float* labels, uint8_t* valid, int32_t* status, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Video frame pooling of per-frame logits, nets_factory.py:354-374.  logits f32 [B*F, K] (F
  * consecutive rows per video) -> pooled f32 [B, K].

@@ -507,3 +507,49 @@ def test_softmax_xent_shapes_vs_float64(gpu, N, K):
     assert torch.equal(pred.cpu(), lg.argmax(1))
     lb2, G2, _, _ = cof.softmax_xent_fwd_bwd(lg.to(gpu), lab.to(gpu), want_grad=False)   # loss only
     assert G2 is None and float(lb2[0]) == float(lb[0])
+
+
+def test_device_label_path_bit_exact_vs_host_functions(gpu):
+    """apa_pose_labels_device (one fused, canvas-free kernel per batch) == the host functions
+    apa_pose_to_heatmap (no blur) -> *255 -> apa_pose_label_replay_resize, bit for bit: multiple
+    people, missing keypoints (-1), keypoints on the border, crops, flips, 0.05 and 0.1 markers,
+    plus the degenerate crops (nothing visible; a crop fully inside a disc)."""
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    rng = np.random.RandomState(7)
+    J = 16
+    for ratio in (0.1, 0.05):
+        poses, geoms = [], []
+        for i in range(24):
+            im_ht, im_wd = int(rng.randint(200, 700)), int(rng.randint(200, 700))
+            n_people = int(rng.randint(1, 4))
+            p = np.zeros((n_people, J, 3), dtype=np.int64)
+            p[..., 0] = rng.randint(-20, im_wd + 20, size=(n_people, J))
+            p[..., 1] = rng.randint(-20, im_ht + 20, size=(n_people, J))
+            p[..., 2] = 1
+            miss = rng.rand(n_people, J) < 0.3
+            p[miss] = -1
+            p[..., 0] = np.where(p[..., 0] >= im_wd, im_wd - 1, p[..., 0])
+            p[..., 1] = np.where(p[..., 1] >= im_ht, im_ht - 1, p[..., 1])
+            if i == 0:
+                p[...] = -1                              # nothing visible -> all-zero label
+            crop_h, crop_w = int(rng.randint(im_ht // 2, im_ht + 1)), int(rng.randint(im_wd // 2, im_wd + 1))
+            crop_y, crop_x = int(rng.randint(0, im_ht - crop_h + 1)), int(rng.randint(0, im_wd - crop_w + 1))
+            if i == 1:                                   # a tiny crop fully inside every joint's disc
+                p[..., 0], p[..., 1], p[..., 2] = im_wd // 2, im_ht // 2, 1
+                crop_h = crop_w = max(8, min(im_ht, im_wd) // 40)
+                crop_y, crop_x = im_ht // 2 - crop_h // 2, im_wd // 2 - crop_w // 2
+            poses.append(p.reshape(-1))
+            geoms.append((im_ht, im_wd, crop_y, crop_x, crop_h, crop_w, int(rng.rand() < 0.5)))
+        labels, valid, status = cof.pose_labels_device(poses, geoms, marker_wd_ratio=ratio, device=gpu)
+        labels, valid, status = labels.cpu().numpy(), valid.cpu().numpy(), status.cpu().numpy()
+        assert (status == 0).all()
+        for i, (p, g) in enumerate(zip(poses, geoms)):
+            hm, v = cof.pose_to_heatmap(p, g[0], g[1], 200, out_channels=J, marker_wd_ratio=ratio,
+                                        do_gauss_blur=False)
+            ref = cof.pose_label_replay_resize(hm, (g[0], g[1]), [g[2], g[3], g[4], g[5]], bool(g[6]), 15)
+            assert np.array_equal(valid[i], v), i
+            assert np.array_equal(labels[i], ref), (i, float(np.abs(labels[i] - ref).max()))
+        assert labels[0].max() == 0.0 and labels[2:].max() == 1.0
+    # a crop outside the image is reported, not silently accepted
+    _, _, st = cof.pose_labels_device([poses[3]], [(300, 300, 250, 0, 100, 100, 0)], device=gpu)
+    assert int(st[0]) == 1
