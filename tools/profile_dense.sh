@@ -21,7 +21,7 @@ with open(prefix + '_summary.md', 'w') as o:
     o.write('| kernel | calls | avg us | % |\n|---|---|---|---|\n')
     for r in rows:
         if int(r['Calls']) >= 50 and float(r['Percentage']) >= 0.5:
-            o.write('| `{}` | {} | {:.2f} | {} |\n'.format(r['Name'].split('(')[0][:100], r['Calls'], float(r['AverageNs']) / 1e3, r['Percentage']))
+            o.write('| `{}` | {} | {:.2f} | {} |\n'.format(r['Name'].replace('(anonymous namespace)::', '').split('(')[0][:100], r['Calls'], float(r['AverageNs']) / 1e3, r['Percentage']))
 print(open(prefix + '_summary.md').read())
 PY
 done

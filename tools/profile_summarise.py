@@ -63,7 +63,7 @@ def main():
         f.write('bench line under the profiler: {} img/s, {:.2f} us/step\n\n'.format(bench['value'], bench['ms_per_step'] * 1e3))
         f.write('| kernel | calls | avg us | % |\n|---|---|---|---|\n')
         for r in per_step:
-            f.write('| `{}` | {} | {:.2f} | {} |\n'.format(r['Name'].split('(')[0], r['Calls'], float(r['AverageNs']) / 1e3, r['Percentage']))
+            f.write('| `{}` | {} | {:.2f} | {} |\n'.format(r['Name'].replace('(anonymous namespace)::', '').split('(')[0], r['Calls'], float(r['AverageNs']) / 1e3, r['Percentage']))
         f.write('\nrocprofv3 kernel durations include ~1.5 us of dispatch overhead per kernel (an empty kernel '
                 'reads 1.5 us min / 4.6 us median under the profiler, tools/ubench.hip), so the small kernels look '
                 'bigger here than their marginal cost in the un-profiled step (tools/kbench.cpp ablation).\n\n')
