@@ -156,7 +156,7 @@ extern "C" int apa_attn_pool_fwd(const void* X, const void* Xatt, const float* W
       return APA_ERR_INVALID_ARG;
     }
     if (!m1_supported(C, Ca, dtype, Xatt == X)) {
-      set_error("apa_attn_pool_fwd: M==1 kernels need C in {256,512,1024,2048} (f32) or "
+      set_error("apa_attn_pool_fwd: M==1 kernels need C in {256,512,1024,2048,4096} (f32) or "
                 "{512,1024,2048} (bf16); got C=%d Ca=%d dtype=%d", C, Ca, dtype);
       return APA_ERR_UNSUPPORTED;
     }

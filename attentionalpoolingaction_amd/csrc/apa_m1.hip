@@ -603,8 +603,11 @@ static int env_int(const char* name, int dflt) {
   return (s && *s) ? atoi(s) : dflt;
 }
 
+static bool use_stream_kernels(int C, int dtype);
 bool m1_supported(int C, int Ca, int dtype, bool fused) {
   const int epv = dtype == APA_DTYPE_BF16 ? 8 : 4;
+  // C = 4096 fp32 exists only in the channel-split kernels (apa_m1_stream.hip)
+  if (use_stream_kernels(C, dtype) && (fused || Ca % epv == 0)) return true;
   if (C % (64 * epv) != 0) return false;
   const int vec = C / (64 * epv);
   if (!(vec == 1 || vec == 2 || vec == 4 || vec == 8)) return false;

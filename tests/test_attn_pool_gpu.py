@@ -287,3 +287,20 @@ def test_m1_full_baseline_workload_parity(gpu):
     got2 = _run_hip(inp, gpu, train=True, keep=keep, seed=seed, offset=offset)
     for k in ('logits', 'dX', 'dWa', 'dba', 'dWt', 'dbt'):
         assert torch.equal(got[k], got2[k]), k
+
+
+@pytest.mark.parametrize('N,H,W,C,dt', [(2, 1, 1, 2048, torch.float32), (3, 2, 1, 2048, torch.float32),
+                                        (1, 3, 3, 1024, torch.float32), (2, 5, 4, 1024, torch.bfloat16),
+                                        (2, 3, 3, 512, torch.bfloat16), (1, 14, 14, 4096, torch.float32)])
+def test_m1_edge_shapes(gpu, N, H, W, C, dt):
+    """Degenerate maps (a single pixel, fewer pixels than a chunk), the narrow-map kernels in bf16,
+    and the widest instantiated map (C = 4096)."""
+    inp = make_head_inputs(N=N, H=H, W=W, C=C, K=51, seed=N * 100 + H * 10 + W, dtype=dt)
+    softmax = H * W > 2      # (a softmax over one or two pixels has ~zero gradients: nothing to compare)
+    ref = _oracle(inp, orc.AttnFlags(softmax_att=softmax))
+    got = _run_hip(inp, gpu, softmax=softmax)
+    _close(got['logits'], ref['logits'], TIGHT, 'logits')
+    _close(got['att'].reshape(ref['att'].shape), ref['att'], TIGHT, 'attention map')
+    assert torch.equal(got['pred'], ref['logits'].argmax(dim=1))
+    keys = ('dWa', 'dba', 'dWt', 'dbt') + (() if dt == torch.bfloat16 else ('dX',))
+    _grads_close(got, ref, keys)
