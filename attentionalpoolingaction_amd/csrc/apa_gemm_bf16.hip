@@ -116,6 +116,78 @@ struct FastParams {
   int vec_epi;   // N % 8 == 0 and C / bias / partial rows 16-byte addressable
 };
 
+// 8 consecutive output columns of one row: split-K partial, or bias / relu / output dropout /
+// + beta*C / pack and one 16-byte store
+template <typename TC>
+__device__ __forceinline__ void store8(const FastParams& p, TC* C, int grow, int gcol, float4 x0, float4 x1,
+                                       uint32_t h0, uint32_t h1) {
+  float o[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+  if (p.partial) {
+    float* dst = p.partial + ((size_t)blockIdx.z * p.M + grow) * p.Nout + gcol;
+    *reinterpret_cast<float4*>(dst) = x0;
+    *reinterpret_cast<float4*>(dst + 4) = x1;
+    return;
+  }
+  if (p.bias) {
+    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + gcol);
+    const float4 b1 = *reinterpret_cast<const float4*>(p.bias + gcol + 4);
+    o[0] += b0.x; o[1] += b0.y; o[2] += b0.z; o[3] += b0.w;
+    o[4] += b1.x; o[5] += b1.y; o[6] += b1.z; o[7] += b1.w;
+  }
+  if (p.act == 1) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = fmaxf(o[e], 0.f);
+  }
+  if (p.drop_c) {
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      float k0, k1;
+      rng_keep2((uint64_t)grow * p.Nout + gcol + e, h0, h1, p.thresh, k0, k1);
+      o[e] *= k0 * p.inv_keep;
+      o[e + 1] *= k1 * p.inv_keep;
+    }
+  }
+  TC* dst = C + (long)grow * p.ldc + gcol;
+  if constexpr (sizeof(TC) == 2) {
+    if (p.beta != 0.f) {
+      float c[8];
+      Vec<bf16_t>::unpack(ld16(dst), c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += c[e];
+    }
+    st16(dst, Vec<bf16_t>::pack(o));
+  } else {
+    float* d = reinterpret_cast<float*>(dst);
+    if (p.beta != 0.f) {
+      const float4 c0 = *reinterpret_cast<const float4*>(d), c1 = *reinterpret_cast<const float4*>(d + 4);
+      o[0] += c0.x; o[1] += c0.y; o[2] += c0.z; o[3] += c0.w;
+      o[4] += c1.x; o[5] += c1.y; o[6] += c1.z; o[7] += c1.w;
+    }
+    *reinterpret_cast<float4*>(d) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(d + 4) = make_float4(o[4], o[5], o[6], o[7]);
+  }
+}
+
+// one output element (unaligned / ragged outputs)
+template <typename TC>
+__device__ __forceinline__ void store1(const FastParams& p, TC* C, int row, int col, float v, float bv,
+                                       uint32_t h0, uint32_t h1) {
+  if (p.partial) {
+    p.partial[((size_t)blockIdx.z * p.M + row) * p.Nout + col] = v;
+    return;
+  }
+  v += bv;
+  if (p.act == 1) v = fmaxf(v, 0.f);
+  if (p.drop_c) {
+    const uint64_t e = (uint64_t)row * p.Nout + col;
+    float k0, k1;
+    rng_keep2(e & ~1ull, h0, h1, p.thresh, k0, k1);
+    v *= ((e & 1) ? k1 : k0) * p.inv_keep;
+  }
+  if (p.beta != 0.f) v += c_get<TC>(C, (long)row * p.ldc + col);
+  c_put<TC>(C, (long)row * p.ldc + col, v);
+}
+
 template <typename TC>
 __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][4], const FastParams& p, short* smem, int m0,
                                          int n0, int tid) {
@@ -415,6 +487,170 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(FastParams p) {
   epilogue<TC>(acc, p, smem, m0, n0, tid);
 }
 
+// ---------------------------------------------------------------------------------------------
+// 128 x 64 tile variant of the DMA-staged kernel (4 waves as 2 x 2, 64 x 32 per wave).  Twice the
+// tiles (the pose-head products are 294 / 784 / 96 x splits tiles of 128 x 128 against 256 CUs, so
+// the ragged last round costs up to 40 %), 24 KiB per LDS stage -> three blocks per CU.
+// B images are 64 rows wide: [n][k] is the A layout with fewer rows; [k][n] has 128-byte rows and the
+// swizzle chunk' = chunk ^ 2*((k >> 1) & 1) ^ 4*((k >> 3) & 1) (odd k already sits in the other bank half).
+// ---------------------------------------------------------------------------------------------
+constexpr int IMGB64 = 64 * TK;   // 4096 elements = 8 KiB
+
+template <bool KM>
+__device__ __forceinline__ long glds_src_offset_b64(int g, int lane, long ld, int r0, int rlim) {
+  if (!KM) return glds_src_offset<false>(g, lane, ld, r0, rlim);
+  const int k = 8 * g + (lane >> 3);
+  const int chunk = (lane & 7) ^ (2 * ((k >> 1) & 1)) ^ (4 * ((k >> 3) & 1));
+  return (long)k * ld + min(r0 + chunk * 8, rlim - 8);
+}
+
+template <bool KM>
+__device__ __forceinline__ bf16x8 fragment_b64(const short* img, int rbase, int ks, int lane) {
+  if (!KM) return fragment_sw<false>(img, rbase, ks, lane);
+  typedef bf16x4 __attribute__((address_space(3))) * lds_v4;
+  const int l16 = lane & 15, kb = lane >> 4;
+  const int k = ks * 32 + kb * 8 + (l16 >> 2);
+  const int r = rbase + 4 * (l16 & 3);
+  const int chunk = (r >> 3) ^ (2 * ((k >> 1) & 1)) ^ (4 * (kb & 1));
+  const short* s0 = img + k * 64 + chunk * 8 + (r & 7);
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(s0));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(s0 + 4 * 64));   // k + 4: same swizzle
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <typename TC, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(256, 3) void gemm_bf16_glds64_kernel(FastParams p) {
+  extern __shared__ __attribute__((aligned(16))) short smem[];   // [2 stages][A 16 KiB | B 8 KiB]
+  constexpr int BN = 64, STAGE = IMG + IMGB64;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntm = (p.M + TM - 1) / TM, ntn = (p.N + BN - 1) / BN;
+  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (tile / ntn) * TM, n0 = (tile % ntn) * BN;
+  const int kbeg = blockIdx.z * p.k_per_split, kend = min(p.K, kbeg + p.k_per_split);
+  const int nk = (kend - kbeg) / TK;
+
+  const bf16_t* asrc[4];
+  const bf16_t* bsrc[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    asrc[j] = static_cast<const bf16_t*>(p.A) + glds_src_offset<A_KM>(wave * 4 + j, lane, p.lda, m0, p.M) +
+              (A_KM ? (long)kbeg * p.lda : (long)kbeg);
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    bsrc[j] = static_cast<const bf16_t*>(p.B) + glds_src_offset_b64<B_KM>(wave * 2 + j, lane, p.ldb, n0, p.N) +
+              (B_KM ? (long)kbeg * p.ldb : (long)kbeg);
+  const long a_step = A_KM ? (long)TK * p.lda : (long)TK;
+  const long b_step = B_KM ? (long)TK * p.ldb : (long)TK;
+  typedef __attribute__((address_space(1))) const void* gptr;
+  typedef __attribute__((address_space(3))) void* lptr;
+  auto issue = [&](int buf) {
+    short* a_img = smem + buf * STAGE;
+    short* b_img = a_img + IMG;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_global_load_lds((gptr)asrc[j], (lptr)(a_img + (wave * 4 + j) * 512), 16, 0, 0);
+      asrc[j] += a_step;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      __builtin_amdgcn_global_load_lds((gptr)bsrc[j], (lptr)(b_img + (wave * 2 + j) * 512), 16, 0, 0);
+      bsrc[j] += b_step;
+    }
+  };
+
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) issue(0);
+  __syncthreads();
+  for (int t = 0; t < nk; ++t) {
+    const short* a_img = smem + (t & 1) * STAGE;
+    const short* b_img = a_img + IMG;
+    if (t + 1 < nk) issue((t + 1) & 1);
+#pragma unroll
+    for (int ks = 0; ks < TK / 32; ++ks) {
+      bf16x8 af[4], bf[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = fragment_sw<A_KM>(a_img, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = fragment_b64<B_KM>(b_img, wn * 32 + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: same contract as `epilogue` above, 128 x 64 geometry
+  TC* C = static_cast<TC*>(p.C);
+  const int l16 = lane & 15, kb = lane >> 4;
+  uint32_t h0 = 0, h1 = 0;
+  if (p.drop_c) rng_key_dev(p.seed, p.offset_dev ? *p.offset_dev : p.offset, h0, h1);
+  if (p.vec_epi) {
+    float* stage = reinterpret_cast<float*>(smem);   // 128 * 68 * 4 = 34 816 B <= 49 152 B
+    constexpr int LDS_C = BN + 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          stage[(wm * 64 + i * 16 + 4 * kb + r) * LDS_C + wn * 32 + j * 16 + l16] = acc[i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int v = tid + it * 256;
+      const int row = v >> 3, c8 = (v & 7) * 8;
+      const int grow = m0 + row, gcol = n0 + c8;
+      if (grow >= p.M || gcol >= p.Nout) continue;
+      const float4 x0 = *reinterpret_cast<const float4*>(stage + row * LDS_C + c8);
+      const float4 x1 = *reinterpret_cast<const float4*>(stage + row * LDS_C + c8 + 4);
+      store8<TC>(p, C, grow, gcol, x0, x1, h0, h1);
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wn * 32 + j * 16 + l16;
+    if (col >= p.Nout) continue;
+    const float bv = (p.bias && !p.partial) ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 64 + i * 16 + 4 * kb + r;
+        if (row >= p.M) continue;
+        store1<TC>(p, C, row, col, acc[i][j][r], bv, h0, h1);
+      }
+    }
+  }
+}
+
+template <typename TC, bool A_KM, bool B_KM>
+int launch_glds64(const FastParams& p, int splits, hipStream_t st) {
+  const size_t shm = (size_t)2 * (IMG + IMGB64) * sizeof(short);   // 49 152 B
+  const int tiles = ((p.M + TM - 1) / TM) * ((p.N + 63) / 64);
+  hipLaunchKernelGGL((gemm_bf16_glds64_kernel<TC, A_KM, B_KM>), dim3(tiles, 1, splits), dim3(256), shm, st, p);
+  APA_LAUNCH_CHECK("gemm_bf16_glds64_kernel");
+  return APA_OK;
+}
+
+template <typename TC>
+int launch_glds64_layout(const FastParams& p, bool a_km, bool b_km, int splits, hipStream_t st) {
+  if (a_km) {
+    if (b_km) return launch_glds64<TC, true, true>(p, splits, st);
+    return launch_glds64<TC, true, false>(p, splits, st);
+  }
+  if (b_km) return launch_glds64<TC, false, true>(p, splits, st);
+  return launch_glds64<TC, false, false>(p, splits, st);
+}
+
 template <typename TC, bool A_KM, bool B_KM>
 int launch_glds(const FastParams& p, int splits, hipStream_t st) {
   const size_t shm = (size_t)2 * 2 * OP_ELEMS * sizeof(short);   // epilogue stage needs 67 584 B
@@ -499,6 +735,16 @@ int gemm_bf16_launch(const GemmDesc& d, int splits, int k_per_split, hipStream_t
               (!p.partial || (reinterpret_cast<uintptr_t>(p.partial) & 15) == 0);
   static const int use_glds = [] { const char* e = getenv("APA_GEMM_GLDS"); return e ? atoi(e) : 1; }();
   if (use_glds && d.tb == 1 && k_per_split % TK == 0 && d.K % TK == 0) {   // all-bf16, whole K tiles: DMA staging
+    // tile shape: with fewer than ~2.5 tiles of 128 x 128 per CU the ragged last round dominates and
+    // the 128 x 64 variant (twice the tiles, three blocks per CU) wins -- measured on the pose head:
+    // 294 tiles 38.2 -> 32.6 us, 96 x 3 splits 40.0 -> 35.2 us, but 784 tiles 34.4 -> 37.4 us
+    static const int bn_env = [] { const char* e = getenv("APA_GEMM_BN"); return e ? atoi(e) : 0; }();
+    const long tiles128 = (long)((d.M + TM - 1) / TM) * ((d.N + TN - 1) / TN) * splits;
+    const int bn = bn_env ? bn_env : (tiles128 < 640 ? 64 : 128);
+    if (bn == 64) {
+      if (d.tc == 1) return launch_glds64_layout<bf16_t>(p, !d.a_kc, !d.b_kc, splits, st);
+      return launch_glds64_layout<float>(p, !d.a_kc, !d.b_kc, splits, st);
+    }
     if (d.tc == 1) return launch_glds_layout<bf16_t>(p, !d.a_kc, !d.b_kc, splits, st);
     return launch_glds_layout<float>(p, !d.a_kc, !d.b_kc, splits, st);
   }
