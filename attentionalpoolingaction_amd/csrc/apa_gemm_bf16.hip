@@ -377,6 +377,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(FastParams p) {
 //   2 LDS stages, 4 waves, 2 blocks/CU (this file)              38 / 34 / 40 us   (~520-580 TFLOP/s)
 //   3 stages + counted vmcnt + raw s_barrier, 4 waves, 1 block/CU   55 / 53 / 55 us
 //   3 stages, 8 waves (2 per SIMD), 1 block/CU                   44 / 43 / 51 us
+//   128 x 64 tiles: 2 stages x 3 blocks/CU  32.6 / 37.4 / 35.2 us;  3 stages (asm DMA) x 2 blocks/CU  38.6 / - / 44.5 us
 // (the 3-stage variants need the DMA in inline asm: with the builtin hipcc guards the transposing
 // LDS reads with s_waitcnt vmcnt(0) and drains the queue every K-tile).  At these sizes the tile
 // count (294 / 784 / 96 x splits) against 256 CUs matters more than pipeline depth: two resident
