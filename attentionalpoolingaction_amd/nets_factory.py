@@ -300,6 +300,47 @@ class AttentionalPoolingHead(nn.Module):
         return logits, end_points
 
 
+class BaselineHead(nn.Module):
+    """cfg 001 (`experiments/001_MPII_ResNet.yaml`, no attention): the slim ResNet's own head --
+    global average pool, dropout, 1x1 conv `resnet_v1_101/logits` (models/slim/nets/resnet_v1.py:206-217
+    with the dropout of nets_factory.py:143-146 forwarded as dropout_keep_prob).  Not the hot path: it is
+    the plumbing baseline of BASELINE configs[0].  In eval mode it IS the attentional-pooling op with
+    a constant attention map (mean_p X . W + b, one streaming pass in HIP); in training the dropout
+    sits between the pooled vector and the classifier, so the [N,C]-sized tail is torch ops."""
+
+    TF_NAMES = {'logits_weights': 'logits/weights', 'logits_biases': 'logits/biases'}
+
+    def __init__(self, num_classes: int, cfg, in_channels: int = 2048, is_training: bool = False, seed: int = 42):
+        super().__init__()
+        self.num_classes = num_classes
+        self.keep_prob = dropout_keep_prob(cfg)
+        self.is_training = is_training
+        self.seed = seed
+        self._step = 0
+        # slim.variance_scaling_initializer(): truncated normal, std = sqrt(1.3 * 2 / fan_in)
+        self.logits_weights = nn.Parameter(torch.randn(in_channels, num_classes).clamp_(-2, 2) *
+                                           (2.6 / in_channels) ** 0.5)
+        self.logits_biases = nn.Parameter(torch.zeros(num_classes))
+
+    def regularized_weights(self):
+        return [self.logits_weights]
+
+    def forward(self, last_conv: torch.Tensor):
+        n, h, w = last_conv.shape[0], last_conv.shape[1], last_conv.shape[2]
+        if self.is_training and self.keep_prob < 1.0:
+            z = last_conv.float().mean(dim=(1, 2))
+            g = torch.Generator(device=z.device).manual_seed(self.seed * 1000003 + self._step)
+            self._step += 1
+            keep = torch.rand(z.shape, generator=g, device=z.device) < self.keep_prob
+            logits = (z * keep / self.keep_prob) @ self.logits_weights + self.logits_biases
+        else:
+            ones_in = torch.zeros(n, h, w, 8, device=last_conv.device, dtype=last_conv.dtype)
+            logits, _, _ = attentional_pooling(
+                last_conv, ones_in, torch.zeros(8, 1, device=last_conv.device),
+                torch.ones(1, device=last_conv.device), self.logits_weights, self.logits_biases)
+        return logits, {'Logits': logits}
+
+
 class FramePoolFunction(torch.autograd.Function):
     """[B*F,K] -> [B,K]: mean over frames, optionally weighted by the temporal attention
     a = logits.w + b (nets_factory.py:354-374), forward and backward in HIP."""
@@ -369,9 +410,13 @@ def get_network_fn(name: str, num_classes: int, num_pose_keypoints: int, cfg,
             with torch.autocast('cuda', dtype=_dt):
                 return _net(images)
         backbone.module = net
-    head = AttentionalPoolingHead(num_classes, cfg, in_channels=channels,
-                                  num_pose_keypoints=num_pose_keypoints, is_training=is_training,
-                                  seed=cfg.RNG_SEED, **head_kwargs).to(device)
+    if cfg.NET.USE_POSE_PRELOGITS_BASED_ATTENTION:
+        head = AttentionalPoolingHead(num_classes, cfg, in_channels=channels,
+                                      num_pose_keypoints=num_pose_keypoints, is_training=is_training,
+                                      seed=cfg.RNG_SEED, **head_kwargs).to(device)
+    else:   # cfg 001: the backbone's own average-pool + logits head
+        head = BaselineHead(num_classes, cfg, in_channels=channels, is_training=is_training,
+                            seed=cfg.RNG_SEED).to(device)
     temporal = None
     if cfg.NET.USE_TEMPORAL_ATT:
         # 'TemporalAttention/Conv/{weights,biases}': 1x1 conv K->1, N(0,1e-3) weights; the bias is

@@ -553,3 +553,32 @@ def test_device_label_path_bit_exact_vs_host_functions(gpu):
     # a crop outside the image is reported, not silently accepted
     _, _, st = cof.pose_labels_device([poses[3]], [(300, 300, 250, 0, 100, 100, 0)], device=gpu)
     assert int(st[0]) == 1
+
+
+def test_cfg001_baseline_head_matches_oracle(gpu):
+    """BASELINE configs[0] (001_MPII_ResNet.yaml, no attention, eval batch 1): the shipped YAML loads
+    unchanged and network_fn returns global-average-pool + logits (resnet_v1.py:206-217)."""
+    from attentionalpoolingaction_amd import config as apa_config, nets_factory
+    ref_yaml = '/root/reference/experiments/001_MPII_ResNet.yaml'
+    cfg = apa_config.reset_cfg()
+    if os.path.exists(ref_yaml):
+        apa_config.cfg_from_file(ref_yaml)
+    else:   # the GPU box has no reference tree: the same keys by hand
+        apa_config.cfg_from_dict({'MODEL_NAME': 'resnet_v1_101', 'TEST': {'BATCH_SIZE': 1}})
+    assert not cfg.NET.USE_POSE_PRELOGITS_BASED_ATTENTION
+    fn = nets_factory.get_network_fn('resnet_v1_101', 393, 16, cfg, is_training=False, device=gpu)
+    g = torch.Generator().manual_seed(3)
+    X = torch.relu(torch.randn(1, 15, 15, 2048, generator=g))
+    Xd = X.to(gpu).requires_grad_(True)
+    logits, ep = fn(Xd)
+    w, b = fn.head.logits_weights.detach().cpu().double(), fn.head.logits_biases.detach().cpu().double()
+    ref = orc.baseline_avgpool_logits(X.double(), w, b)
+    assert _rel(logits.detach().cpu().numpy(), ref.numpy()) < 2e-5 and 'Logits' in ep
+    logits.sum().backward()
+    assert _rel(Xd.grad.cpu().numpy(), np.broadcast_to((w.sum(1) / 225.0).numpy(), (1, 15, 15, 2048))) < 5e-5
+    # training mode: dropout on the pooled vector (keep 0.2), unbiased in expectation
+    fnt = nets_factory.get_network_fn('resnet_v1_101', 393, 16, cfg, is_training=True, device=gpu)
+    fnt.head.load_state_dict(fn.head.state_dict())
+    acc = sum(fnt(X.to(gpu))[0].detach() for _ in range(200)) / 200
+    assert float((acc.cpu() - logits.detach().cpu()).abs().max()) < 0.25 * float(logits.detach().abs().max()) + 0.05
+    apa_config.reset_cfg()
