@@ -582,3 +582,63 @@ def test_cfg001_baseline_head_matches_oracle(gpu):
     acc = sum(fnt(X.to(gpu))[0].detach() for _ in range(200)) / 200
     assert float((acc.cpu() - logits.detach().cpu()).abs().max()) < 0.25 * float(logits.detach().abs().max()) + 0.05
     apa_config.reset_cfg()
+
+
+def test_yaml_driven_training_loop_matches_cpu_reference_loop(gpu):
+    """The pieces together the way src/train.py drives them: cfg 002 YAML -> network_fn -> gen_losses
+    -> flat gradient bucket -> ITER_SIZE accumulation (averaged, train.py:547-566) -> fused
+    momentum-SGD with L2 on the conv weights and the staircase learning rate.  Three parameter updates
+    on a fixed synthetic batch must land where the same loop on the CPU oracle + torch.optim.SGD
+    lands (dropout off: cfg.NET.DROPOUT = 0, so both loops are deterministic)."""
+    from attentionalpoolingaction_amd import config as apa_config, deploy, loss as apa_loss, nets_factory
+    ref_yaml = '/root/reference/experiments/002_MPII_ResNet_withAttention.yaml'
+    cfg = apa_config.reset_cfg()
+    if os.path.exists(ref_yaml):
+        apa_config.cfg_from_file(ref_yaml)
+    else:
+        apa_config.cfg_from_dict({'MODEL_NAME': 'resnet_v1_101', 'TRAIN': {'ITER_SIZE': 2}, 'NET': {
+            'USE_POSE_PRELOGITS_BASED_ATTENTION': True,
+            'USE_POSE_PRELOGITS_BASED_ATTENTION_SINGLE_LAYER_ATT': True}})
+    apa_config.cfg_from_dict({'NET': {'DROPOUT': 0.0}})
+    assert cfg.TRAIN.ITER_SIZE == 2 and apa_config.dropout_keep_prob(cfg) == 1.0
+    K, N, wd, lr0 = 10, 8, cfg.TRAIN.WEIGHT_DECAY, 5e-3
+    fn = nets_factory.get_network_fn(cfg.MODEL_NAME, K, 16, cfg, weight_decay=wd, is_training=True, device=gpu)
+    head = fn.head
+    g = torch.Generator().manual_seed(0)
+    names = ['att_weights', 'att_biases', 'td_weights', 'td_biases']
+    with torch.no_grad():
+        head.att_weights.copy_(torch.randn(2048, 1, generator=g) / 45)
+        head.td_weights.copy_(torch.randn(2048, K, generator=g) / 45)
+    X = torch.relu(torch.randn(2, N, 14, 14, 2048, generator=g)) * 0.5      # two micro-batches
+    y = torch.randint(0, K, (2, N), generator=g)
+    ref = {k: getattr(head, k).detach().cpu().double().clone().requires_grad_(True) for k in names}
+    opt_ref = torch.optim.SGD([{'params': [ref['att_weights'], ref['td_weights']], 'weight_decay': wd},
+                               {'params': [ref['att_biases'], ref['td_biases']], 'weight_decay': 0.0}],
+                              lr=lr0, momentum=0.9)
+    params = {k: getattr(head, k) for k in names}
+    bucket = deploy.GradientBucket({k: v.shape for k, v in params.items()}, gpu)
+    accum = deploy.GradientAccumulator(bucket, cfg.TRAIN.ITER_SIZE)
+    opt = deploy.MomentumSGD(params, bucket, lr=lr0, momentum=0.9, weight_decay=wd,
+                             regularized=['att_weights', 'td_weights'])
+    Xd, yd = X.to(gpu), y.to(gpu)
+    for step in range(3):
+        lr = deploy.exponential_decay_lr(lr0, step, 2, cfg.TRAIN.LEARNING_RATE_DECAY_RATE)
+        for grp in opt_ref.param_groups:
+            grp['lr'] = lr
+        opt_ref.zero_grad()
+        for mb in range(cfg.TRAIN.ITER_SIZE):
+            logits, ep = fn(Xd[mb])
+            total = sum(apa_loss.gen_losses(yd[mb], logits, cfg.TRAIN.LOSS_FN_ACTION, K, 1.0, None, None, '',
+                                            None, 1.0, ep, cfg))
+            grads = torch.autograd.grad(total, [params[k] for k in names])
+            for k, gk in zip(names, grads):
+                bucket.views[k].copy_(gk)
+            if accum.step():
+                opt.step(lr=lr)
+            lr_, _ = orc.attentional_pooling(X[mb].double(), None, None, [ref['att_weights']], [ref['att_biases']],
+                                             [ref['td_weights']], [ref['td_biases']], orc.AttnFlags())
+            (orc.action_softmax_xent(lr_, y[mb], K) / cfg.TRAIN.ITER_SIZE).backward()   # averaged over micro-steps
+        opt_ref.step()
+    for k in names:
+        assert _rel(params[k].detach().cpu().numpy(), ref[k].detach().numpy()) < 2e-5, k
+    apa_config.reset_cfg()
