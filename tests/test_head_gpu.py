@@ -642,3 +642,30 @@ def test_yaml_driven_training_loop_matches_cpu_reference_loop(gpu):
     for k in names:
         assert _rel(params[k].detach().cpu().numpy(), ref[k].detach().numpy()) < 2e-5, k
     apa_config.reset_cfg()
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields(gpu):
+    """bench.py's stdout contract: exactly one JSON line carrying the driver's fields plus the
+    `roofline` and `cpu_baseline` objects; also through the N > 1 code path (1-rank RCCL group)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in (['--cpu-seconds', '1'], ['--no-cpu-baseline', '--force-dist']):
+        out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '20', '--warmup', '3'] + extra,
+                             capture_output=True, text=True, timeout=600, cwd=root)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1, lines
+        d = json.loads(lines[0])
+        for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+                  'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
+            assert k in d, k
+        assert d['unit'] == 'images/sec' and d['steps'] == 20 and d['warmup'] == 3 and d['n_gpus'] == 1
+        assert d['vs_baseline'] is None and d['dtype'] == 'f32' and 'workload' in d['config']
+        r = d['roofline']
+        assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+        assert 0.2 < r['frac'] < 1.0 and d['value'] > 2000          # BASELINE target: >= 2000 img/s
+        if '--no-cpu-baseline' not in extra:
+            c = d['cpu_baseline']
+            assert c['kind'] == 'port' and c['unit'] == 'images/sec' and c['cores'] >= 1 and c['value'] > 0
