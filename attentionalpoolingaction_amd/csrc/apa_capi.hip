@@ -29,6 +29,8 @@ void prof_kernel_events(hipEvent_t* start, hipEvent_t* stop) {
 }
 static thread_local hipEvent_t g_grad_ready = nullptr;
 hipEvent_t grad_ready_event() { return g_grad_ready; }
+static thread_local hipEvent_t g_td_ready = nullptr;
+hipEvent_t td_weights_ready_event() { return g_td_ready; }
 void prof_null_events(hipEvent_t* start, hipEvent_t* stop) {
   *start = g_null_start;
   *stop = g_null_stop;
@@ -49,8 +51,18 @@ extern "C" void apa_debug_set_skip(int mask) { apa::g_dbg_skip = mask; }
 
 extern "C" int apa_prof_event_create(void** event) {
   if (!event) { set_error("apa_prof_event_create: null"); return APA_ERR_INVALID_ARG; }
+  // Timing-only events: no system-scope fence at the record (hip_runtime_api.h,
+  // hipEventDisableSystemFence: "can improve the accuracy of timing measurements by avoiding the
+  // cost of cache writeback and invalidation"); APA_PROF_EVENT_FLAGS overrides (0 = hipEventDefault).
+  static const unsigned flags = [] {
+    const char* e = getenv("APA_PROF_EVENT_FLAGS");
+    return e ? (unsigned)strtoul(e, nullptr, 0) : (unsigned)hipEventDisableSystemFence;
+  }();
   hipEvent_t e;
-  APA_HIP_CHECK(hipEventCreate(&e));
+  if (hipEventCreateWithFlags(&e, flags) != hipSuccess) {
+    (void)hipGetLastError();
+    APA_HIP_CHECK(hipEventCreate(&e));
+  }
   *event = e;
   return APA_OK;
 }
@@ -76,6 +88,11 @@ extern "C" int apa_prof_set_kernel_events(void* start, void* stop) {
 
 extern "C" int apa_set_grad_ready_event(void* event) {
   g_grad_ready = static_cast<hipEvent_t>(event);
+  return APA_OK;
+}
+
+extern "C" int apa_set_td_weights_ready_event(void* event) {
+  g_td_ready = static_cast<hipEvent_t>(event);
   return APA_OK;
 }
 
@@ -196,6 +213,7 @@ extern "C" int apa_attn_pool_fwd(const void* X, const void* Xatt, const float* W
     set_error("apa_attn_pool_fwd: workspace too small (%zu < %zu)", ws_bytes, need);
     return APA_ERR_WORKSPACE;
   }
+  if (td_weights_ready_event()) APA_HIP_CHECK(hipStreamWaitEvent(st, td_weights_ready_event(), 0));
   return pc_forward(X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, topdown, ws, N, P, C, Ca, K, flags,
                     keep_prob, seed, offset, dtype, st);
 }
@@ -252,4 +270,28 @@ extern "C" int apa_attn_pool_bwd(const void* X, const void* Xatt, const float* W
                    flags, keep_prob, seed, offset, dtype, st);
   if (rc == APA_OK && grad_ready_event()) APA_HIP_CHECK(hipEventRecord(grad_ready_event(), st));
   return rc;
+}
+
+extern "C" int apa_attn_head_train_step(const void* X, const void* Xatt, const float* Wa,
+                                        const float* ba, const float* Wt, const float* bt,
+                                        const int64_t* labels, float loss_wt, float grad_scale,
+                                        float* logits, float* att, float* zsave, float* abar,
+                                        float* loss, float* G, void* dX, void* dXatt, float* dWa,
+                                        float* dba, float* dWt, float* dbt, void* ws, size_t ws_bytes,
+                                        int N, int P, int C, int Ca, int K, int M, unsigned flags,
+                                        float keep_prob, uint64_t seed, uint64_t offset, int dtype,
+                                        void* stream) {
+  if (!labels || !loss || !G) {
+    apa::set_error("apa_attn_head_train_step: null labels / loss / G pointer");
+    return APA_ERR_INVALID_ARG;
+  }
+  int rc = apa_attn_pool_fwd(X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar, nullptr, ws, ws_bytes,
+                             N, P, C, Ca, K, M, flags, keep_prob, seed, offset, dtype, stream);
+  if (rc != APA_OK) return rc;
+  rc = apa_softmax_xent_fwd_bwd(logits, labels, loss, G, nullptr, nullptr, N, K, loss_wt, grad_scale,
+                                stream);
+  if (rc != APA_OK) return rc;
+  return apa_attn_pool_bwd(X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, dX, dXatt, dWa, dba, dWt, dbt,
+                           ws, ws_bytes, N, P, C, Ca, K, M, flags, keep_prob, seed, offset, dtype,
+                           stream);
 }

@@ -30,6 +30,8 @@ void prof_kernel_events(hipEvent_t* start, hipEvent_t* stop);
 void prof_null_events(hipEvent_t* start, hipEvent_t* stop);
 // apa_set_grad_ready_event: recorded once dWt / dbt are final (nullptr when unset)
 hipEvent_t grad_ready_event();
+// apa_set_td_weights_ready_event: waited for before the first kernel that reads Wt / bt
+hipEvent_t td_weights_ready_event();
 
 // Ablation hook for profiling experiments only (make ABLATE=1): a bit mask of kernels NOT to launch
 // (results are then wrong by construction).  Compiled out of the product build.

@@ -777,7 +777,8 @@ int m1_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
                        pstat, zsave, abar, att, P, pl.S, C, online);
     APA_LAUNCH_CHECK("m1_finalize_fwd_kernel");
   }
-  // logits = z . Wt + abar (x) bt
+  // logits = z . Wt + abar (x) bt -- the first reader of Wt / bt (apa_set_td_weights_ready_event)
+  if (td_weights_ready_event()) APA_HIP_CHECK(hipStreamWaitEvent(st, td_weights_ready_event(), 0));
   static const int use_l2 = env_int("APA_M1_LOGITS2", 1);
   if (use_l2 && m1_logits2_supported(C, K) && (reinterpret_cast<uintptr_t>(zsave) & 15) == 0)
     return m1_logits2(zsave, Wt, abar, bt, logits, gemm_ws, N, C, K, st);

@@ -60,7 +60,11 @@ _SIGNATURES = {
                                        c_void_p, c_void_p, c_void_p, c_void_p]),
     'apa_frame_pool_fwd': (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),
     'apa_frame_pool_bwd': (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),
+    'apa_attn_head_train_step': (c_int, [c_void_p] * 7 + [c_float, c_float] + [c_void_p] * 13 +
+                                 [c_size_t] + [c_int] * 6 + [c_uint, c_float, c_uint64, c_uint64, c_int,
+                                                             c_void_p]),
     'apa_set_grad_ready_event': (c_int, [c_void_p]),
+    'apa_set_td_weights_ready_event': (c_int, [c_void_p]),
     'apa_momentum_sgd_step': (c_int, [c_int, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_float),
                                       c_void_p, c_void_p, c_float, c_float, c_float, c_void_p]),
     'apa_prof_event_create': (c_int, [POINTER(c_void_p)]),
@@ -466,6 +470,58 @@ def frame_pool_bwd(logits, frames_per_video, w, tatt, dpooled):
     return dlogits, dw, db
 
 
+class HeadTrainStep:
+    """apa_attn_head_train_step bound to caller-owned buffers: forward, softmax cross-entropy and
+    backward of the head as ONE foreign call per step (the reference runs the same sequence inside
+    one `sess.run(train_op)`, src/train.py:529-566).  All marshalling happens once, here; `run()`
+    costs one ctypes call plus the kernel launches, which keeps the host ahead of a ~55 us step.
+
+    Outputs live in the attributes `logits [N,K]`, `att [N,P,M]`, `zsave`, `abar`, `loss [1+N]`,
+    `G [N,K]`, and in the gradient buffers passed as `grads = (dX, dXatt, dWa, dba, dWt, dbt)`
+    (e.g. views into a flat data-parallel bucket).  `offset`: int, or a 1-element int64 CUDA tensor
+    (device-side dropout counter, advanced by the backward pass)."""
+
+    def __init__(self, X, Xatt, Wa, ba, Wt, bt, labels, grads, *, flags=0, keep_prob=1.0, seed=0,
+                 offset=0, loss_wt=1.0, grad_scale=1.0, workspace=None):
+        self.lib = load_library()
+        N, C = X.shape[0], X.shape[-1]
+        P = X.numel() // (N * C)
+        Ca, M, K = Xatt.shape[-1], Wa.shape[1], Wt.shape[1]
+        dev = X.device
+        fused = Xatt is X
+        dX, dXatt, dWa, dba, dWt, dbt = grads
+        self.logits = torch.empty((N, K), dtype=torch.float32, device=dev)
+        self.att = torch.empty((N, P, M), dtype=torch.float32, device=dev)
+        self.zsave = torch.empty((N, C) if M == 1 else (N, P, K), dtype=torch.float32, device=dev)
+        self.abar = torch.empty((N,), dtype=torch.float32, device=dev) if M == 1 else None
+        self.loss = torch.empty((1 + N,), dtype=torch.float32, device=dev)
+        self.G = torch.empty((N, K), dtype=torch.float32, device=dev)
+        need = int(self.lib.apa_attn_pool_workspace_bytes(N, P, C, Ca, K, M, flags))
+        if workspace is None or workspace.numel() < need:
+            workspace = torch.empty((max(need, 16),), dtype=torch.uint8, device=dev)
+        self.workspace = workspace
+        off, flags = _rng_offset(offset, flags)
+        self._keep = (X, Xatt, Wa, ba, Wt, bt, labels, grads, offset)     # the pointers below stay valid
+        self._args = [
+            _dev_ptr(X, 'X'), _dev_ptr(X, 'X') if fused else _dev_ptr(Xatt, 'Xatt', X.dtype),
+            _dev_ptr(Wa, 'Wa', torch.float32), _dev_ptr(ba, 'ba', torch.float32),
+            _dev_ptr(Wt, 'Wt', torch.float32), _dev_ptr(bt, 'bt', torch.float32),
+            _dev_ptr(labels, 'labels', torch.int64), float(loss_wt), float(grad_scale),
+            self.logits.data_ptr(), self.att.data_ptr(), self.zsave.data_ptr(), _dev_ptr(self.abar, 'abar'),
+            self.loss.data_ptr(), self.G.data_ptr(), _dev_ptr(dX, 'dX', X.dtype),
+            None if fused else _dev_ptr(dXatt, 'dXatt', X.dtype), _dev_ptr(dWa, 'dWa', torch.float32),
+            _dev_ptr(dba, 'dba', torch.float32), _dev_ptr(dWt, 'dWt', torch.float32),
+            _dev_ptr(dbt, 'dbt', torch.float32), workspace.data_ptr(), workspace.numel(), N, P, C, Ca, K, M,
+            flags, float(keep_prob), int(seed), off, _feat_dtype(X)]
+        self._fn = self.lib.apa_attn_head_train_step
+
+    def run(self, stream: Optional[int] = None) -> None:
+        """Enqueue one step on `stream` (a raw hipStream_t) or torch's current stream."""
+        rc = self._fn(*self._args, _stream_ptr() if stream is None else stream)
+        if rc != 0:
+            _check(rc, 'apa_attn_head_train_step')
+
+
 def set_grad_ready_event(event) -> None:
     """Register (or clear, with None) the event apa_attn_pool_bwd records as soon as dWt / dbt are
     final.  `event`: a torch.cuda.Event that has been recorded at least once (so its handle
@@ -478,6 +534,20 @@ def set_grad_ready_event(event) -> None:
     else:
         handle = c_void_p(event)
     _check(lib.apa_set_grad_ready_event(handle), 'apa_set_grad_ready_event')
+
+
+def set_td_weights_ready_event(event) -> None:
+    """Register (or clear, with None) the event apa_attn_pool_fwd waits for right before its first
+    kernel that reads td_weights / td_biases (include/apa.h): record it on the communication stream
+    after the all-reduce / update of those tensors.  Same handle rules as set_grad_ready_event."""
+    lib = load_library()
+    if event is None:
+        handle = None
+    elif isinstance(event, torch.cuda.Event):
+        handle = c_void_p(event.cuda_event)
+    else:
+        handle = c_void_p(event)
+    _check(lib.apa_set_td_weights_ready_event(handle), 'apa_set_td_weights_ready_event')
 
 
 def momentum_sgd_step(weights, weight_decay, grad_flat, acc_flat, lr, momentum=0.9, grad_scale=1.0):

@@ -87,6 +87,59 @@ def sum_clone_gradients(bucket: GradientBucket, config: DeploymentConfig, async_
                            async_op=async_op)
 
 
+class OverlappedGradientSum:
+    """Two-stream gradient sum for the M == 1 head: the classifier part of the bucket (td_weights |
+    td_biases, 99.7 % of the bytes) is final after the FIRST kernel of `apa_attn_pool_bwd` and is not
+    read again before the logits product of the NEXT forward call, so its all-reduce (and, if given,
+    its optimizer update) runs on a communication stream underneath the streaming backward pass of
+    step k and the pooling / finalize passes of step k+1.  Only the attention part (att_weights |
+    att_biases, 8 KB), produced by the last kernel of the backward call and needed by the first
+    kernel of the next forward, is reduced on the compute stream.
+
+        compute stream   fwd(k): pool, finalize, [wait td_done(k-1)] logits ... xent
+                         bwd(k): head kernel -> record ready(k); streaming pass; column sums
+                         all-reduce(att part)                          <- only exposed collective
+        comm stream      [wait ready(k)] all-reduce(td part) -> update -> record td_done(k)
+
+    The two waits are the library hooks `apa_set_grad_ready_event` / `apa_set_td_weights_ready_event`
+    (include/apa.h).  Each stream drives its own communicator: two collectives of one communicator
+    must not be in flight at the same time.  Every rank enqueues them in the same order.  Same sums
+    as `sum_clone_gradients` (model_deploy.py:421-451), only the schedule differs."""
+
+    def __init__(self, bucket_att: torch.Tensor, bucket_td: torch.Tensor, comm_att, comm_td, device):
+        from .custom_ops import custom_ops_factory as cof
+        self._cof = cof
+        self.bucket_att, self.bucket_td = bucket_att, bucket_td
+        self.comm_att, self.comm_td = comm_att, comm_td
+        self.compute = torch.cuda.current_stream(device)
+        self.side = torch.cuda.Stream(device)
+        self.ready, self.td_done = torch.cuda.Event(), torch.cuda.Event()
+        self.ready.record(self.compute)          # materialise the handles; both start out signalled
+        self.td_done.record(self.compute)
+        torch.cuda.synchronize(device)
+        cof.set_grad_ready_event(self.ready)
+        cof.set_td_weights_ready_event(self.td_done)
+
+    def after_backward(self, update_td=None, update_att=None) -> None:
+        """Call right after `attn_pool_bwd` was enqueued on the compute stream.  `update_td()` /
+        `update_att()`: optional optimizer launches for the two parts; `update_td` runs with the
+        communication stream current."""
+        self.side.wait_event(self.ready)
+        self.comm_td.all_reduce_(self.bucket_td, self.side)
+        if update_td is not None:
+            with torch.cuda.stream(self.side):
+                update_td()
+        self.td_done.record(self.side)
+        self.comm_att.all_reduce_(self.bucket_att, self.compute)
+        if update_att is not None:
+            update_att()
+
+    def close(self) -> None:
+        self._cof.set_grad_ready_event(None)
+        self._cof.set_td_weights_ready_event(None)
+        self.side.synchronize()
+
+
 def add_regularization_gradient(bucket: GradientBucket, params: Dict[str, torch.Tensor],
                                 weight_decay: float, regularized: Sequence[str]) -> None:
     """d/dW [ wd * 0.5 * |W|^2 ] = wd * W, added ONCE after the reduce -- equivalent to the

@@ -47,17 +47,22 @@ def parse_args():
     ap.add_argument('--graph', action='store_true',
                     help='capture the step in a hipGraph (measured: replay overhead makes it ~5%% '
                          'slower than eager launches for this 8-kernel step, so off by default)')
-    ap.add_argument('--overlap', action='store_true',
-                    help='N > 1: start the all-reduce of dWt|dbt (99.7 %% of the bytes) on a side stream as '
-                         'soon as they are final (apa_set_grad_ready_event) instead of one all-reduce of the '
-                         'whole bucket after the backward call.  Off by default: at this step size the two '
-                         'extra torch.distributed calls cost more host time than the overlap buys '
-                         '(measured 129 vs 67 us/step on a 1-rank RCCL group)')
+    ap.add_argument('--overlap', default='auto', choices=['auto', 'on', 'off'],
+                    help='N > 1: reduce dWt|dbt (99.7 %% of the bytes) on a communication stream with its own '
+                         'RCCL communicator, between the library\'s grad-ready and td-weights-ready hooks '
+                         '(hidden under the streaming backward pass and the next pooling pass), and only '
+                         'dWa|dba (8 KB) on the compute stream (deploy.OverlappedGradientSum).  auto = on '
+                         'with --comm rccl, off (one in-stream bucket) with --comm torch, whose extra host '
+                         'calls cost more than the overlap buys at this step size')
     ap.add_argument('--comm', default='rccl', choices=['rccl', 'torch'],
                     help='N > 1 gradient sum: direct in-stream ncclAllReduce through librccl (default), '
                          'or torch.distributed.all_reduce')
     ap.add_argument('--force-dist', action='store_true',
                     help='run the N > 1 code path (RCCL group, side stream, split all-reduce) on one GPU')
+    ap.add_argument('--per-op-calls', action='store_true',
+                    help='drive the step as three separately marshalled calls (apa_attn_pool_fwd, '
+                         'apa_softmax_xent_fwd_bwd, apa_attn_pool_bwd) with per-step output allocation instead '
+                         'of one apa_attn_head_train_step call: same kernels, more host time per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=10.0)
     ap.add_argument('--traffic-bytes', type=float, default=None,
@@ -188,7 +193,16 @@ def main():
     # step (and every hipGraph replay) draws a fresh mask like a fresh tf.nn.dropout per sess.run
     rng_ctr = torch.zeros(1, dtype=torch.int64, device=dev)
 
+    # one foreign call per step (apa_attn_head_train_step = the three entry points back to back,
+    # arguments marshalled once): keeps the host ahead of the ~55 us step on any CPU
+    stepper = None if args.per_op_calls else cof.HeadTrainStep(
+        X, X, Wa, ba, Wt, bt, labels, (dX, None, dWa, dba, dWt, dbt), flags=flags, keep_prob=keep, seed=42,
+        offset=rng_ctr, grad_scale=grad_scale, workspace=ws)
+
     def compute():
+        if stepper is not None:
+            stepper.run()
+            return
         logits, att, zsave, abar, _, _ = cof.attn_pool_fwd(X, X, Wa, ba, Wt, bt, flags=flags,
                                                            keep_prob=keep, seed=42, offset=rng_ctr,
                                                            workspace=ws)
@@ -216,13 +230,16 @@ def main():
     # after the first kernel of the backward call: the library records `ready` there and their
     # all-reduce starts on a side stream underneath the streaming pass; dWa|dba (8 KB) follow on the
     # main stream once the call is done.
-    comm = None
+    comm = comm_td = None
     if dist is not None and args.comm == 'rccl':
         from attentionalpoolingaction_amd import rccl
         ok = 1
         try:
             comm = rccl.RcclCommunicator(rank, max(world, 1), dev, group=None)
             comm.all_reduce_(torch.zeros(8, device=dev))      # first call builds the rings
+            if args.overlap != 'off' and not args.graph:      # one communicator per stream
+                comm_td = rccl.RcclCommunicator(rank, max(world, 1), dev, group=None)
+                comm_td.all_reduce_(torch.zeros(8, device=dev))
             torch.cuda.synchronize()
         except Exception as e:                                 # noqa: BLE001 -- any failure -> fallback
             print('direct RCCL unavailable on rank {}: {}'.format(rank, e), file=sys.stderr)
@@ -230,9 +247,10 @@ def main():
         flag = torch.tensor([ok], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)            # every rank takes the same branch
         if int(flag.item()) == 0:                              # fall back to torch.distributed's RCCL
-            if comm is not None:
-                comm.close()
-            comm = None
+            for c in (comm, comm_td):
+                if c is not None:
+                    c.close()
+            comm = comm_td = None
             args.comm = 'torch'
             dist.destroy_process_group()
             dist.init_process_group('nccl', device_id=dev)
@@ -243,31 +261,25 @@ def main():
             return None
         return dist.all_reduce(t, async_op=async_op)
 
-    overlap = dist is not None and args.overlap and graph is None
-    if overlap:
-        ready = torch.cuda.Event()
-        ready.record()
-        torch.cuda.synchronize()
-        cof.set_grad_ready_event(ready)
-        side = torch.cuda.Stream()
-        bucket_att, bucket_td = bucket[:C + 1], bucket[C + 1:]
+    overlap = None
+    bucket_att, bucket_td = bucket[:C + 1], bucket[C + 1:]
+    if dist is not None and graph is None and comm_td is not None:
+        from attentionalpoolingaction_amd import deploy
+        overlap = deploy.OverlappedGradientSum(bucket_att, bucket_td, comm, comm_td, dev)
+    torch_overlap = dist is not None and graph is None and comm is None and args.overlap == 'on'
 
     def step(eager=False):
         if graph is not None and not eager:
             graph.replay()
         else:
             compute()
-        if overlap:
-            side.wait_event(ready)
-            with torch.cuda.stream(side):
-                w_td = allreduce(bucket_td, side, async_op=True)
-            if comm is not None:                # in-stream collectives: join the side stream
-                torch.cuda.current_stream().wait_stream(side)
-                allreduce(bucket_att)
-            else:
-                w_att = allreduce(bucket_att, async_op=True)
-                w_td.wait()                     # the main stream waits for both (no host block)
-                w_att.wait()
+        if overlap is not None:
+            overlap.after_backward()
+        elif torch_overlap:
+            w_td = allreduce(bucket_td, async_op=True)
+            w_att = allreduce(bucket_att, async_op=True)
+            w_td.wait()                         # the main stream waits for both (no host block)
+            w_att.wait()
         elif dist is not None:
             allreduce(bucket)
 
@@ -283,8 +295,11 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_enq = time.perf_counter() - t0            # host time to enqueue the K steps (no device wait)
     barrier()
     elapsed = time.perf_counter() - t0
+    print('host enqueue {:.1f} us/step, wall {:.1f} us/step'.format(t_enq / args.steps * 1e6,
+                                                                 elapsed / args.steps * 1e6), file=sys.stderr)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.comm == 'torch' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -354,10 +369,13 @@ def main():
                 'parallelism': 'dp{}'.format(world),
                 'softmax_att': bool(args.softmax_att),
                 'hip_graph': graph is not None,
+                'host_calls_per_step': 3 if args.per_op_calls else 1,
                 'comm': None if dist is None else ('librccl ncclAllReduce, in-stream' if comm is not None
                                                    else 'torch.distributed nccl'),
                 'allreduce': ('none' if dist is None else
-                              'dWt|dbt overlapped with the streaming pass + dWa|dba' if overlap else 'one bucket'),
+                              'dWt|dbt on a communication stream (own communicator) between the grad-ready and '
+                              'td-weights-ready hooks; dWa|dba in-stream' if overlap is not None else
+                              'two async buckets' if torch_overlap else 'one bucket, in-stream'),
             },
             'roofline': {
                 'bound': 'hbm',
@@ -378,11 +396,12 @@ def main():
             out['cpu_baseline'] = cpu_baseline(args, args.cpu_seconds)
         print(json.dumps(out), file=real_stdout, flush=True)
     if dist is not None:
-        if overlap:
-            cof.set_grad_ready_event(None)
-        if comm is not None:
-            torch.cuda.synchronize()
-            comm.close()
+        torch.cuda.synchronize()
+        if overlap is not None:
+            overlap.close()
+        for c in (comm, comm_td):
+            if c is not None:
+                c.close()
         dist.barrier()
         dist.destroy_process_group()
 

@@ -144,6 +144,24 @@ int apa_softmax_xent_fwd_bwd(const float* logits, const int64_t* labels, float* 
                              float* probs, int64_t* pred, int N, int K, float wt, float grad_scale,
                              void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * One training step of the head as ONE host call: apa_attn_pool_fwd -> apa_softmax_xent_fwd_bwd ->
+ * apa_attn_pool_bwd with the same arguments, on the same stream, launching the same kernels (the
+ * three entry points above are called back to back; results are bit-identical to calling them
+ * separately).  The reference runs this sequence inside one `sess.run(train_op)` (src/train.py:
+ * 529-566) in TensorFlow's C++ executor, with no per-op interpreter cost; at ~55 us per step on
+ * MI355X three separately marshalled foreign calls would make the HOST the bottleneck, so the
+ * native sequence is part of the boundary.  All buffers are caller-owned (see the three functions
+ * for shapes); loss f32 [1+N], G f32 [N,K].
+ */
+int apa_attn_head_train_step(const void* X, const void* Xatt, const float* Wa, const float* ba,
+                             const float* Wt, const float* bt, const int64_t* labels, float loss_wt,
+                             float grad_scale, float* logits, float* att, float* zsave, float* abar,
+                             float* loss, float* G, void* dX, void* dXatt, float* dWa, float* dba,
+                             float* dWt, float* dbt, void* ws, size_t ws_bytes, int N, int P, int C,
+                             int Ca, int K, int M, unsigned flags, float keep_prob, uint64_t seed,
+                             uint64_t offset, int dtype, void* stream);
+
 /* Pose loss: src/loss.py:29-70 ('l2', LOSS_FN_POSE_SAMPLED off) fused with its gradient.
  *   loss[0] = wt * sum_j mean_n( valid[n,j] ? 0.5*sum_p (Pl-lbl)^2 / (N*P) : 0 )
  *   dPl = grad_scale * wt * valid[n,j] * (Pl - lbl) / (N*N*P)
@@ -218,6 +236,17 @@ int apa_zero_out_channels(const float* in, const uint8_t* channels, float* out, 
  * produced (bench.py, deploy.py).  NULL clears.  Purely an ordering aid: results are unaffected.
  */
 int apa_set_grad_ready_event(void* event);
+
+/* The mirror-image hook on the forward side.  If an event is registered (per host thread),
+ * apa_attn_pool_fwd makes its stream wait for it (hipStreamWaitEvent) immediately before the first
+ * kernel that reads td_weights / td_biases -- on the M == 1 path that is the logits product, AFTER
+ * the pooling and finalize passes, which only need the attention weights.  A data-parallel
+ * trainer records the event on its communication stream once the all-reduce (and the optimizer
+ * update) of td_weights / td_biases of the previous step is done: that collective is then hidden
+ * under the streaming backward pass of step k AND the pooling pass of step k+1, and only the 8 KB
+ * attention-weight all-reduce stays on the critical path (bench.py --gpus N).
+ * On the other paths the wait is placed at the start of the call.  NULL clears. */
+int apa_set_td_weights_ready_event(void* event);
 
 /* ------------------------------------------------------------------------------------------
  * Fused optimizer step (src/train.py:90-94 tf.train.MomentumOptimizer + the slim L2 regulariser of

@@ -1,0 +1,12 @@
+#!/bin/bash
+cd /tmp; export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof512; rm -rf $O; mkdir -p $O; cd $R
+for B in 128 512; do
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/b$B -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline --batch $B > $O/b$B.log 2>&1
+f=$(find $O/b$B -name '*kernel_stats.csv' | head -1)
+echo "== batch $B"; python - "$f" <<'PY'
+import csv,sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if int(r['Calls'])>=50: print('%-60s %5s %9.2f %6s'%(r['Name'].replace('(anonymous namespace)::','').split('(')[0][:60], r['Calls'], float(r['AverageNs'])/1e3, r['Percentage']))
+PY
+done

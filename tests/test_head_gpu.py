@@ -486,6 +486,112 @@ def test_direct_rccl_allreduce_single_rank(gpu):
     comm.close()
 
 
+def test_head_train_step_single_call_equals_the_three_entry_points(gpu):
+    """apa_attn_head_train_step (one foreign call per step, cof.HeadTrainStep) launches the same
+    kernels as apa_attn_pool_fwd + apa_softmax_xent_fwd_bwd + apa_attn_pool_bwd: bit-identical
+    outputs, for both feature dtypes, with the device-side dropout counter advancing per step."""
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    N, P, C, K = 6, 49, 2048, 51
+    for dtype in (torch.float32, torch.bfloat16):
+        g = torch.Generator().manual_seed(3)
+        X = torch.relu(torch.randn(N, P, C, generator=g)).to(dtype).to(gpu)
+        Wa = (torch.randn(C, 1, generator=g) / C ** 0.5).to(gpu)
+        ba = torch.full((1,), 0.1, device=gpu)
+        Wt = (torch.randn(C, K, generator=g) / C ** 0.5).to(gpu)
+        bt = (torch.randn(K, generator=g) * 0.1).to(gpu)
+        labels = torch.randint(0, K, (N,), generator=g).to(gpu)
+        flags = cof.attn_flags(True, False, True)
+
+        def grads():
+            return (torch.empty_like(X), None, torch.empty_like(Wa), torch.empty_like(ba),
+                    torch.empty_like(Wt), torch.empty_like(bt))
+        ctr_a = torch.zeros(1, dtype=torch.int64, device=gpu)
+        ga = grads()
+        st = cof.HeadTrainStep(X, X, Wa, ba, Wt, bt, labels, ga, flags=flags, keep_prob=0.5, seed=7,
+                               offset=ctr_a, grad_scale=0.5)
+        ctr_b = torch.zeros(1, dtype=torch.int64, device=gpu)
+        gb = grads()
+        for step in range(2):
+            st.run()
+            logits, att, zsave, abar, _, ws = cof.attn_pool_fwd(X, X, Wa, ba, Wt, bt, flags=flags, keep_prob=0.5,
+                                                                seed=7, offset=ctr_b)
+            loss, G, _, _ = cof.softmax_xent_fwd_bwd(logits, labels, grad_scale=0.5)
+            cof.attn_pool_bwd(X, X, Wa, ba, Wt, bt, att, zsave, abar, G, flags=flags, keep_prob=0.5, seed=7,
+                              offset=ctr_b, workspace=ws, out=gb)
+            torch.cuda.synchronize()
+            assert int(ctr_a.item()) == int(ctr_b.item()) == step + 1
+            for a, b, name in ((st.logits, logits, 'logits'), (st.att, att, 'att'), (st.loss, loss, 'loss'),
+                               (st.G, G, 'G'), (ga[0], gb[0], 'dX'), (ga[2], gb[2], 'dWa'), (ga[3], gb[3], 'dba'),
+                               (ga[4], gb[4], 'dWt'), (ga[5], gb[5], 'dbt')):
+                assert torch.equal(a, b), (dtype, step, name)
+    with pytest.raises(cof.ApaError):
+        cof.HeadTrainStep(X.cpu(), X.cpu(), Wa, ba, Wt, bt, labels, ga)
+
+
+def test_overlapped_gradient_sum_schedule_matches_the_sequential_loop(gpu):
+    """deploy.OverlappedGradientSum: td part reduced + updated on the communication stream between the
+    library's grad-ready and td-weights-ready hooks, att part in-stream.  Four SGD steps must be
+    bit-identical to the plain sequential loop -- with the communication stream artificially slowed
+    down (spin kernel before the td update), so a missing wait in either direction (forward reading
+    td_weights early, backward overwriting dWt under the collective) would change the result."""
+    from attentionalpoolingaction_amd import deploy, rccl
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    N, P, C, K, lr = 8, 49, 2048, 51, 0.05
+    g = torch.Generator().manual_seed(11)
+    X = torch.relu(torch.randn(N, P, C, generator=g)).to(gpu)
+    labels = torch.randint(0, K, (N,), generator=g).to(gpu)
+    init = [(torch.randn(C, 1, generator=g) / C ** 0.5), torch.zeros(1),
+            (torch.randn(C, K, generator=g) / C ** 0.5), torch.zeros(K)]
+    flags = cof.attn_flags(False, False, True)
+    ws = torch.empty((cof.attn_pool_workspace_bytes(N, P, C, C, K, 1, flags),), dtype=torch.uint8, device=gpu)
+
+    def run(overlapped):
+        Wa, ba, Wt, bt = [t.clone().to(gpu) for t in init]
+        bucket = torch.zeros(C + 1 + C * K + K, device=gpu)
+        b_att, b_td = bucket[:C + 1], bucket[C + 1:]
+        dWa, dba = b_att[:C].view(C, 1), b_att[C:]
+        dWt, dbt = b_td[:C * K].view(C, K), b_td[C * K:]
+        dX = torch.empty_like(X)
+        ctr = torch.zeros(1, dtype=torch.int64, device=gpu)
+        sync = None
+        if overlapped:
+            comms = [rccl.RcclCommunicator(0, 1, gpu), rccl.RcclCommunicator(0, 1, gpu)]
+            sync = deploy.OverlappedGradientSum(b_att, b_td, comms[0], comms[1], gpu)
+
+        def update_td():
+            if overlapped:
+                torch.cuda._sleep(3000000)          # >1 ms: far longer than a whole step
+            Wt.add_(dWt, alpha=-lr)
+            bt.add_(dbt, alpha=-lr)
+
+        def update_att():
+            Wa.add_(dWa, alpha=-lr)
+            ba.add_(dba, alpha=-lr)
+        losses = []
+        for _ in range(4):
+            logits, att, zsave, abar, _, _ = cof.attn_pool_fwd(X, X, Wa, ba, Wt, bt, flags=flags, keep_prob=0.5,
+                                                               seed=42, offset=ctr, workspace=ws)
+            loss, G, _, _ = cof.softmax_xent_fwd_bwd(logits, labels)
+            losses.append(loss.clone())
+            cof.attn_pool_bwd(X, X, Wa, ba, Wt, bt, att, zsave, abar, G, flags=flags, keep_prob=0.5, seed=42,
+                              offset=ctr, workspace=ws, out=(dX, None, dWa, dba, dWt, dbt))
+            if overlapped:
+                sync.after_backward(update_td, update_att)
+            else:
+                update_td()
+                update_att()
+        torch.cuda.synchronize()
+        if overlapped:
+            sync.close()
+            for c in comms:
+                c.close()
+        return [t.cpu() for t in (Wa, ba, Wt, bt, dX, torch.stack(losses).flatten())]
+    seq, ovl = run(False), run(True)
+    for a, b, name in zip(seq, ovl, ('Wa', 'ba', 'Wt', 'bt', 'dX', 'losses')):
+        assert torch.equal(a, b), name
+    assert float(seq[5][0]) != float(seq[5][3 * (1 + N)])      # the weights did move
+
+
 @pytest.mark.parametrize('N,K', [(1, 3), (5, 4), (32, 393), (33, 51), (64, 129), (65, 512), (200, 513),
                                  (7, 1024), (3, 1500)])
 def test_softmax_xent_shapes_vs_float64(gpu, N, K):
