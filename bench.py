@@ -392,7 +392,7 @@ def main():
             },
             'step_roofline_frac': round((3.0 * N * P * C * esz) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N = 1 only
             out['cpu_baseline'] = cpu_baseline(args, args.cpu_seconds)
         print(json.dumps(out), file=real_stdout, flush=True)
     if dist is not None:
