@@ -146,7 +146,7 @@ extern "C" size_t apa_attn_pool_workspace_bytes(int N, int P, int C, int Ca, int
   return 0;
 }
 
-extern "C" int apa_attn_pool_fwd(const void* X, const void* Xatt, const float* Wa, const float* ba,
+static int attn_pool_fwd_impl(M1Xent* xf, const void* X, const void* Xatt, const float* Wa, const float* ba,
                                  const float* Wt, const float* bt, float* logits, float* att,
                                  float* zsave, float* abar, void* topdown, void* ws,
                                  size_t ws_bytes, int N, int P, int C, int Ca, int K, int M,
@@ -183,7 +183,7 @@ extern "C" int apa_attn_pool_fwd(const void* X, const void* Xatt, const float* W
       return APA_ERR_WORKSPACE;
     }
     rc = m1_forward(X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar, ws, N, P, C, Ca, K, flags,
-                    keep_prob, seed, offset, dtype, st);
+                    keep_prob, seed, offset, dtype, st, xf);
     if (rc != APA_OK || !topdown) return rc;
     // end_points['TopDownAttention'] = dropout(X).Wt + bt  (nets_factory.py:296-309): the factorised
     // path never needs it; it is materialised only on request (eval.py --ept dumps) by one GEMM.
@@ -218,7 +218,17 @@ extern "C" int apa_attn_pool_fwd(const void* X, const void* Xatt, const float* W
                     keep_prob, seed, offset, dtype, st);
 }
 
-extern "C" int apa_attn_pool_bwd(const void* X, const void* Xatt, const float* Wa, const float* ba,
+extern "C" int apa_attn_pool_fwd(const void* X, const void* Xatt, const float* Wa, const float* ba,
+                                 const float* Wt, const float* bt, float* logits, float* att,
+                                 float* zsave, float* abar, void* topdown, void* ws,
+                                 size_t ws_bytes, int N, int P, int C, int Ca, int K, int M,
+                                 unsigned flags, float keep_prob, uint64_t seed, uint64_t offset,
+                                 int dtype, void* stream) {
+  return attn_pool_fwd_impl(nullptr, X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar, topdown, ws,
+                            ws_bytes, N, P, C, Ca, K, M, flags, keep_prob, seed, offset, dtype, stream);
+}
+
+static int attn_pool_bwd_impl(const M1Xent* xf, const void* X, const void* Xatt, const float* Wa, const float* ba,
                                  const float* Wt, const float* bt, const float* att,
                                  const float* zsave, const float* abar, const float* G, void* dX,
                                  void* dXatt, float* dWa, float* dba, float* dWt, float* dbt,
@@ -255,7 +265,7 @@ extern "C" int apa_attn_pool_bwd(const void* X, const void* Xatt, const float* W
       return APA_ERR_WORKSPACE;
     }
     return m1_backward(X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, dX, dXatt, dWa, dba, dWt, dbt,
-                       ws, N, P, C, Ca, K, flags, keep_prob, seed, offset, dtype, st);
+                       ws, N, P, C, Ca, K, flags, keep_prob, seed, offset, dtype, st, xf);
   }
   if (!zsave) {
     set_error("apa_attn_pool_bwd: M==K needs zsave (the fp32 [N,P,K] top-down map from forward)");
@@ -272,6 +282,18 @@ extern "C" int apa_attn_pool_bwd(const void* X, const void* Xatt, const float* W
   return rc;
 }
 
+extern "C" int apa_attn_pool_bwd(const void* X, const void* Xatt, const float* Wa, const float* ba,
+                                 const float* Wt, const float* bt, const float* att,
+                                 const float* zsave, const float* abar, const float* G, void* dX,
+                                 void* dXatt, float* dWa, float* dba, float* dWt, float* dbt,
+                                 void* ws, size_t ws_bytes, int N, int P, int C, int Ca, int K,
+                                 int M, unsigned flags, float keep_prob, uint64_t seed,
+                                 uint64_t offset, int dtype, void* stream) {
+  return attn_pool_bwd_impl(nullptr, X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, dX, dXatt, dWa, dba,
+                            dWt, dbt, ws, ws_bytes, N, P, C, Ca, K, M, flags, keep_prob, seed, offset,
+                            dtype, stream);
+}
+
 extern "C" int apa_attn_head_train_step(const void* X, const void* Xatt, const float* Wa,
                                         const float* ba, const float* Wt, const float* bt,
                                         const int64_t* labels, float loss_wt, float grad_scale,
@@ -285,13 +307,24 @@ extern "C" int apa_attn_head_train_step(const void* X, const void* Xatt, const f
     apa::set_error("apa_attn_head_train_step: null labels / loss / G pointer");
     return APA_ERR_INVALID_ARG;
   }
-  int rc = apa_attn_pool_fwd(X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar, nullptr, ws, ws_bytes,
-                             N, P, C, Ca, K, M, flags, keep_prob, seed, offset, dtype, stream);
+  // Inside one call the loss can be folded into its neighbours (M == 1, N <= 64, K <= 512): the
+  // logits reduction also does the row's softmax cross-entropy, the backward head kernel the batch
+  // mean -- one launch fewer, bit-identical results (same reduction trees).
+  M1Xent xf;
+  xf.labels = labels; xf.loss = loss; xf.G = G;
+  xf.lscale = N > 0 ? loss_wt / (float)N : 0.f;
+  xf.gscale = N > 0 ? loss_wt * grad_scale / (float)N : 0.f;
+  xf.done = false;
+  int rc = attn_pool_fwd_impl(M == 1 ? &xf : nullptr, X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar,
+                              nullptr, ws, ws_bytes, N, P, C, Ca, K, M, flags, keep_prob, seed, offset,
+                              dtype, stream);
   if (rc != APA_OK) return rc;
-  rc = apa_softmax_xent_fwd_bwd(logits, labels, loss, G, nullptr, nullptr, N, K, loss_wt, grad_scale,
-                                stream);
-  if (rc != APA_OK) return rc;
-  return apa_attn_pool_bwd(X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, dX, dXatt, dWa, dba, dWt, dbt,
-                           ws, ws_bytes, N, P, C, Ca, K, M, flags, keep_prob, seed, offset, dtype,
-                           stream);
+  if (!xf.done) {
+    rc = apa_softmax_xent_fwd_bwd(logits, labels, loss, G, nullptr, nullptr, N, K, loss_wt, grad_scale,
+                                  stream);
+    if (rc != APA_OK) return rc;
+  }
+  return attn_pool_bwd_impl(xf.done ? &xf : nullptr, X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, dX,
+                            dXatt, dWa, dba, dWt, dbt, ws, ws_bytes, N, P, C, Ca, K, M, flags, keep_prob,
+                            seed, offset, dtype, stream);
 }

@@ -194,4 +194,16 @@ __device__ __forceinline__ int xcd_remap(int b, int nblk) {
   return base + idx;
 }
 
+// reductions over HALF a wave (lanes 0-31 / 32-63 reduce independently): softmax rows
+__device__ __forceinline__ float half_sum(float v, int lane) {
+  v = row_sum16(v);
+  const float s0 = readlane_f(v, 0) + readlane_f(v, 16), s1 = readlane_f(v, 32) + readlane_f(v, 48);
+  return lane < 32 ? s0 : s1;
+}
+__device__ __forceinline__ float half_max(float v, int lane) {
+  v = row_max16(v);
+  const float s0 = fmaxf(readlane_f(v, 0), readlane_f(v, 16)), s1 = fmaxf(readlane_f(v, 32), readlane_f(v, 48));
+  return lane < 32 ? s0 : s1;
+}
+
 }  // namespace apa

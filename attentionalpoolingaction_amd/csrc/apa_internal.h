@@ -105,6 +105,16 @@ int gemm_bf16_launch(const GemmDesc& d, int splits, int k_per_split, hipStream_t
 // ------------------------------------------------------------------------------------------
 // M == 1 factorised path (apa_m1.hip)
 // ------------------------------------------------------------------------------------------
+// Fused train step (apa_attn_head_train_step): softmax cross-entropy folded into the logits
+// reduction (forward sets `done` when it ran), batch-mean loss written by the backward head kernel.
+struct M1Xent {
+  const int64_t* labels;
+  float* loss;   // [1+N]
+  float* G;      // [N,K]
+  float gscale, lscale;
+  bool done;
+};
+
 struct M1Plan {
   int S;        // pixel splits per image
   int ppb;      // pixels per block
@@ -118,12 +128,13 @@ M1Plan m1_plan(int N, int P, int C, int Ca, int K);
 int m1_forward(const void* X, const void* Xatt, const float* Wa, const float* ba, const float* Wt,
                const float* bt, float* logits, float* att, float* zsave, float* abar, void* ws,
                int N, int P, int C, int Ca, int K, unsigned flags, float keep_prob, uint64_t seed,
-               uint64_t offset, int dtype, hipStream_t stream);
+               uint64_t offset, int dtype, hipStream_t stream, M1Xent* xf = nullptr);
 int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* ba, const float* Wt,
                 const float* bt, const float* att, const float* zsave, const float* abar,
                 const float* G, void* dX, void* dXatt, float* dWa, float* dba, float* dWt,
                 float* dbt, void* ws, int N, int P, int C, int Ca, int K, unsigned flags,
-                float keep_prob, uint64_t seed, uint64_t offset, int dtype, hipStream_t stream);
+                float keep_prob, uint64_t seed, uint64_t offset, int dtype, hipStream_t stream,
+                const M1Xent* xf = nullptr);
 bool m1_supported(int C, int Ca, int dtype, bool fused);
 
 // apa_m1_stream.hip: "pixel tile x channel split" streaming passes for wide maps
@@ -158,7 +169,11 @@ int m1_logits2(const float* z, const float* Wt, const float* abar, const float* 
 bool m1_bwd_head_supported(int N, int C, int K);
 int m1_bwd_head(const float* G, const float* Wt, const float* zsave, const float* abar,
                 const float* bt, float* dz, float* dWt, float* dbt, float* sn, int N, int C, int K,
-                hipStream_t st);
+                hipStream_t st, float* loss = nullptr, float lscale = 0.f);
+bool m1_logits_xent_supported(int N, int C, int K);
+int m1_logits2_xent(const float* z, const float* Wt, const float* abar, const float* bt,
+                    const int64_t* labels, float* logits, float* loss, float* G, float gscale,
+                    float* part_ws, int N, int C, int K, hipStream_t st);
 int m1_colsum(const float* pdwa, const float* pdba, float* dwa, float* dba, int nblk, int C, int ld,
               uint64_t* rng_bump, hipStream_t st);
 

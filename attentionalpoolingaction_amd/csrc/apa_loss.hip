@@ -33,16 +33,6 @@ namespace apa {
 //   mode 2: block 0 computes the losses / predictions of ALL rows (the batch mean needs every row
 //           anyway), blocks 1.. write G / probs: one CU moving 2 x 50 KB alone is 3 us of queueing;
 //   mode 0: N > 64, out_loss[0] is summed by sum_scale_kernel.
-__device__ __forceinline__ float half_sum(float v, int lane) {
-  v = row_sum16(v);
-  const float s0 = readlane_f(v, 0) + readlane_f(v, 16), s1 = readlane_f(v, 32) + readlane_f(v, 48);
-  return lane < 32 ? s0 : s1;
-}
-__device__ __forceinline__ float half_max(float v, int lane) {
-  v = row_max16(v);
-  const float s0 = fmaxf(readlane_f(v, 0), readlane_f(v, 16)), s1 = fmaxf(readlane_f(v, 32), readlane_f(v, 48));
-  return lane < 32 ? s0 : s1;
-}
 __device__ __forceinline__ int half_min_i(int v, int lane) {
   v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0xB1, 0xf, 0xf, false));
   v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x4E, 0xf, 0xf, false));

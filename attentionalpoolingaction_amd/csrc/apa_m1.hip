@@ -734,7 +734,7 @@ static RngArgs rng_args(bool train, float keep_prob, uint64_t seed, uint64_t off
 int m1_forward(const void* X, const void* Xatt, const float* Wa, const float* ba, const float* Wt,
                const float* bt, float* logits, float* att, float* zsave, float* abar, void* ws,
                int N, int P, int C, int Ca, int K, unsigned flags, float keep_prob, uint64_t seed,
-               uint64_t offset, int dtype, hipStream_t st) {
+               uint64_t offset, int dtype, hipStream_t st, M1Xent* xf) {
   const bool fused = (Xatt == X);
   const bool train = (flags & APA_FLAG_TRAIN) && keep_prob < 1.0f;
   const int act = act_of(flags);
@@ -780,6 +780,18 @@ int m1_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
   // logits = z . Wt + abar (x) bt -- the first reader of Wt / bt (apa_set_td_weights_ready_event)
   if (td_weights_ready_event()) APA_HIP_CHECK(hipStreamWaitEvent(st, td_weights_ready_event(), 0));
   static const int use_l2 = env_int("APA_M1_LOGITS2", 1);
+  static const int use_lx = env_int("APA_M1_LOGITS_XENT", 1);
+  static const int use_bh = env_int("APA_M1_BWD_HEAD", 1);
+  if (xf && use_l2 && use_lx && use_bh && m1_logits_xent_supported(N, C, K) &&
+      m1_small_supported(C, K) &&
+      ((reinterpret_cast<uintptr_t>(zsave) | reinterpret_cast<uintptr_t>(Wt) |
+        reinterpret_cast<uintptr_t>(xf->G)) & 15) == 0) {
+    // the same conditions under which m1_backward takes the head kernel, which finishes loss[0]
+    rc = m1_logits2_xent(zsave, Wt, abar, bt, xf->labels, logits, xf->loss, xf->G, xf->gscale, gemm_ws,
+                         N, C, K, st);
+    xf->done = rc == APA_OK;
+    return rc;
+  }
   if (use_l2 && m1_logits2_supported(C, K) && (reinterpret_cast<uintptr_t>(zsave) & 15) == 0)
     return m1_logits2(zsave, Wt, abar, bt, logits, gemm_ws, N, C, K, st);
   if (m1_small_supported(C, K) && (reinterpret_cast<uintptr_t>(zsave) & 15) == 0)
@@ -791,7 +803,8 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
                 const float* bt, const float* att, const float* zsave, const float* abar,
                 const float* G, void* dX, void* dXatt, float* dWa, float* dba, float* dWt,
                 float* dbt, void* ws, int N, int P, int C, int Ca, int K, unsigned flags,
-                float keep_prob, uint64_t seed, uint64_t offset, int dtype, hipStream_t st) {
+                float keep_prob, uint64_t seed, uint64_t offset, int dtype, hipStream_t st,
+                const M1Xent* xf) {
   (void)ba;
   const bool fused = (Xatt == X);
   const bool train = (flags & APA_FLAG_TRAIN) && keep_prob < 1.0f;
@@ -816,11 +829,20 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
     // dz = G . Wt^T, dWt = z^T . G, dbt = abar^T G in one launch
     static const int use_head = env_int("APA_M1_BWD_HEAD", 1);
     if (use_head && m1_bwd_head_supported(N, C, K))
-      rc = m1_bwd_head(G, Wt, zsave, abar, bt, dz, dWt, dbt, sn_buf, N, C, K, st);
-    else
+      rc = m1_bwd_head(G, Wt, zsave, abar, bt, dz, dWt, dbt, sn_buf, N, C, K, st,
+                       xf && xf->done ? xf->loss : nullptr, xf ? xf->lscale : 0.f);
+    else if (xf && xf->done) {
+      set_error("attn_pool M=1: fused loss path without the head kernel (internal)");
+      return APA_ERR_UNSUPPORTED;
+    }
+    if (!(use_head && m1_bwd_head_supported(N, C, K)))
       rc = m1_bwd_small(G, Wt, zsave, abar, bt, dz, dWt, dbt, sn_buf, N, C, K, st);
     if (rc != APA_OK) return rc;
   } else {
+    if (xf && xf->done) {
+      set_error("attn_pool M=1: fused loss path without the head kernel (internal)");
+      return APA_ERR_UNSUPPORTED;
+    }
     // generic fallback (very large K): dz[n,c] = sum_k G[n,k] Wt[c,k]; dWt[c,k] = sum_n z[n,c] G[n,k]
     rc = sgemm_small(G, K, 1, Wt, 1, K, dz, C, N, C, K, 1, nullptr, nullptr, gemm_ws, st);
     if (rc != APA_OK) return rc;

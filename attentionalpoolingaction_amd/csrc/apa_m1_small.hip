@@ -111,6 +111,110 @@ __global__ __launch_bounds__(256) void m1_logits_reduce_kernel(const float* __re
   logits[idx] = fmaf(abar[n], bt[k], acc);
 }
 
+// L2x: L2 fused with the softmax cross-entropy of the row (apa_attn_head_train_step only).
+// One block per image: 256 threads sum the row's partials (same fixed order as L2), publish the
+// logits row to memory and to LDS; then half a wave runs the row code of softmax_xent_kernel
+// (apa_loss.hip) on the LDS copy -- same lane layout, same reduction trees, so logits, per-example
+// loss and G are bit-identical to the two separate launches.  The batch-mean loss (needs every row)
+// is left to the backward head kernel, which follows in the same host call.
+template <int NV4>   // 16-byte vectors per lane of the half-wave: ceil(ceil(K/4)/32), K <= 512
+__global__ __launch_bounds__(256) void m1_logits_xent_kernel(
+    const float* __restrict__ part, const float* __restrict__ abar, const float* __restrict__ bt,
+    const int64_t* __restrict__ labels, float* __restrict__ logits, float* __restrict__ out_loss,
+    float* __restrict__ G, int N, int K, int nchunks, float gscale) {
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  constexpr int EPT = NV4 == 4 ? 2 : 1;
+  __shared__ float row[NV4 * 128];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const size_t stride = (size_t)N * K;
+  const float* prow = part + (size_t)n * K;
+  const float ab = abar[n];
+  const int lab = (int)labels[n];
+  float btv[EPT], acc[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    btv[e] = bt[min(tid + 256 * e, K - 1)];
+    acc[e] = 0.f;
+  }
+  for (int c = 0; c < nchunks; c += 32) {   // one round trip for up to 32 partials
+    float v[EPT][32];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e)
+#pragma unroll
+      for (int u = 0; u < 32; ++u)
+        v[e][u] = prow[(size_t)min(c + u, nchunks - 1) * stride + min(tid + 256 * e, K - 1)];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e)
+#pragma unroll
+      for (int u = 0; u < 32; ++u) acc[e] += (c + u < nchunks) ? v[e][u] : 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int j = tid + 256 * e;
+    if (j < K) {
+      const float lg = fmaf(ab, btv[e], acc[e]);
+      logits[(size_t)n * K + j] = lg;
+      row[j] = lg;
+    }
+  }
+  __syncthreads();
+  if (tid >= 64) return;
+  // ---- the row, on wave 0: both halves hold the same row, half 0 stores ----
+  const int lane = tid, hl = lane & 31;
+  f4u v[NV4];
+  int colc[NV4];
+#pragma unroll
+  for (int i = 0; i < NV4; ++i) {
+    colc[i] = min(4 * (hl + 32 * i), K - 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[i][e] = row[colc[i] + e];
+  }
+  const bool lab_ok = lab >= 0 && lab < K;
+  const float xl = row[lab_ok ? lab : 0];
+#pragma unroll
+  for (int i = 0; i < NV4; ++i) {
+    const int col0 = 4 * (hl + 32 * i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[i][e] = colc[i] + e >= col0 ? v[i][e] : -INFINITY;
+  }
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NV4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m = v[i][e] > m ? v[i][e] : m;
+  const float mw = half_max(m, lane);
+  float l = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV4; ++i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[i][e] = exp_fast(v[i][e] - mw);   // 0 for the excluded columns
+      l += v[i][e];
+    }
+  }
+  l = half_sum(l, lane);
+  const float inv = 1.0f / l;
+  const float lv = lab_ok ? -(xl - mw - logf(l)) : 0.f;
+  if (lane < 32) {
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+      const int col0 = 4 * (hl + 32 * i);
+      f4u g;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pe = v[i][e] * inv;
+        g[e] = fmaf(pe, gscale, colc[i] + e == lab ? -gscale : 0.f);
+      }
+      if (colc[i] == col0) {
+        *reinterpret_cast<f4u*>(G + (size_t)n * K + colc[i]) = g;
+      } else if (col0 < K) {   // the one ragged lane of the row: its own columns only
+        for (int e = col0 - colc[i]; e < 4; ++e) G[(size_t)n * K + colc[i] + e] = g[e];
+      }
+    }
+    if (lane == 0) out_loss[1 + n] = lv;
+  }
+}
+
 // --------------------------------------------------------------------------------------------
 // B12: the three small products of the backward pass in ONE launch.
 //   blocks [0, nA)        role A: dz[n, c0:c0+16] for all n         (nA = C/16)
@@ -399,7 +503,7 @@ __global__ __launch_bounds__(256) void m1_bwd_head_kernel(
     const float* __restrict__ G, const float* __restrict__ Wt, const float* __restrict__ zsave,
     const float* __restrict__ abar, const float* __restrict__ bt, float* __restrict__ dz,
     float* __restrict__ dWt, float* __restrict__ dbt, float* __restrict__ sn, int N, int C, int K,
-    int kpb) {
+    int kpb, float* __restrict__ loss, float lscale) {
   __shared__ float red[4 * 2 * 256];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 15, kq = lane >> 4;
@@ -485,6 +589,11 @@ __global__ __launch_bounds__(256) void m1_bwd_head_kernel(
   // dbt[k] = sum_n abar[n] G[n,k]: k slice [b*kpb, (b+1)*kpb) of this block, on wave 3:
   // 16 lanes per k (two rows each), 4 k per round
   const bool do_dbt = wave == 3;
+  // fused step: loss[0] = lscale * sum_n loss[1+n] (the rows were written by m1_logits_xent_kernel),
+  // in the slot order of softmax_xent_kernel's loss block: slot s = rows s, s + 32; slots 0..31
+  const bool do_loss = loss != nullptr && b == 0 && wave == 2;
+  float lrow = 0.f;
+  if (do_loss && lane < N) lrow = loss[1 + lane];
   for (int n0 = 0; n0 < N; n0 += 32) {
     float az[8], bg[UG][8];
 #pragma unroll
@@ -522,6 +631,15 @@ __global__ __launch_bounds__(256) void m1_bwd_head_kernel(
   }
   APA_TS(4);
   if (do_dbt && r == 0 && kq < kpb && b * kpb + kq < K) dbt[b * kpb + kq] = dbt_acc;
+  if (do_loss) {   // wave-uniform; `red` is unused by this role
+    red[lane] = lrow;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      float t = 0.f;
+      for (int w = 0; w < 32; ++w) t += (0.f + red[w]) + red[w + 32];
+      loss[0] = t * lscale;
+    }
+  }
   APA_TS(5);
 }
 
@@ -626,6 +744,33 @@ int m1_logits2(const float* z, const float* Wt, const float* abar, const float* 
   return APA_OK;
 }
 
+bool m1_bwd_head_supported(int N, int C, int K);
+// L1v2 + L2x (fused train step): partial logits, then reduce + softmax cross-entropy per image
+bool m1_logits_xent_supported(int N, int C, int K) {
+  return m1_logits2_supported(C, K) && N >= 1 && N <= 64 && K >= 4 && K <= 512 &&
+         m1_bwd_head_supported(N, C, K);
+}
+
+int m1_logits2_xent(const float* z, const float* Wt, const float* abar, const float* bt,
+                    const int64_t* labels, float* logits, float* loss, float* G, float gscale,
+                    float* part_ws, int N, int C, int K, hipStream_t st) {
+  constexpr int KG = 7;
+  const int ktiles = (K + 15) / 16;
+  dim3 grid(C / 64, (ktiles + KG - 1) / KG, (N + 31) / 32);
+  const size_t shm = (size_t)4 * 2 * KG * 256 * sizeof(float);
+  hipLaunchKernelGGL(m1_logits2_kernel<KG>, grid, dim3(256), shm, st, z, Wt, part_ws, N, C, K);
+  APA_LAUNCH_CHECK("m1_logits2_kernel");
+#define APA_LX(NV4)                                                                             \
+  hipLaunchKernelGGL(m1_logits_xent_kernel<NV4>, dim3(N), dim3(256), 0, st, part_ws, abar, bt,  \
+                     labels, logits, loss, G, N, K, C / 64, gscale)
+  if (K <= 128) APA_LX(1);
+  else if (K <= 256) APA_LX(2);
+  else APA_LX(4);
+#undef APA_LX
+  APA_LAUNCH_CHECK("m1_logits_xent_kernel");
+  return APA_OK;
+}
+
 int m1_bwd_small(const float* G, const float* Wt, const float* zsave, const float* abar,
                  const float* bt, float* dz, float* dWt, float* dbt, float* sn, int N, int C, int K,
                  hipStream_t st) {
@@ -666,13 +811,13 @@ bool m1_bwd_head_supported(int N, int C, int K) {
 
 int m1_bwd_head(const float* G, const float* Wt, const float* zsave, const float* abar,
                 const float* bt, float* dz, float* dWt, float* dbt, float* sn, int N, int C, int K,
-                hipStream_t st) {
+                hipStream_t st, float* loss, float lscale) {
   const int nb = C / 16;
   const int kpb = (K + nb - 1) / nb;
   const int ug = (((K + 15) / 16) + 3) / 4;
 #define APA_BH(UG)                                                                                \
   hipLaunchKernelGGL(m1_bwd_head_kernel<UG>, dim3(2 * nb), dim3(256), 0, st, G, Wt, zsave, abar, \
-                     bt, dz, dWt, dbt, sn, N, C, K, kpb)
+                     bt, dz, dWt, dbt, sn, N, C, K, kpb, loss, lscale)
   if (ug <= 1) APA_BH(1);
   else if (ug <= 2) APA_BH(2);
   else if (ug <= 4) APA_BH(4);

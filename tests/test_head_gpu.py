@@ -486,12 +486,15 @@ def test_direct_rccl_allreduce_single_rank(gpu):
     comm.close()
 
 
-def test_head_train_step_single_call_equals_the_three_entry_points(gpu):
-    """apa_attn_head_train_step (one foreign call per step, cof.HeadTrainStep) launches the same
-    kernels as apa_attn_pool_fwd + apa_softmax_xent_fwd_bwd + apa_attn_pool_bwd: bit-identical
-    outputs, for both feature dtypes, with the device-side dropout counter advancing per step."""
+@pytest.mark.parametrize('N,K', [(6, 51), (32, 393), (33, 512), (64, 129), (1, 4), (5, 600), (70, 51)])
+def test_head_train_step_single_call_equals_the_three_entry_points(gpu, N, K):
+    """apa_attn_head_train_step (one foreign call per step, cof.HeadTrainStep) against
+    apa_attn_pool_fwd + apa_softmax_xent_fwd_bwd + apa_attn_pool_bwd: bit-identical outputs, for both
+    feature dtypes, with the device-side dropout counter advancing per step.  N <= 64 and K <= 512
+    take the folded loss (logits reduction + row cross-entropy in one kernel, batch mean in the
+    backward head kernel: same reduction trees); (5, 600) and (70, 51) the plain three-call sequence."""
     from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
-    N, P, C, K = 6, 49, 2048, 51
+    P, C = 49, 2048
     for dtype in (torch.float32, torch.bfloat16):
         g = torch.Generator().manual_seed(3)
         X = torch.relu(torch.randn(N, P, C, generator=g)).to(dtype).to(gpu)
