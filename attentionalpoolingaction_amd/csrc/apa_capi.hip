@@ -307,7 +307,7 @@ extern "C" int apa_attn_head_train_step(const void* X, const void* Xatt, const f
     apa::set_error("apa_attn_head_train_step: null labels / loss / G pointer");
     return APA_ERR_INVALID_ARG;
   }
-  // Inside one call the loss can be folded into its neighbours (M == 1, N <= 64, K <= 512): the
+  // Inside one call the loss can be folded into its neighbours (M == 1, K <= 512): the
   // logits reduction also does the row's softmax cross-entropy, the backward head kernel the batch
   // mean -- one launch fewer, bit-identical results (same reduction trees).
   M1Xent xf;

@@ -591,9 +591,16 @@ __global__ __launch_bounds__(256) void m1_bwd_head_kernel(
   const bool do_dbt = wave == 3;
   // fused step: loss[0] = lscale * sum_n loss[1+n] (the rows were written by m1_logits_xent_kernel),
   // in the slot order of softmax_xent_kernel's loss block: slot s = rows s, s + 32; slots 0..31
-  const bool do_loss = loss != nullptr && b == 0 && wave == 2;
+  // (N > 64: the order of sum_scale_kernel, apa_loss.hip -- strided per-thread sums, wave_sum, 4 waves)
+  const bool do_loss = loss != nullptr && b == 0;
   float lrow = 0.f;
-  if (do_loss && lane < N) lrow = loss[1 + lane];
+  if (do_loss) {
+    if (N <= 64) {
+      if (wave == 2 && lane < N) lrow = loss[1 + lane];
+    } else {
+      for (int i = tid; i < N; i += 256) lrow += loss[1 + i];
+    }
+  }
   for (int n0 = 0; n0 < N; n0 += 32) {
     float az[8], bg[UG][8];
 #pragma unroll
@@ -631,13 +638,22 @@ __global__ __launch_bounds__(256) void m1_bwd_head_kernel(
   }
   APA_TS(4);
   if (do_dbt && r == 0 && kq < kpb && b * kpb + kq < K) dbt[b * kpb + kq] = dbt_acc;
-  if (do_loss) {   // wave-uniform; `red` is unused by this role
-    red[lane] = lrow;
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
-      float t = 0.f;
-      for (int w = 0; w < 32; ++w) t += (0.f + red[w]) + red[w + 32];
-      loss[0] = t * lscale;
+  if (do_loss) {   // block-uniform; `red` is unused by this role
+    if (N <= 64) {
+      if (wave == 2) {
+        red[lane] = lrow;
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+          float t = 0.f;
+          for (int w = 0; w < 32; ++w) t += (0.f + red[w]) + red[w + 32];
+          loss[0] = t * lscale;
+        }
+      }
+    } else {
+      lrow = wave_sum(lrow);
+      if (lane == 0) red[wave] = lrow;
+      __syncthreads();
+      if (tid == 0) loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) * lscale;
     }
   }
   APA_TS(5);
@@ -747,7 +763,7 @@ int m1_logits2(const float* z, const float* Wt, const float* abar, const float* 
 bool m1_bwd_head_supported(int N, int C, int K);
 // L1v2 + L2x (fused train step): partial logits, then reduce + softmax cross-entropy per image
 bool m1_logits_xent_supported(int N, int C, int K) {
-  return m1_logits2_supported(C, K) && N >= 1 && N <= 64 && K >= 4 && K <= 512 &&
+  return m1_logits2_supported(C, K) && N >= 1 && K >= 4 && K <= 512 &&
          m1_bwd_head_supported(N, C, K);
 }
 

@@ -228,10 +228,12 @@ def test_device_side_dropout_counter_and_graph_replay(gpu):
         assert torch.equal(lg_g, ref[i][0]) and torch.equal(dX_g, ref[i][1]), 'replay {}'.format(i)
 
 
-@pytest.mark.parametrize('N,K', [(1, 393), (33, 393), (70, 51), (40, 600)])
+@pytest.mark.parametrize('N,K', [(1, 393), (33, 393), (70, 51), (40, 600), (130, 393), (257, 100), (300, 393),
+                                 (520, 51)])
 def test_m1_batch_and_class_tails(gpu, N, K):
     """Tile tails of the small MFMA kernels: N not a multiple of 32 (and > 64: multi-block
-    cross-entropy), K not a multiple of 16/32/128, K > 512 (streaming softmax variant)."""
+    cross-entropy), K not a multiple of 16/32/128, K > 512 (streaming softmax variant); large
+    batches (many row tiles per block in the small MFMA kernels)."""
     inp = make_head_inputs(N=N, H=4, W=4, C=2048, K=K, seed=100 + N)
     ref = _oracle(inp, orc.AttnFlags())
     got = _run_hip(inp, gpu)
