@@ -167,6 +167,11 @@ static int attn_pool_fwd_impl(M1Xent* xf, const void* X, const void* Xatt, const
     return APA_ERR_INVALID_ARG;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if ((flags & APA_FLAG_RELU_INPUT) && (M != 1 || topdown)) {
+    set_error("apa_attn_pool_fwd: APA_FLAG_RELU_INPUT is an M == 1 fast path without the "
+              "TopDownAttention dump");
+    return APA_ERR_UNSUPPORTED;
+  }
   if (M == 1) {
     if (!zsave || !abar) {
       set_error("apa_attn_pool_fwd: M==1 needs zsave and abar buffers");
@@ -250,6 +255,10 @@ static int attn_pool_bwd_impl(const M1Xent* xf, const void* X, const void* Xatt,
     return APA_ERR_INVALID_ARG;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if ((flags & APA_FLAG_RELU_INPUT) && M != 1) {
+    set_error("apa_attn_pool_bwd: APA_FLAG_RELU_INPUT is an M == 1 fast path");
+    return APA_ERR_UNSUPPORTED;
+  }
   if (M == 1) {
     if (!zsave || !abar) {
       set_error("apa_attn_pool_bwd: M==1 needs zsave and abar from the forward call");

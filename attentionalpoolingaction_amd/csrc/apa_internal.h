@@ -143,6 +143,7 @@ struct M1Rng {
   uint32_t thresh;
   uint64_t seed, offset;
   const uint64_t* offset_dev;
+  bool relu_input = false;   // APA_FLAG_RELU_INPUT
 };
 bool m1s_supported(int C, int dtype);
 int m1s_launch_pool_fwd(int dtype, int C, bool fused, bool train, int nblk, hipStream_t st,

@@ -728,6 +728,7 @@ static RngArgs rng_args(bool train, float keep_prob, uint64_t seed, uint64_t off
   r.offset_dev = (flags & APA_FLAG_RNG_DEVICE)
                      ? reinterpret_cast<const uint64_t*>(static_cast<uintptr_t>(offset))
                      : nullptr;
+  r.relu_input = (flags & APA_FLAG_RELU_INPUT) != 0;
   return r;
 }
 
@@ -745,6 +746,10 @@ int m1_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
   float* gemm_ws = reinterpret_cast<float*>(w + pl.off_gemm);
   const RngArgs r = rng_args(train, keep_prob, seed, offset, flags);
 
+  if (r.relu_input && !(fused && use_stream_kernels(C, dtype))) {
+    set_error("APA_FLAG_RELU_INPUT: needs Xatt == X and C in {1024,2048,4096} (f32) / 2048 (bf16)");
+    return APA_ERR_UNSUPPORTED;
+  }
   int pool_act = act;
   if (!fused) {
     const long NP = (long)N * P;
@@ -818,6 +823,10 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
   float* gemm_ws = reinterpret_cast<float*>(w + pl.off_gemm);
   float* sn_buf = pdba + pl.nblk;   // [N] floats: the pdba region is sized nblk + N
   const RngArgs r = rng_args(train, keep_prob, seed, offset, flags);
+  if (r.relu_input && !(fused && use_stream_kernels(C, dtype))) {
+    set_error("APA_FLAG_RELU_INPUT: needs Xatt == X and C in {1024,2048,4096} (f32) / 2048 (bf16)");
+    return APA_ERR_UNSUPPORTED;
+  }
 
   // the staged kernels read G / Wt / z with 16-byte loads
   const bool small_ok = m1_small_supported(C, K) &&

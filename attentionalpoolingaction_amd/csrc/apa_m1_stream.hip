@@ -65,6 +65,16 @@ __device__ __forceinline__ uint32_t rng_keep2_bits(uint64_t e, uint32_t k0, uint
 }
 }  // namespace
 
+// APA_FLAG_RELU_INPUT: the map in memory is the backbone's PRE-activation; X = max(Xin, 0) is
+// applied where a vector is unpacked (never on the packed registers: that would wait for the load)
+template <bool RIN, int EPV>
+__device__ __forceinline__ void relu_in(float (&x)[EPV]) {
+  if (RIN) {
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) x[e] = fmaxf(x[e], 0.f);
+  }
+}
+
 // --------------------------------------------------------------------------------------------
 // Chunk helpers.  A chunk = np (<= PIX) consecutive pixels starting at q0; xr holds this wave's
 // channel share of them.  Chunks are double-buffered: the loads of chunk k+1 are in flight while
@@ -117,7 +127,7 @@ struct FwdState {
   float bias, m_run, l_run, a_sum;
 };
 
-template <typename T, int VW, int PIX, bool FUSED, bool TRAIN>
+template <typename T, int VW, int PIX, bool FUSED, bool TRAIN, bool RIN>
 __device__ __forceinline__ void fwd_chunk(FwdState<T, VW, PIX, FUSED, TRAIN>& st,
                                           const uint4 (&xr)[PIX][VW], ChunkRange cr, float* sm,
                                           float* __restrict__ att_im, int n, int P, int C, int cbase,
@@ -137,6 +147,7 @@ __device__ __forceinline__ void fwd_chunk(FwdState<T, VW, PIX, FUSED, TRAIN>& st
       for (int j = 0; j < VW; ++j) {
         float x[EPV];
         Vec<T>::unpack(xr[i][j], x);
+        relu_in<RIN>(x);
 #pragma unroll
         for (int e = 0; e < EPV; e += 2) {
           d0 = fmaf(x[e], st.wa[j * EPV + e], d0);
@@ -174,6 +185,7 @@ __device__ __forceinline__ void fwd_chunk(FwdState<T, VW, PIX, FUSED, TRAIN>& st
     for (int j = 0; j < VW; ++j) {
       float x[EPV];
       Vec<T>::unpack(xr[i][j], x);
+      relu_in<RIN>(x);
       if (TRAIN) {
 #pragma unroll
         for (int e = 0; e < EPV; e += 2) {
@@ -190,7 +202,7 @@ __device__ __forceinline__ void fwd_chunk(FwdState<T, VW, PIX, FUSED, TRAIN>& st
   }
 }
 
-template <typename T, int VW, int PIX, bool FUSED, bool TRAIN>
+template <typename T, int VW, int PIX, bool FUSED, bool TRAIN, bool RIN = false>
 __global__ __launch_bounds__(256, 2) void m1s_pool_fwd_kernel(
     const T* __restrict__ X, const float* __restrict__ Wa, const float* __restrict__ ba,
     float* __restrict__ att, float* __restrict__ pacc, float* __restrict__ pstat, int P, int S,
@@ -239,12 +251,12 @@ __global__ __launch_bounds__(256, 2) void m1s_pool_fwd_kernel(
   // chunk k+1 is always fetched (clamped to the block's last pixel past the end: L1/L2 hits)
   for (int ch = 0; ch < nchunk; ch += 2) {
     load_chunk<T, VW, PIX>(xb, xim, p_begin + (ch + 1) * PIX, p_last, C, cbase);
-    fwd_chunk<T, VW, PIX, FUSED, TRAIN>(st, xa, chunk_range<PIX>(p_begin, p_end, ch), sm_x[0],
+    fwd_chunk<T, VW, PIX, FUSED, TRAIN, RIN>(st, xa, chunk_range<PIX>(p_begin, p_end, ch), sm_x[0],
                                         att_im, n, P, C, cbase, wave, lane, act, inv_keep, thresh,
                                         k0, k1);
     if (ch + 1 >= nchunk) break;
     load_chunk<T, VW, PIX>(xa, xim, p_begin + (ch + 2) * PIX, p_last, C, cbase);
-    fwd_chunk<T, VW, PIX, FUSED, TRAIN>(st, xb, chunk_range<PIX>(p_begin, p_end, ch + 1), sm_x[1],
+    fwd_chunk<T, VW, PIX, FUSED, TRAIN, RIN>(st, xb, chunk_range<PIX>(p_begin, p_end, ch + 1), sm_x[1],
                                         att_im, n, P, C, cbase, wave, lane, act, inv_keep, thresh,
                                         k0, k1);
   }
@@ -281,7 +293,7 @@ struct BwdState {
   float dba_acc, sn, corr;
 };
 
-template <typename T, int VW, int PIX, bool FUSED, bool TRAIN>
+template <typename T, int VW, int PIX, bool FUSED, bool TRAIN, bool RIN>
 __device__ __forceinline__ void bwd_chunk(BwdState<T, VW, PIX, FUSED, TRAIN>& st,
                                           const uint4 (&xr)[PIX][VW], float a_l, ChunkRange cr,
                                           float* sm, T* __restrict__ dxim,
@@ -308,6 +320,7 @@ __device__ __forceinline__ void bwd_chunk(BwdState<T, VW, PIX, FUSED, TRAIN>& st
     for (int j = 0; j < VW; ++j) {
       float x[EPV];
       Vec<T>::unpack(xr[i][j], x);
+      relu_in<RIN>(x);
 #pragma unroll
       for (int e = 0; e < EPV; e += 2) {
         const int c = j * EPV + e;
@@ -358,7 +371,12 @@ __device__ __forceinline__ void bwd_chunk(BwdState<T, VW, PIX, FUSED, TRAIN>& st
         }
         if (FUSED) {
           o[e] = fmaf(t, st.dzr[c], dZ * st.wa[c]);
-          st.dwa[c] = fmaf(dZa, x[e], st.dwa[c]);
+          if (RIN) {   // d/dXin of max(Xin, 0): the gradient passes where Xin > 0
+            o[e] = x[e] > 0.f ? o[e] : 0.f;
+            st.dwa[c] = fmaf(dZa, fmaxf(x[e], 0.f), st.dwa[c]);
+          } else {
+            st.dwa[c] = fmaf(dZa, x[e], st.dwa[c]);
+          }
         } else {
           o[e] = t * st.dzr[c];
         }
@@ -368,7 +386,7 @@ __device__ __forceinline__ void bwd_chunk(BwdState<T, VW, PIX, FUSED, TRAIN>& st
   }
 }
 
-template <typename T, int VW, int PIX, bool FUSED, bool TRAIN>
+template <typename T, int VW, int PIX, bool FUSED, bool TRAIN, bool RIN = false>
 __global__ __launch_bounds__(256, 2) void m1s_bwd_main_kernel(
     const T* __restrict__ X, const float* __restrict__ Wa, const float* __restrict__ att,
     const float* __restrict__ dz, const float* __restrict__ zsave, const float* __restrict__ abar,
@@ -448,13 +466,13 @@ __global__ __launch_bounds__(256, 2) void m1s_bwd_main_kernel(
   for (int ch = 0; ch < nchunk; ch += 2) {
     load_chunk<T, VW, PIX, APA_BWD_NT_LOAD>(xb, xim, p_begin + (ch + 1) * PIX, p_last, C, cbase);
     a_b = att_im[min(p_begin + (ch + 1) * PIX + l16, p_last)];
-    bwd_chunk<T, VW, PIX, FUSED, TRAIN>(st, xa, a_a, chunk_range<PIX>(p_begin, p_end, ch), sm_x[0],
+    bwd_chunk<T, VW, PIX, FUSED, TRAIN, RIN>(st, xa, a_a, chunk_range<PIX>(p_begin, p_end, ch), sm_x[0],
                                         dxim, dZout_im, n, P, C, cbase, wave, lane, act, invP,
                                         inv_keep, thresh, k0, k1);
     if (ch + 1 >= nchunk) break;
     load_chunk<T, VW, PIX, APA_BWD_NT_LOAD>(xa, xim, p_begin + (ch + 2) * PIX, p_last, C, cbase);
     a_a = att_im[min(p_begin + (ch + 2) * PIX + l16, p_last)];
-    bwd_chunk<T, VW, PIX, FUSED, TRAIN>(st, xb, a_b, chunk_range<PIX>(p_begin, p_end, ch + 1),
+    bwd_chunk<T, VW, PIX, FUSED, TRAIN, RIN>(st, xb, a_b, chunk_range<PIX>(p_begin, p_end, ch + 1),
                                         sm_x[1], dxim, dZout_im, n, P, C, cbase, wave, lane, act,
                                         invP, inv_keep, thresh, k0, k1);
   }
@@ -496,6 +514,24 @@ static int launch_fwd_t(bool fused, bool train, int nblk, hipStream_t st, const 
                         const float* Wa, const float* ba, float* att, float* pacc, float* pstat,
                         int P, int S, int act, const M1Rng& r) {
   const T* x = static_cast<const T*>(X);
+  if (r.relu_input) {   // instantiated for the default chunk width and the fused map only
+    if (!fused || PIX != 2) {
+      set_error("APA_FLAG_RELU_INPUT needs Xatt == X (and the default APA_M1S_PIX)");
+      return APA_ERR_UNSUPPORTED;
+    }
+    if constexpr (PIX == 2) {
+      if (train)
+        hipLaunchKernelGGL((m1s_pool_fwd_kernel<T, VW, 2, true, true, true>), dim3(nblk), dim3(256), 0,
+                           st, x, Wa, ba, att, pacc, pstat, P, S, act, r.inv_keep, r.thresh, r.seed,
+                           r.offset, r.offset_dev);
+      else
+        hipLaunchKernelGGL((m1s_pool_fwd_kernel<T, VW, 2, true, false, true>), dim3(nblk), dim3(256), 0,
+                           st, x, Wa, ba, att, pacc, pstat, P, S, act, r.inv_keep, r.thresh, r.seed,
+                           r.offset, r.offset_dev);
+    }
+    APA_LAUNCH_CHECK("m1s_pool_fwd_kernel");
+    return APA_OK;
+  }
 #define APA_GO(F, TR)                                                                            \
   hipLaunchKernelGGL((m1s_pool_fwd_kernel<T, VW, PIX, F, TR>), dim3(nblk), dim3(256), 0, st, x,  \
                      Wa, ba, att, pacc, pstat, P, S, act, r.inv_keep, r.thresh, r.seed,          \
@@ -515,6 +551,24 @@ static int launch_bwd_t(bool fused, bool train, int nblk, hipStream_t st, const 
                         int act, const M1Rng& r) {
   const T* x = static_cast<const T*>(X);
   T* dx = static_cast<T*>(dX);
+  if (r.relu_input) {
+    if (!fused || PIX != 2) {
+      set_error("APA_FLAG_RELU_INPUT needs Xatt == X (and the default APA_M1S_PIX)");
+      return APA_ERR_UNSUPPORTED;
+    }
+    if constexpr (PIX == 2) {
+      if (train)
+        hipLaunchKernelGGL((m1s_bwd_main_kernel<T, VW, 2, true, true, true>), dim3(nblk), dim3(256), 0,
+                           st, x, Wa, att, dz, zsave, abar, G, bt, sn_pre, dx, dZout, pdwa, pdba, P, S, K,
+                           act, r.inv_keep, r.thresh, r.seed, r.offset, r.offset_dev);
+      else
+        hipLaunchKernelGGL((m1s_bwd_main_kernel<T, VW, 2, true, false, true>), dim3(nblk), dim3(256), 0,
+                           st, x, Wa, att, dz, zsave, abar, G, bt, sn_pre, dx, dZout, pdwa, pdba, P, S, K,
+                           act, r.inv_keep, r.thresh, r.seed, r.offset, r.offset_dev);
+    }
+    APA_LAUNCH_CHECK("m1s_bwd_main_kernel");
+    return APA_OK;
+  }
 #define APA_GO(F, TR)                                                                            \
   hipLaunchKernelGGL((m1s_bwd_main_kernel<T, VW, PIX, F, TR>), dim3(nblk), dim3(256), 0, st, x,  \
                      Wa, att, dz, zsave, abar, G, bt, sn_pre, dx, dZout, pdwa, pdba, P, S, K,    \

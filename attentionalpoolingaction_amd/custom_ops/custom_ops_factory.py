@@ -31,6 +31,7 @@ APA_FLAG_SOFTMAX_ATT = 1
 APA_FLAG_RELU_ATT = 2
 APA_FLAG_TRAIN = 4
 APA_FLAG_RNG_DEVICE = 8
+APA_FLAG_RELU_INPUT = 16  # X in memory is the pre-activation map: relu fused into both passes
 
 # every symbol include/apa.h declares: name -> (restype, argtypes)
 _SIGNATURES = {
@@ -150,9 +151,9 @@ def _rng_offset(offset, flags):
     return int(offset), flags
 
 
-def attn_flags(softmax_att=False, relu_att=False, is_training=False) -> int:
+def attn_flags(softmax_att=False, relu_att=False, is_training=False, relu_input=False) -> int:
     return ((APA_FLAG_SOFTMAX_ATT if softmax_att else 0) | (APA_FLAG_RELU_ATT if relu_att else 0) |
-            (APA_FLAG_TRAIN if is_training else 0))
+            (APA_FLAG_TRAIN if is_training else 0) | (APA_FLAG_RELU_INPUT if relu_input else 0))
 
 
 # --------------------------------------------------------------------------------------------

@@ -107,8 +107,11 @@ class PoseHeadFunction(torch.autograd.Function):
 
 
 def attentional_pooling(X, Xatt, Wa, ba, Wt, bt, *, softmax_att=False, relu_att=False,
-                        is_training=False, keep_prob=0.2, seed=0, offset=0, want_topdown=False):
-    flags = cof.attn_flags(softmax_att, relu_att, is_training)
+                        is_training=False, keep_prob=0.2, seed=0, offset=0, want_topdown=False,
+                        relu_input=False):
+    """`relu_input=True`: X is the backbone's pre-activation map; the op computes with max(X, 0) and
+    returns the gradient w.r.t. the pre-activation (APA_FLAG_RELU_INPUT, include/apa.h)."""
+    flags = cof.attn_flags(softmax_att, relu_att, is_training, relu_input)
     return AttentionalPoolingFunction.apply(X, Xatt, Wa, ba, Wt, bt, flags,
                                             keep_prob if is_training else 1.0, seed, offset,
                                             want_topdown)
@@ -222,7 +225,18 @@ class AttentionalPoolingHead(nn.Module):
             ws += [self.pose_w1, self.pose_w2]
         return ws
 
-    def forward(self, last_conv: torch.Tensor) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+    def can_fuse_input_relu(self, dtype=torch.float32) -> bool:
+        """True when the conv5 map has no consumer but the rank-1, single-layer attention op of the
+        streaming kernels -- then the backbone may hand over its PRE-activation map and the op applies
+        the final ReLU on the fly (forward(..., preactivation=True))."""
+        c_ok = self.in_channels in ((1024, 2048, 4096) if dtype == torch.float32 else (2048,))
+        return (self.rank == 1 and self.single_layer and not self.per_class and not self.with_pose_logits
+                and not self.with_pose_feat and not self.want_topdown and c_ok)
+
+    def forward(self, last_conv: torch.Tensor, preactivation: bool = False
+                ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        if preactivation and not self.can_fuse_input_relu(last_conv.dtype):
+            last_conv, preactivation = torch.relu(last_conv), False
         end_points: Dict[str, torch.Tensor] = {}
         pose_pre = None
         if self.with_pose_logits or not self.single_layer:          # :147-160
@@ -242,7 +256,7 @@ class AttentionalPoolingHead(nn.Module):
             wt_x = self.td_weights[:C] if self.with_pose_feat else self.td_weights
             logits, att, topdown = attentional_pooling(
                 last_conv, xatt, self.att_weights, self.att_biases, wt_x, self.td_biases,
-                want_topdown=self.want_topdown and not self.with_pose_feat, **kw)
+                want_topdown=self.want_topdown and not self.with_pose_feat, relu_input=preactivation, **kw)
             end_points['PosePrelogitsBasedAttention'] = att.view(n, h, w, -1)    # :287
             if self.with_pose_feat:
                 # :289-296: the J extra channels of concat(last_conv, pose_logits) go through the
@@ -384,7 +398,8 @@ def frame_pooling(logits: torch.Tensor, frames_per_video: int, end_points: Dict[
 def get_network_fn(name: str, num_classes: int, num_pose_keypoints: int, cfg,
                    weight_decay: float = 0.0, is_training: bool = False,
                    backbone: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
-                   device='cuda', with_backbone: bool = False, backbone_dtype=None, **head_kwargs):
+                   device='cuda', with_backbone: bool = False, backbone_dtype=None,
+                   fuse_final_relu: bool = False, **head_kwargs):
     """Same signature as nets_factory.py:94-95 (+ optional backbone/device).
 
     Returns `network_fn(images) -> (logits, end_points)`; `network_fn.head` exposes the module
@@ -393,6 +408,10 @@ def get_network_fn(name: str, num_classes: int, num_pose_keypoints: int, cfg,
     nets_factory.py:121-125).  `with_backbone=True` builds the slim ResNet-v1 of `resnet_v1.py`
     (PyTorch-ROCm, channels-last: its block4 tap is read by the HIP op with no layout change);
     `backbone_dtype=torch.bfloat16` runs it under autocast so the tap arrives as bf16.
+    `fuse_final_relu=True` (with the built-in backbone): block4 hands over its residual sum BEFORE the
+    last ReLU and the pooling op applies it on the fly in both passes (the ReLU's
+    own read + write of the map and its backward pass never run); used whenever the head is the map's
+    only consumer (`head.can_fuse_input_relu`), otherwise the ReLU is applied explicitly.
     """
     if name not in last_conv_map:
         raise ValueError('Name of network unknown %s' % name)
@@ -401,7 +420,7 @@ def get_network_fn(name: str, num_classes: int, num_pose_keypoints: int, cfg,
         from . import resnet_v1
         if name not in resnet_v1.BLOCKS:
             raise ValueError('no built-in backbone for %s (pass backbone=callable)' % name)
-        net = resnet_v1.ResNetV1(name).to(device)
+        net = resnet_v1.ResNetV1(name, final_relu=not fuse_final_relu).to(device)
         net.train(is_training)
 
         def backbone(images, _net=net, _dt=backbone_dtype):
@@ -410,6 +429,8 @@ def get_network_fn(name: str, num_classes: int, num_pose_keypoints: int, cfg,
             with torch.autocast('cuda', dtype=_dt):
                 return _net(images)
         backbone.module = net
+    else:
+        fuse_final_relu = False
     if cfg.NET.USE_POSE_PRELOGITS_BASED_ATTENTION:
         head = AttentionalPoolingHead(num_classes, cfg, in_channels=channels,
                                       num_pose_keypoints=num_pose_keypoints, is_training=is_training,
@@ -432,7 +453,12 @@ def get_network_fn(name: str, num_classes: int, num_pose_keypoints: int, cfg,
             frames_per_video = images.shape[1]
             images = images.reshape(-1, *images.shape[2:])
         last_conv = backbone(images) if backbone is not None else images
-        logits, end_points = head(last_conv)
+        if fuse_final_relu and isinstance(head, AttentionalPoolingHead):
+            logits, end_points = head(last_conv, preactivation=True)
+        elif fuse_final_relu:
+            logits, end_points = head(torch.relu(last_conv))
+        else:
+            logits, end_points = head(last_conv)
         if frames_per_video > 1:                                # :354-374
             tw = tb = None
             if temporal is not None:

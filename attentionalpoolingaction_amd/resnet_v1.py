@@ -66,9 +66,10 @@ class ConvBN(nn.Module):
 class Bottleneck(nn.Module):
     """resnet_v1.bottleneck(inputs, depth, depth_bottleneck, stride)."""
 
-    def __init__(self, depth_in, depth, depth_bottleneck, stride):
+    def __init__(self, depth_in, depth, depth_bottleneck, stride, final_relu: bool = True):
         super().__init__()
         self.stride = stride
+        self.final_relu = final_relu     # False: return the residual sum (the consumer applies the ReLU)
         self.shortcut = None if depth == depth_in else ConvBN(depth_in, depth, 1, stride, relu=False)
         self.conv1 = ConvBN(depth_in, depth_bottleneck, 1)
         self.conv2 = ConvBN(depth_bottleneck, depth_bottleneck, 3, stride)
@@ -76,7 +77,8 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         sc = subsample(x, self.stride) if self.shortcut is None else self.shortcut(x)
-        return F.relu(sc + self.conv3(self.conv2(self.conv1(x))), inplace=True)
+        y = sc + self.conv3(self.conv2(self.conv1(x)))
+        return F.relu(y, inplace=True) if self.final_relu else y
 
 
 BLOCKS = {   # resnet_v1.py:224-313: (depth, depth_bottleneck, units); stride 2 in the last unit
@@ -92,7 +94,9 @@ class ResNetV1(nn.Module):
     `resnet_v1_101/block4` of nets_factory.py:63-67)."""
 
     def __init__(self, name: str = 'resnet_v1_101', blocks: Sequence[Tuple[int, int, int]] = None,
-                 include_root_block: bool = True, in_channels: int = 3):
+                 include_root_block: bool = True, in_channels: int = 3, final_relu: bool = True):
+        """`final_relu=False`: the very last unit returns its residual sum without the ReLU -- for a
+        consumer that applies it on the fly (APA_FLAG_RELU_INPUT of the pooling op)."""
         super().__init__()
         self.name = name
         spec = list(blocks) if blocks is not None else BLOCKS[name]
@@ -104,7 +108,8 @@ class ResNetV1(nn.Module):
             layers: List[nn.Module] = []
             for u in range(units):
                 stride = 2 if (u == units - 1 and not last_block) else 1
-                layers.append(Bottleneck(depth_in, depth, neck, stride))
+                is_last = last_block and u == units - 1
+                layers.append(Bottleneck(depth_in, depth, neck, stride, final_relu=final_relu or not is_last))
                 depth_in = depth
             self.blocks.append(nn.Sequential(*layers))
         self.out_channels = depth_in

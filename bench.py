@@ -59,6 +59,9 @@ def parse_args():
                          'or torch.distributed.all_reduce')
     ap.add_argument('--force-dist', action='store_true',
                     help='run the N > 1 code path (RCCL group, side stream, split all-reduce) on one GPU')
+    ap.add_argument('--relu-input', action='store_true',
+                    help='APA_FLAG_RELU_INPUT: feed the pre-activation map (randn, not rectified) and let the '
+                         'op apply the backbone\'s last ReLU on the fly in both passes')
     ap.add_argument('--per-op-calls', action='store_true',
                     help='drive the step as three separately marshalled calls (apa_attn_pool_fwd, '
                          'apa_softmax_xent_fwd_bwd, apa_attn_pool_bwd) with per-step output allocation instead '
@@ -165,7 +168,8 @@ def main():
     P = H * H
     tdtype = torch.float32 if args.dtype == 'f32' else torch.bfloat16
     g = torch.Generator(device='cpu').manual_seed(42 + rank)     # cfg.RNG_SEED = 42
-    X = torch.relu(torch.randn(N, P, C, generator=g)).to(tdtype).to(dev)
+    X = torch.randn(N, P, C, generator=g)
+    X = (X if args.relu_input else torch.relu(X)).to(tdtype).to(dev)
     gw = torch.Generator(device='cpu').manual_seed(42)            # replicated weights
     Wa = (torch.randn(C, 1, generator=gw) / C ** 0.5).to(dev)
     ba = torch.zeros(1, device=dev)
@@ -174,7 +178,7 @@ def main():
     labels = torch.randint(0, K, (N,), generator=g).to(dev)
 
     train = not args.eval_mode
-    flags = cof.attn_flags(args.softmax_att, False, train)
+    flags = cof.attn_flags(args.softmax_att, False, train, relu_input=args.relu_input)
     keep = args.keep_prob if train else 1.0
 
     # flat fp32 gradient bucket [dWa | dba | dWt | dbt]: one all-reduce per step, no packing copy

@@ -57,6 +57,12 @@ typedef enum apa_status {
                                 /* kernels read it at run time and apa_attn_pool_bwd adds 1 to it */
                                 /* when it is done, so a captured hipGraph draws a fresh dropout  */
                                 /* mask on every replay                                           */
+#define APA_FLAG_RELU_INPUT 16u /* X in memory is the backbone's PRE-activation (block4's residual */
+                                /* sum, resnet_v1.py:108-109): the op applies X = max(X, 0) on the  */
+                                /* fly in both passes and returns dX already multiplied by [X > 0], */
+                                /* so the ReLU's own read+write of the map and its backward pass    */
+                                /* (2 + 3 streams of P*C*s bytes) disappear.    */
+                                /* M == 1, Xatt == X, C in {1024,2048,4096} (f32) / 2048 (bf16)     */
 
 int apa_version(void);
 /* Thread-local, never NULL; describes the last failure on the calling thread. */

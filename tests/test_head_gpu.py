@@ -436,6 +436,93 @@ def test_network_fn_with_resnet_backbone_end_to_end(gpu, bdtype):
     apa_config.reset_cfg()
 
 
+@pytest.mark.parametrize('C,dtype,softmax,train', [(2048, torch.float32, False, True), (2048, torch.float32, True, False),
+                                                   (1024, torch.float32, True, True), (4096, torch.float32, False, False),
+                                                   (2048, torch.bfloat16, False, True), (2048, torch.bfloat16, True, False)])
+def test_relu_input_flag_equals_explicit_relu(gpu, C, dtype, softmax, train):
+    """APA_FLAG_RELU_INPUT (second half): the op is handed block4's residual sum
+    BEFORE the last ReLU (resnet_v1.py:108-109) and applies max(X, 0) on the fly.  Against the op on
+    an explicitly rectified map: every forward output and every parameter gradient bit-identical,
+    dX == dX_ref * [Xpre > 0] bit-identical (the ReLU's backward, fused into the dX store)."""
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    N, P, K = 5, 30, 51
+    g = torch.Generator().manual_seed(C + 7 * int(softmax))
+    Xpre = torch.randn(N, P, C, generator=g).to(dtype).to(gpu)          # about half negative
+    X = torch.relu(Xpre)
+    Wa = (torch.randn(C, 1, generator=g) / C ** 0.5).to(gpu)
+    ba = torch.full((1,), 0.05, device=gpu)
+    Wt = (torch.randn(C, K, generator=g) / C ** 0.5).to(gpu)
+    bt = (torch.randn(K, generator=g) * 0.1).to(gpu)
+    G = (torch.randn(N, K, generator=g) / N).to(gpu)
+    outs = []
+    for x, rin in ((X, False), (Xpre, True)):
+        flags = cof.attn_flags(softmax, False, train, relu_input=rin)
+        logits, att, zsave, abar, _, ws = cof.attn_pool_fwd(x, x, Wa, ba, Wt, bt, flags=flags, keep_prob=0.5,
+                                                            seed=9, offset=3)
+        grads = cof.attn_pool_bwd(x, x, Wa, ba, Wt, bt, att, zsave, abar, G, flags=flags, keep_prob=0.5,
+                                  seed=9, offset=3, workspace=ws)
+        torch.cuda.synchronize()
+        outs.append((logits, att, zsave, abar) + tuple(grads))
+    ref, got = outs
+    for i, name in enumerate(('logits', 'att', 'zsave', 'abar')):
+        assert torch.equal(ref[i], got[i]), name
+    dX_ref, dX = ref[4], got[4]
+    assert torch.equal(dX, torch.where(Xpre > 0, dX_ref, torch.zeros_like(dX_ref)))
+    assert float((dX == 0).float().mean()) > 0.3                          # the mask did something
+    for i, name in zip((6, 7, 8, 9), ('dWa', 'dba', 'dWt', 'dbt')):
+        assert torch.equal(ref[i], got[i]), name
+
+
+def test_relu_input_flag_rejects_paths_without_the_fused_kernels(gpu):
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    N, P, K = 2, 9, 8
+    for C, M, sep in ((512, 1, False), (2048, 8, False), (2048, 1, True)):
+        X = torch.randn(N, P, C, device=gpu)
+        Xatt = torch.randn(N, P, C, device=gpu) if sep else X
+        Wa, ba = torch.randn(C, M, device=gpu), torch.zeros(M, device=gpu)
+        Wt, bt = torch.randn(C, K, device=gpu), torch.zeros(K, device=gpu)
+        with pytest.raises(cof.ApaError):
+            cof.attn_pool_fwd(X, Xatt, Wa, ba, Wt, bt, flags=cof.attn_flags(relu_input=True))
+
+
+def test_backbone_preactivation_tap_matches_explicit_final_relu(gpu):
+    """get_network_fn(with_backbone=True, fuse_final_relu=True): the last bottleneck unit returns its
+    residual sum, the head applies the ReLU inside the op.  Same weights, same images: logits, attention
+    map and the gradients that reach the backbone equal the unfused network's."""
+    from attentionalpoolingaction_amd import config as apa_config, nets_factory
+    cfg = apa_config.reset_cfg()
+    apa_config.cfg_from_dict({'MODEL_NAME': 'resnet_v1_101', 'NET': {
+        'USE_POSE_PRELOGITS_BASED_ATTENTION': True,
+        'USE_POSE_PRELOGITS_BASED_ATTENTION_SINGLE_LAYER_ATT': True}})
+    fns = []
+    for fuse in (False, True):
+        torch.manual_seed(0)
+        fns.append(nets_factory.get_network_fn('resnet_v1_101', 51, 16, cfg, is_training=False, device=gpu,
+                                               with_backbone=True, fuse_final_relu=fuse))
+    fns[1].backbone.load_state_dict(fns[0].backbone.state_dict())
+    fns[1].head.load_state_dict(fns[0].head.state_dict())
+    with torch.no_grad():
+        for fn in fns:
+            fn.head.att_weights.copy_(torch.linspace(-1, 1, 2048, device=gpu).view(2048, 1) / 45)
+            fn.head.td_weights.copy_(torch.sin(torch.arange(2048 * 51, device=gpu).float()).view(2048, 51) / 45)
+    assert fns[1].head.can_fuse_input_relu()
+    images = (torch.rand(2, 128, 128, 3, generator=torch.Generator().manual_seed(1)) * 255 - 128).to(gpu)
+    res = []
+    for fn in fns:
+        fn.backbone.zero_grad()
+        logits, ep = fn(images)
+        torch.nn.functional.cross_entropy(logits, torch.tensor([3, 40], device=gpu)).backward()
+        res.append((logits.detach().clone(), ep['PosePrelogitsBasedAttention'].detach().clone(),
+                    fn.backbone.blocks[3][2].conv3.conv.weight.grad.clone(), fn.backbone.conv1.conv.weight.grad.clone()))
+    # two separately built backbones: MIOpen may pick different conv algorithms, so not bit-level here
+    # (the op-level test above is); 1e-5 relative on logits and attention map, 2e-3 on the weight
+    # gradients (MIOpen's weight-gradient kernels accumulate atomically: run-to-run noise of ~2e-4 on
+    # conv1 after 101 layers, measured on the UNFUSED network against itself too)
+    for i in range(4):
+        assert _rel(res[1][i].cpu().numpy(), res[0][i].cpu().numpy()) < (1e-5 if i < 2 else 2e-3), i
+    apa_config.reset_cfg()
+
+
 def test_fused_momentum_sgd_matches_torch_sgd(gpu):
     """apa_momentum_sgd_step == tf.train.MomentumOptimizer + slim L2 on weights only
     (src/train.py:90-94, resnet_utils.py:241) == torch.optim.SGD(momentum, per-group weight_decay);
