@@ -516,8 +516,8 @@ def test_backbone_preactivation_tap_matches_explicit_final_relu(gpu):
                     fn.backbone.blocks[3][2].conv3.conv.weight.grad.clone(), fn.backbone.conv1.conv.weight.grad.clone()))
     # two separately built backbones: MIOpen may pick different conv algorithms, so not bit-level here
     # (the op-level test above is); 1e-5 relative on logits and attention map, 2e-3 on the weight
-    # gradients (MIOpen's weight-gradient kernels accumulate atomically: run-to-run noise of ~2e-4 on
-    # conv1 after 101 layers, measured on the UNFUSED network against itself too)
+    # gradients (observed run-to-run: 1e-5 .. 2e-4 on conv1 after 101 layers of MIOpen backward kernels,
+    # with identical logits -- the noise is in the backbone's own backward, not in the op)
     for i in range(4):
         assert _rel(res[1][i].cpu().numpy(), res[0][i].cpu().numpy()) < (1e-5 if i < 2 else 2e-3), i
     apa_config.reset_cfg()
