@@ -54,9 +54,11 @@ def parse_args():
                          'dWa|dba (8 KB) on the compute stream (deploy.OverlappedGradientSum).  auto = on '
                          'with --comm rccl, off (one in-stream bucket) with --comm torch, whose extra host '
                          'calls cost more than the overlap buys at this step size')
-    ap.add_argument('--comm', default='rccl', choices=['rccl', 'torch'],
+    ap.add_argument('--comm', default='rccl', choices=['rccl', 'torch', 'gloo'],
                     help='N > 1 gradient sum: direct in-stream ncclAllReduce through librccl (default), '
-                         'or torch.distributed.all_reduce')
+                         'torch.distributed.all_reduce over RCCL, or over gloo (host-staged; lets two ranks '
+                         'share ONE GPU so the whole N > 1 flow can be exercised on a single-GPU box -- a '
+                         'functional check, not a performance path)')
     ap.add_argument('--force-dist', action='store_true',
                     help='run the N > 1 code path (RCCL group, side stream, split all-reduce) on one GPU')
     ap.add_argument('--relu-input', action='store_true',
@@ -145,6 +147,8 @@ def main():
             raise SystemExit('launch N>1 with: python -m torch.distributed.run --nproc-per-node N ... '
                              'bench.py --gpus N (one process per GPU)')
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback for the product path)'
+    if args.comm == 'gloo':                      # ranks may share a GPU in this mode
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
@@ -305,7 +309,7 @@ def main():
     print('host enqueue {:.1f} us/step, wall {:.1f} us/step'.format(t_enq / args.steps * 1e6,
                                                                  elapsed / args.steps * 1e6), file=sys.stderr)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.comm == 'torch' else 'cpu')
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -375,7 +379,7 @@ def main():
                 'hip_graph': graph is not None,
                 'host_calls_per_step': 3 if args.per_op_calls else 1,
                 'comm': None if dist is None else ('librccl ncclAllReduce, in-stream' if comm is not None
-                                                   else 'torch.distributed nccl'),
+                                                   else 'torch.distributed ' + dist.get_backend()),
                 'allreduce': ('none' if dist is None else
                               'dWt|dbt on a communication stream (own communicator) between the grad-ready and '
                               'td-weights-ready hooks; dWa|dba in-stream' if overlap is not None else

@@ -840,6 +840,35 @@ def test_yaml_driven_training_loop_matches_cpu_reference_loop(gpu):
     apa_config.reset_cfg()
 
 
+def test_bench_two_ranks_sharing_one_gpu_over_gloo(gpu):
+    """The driver's N > 1 launch line (`python -m torch.distributed.run --nproc-per-node N ... bench.py
+    --gpus N`) on this single-GPU box: two ranks share the GPU and sum their gradient buckets over gloo
+    (`--comm gloo`).  Covers rendezvous on 127.0.0.1, per-rank inputs, the barrier-bracketed timing with
+    the max over ranks, whole-job throughput, rank-0-only JSON and the teardown -- everything of the
+    N > 1 flow except the RCCL transport itself."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                          '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'),
+                          '--gpus', '2', '--steps', '20', '--warmup', '3', '--comm', 'gloo'],
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 64 and d['config']['parallelism'] == 'dp2'
+    assert d['scaling'] == 'weak' and d['value'] > 0 and 'cpu_baseline' not in d
+    assert abs(d['value'] - 64 / (d['ms_per_step'] * 1e-3)) < 0.01 * d['value']   # whole-job images / max-rank time
+    assert 'gloo' in d['config']['comm']
+
+
 def test_bench_prints_one_json_line_with_the_contract_fields(gpu):
     """bench.py's stdout contract: exactly one JSON line carrying the driver's fields plus the
     `roofline` and `cpu_baseline` objects; also through the N > 1 code path (1-rank RCCL group)."""
