@@ -317,24 +317,69 @@ extern "C" int apa_pose_head_bwd(const void* X, const float* W1, const float* W2
 // =============================================================================================
 namespace apa {
 
-__global__ __launch_bounds__(256) void pc_pad_kernel(const float* __restrict__ W, float* __restrict__ Wp,
-                                                     int rows, int K, int Kp) {
+// Zero-padded copies of up to three [rows][K] fp32 parameters as [rows][Kp] in ONE launch; a segment
+// marked bf16 is also converted, so that the bf16 products take the DMA-staged MFMA kernels (both
+// operands bf16, whole 64-wide k tiles).
+struct PcPadSegs {
+  const float* src[3];
+  void* dst[3];
+  long end[3];     // cumulative element counts (rows * Kp)
+  int bf16[3];
+  int n;
+};
+__global__ __launch_bounds__(256) void pc_pad_kernel(PcPadSegs sg, int K, int Kp) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long)rows * Kp) return;
-  const int r = (int)(idx / Kp), k = (int)(idx - (long)r * Kp);
-  Wp[idx] = k < K ? W[(size_t)r * K + k] : 0.f;
+  if (idx >= sg.end[sg.n - 1]) return;
+  int s = 0;
+  long base = 0;
+  if (sg.n > 1 && idx >= sg.end[0]) { s = 1; base = sg.end[0]; }
+  if (sg.n > 2 && idx >= sg.end[1]) { s = 2; base = sg.end[1]; }
+  const long j = idx - base;
+  const long r = j / Kp;
+  const int k = (int)(j - r * Kp);
+  const float v = k < K ? sg.src[s][(size_t)r * K + k] : 0.f;
+  if (sg.bf16[s]) static_cast<bf16_t*>(sg.dst[s])[j].v = (uint16_t)f32_to_bf16_bits(v);
+  else static_cast<float*>(sg.dst[s])[j] = v;
+}
+struct PcPadList {
+  PcPadSegs sg;
+  PcPadList() { sg.n = 0; }
+  void add(const float* W, void* Wp, int rows, int Kp, bool to_bf16) {
+    const int i = sg.n++;
+    sg.src[i] = W; sg.dst[i] = Wp; sg.bf16[i] = to_bf16 ? 1 : 0;
+    sg.end[i] = (i ? sg.end[i - 1] : 0) + (long)rows * Kp;
+  }
+  void launch(int K, int Kp, hipStream_t st) const {
+    hipLaunchKernelGGL(pc_pad_kernel, dim3((unsigned)((sg.end[sg.n - 1] + 255) / 256)), dim3(256), 0, st, sg, K, Kp);
+  }
+};
+
+constexpr int PC_PG = 16;   // pixel groups per block of the per-class activation passes
+__device__ __forceinline__ float pc_colsum(const float (&red)[PC_PG][64], int kk) {
+  float s = 0.f;
+#pragma unroll
+  for (int g = 0; g < PC_PG; ++g) s += red[g][kk];   // fixed order
+  return s;
+}
+__device__ __forceinline__ float pc_colmax(const float (&red)[PC_PG][64], int kk) {
+  float m = red[0][kk];
+#pragma unroll
+  for (int g = 1; g < PC_PG; ++g) m = fmaxf(m, red[g][kk]);
+  return m;
 }
 
-// forward activation + spatial mean.  grid (N, ceil(K/64)); 256 threads = 64 classes x 4 pixel groups
+// forward activation + spatial mean.  grid (N, ceil(K/64)); 1024 threads = 64 classes x PC_PG pixel
+// groups (16 waves per block: these passes are short dependent-load chains, 4 groups measured 27 us
+// at K = 51 where 32 blocks of 4 waves cannot hide any latency)
 //   A[n,p,k] = f(Z[n,p,k]);  logits[n,k] = (1/P) sum_p A * T;  optional TopDownAttention copy
 template <typename T>
-__global__ __launch_bounds__(256) void pc_fwd_act_kernel(const float* __restrict__ Z, int ldz,
+__global__ __launch_bounds__(1024) void pc_fwd_act_kernel(const float* __restrict__ Z, int ldz,
                                                          const float* __restrict__ Tm,
                                                          float* __restrict__ att,
                                                          float* __restrict__ logits,
                                                          T* __restrict__ topdown, int P, int K,
                                                          int act) {
-  __shared__ float red[4][64];
+  __shared__ float red[PC_PG][64];
   const int n = blockIdx.x;
   const int kk = threadIdx.x & 63, pg = threadIdx.x >> 6;
   const int k = blockIdx.y * 64 + kk;
@@ -343,23 +388,23 @@ __global__ __launch_bounds__(256) void pc_fwd_act_kernel(const float* __restrict
   float m = -INFINITY, l = 1.f;
   if (act == 2) {  // spatial softmax over p (tf.nn.softmax: max-subtracted)
     if (ok)
-      for (int p = pg; p < P; p += 4) m = fmaxf(m, Z[(rbase + p) * ldz + k]);
+      for (int p = pg; p < P; p += PC_PG) m = fmaxf(m, Z[(rbase + p) * ldz + k]);
     red[pg][kk] = m;
     __syncthreads();
-    m = fmaxf(fmaxf(red[0][kk], red[1][kk]), fmaxf(red[2][kk], red[3][kk]));
+    m = pc_colmax(red, kk);
     __syncthreads();
     float s = 0.f;
     if (ok)
-      for (int p = pg; p < P; p += 4) s += expf(Z[(rbase + p) * ldz + k] - m);
+      for (int p = pg; p < P; p += PC_PG) s += expf(Z[(rbase + p) * ldz + k] - m);
     red[pg][kk] = s;
     __syncthreads();
-    l = (red[0][kk] + red[1][kk]) + (red[2][kk] + red[3][kk]);
+    l = pc_colsum(red, kk);
     __syncthreads();
   }
   const float invl = 1.0f / l;
   float acc = 0.f;
   if (ok) {
-    for (int p = pg; p < P; p += 4) {
+    for (int p = pg; p < P; p += PC_PG) {
       const float z = Z[(rbase + p) * ldz + k];
       float a = z;
       if (act == 2) a = expf(z - m) * invl;
@@ -373,21 +418,21 @@ __global__ __launch_bounds__(256) void pc_fwd_act_kernel(const float* __restrict
   red[pg][kk] = acc;
   __syncthreads();
   if (pg == 0 && ok)
-    logits[(size_t)n * K + k] = ((red[0][kk] + red[1][kk]) + (red[2][kk] + red[3][kk])) / (float)P;
+    logits[(size_t)n * K + k] = pc_colsum(red, kk) / (float)P;
 }
 
 // backward of the same: dT = G*A/P, dA = G*T/P, dZ = act'(dA); column partials for dbt / dba.
 // dT/dZ are written with leading dimension Kp (pad columns zeroed) in the intermediate dtype.
 template <typename T>
-__global__ __launch_bounds__(256) void pc_bwd_act_kernel(const float* __restrict__ G,
+__global__ __launch_bounds__(1024) void pc_bwd_act_kernel(const float* __restrict__ G,
                                                          const float* __restrict__ att,
                                                          const float* __restrict__ Tm,
                                                          T* __restrict__ dT, T* __restrict__ dZ,
                                                          float* __restrict__ pdbt,
                                                          float* __restrict__ pdba, int P, int K,
                                                          int Kp, int act) {
-  __shared__ float red[4][64];
-  __shared__ float red2[4][64];
+  __shared__ float red[PC_PG][64];
+  __shared__ float red2[PC_PG][64];
   const int n = blockIdx.x;
   const int kk = threadIdx.x & 63, pg = threadIdx.x >> 6;
   const int k = blockIdx.y * 64 + kk;
@@ -400,14 +445,14 @@ __global__ __launch_bounds__(256) void pc_bwd_act_kernel(const float* __restrict
   if (act == 2) {  // sum_p A * dA
     float s = 0.f;
     if (ok)
-      for (int p = pg; p < P; p += 4) s = fmaf(att[(rbase + p) * K + k], g * Tm[(rbase + p) * K + k], s);
+      for (int p = pg; p < P; p += PC_PG) s = fmaf(att[(rbase + p) * K + k], g * Tm[(rbase + p) * K + k], s);
     red[pg][kk] = s;
     __syncthreads();
-    corr = (red[0][kk] + red[1][kk]) + (red[2][kk] + red[3][kk]);
+    corr = pc_colsum(red, kk);
     __syncthreads();
   }
   float sdt = 0.f, sdz = 0.f;
-  for (int p = pg; p < P; p += 4) {
+  for (int p = pg; p < P; p += PC_PG) {
     if (ok) {
       const float a = att[(rbase + p) * K + k];
       const float dA = g * Tm[(rbase + p) * K + k];
@@ -428,8 +473,8 @@ __global__ __launch_bounds__(256) void pc_bwd_act_kernel(const float* __restrict
   red2[pg][kk] = sdz;
   __syncthreads();
   if (pg == 0 && ok) {
-    pdbt[(size_t)n * K + k] = (red[0][kk] + red[1][kk]) + (red[2][kk] + red[3][kk]);
-    pdba[(size_t)n * K + k] = (red2[0][kk] + red2[1][kk]) + (red2[2][kk] + red2[3][kk]);
+    pdbt[(size_t)n * K + k] = pc_colsum(red, kk);
+    pdba[(size_t)n * K + k] = pc_colsum(red2, kk);
   }
 }
 
@@ -441,7 +486,8 @@ struct PcPlan {
 static PcPlan pc_plan(int N, int P, int C, int Ca, int K, int dtype) {
   PcPlan pl;
   pl.R = (long)N * P;
-  pl.Kp = (K + 7) / 8 * 8;
+  // bf16: whole 64-wide k tiles for the products that contract over the class axis (dX)
+  pl.Kp = dtype == APA_DTYPE_BF16 ? (K + 63) / 64 * 64 : (K + 7) / 8 * 8;
   size_t off = 0;
   pl.off_wap = off;  off += align_up((size_t)Ca * pl.Kp * 4, 256);
   pl.off_wtp = off;  off += align_up((size_t)C * pl.Kp * 4, 256);
@@ -526,18 +572,25 @@ int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
                uint64_t offset, int dtype, hipStream_t st) {
   const PcPlan pl = pc_plan(N, P, C, Ca, K, dtype);
   char* w = static_cast<char*>(ws);
-  float* WaP = reinterpret_cast<float*>(w + pl.off_wap);
+  void* WaP = w + pl.off_wap;
   float* baP = reinterpret_cast<float*>(w + pl.off_bap);
   float* Z = reinterpret_cast<float*>(w + pl.off_z);
   const int Kp = pl.Kp, R = (int)pl.R;
   const bool train = (flags & APA_FLAG_TRAIN) && keep_prob < 1.0f;
   const int tdt = dt_code(dtype);
-  hipLaunchKernelGGL(pc_pad_kernel, dim3((unsigned)(((long)Ca * Kp + 255) / 256)), dim3(256), 0, st, Wa, WaP, Ca, K, Kp);
-  hipLaunchKernelGGL(pc_pad_kernel, dim3((unsigned)((Kp + 255) / 256)), dim3(256), 0, st, ba, baP, 1, K, Kp);
-  APA_LAUNCH_CHECK("pc_pad_kernel");
+  const bool wb16 = dtype == APA_DTYPE_BF16;   // padded weights stored as bf16
+  const bool fast = dtype == APA_DTYPE_BF16 && C % 8 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+  {
+    PcPadList pads;
+    pads.add(Wa, WaP, Ca, Kp, wb16);
+    pads.add(ba, baP, 1, Kp, false);
+    if (fast) pads.add(Wt, w + pl.off_wtp, C, Kp, true);
+    pads.launch(K, Kp, st);
+    APA_LAUNCH_CHECK("pc_pad_kernel");
+  }
   GemmDesc gz;  // Z = Xatt . Wa + ba
   gz.A = Xatt; gz.lda = Ca; gz.ta = tdt; gz.a_kc = true;
-  gz.B = WaP; gz.ldb = Kp; gz.tb = 0; gz.b_kc = false;
+  gz.B = WaP; gz.ldb = Kp; gz.tb = wb16 ? 1 : 0; gz.b_kc = false;
   gz.C = Z; gz.ldc = Kp; gz.tc = 0;
   gz.M = R; gz.N = Kp; gz.K = Ca; gz.bias = baP;
   // N = Kp is one tile column: R/128 blocks cannot fill 256 CUs, so split the contraction
@@ -550,12 +603,9 @@ int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
   gt.A = X; gt.lda = C; gt.ta = tdt; gt.a_kc = true;
   gt.C = Tsave; gt.ldc = K; gt.tc = 0;
   gt.M = R; gt.K = C; gt.bias = bt;
-  const bool fast = dtype == APA_DTYPE_BF16 && C % 8 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
   if (fast) {   // zero-padded weights (16-byte rows) + materialised dropout: the DMA-staged MFMA GEMM
-    float* WtP = reinterpret_cast<float*>(w + pl.off_wtp);
-    hipLaunchKernelGGL(pc_pad_kernel, dim3((unsigned)(((long)C * Kp + 255) / 256)), dim3(256), 0, st, Wt, WtP, C, K, Kp);
-    APA_LAUNCH_CHECK("pc_pad_kernel");
-    gt.B = WtP; gt.ldb = Kp; gt.tb = 0; gt.b_kc = false;
+    void* WtP = w + pl.off_wtp;
+    gt.B = WtP; gt.ldb = Kp; gt.tb = 1; gt.b_kc = false;
     gt.N = Kp; gt.n_valid = K;
     if (train) gt.A = pc_dropped_features(X, w + pl.off_xd, pl.R, C, keep_prob, seed, offset, flags, st);
   } else {      // Wt rows are K floats: unaligned -> scalar staging, mask applied while staging
@@ -569,10 +619,10 @@ int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
   if (rc != APA_OK) return rc;
   dim3 grid(N, (K + 63) / 64);
   if (dtype == APA_DTYPE_F32)
-    hipLaunchKernelGGL(pc_fwd_act_kernel<float>, grid, dim3(256), 0, st, Z, Kp, Tsave, att, logits,
+    hipLaunchKernelGGL(pc_fwd_act_kernel<float>, grid, dim3(64 * PC_PG), 0, st, Z, Kp, Tsave, att, logits,
                        static_cast<float*>(topdown), P, K, act_code(flags));
   else
-    hipLaunchKernelGGL(pc_fwd_act_kernel<bf16_t>, grid, dim3(256), 0, st, Z, Kp, Tsave, att, logits,
+    hipLaunchKernelGGL(pc_fwd_act_kernel<bf16_t>, grid, dim3(64 * PC_PG), 0, st, Z, Kp, Tsave, att, logits,
                        static_cast<bf16_t*>(topdown), P, K, act_code(flags));
   APA_LAUNCH_CHECK("pc_fwd_act_kernel");
   return APA_OK;
@@ -585,8 +635,8 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
                 hipStream_t st) {
   const PcPlan pl = pc_plan(N, P, C, Ca, K, dtype);
   char* w = static_cast<char*>(ws);
-  float* WaP = reinterpret_cast<float*>(w + pl.off_wap);
-  float* WtP = reinterpret_cast<float*>(w + pl.off_wtp);
+  void* WaP = w + pl.off_wap;
+  void* WtP = w + pl.off_wtp;
   void* dT = w + pl.off_dt;
   void* dZ = w + pl.off_dz;
   float* pdbt = reinterpret_cast<float*>(w + pl.off_pdbt);
@@ -596,16 +646,21 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
   const bool train = (flags & APA_FLAG_TRAIN) && keep_prob < 1.0f;
   const bool fused = (Xatt == X);
   const int tdt = dt_code(dtype);
-  hipLaunchKernelGGL(pc_pad_kernel, dim3((unsigned)(((long)Ca * Kp + 255) / 256)), dim3(256), 0, st, Wa, WaP, Ca, K, Kp);
-  hipLaunchKernelGGL(pc_pad_kernel, dim3((unsigned)(((long)C * Kp + 255) / 256)), dim3(256), 0, st, Wt, WtP, C, K, Kp);
-  APA_LAUNCH_CHECK("pc_pad_kernel");
+  const bool wb16 = dtype == APA_DTYPE_BF16;
+  {
+    PcPadList pads;
+    pads.add(Wa, WaP, Ca, Kp, wb16);
+    pads.add(Wt, WtP, C, Kp, wb16);
+    pads.launch(K, Kp, st);
+    APA_LAUNCH_CHECK("pc_pad_kernel");
+  }
   dim3 grid(N, (Kp + 63) / 64);
   if (dtype == APA_DTYPE_F32)
-    hipLaunchKernelGGL(pc_bwd_act_kernel<float>, grid, dim3(256), 0, st, G, att, Tsave,
+    hipLaunchKernelGGL(pc_bwd_act_kernel<float>, grid, dim3(64 * PC_PG), 0, st, G, att, Tsave,
                        static_cast<float*>(dT), static_cast<float*>(dZ), pdbt, pdba, P, K, Kp,
                        act_code(flags));
   else
-    hipLaunchKernelGGL(pc_bwd_act_kernel<bf16_t>, grid, dim3(256), 0, st, G, att, Tsave,
+    hipLaunchKernelGGL(pc_bwd_act_kernel<bf16_t>, grid, dim3(64 * PC_PG), 0, st, G, att, Tsave,
                        static_cast<bf16_t*>(dT), static_cast<bf16_t*>(dZ), pdbt, pdba, P, K, Kp,
                        act_code(flags));
   APA_LAUNCH_CHECK("pc_bwd_act_kernel");
@@ -647,7 +702,7 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
   {  // dX = (dT . Wt^T) * mask/keep
     GemmDesc g;
     g.A = dT; g.lda = Kp; g.ta = tdt; g.a_kc = true;
-    g.B = WtP; g.ldb = Kp; g.tb = 0; g.b_kc = true;
+    g.B = WtP; g.ldb = Kp; g.tb = wb16 ? 1 : 0; g.b_kc = true;
     g.C = dX; g.ldc = C; g.tc = tdt;
     g.M = R; g.N = C; g.K = Kp;
     if (train) set_dropout(g, false, true, keep_prob, seed, offset, flags);
@@ -657,7 +712,7 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
   {  // + dZ . Wa^T  (into dX when the attention input is X itself, else into dXatt)
     GemmDesc g;
     g.A = dZ; g.lda = Kp; g.ta = tdt; g.a_kc = true;
-    g.B = WaP; g.ldb = Kp; g.tb = 0; g.b_kc = true;
+    g.B = WaP; g.ldb = Kp; g.tb = wb16 ? 1 : 0; g.b_kc = true;
     g.C = fused ? dX : dXatt; g.ldc = fused ? C : Ca; g.tc = tdt;
     g.M = R; g.N = fused ? C : Ca; g.K = Kp; g.beta = fused ? 1.f : 0.f;
     rc = gemm_launch(g, st);
