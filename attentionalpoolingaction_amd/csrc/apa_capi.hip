@@ -337,3 +337,39 @@ extern "C" int apa_attn_head_train_step(const void* X, const void* Xatt, const f
                             dXatt, dWa, dba, dWt, dbt, ws, ws_bytes, N, P, C, Ca, K, M, flags, keep_prob,
                             seed, offset, dtype, stream);
 }
+
+extern "C" int apa_attn_head_eval_step(const void* X, const void* Xatt, const float* Wa, const float* ba,
+                                       const float* Wt, const float* bt, const int64_t* labels,
+                                       float* logits, float* att, float* zsave, float* abar, float* loss,
+                                       float* probs, int64_t* pred, void* ws, size_t ws_bytes, int N,
+                                       int P, int C, int Ca, int K, int M, unsigned flags, int dtype,
+                                       void* stream) {
+  if (!probs || !pred) {
+    apa::set_error("apa_attn_head_eval_step: null probs / pred pointer");
+    return APA_ERR_INVALID_ARG;
+  }
+  if ((labels == nullptr) != (loss == nullptr)) {
+    apa::set_error("apa_attn_head_eval_step: labels and loss must be given together");
+    return APA_ERR_INVALID_ARG;
+  }
+  const unsigned eval_flags = flags & ~(unsigned)APA_FLAG_TRAIN;   // is_training=False: no dropout
+  // without ground truth the softmax / argmax of a row rides on the logits reduction (M == 1, K <= 512)
+  M1Xent xf;
+  xf.labels = nullptr; xf.loss = nullptr; xf.G = nullptr; xf.gscale = 0.f; xf.lscale = 0.f; xf.done = false;
+  xf.probs = probs; xf.pred = pred;
+  int rc = attn_pool_fwd_impl((M == 1 && !labels) ? &xf : nullptr, X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar, nullptr, ws,
+                              ws_bytes, N, P, C, Ca, K, M, eval_flags, 1.0f, 0, 0, dtype, stream);
+  if (rc != APA_OK || xf.done) return rc;
+  if (labels)
+    return apa_softmax_xent_fwd_bwd(logits, labels, loss, nullptr, probs, pred, N, K, 1.0f, 1.0f, stream);
+  // no ground truth: the loss slots are scratch at the head of the workspace (label 0 everywhere)
+  const size_t need = ((size_t)N * 8 + (size_t)(1 + N) * 4 + 255) / 256 * 256;
+  if (ws_bytes < need) {
+    apa::set_error("apa_attn_head_eval_step: workspace too small for the label-free form");
+    return APA_ERR_WORKSPACE;
+  }
+  APA_HIP_CHECK(hipMemsetAsync(ws, 0, (size_t)N * 8, static_cast<hipStream_t>(stream)));
+  float* lscratch = reinterpret_cast<float*>(static_cast<char*>(ws) + (size_t)N * 8);
+  return apa_softmax_xent_fwd_bwd(logits, static_cast<const int64_t*>(ws), lscratch, nullptr, probs, pred,
+                                  N, K, 1.0f, 1.0f, stream);
+}

@@ -206,4 +206,15 @@ __device__ __forceinline__ float half_max(float v, int lane) {
   return lane < 32 ? s0 : s1;
 }
 
+// smallest value per half-wave (argmax tie rule: first index)
+__device__ __forceinline__ int half_min_first(int v, int lane) {
+  v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0xB1, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x4E, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x141, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x140, 0xf, 0xf, false));
+  const int s0 = min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16));
+  const int s1 = min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48));
+  return lane < 32 ? s0 : s1;
+}
+
 }  // namespace apa

@@ -113,6 +113,9 @@ struct M1Xent {
   float* G;      // [N,K]
   float gscale, lscale;
   bool done;
+  // evaluation form (apa_attn_head_eval_step without ground truth): probabilities + argmax instead
+  float* probs = nullptr;     // [N,K]
+  int64_t* pred = nullptr;    // [N]
 };
 
 struct M1Plan {
@@ -171,10 +174,10 @@ bool m1_bwd_head_supported(int N, int C, int K);
 int m1_bwd_head(const float* G, const float* Wt, const float* zsave, const float* abar,
                 const float* bt, float* dz, float* dWt, float* dbt, float* sn, int N, int C, int K,
                 hipStream_t st, float* loss = nullptr, float lscale = 0.f);
-bool m1_logits_xent_supported(int N, int C, int K);
+bool m1_logits_xent_supported(int N, int C, int K, bool eval);
 int m1_logits2_xent(const float* z, const float* Wt, const float* abar, const float* bt,
                     const int64_t* labels, float* logits, float* loss, float* G, float gscale,
-                    float* part_ws, int N, int C, int K, hipStream_t st);
+                    float* probs, int64_t* pred, float* part_ws, int N, int C, int K, hipStream_t st);
 int m1_colsum(const float* pdwa, const float* pdba, float* dwa, float* dba, int nblk, int C, int ld,
               uint64_t* rng_bump, hipStream_t st);
 

@@ -787,13 +787,14 @@ int m1_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
   static const int use_l2 = env_int("APA_M1_LOGITS2", 1);
   static const int use_lx = env_int("APA_M1_LOGITS_XENT", 1);
   static const int use_bh = env_int("APA_M1_BWD_HEAD", 1);
-  if (xf && use_l2 && use_lx && use_bh && m1_logits_xent_supported(N, C, K) &&
-      m1_small_supported(C, K) &&
+  const bool xeval = xf && xf->probs;
+  if (xf && use_l2 && use_lx && (xeval || use_bh) && m1_logits_xent_supported(N, C, K, xeval) &&
+      (xeval || m1_small_supported(C, K)) &&
       ((reinterpret_cast<uintptr_t>(zsave) | reinterpret_cast<uintptr_t>(Wt) |
         reinterpret_cast<uintptr_t>(xf->G)) & 15) == 0) {
-    // the same conditions under which m1_backward takes the head kernel, which finishes loss[0]
-    rc = m1_logits2_xent(zsave, Wt, abar, bt, xf->labels, logits, xf->loss, xf->G, xf->gscale, gemm_ws,
-                         N, C, K, st);
+    // training: the same conditions under which m1_backward takes the head kernel, which finishes loss[0]
+    rc = m1_logits2_xent(zsave, Wt, abar, bt, xf->labels, logits, xf->loss, xf->G, xf->gscale, xf->probs,
+                         xf->pred, gemm_ws, N, C, K, st);
     xf->done = rc == APA_OK;
     return rc;
   }

@@ -117,11 +117,14 @@ __global__ __launch_bounds__(256) void m1_logits_reduce_kernel(const float* __re
 // (apa_loss.hip) on the LDS copy -- same lane layout, same reduction trees, so logits, per-example
 // loss and G are bit-identical to the two separate launches.  The batch-mean loss (needs every row)
 // is left to the backward head kernel, which follows in the same host call.
-template <int NV4>   // 16-byte vectors per lane of the half-wave: ceil(ceil(K/4)/32), K <= 512
+// EVAL (apa_attn_head_eval_step without ground truth): no labels, no loss, no gradient -- the row's
+// softmax probabilities and first-index argmax instead (eval.py:193-197).
+template <int NV4, bool EVAL>   // NV4: 16-byte vectors per lane of the half-wave, K <= 512
 __global__ __launch_bounds__(256) void m1_logits_xent_kernel(
     const float* __restrict__ part, const float* __restrict__ abar, const float* __restrict__ bt,
     const int64_t* __restrict__ labels, float* __restrict__ logits, float* __restrict__ out_loss,
-    float* __restrict__ G, int N, int K, int nchunks, float gscale) {
+    float* __restrict__ G, float* __restrict__ probs, int64_t* __restrict__ pred, int N, int K,
+    int nchunks, float gscale) {
   typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
   constexpr int EPT = NV4 == 4 ? 2 : 1;
   __shared__ float row[NV4 * 128];
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(256) void m1_logits_xent_kernel(
   const size_t stride = (size_t)N * K;
   const float* prow = part + (size_t)n * K;
   const float ab = abar[n];
-  const int lab = (int)labels[n];
+  const int lab = EVAL ? 0 : (int)labels[n];
   float btv[EPT], acc[EPT];
 #pragma unroll
   for (int e = 0; e < EPT; ++e) {
@@ -178,11 +181,15 @@ __global__ __launch_bounds__(256) void m1_logits_xent_kernel(
     for (int e = 0; e < 4; ++e) v[i][e] = colc[i] + e >= col0 ? v[i][e] : -INFINITY;
   }
   float m = -INFINITY;
+  int arg = 0x7fffffff;
 #pragma unroll
   for (int i = 0; i < NV4; ++i)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) m = v[i][e] > m ? v[i][e] : m;
+    for (int e = 0; e < 4; ++e)
+      if (v[i][e] > m) { m = v[i][e]; arg = colc[i] + e; }   // first maximal index of this lane
   const float mw = half_max(m, lane);
+  int cand = 0;
+  if (EVAL) cand = half_min_first((m == mw) ? arg : 0x7fffffff, lane);
   float l = 0.f;
 #pragma unroll
   for (int i = 0; i < NV4; ++i) {
@@ -196,6 +203,7 @@ __global__ __launch_bounds__(256) void m1_logits_xent_kernel(
   const float inv = 1.0f / l;
   const float lv = lab_ok ? -(xl - mw - logf(l)) : 0.f;
   if (lane < 32) {
+    float* __restrict__ dst = EVAL ? probs : G;
 #pragma unroll
     for (int i = 0; i < NV4; ++i) {
       const int col0 = 4 * (hl + 32 * i);
@@ -203,15 +211,18 @@ __global__ __launch_bounds__(256) void m1_logits_xent_kernel(
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float pe = v[i][e] * inv;
-        g[e] = fmaf(pe, gscale, colc[i] + e == lab ? -gscale : 0.f);
+        g[e] = EVAL ? pe : fmaf(pe, gscale, colc[i] + e == lab ? -gscale : 0.f);
       }
       if (colc[i] == col0) {
-        *reinterpret_cast<f4u*>(G + (size_t)n * K + colc[i]) = g;
+        *reinterpret_cast<f4u*>(dst + (size_t)n * K + colc[i]) = g;
       } else if (col0 < K) {   // the one ragged lane of the row: its own columns only
-        for (int e = col0 - colc[i]; e < 4; ++e) G[(size_t)n * K + colc[i] + e] = g[e];
+        for (int e = col0 - colc[i]; e < 4; ++e) dst[(size_t)n * K + colc[i] + e] = g[e];
       }
     }
-    if (lane == 0) out_loss[1 + n] = lv;
+    if (lane == 0) {
+      if (EVAL) pred[n] = cand;
+      else out_loss[1 + n] = lv;
+    }
   }
 }
 
@@ -762,23 +773,29 @@ int m1_logits2(const float* z, const float* Wt, const float* abar, const float* 
 
 bool m1_bwd_head_supported(int N, int C, int K);
 // L1v2 + L2x (fused train step): partial logits, then reduce + softmax cross-entropy per image
-bool m1_logits_xent_supported(int N, int C, int K) {
+bool m1_logits_xent_supported(int N, int C, int K, bool eval) {
   return m1_logits2_supported(C, K) && N >= 1 && K >= 4 && K <= 512 &&
-         m1_bwd_head_supported(N, C, K);
+         (eval || m1_bwd_head_supported(N, C, K));   // training: the head kernel finishes loss[0]
 }
 
 int m1_logits2_xent(const float* z, const float* Wt, const float* abar, const float* bt,
                     const int64_t* labels, float* logits, float* loss, float* G, float gscale,
-                    float* part_ws, int N, int C, int K, hipStream_t st) {
+                    float* probs, int64_t* pred, float* part_ws, int N, int C, int K, hipStream_t st) {
   constexpr int KG = 7;
   const int ktiles = (K + 15) / 16;
   dim3 grid(C / 64, (ktiles + KG - 1) / KG, (N + 31) / 32);
   const size_t shm = (size_t)4 * 2 * KG * 256 * sizeof(float);
   hipLaunchKernelGGL(m1_logits2_kernel<KG>, grid, dim3(256), shm, st, z, Wt, part_ws, N, C, K);
   APA_LAUNCH_CHECK("m1_logits2_kernel");
-#define APA_LX(NV4)                                                                             \
-  hipLaunchKernelGGL(m1_logits_xent_kernel<NV4>, dim3(N), dim3(256), 0, st, part_ws, abar, bt,  \
-                     labels, logits, loss, G, N, K, C / 64, gscale)
+#define APA_LX(NV4)                                                                                  \
+  do {                                                                                               \
+    if (probs)                                                                                       \
+      hipLaunchKernelGGL((m1_logits_xent_kernel<NV4, true>), dim3(N), dim3(256), 0, st, part_ws,     \
+                         abar, bt, labels, logits, loss, G, probs, pred, N, K, C / 64, gscale);      \
+    else                                                                                             \
+      hipLaunchKernelGGL((m1_logits_xent_kernel<NV4, false>), dim3(N), dim3(256), 0, st, part_ws,    \
+                         abar, bt, labels, logits, loss, G, probs, pred, N, K, C / 64, gscale);      \
+  } while (0)
   if (K <= 128) APA_LX(1);
   else if (K <= 256) APA_LX(2);
   else APA_LX(4);

@@ -64,6 +64,7 @@ _SIGNATURES = {
     'apa_attn_head_train_step': (c_int, [c_void_p] * 7 + [c_float, c_float] + [c_void_p] * 13 +
                                  [c_size_t] + [c_int] * 6 + [c_uint, c_float, c_uint64, c_uint64, c_int,
                                                              c_void_p]),
+    'apa_attn_head_eval_step': (c_int, [c_void_p] * 15 + [c_size_t] + [c_int] * 6 + [c_uint, c_int, c_void_p]),
     'apa_set_grad_ready_event': (c_int, [c_void_p]),
     'apa_set_td_weights_ready_event': (c_int, [c_void_p]),
     'apa_momentum_sgd_step': (c_int, [c_int, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_float),
@@ -521,6 +522,46 @@ class HeadTrainStep:
         rc = self._fn(*self._args, _stream_ptr() if stream is None else stream)
         if rc != 0:
             _check(rc, 'apa_attn_head_train_step')
+
+
+class HeadEvalStep:
+    """apa_attn_head_eval_step bound to caller-owned inputs: forward + softmax probabilities + argmax
+    (+ per-example loss when `labels` is given) as ONE foreign call (eval.py:181-197).  Outputs:
+    `logits`, `att`, `probs` [N,K], `pred` [N] int64, `loss` [1+N] or None."""
+
+    def __init__(self, X, Xatt, Wa, ba, Wt, bt, labels=None, *, flags=0, workspace=None):
+        self.lib = load_library()
+        N, C = X.shape[0], X.shape[-1]
+        P = X.numel() // (N * C)
+        Ca, M, K = Xatt.shape[-1], Wa.shape[1], Wt.shape[1]
+        dev = X.device
+        flags &= ~APA_FLAG_TRAIN
+        self.logits = torch.empty((N, K), dtype=torch.float32, device=dev)
+        self.att = torch.empty((N, P, M), dtype=torch.float32, device=dev)
+        self.zsave = torch.empty((N, C) if M == 1 else (N, P, K), dtype=torch.float32, device=dev)
+        self.abar = torch.empty((N,), dtype=torch.float32, device=dev) if M == 1 else None
+        self.probs = torch.empty((N, K), dtype=torch.float32, device=dev)
+        self.pred = torch.empty((N,), dtype=torch.int64, device=dev)
+        self.loss = torch.empty((1 + N,), dtype=torch.float32, device=dev) if labels is not None else None
+        need = int(self.lib.apa_attn_pool_workspace_bytes(N, P, C, Ca, K, M, flags))
+        if workspace is None or workspace.numel() < need:
+            workspace = torch.empty((max(need, 16),), dtype=torch.uint8, device=dev)
+        self.workspace = workspace
+        self._keep = (X, Xatt, Wa, ba, Wt, bt, labels)
+        self._args = [
+            _dev_ptr(X, 'X'), _dev_ptr(X, 'X') if Xatt is X else _dev_ptr(Xatt, 'Xatt', X.dtype),
+            _dev_ptr(Wa, 'Wa', torch.float32), _dev_ptr(ba, 'ba', torch.float32),
+            _dev_ptr(Wt, 'Wt', torch.float32), _dev_ptr(bt, 'bt', torch.float32),
+            _dev_ptr(labels, 'labels', torch.int64), self.logits.data_ptr(), self.att.data_ptr(),
+            self.zsave.data_ptr(), _dev_ptr(self.abar, 'abar'), _dev_ptr(self.loss, 'loss'),
+            self.probs.data_ptr(), self.pred.data_ptr(), workspace.data_ptr(), workspace.numel(),
+            N, P, C, Ca, K, M, flags, _feat_dtype(X)]
+        self._fn = self.lib.apa_attn_head_eval_step
+
+    def run(self, stream: Optional[int] = None) -> None:
+        rc = self._fn(*self._args, _stream_ptr() if stream is None else stream)
+        if rc != 0:
+            _check(rc, 'apa_attn_head_eval_step')
 
 
 def set_grad_ready_event(event) -> None:

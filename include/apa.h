@@ -168,6 +168,16 @@ int apa_attn_head_train_step(const void* X, const void* Xatt, const float* Wa, c
                              int Ca, int K, int M, unsigned flags, float keep_prob, uint64_t seed,
                              uint64_t offset, int dtype, void* stream);
 
+/* One evaluation step of the head as ONE host call (eval.py:181-197: network_fn, then
+ * tf.argmax(logits,1) and tf.nn.softmax(logits,-1) in the same sess.run): apa_attn_pool_fwd followed
+ * by apa_softmax_xent_fwd_bwd without the gradient.  probs f32 [N,K]; pred int64 [N] (first maximal
+ * index); labels / loss ([1+N], see above) may both be NULL when no ground truth is at hand.  */
+int apa_attn_head_eval_step(const void* X, const void* Xatt, const float* Wa, const float* ba,
+                            const float* Wt, const float* bt, const int64_t* labels, float* logits,
+                            float* att, float* zsave, float* abar, float* loss, float* probs,
+                            int64_t* pred, void* ws, size_t ws_bytes, int N, int P, int C, int Ca, int K,
+                            int M, unsigned flags, int dtype, void* stream);
+
 /* Pose loss: src/loss.py:29-70 ('l2', LOSS_FN_POSE_SAMPLED off) fused with its gradient.
  *   loss[0] = wt * sum_j mean_n( valid[n,j] ? 0.5*sum_p (Pl-lbl)^2 / (N*P) : 0 )
  *   dPl = grad_scale * wt * valid[n,j] * (Pl - lbl) / (N*N*P)

@@ -618,6 +618,44 @@ def test_head_train_step_single_call_equals_the_three_entry_points(gpu, N, K):
         cof.HeadTrainStep(X.cpu(), X.cpu(), Wa, ba, Wt, bt, labels, ga)
 
 
+def test_head_eval_step_single_call(gpu):
+    """apa_attn_head_eval_step (cof.HeadEvalStep) == apa_attn_pool_fwd (is_training=False) followed by
+    the softmax / argmax consumer of eval.py:193-197, bit for bit; with and without ground truth; a
+    TRAIN flag passed by mistake is ignored (evaluation never drops features)."""
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    N, P, C, K = 7, 49, 2048, 393
+    g = torch.Generator().manual_seed(5)
+    X = torch.relu(torch.randn(N, P, C, generator=g)).to(gpu)
+    Wa = (torch.randn(C, 1, generator=g) / C ** 0.5).to(gpu)
+    ba = torch.zeros(1, device=gpu)
+    Wt = (torch.randn(C, K, generator=g) / C ** 0.5).to(gpu)
+    bt = (torch.randn(K, generator=g) * 0.1).to(gpu)
+    labels = torch.randint(0, K, (N,), generator=g).to(gpu)
+    flags = cof.attn_flags(True, False, False)
+    logits, att, *_ = cof.attn_pool_fwd(X, X, Wa, ba, Wt, bt, flags=flags)
+    loss, _, probs, pred = cof.softmax_xent_fwd_bwd(logits, labels, want_grad=False, want_probs=True, want_pred=True)
+    for lab in (labels, None):
+        ev = cof.HeadEvalStep(X, X, Wa, ba, Wt, bt, lab, flags=flags | cof.APA_FLAG_TRAIN)
+        ev.run()
+        torch.cuda.synchronize()
+        assert torch.equal(ev.logits, logits) and torch.equal(ev.att, att)
+        assert torch.equal(ev.probs, probs) and torch.equal(ev.pred, pred)
+        assert torch.equal(ev.pred, logits.argmax(dim=1))
+        if lab is not None:
+            assert torch.equal(ev.loss, loss)
+        else:
+            assert ev.loss is None
+    # per-class maps go through the same entry
+    Wk = (torch.randn(C, 8, generator=g) / C ** 0.5).to(gpu)
+    ev = cof.HeadEvalStep(X.bfloat16(), X.bfloat16(), Wk, torch.zeros(8, device=gpu), Wk.clone(),
+                          torch.zeros(8, device=gpu))
+    xb = X.bfloat16()
+    ev = cof.HeadEvalStep(xb, xb, Wk, torch.zeros(8, device=gpu), Wk.clone(), torch.zeros(8, device=gpu))
+    ev.run()
+    torch.cuda.synchronize()
+    assert ev.probs.shape == (N, 8) and torch.allclose(ev.probs.sum(dim=1), torch.ones(N, device=gpu), atol=1e-5)
+
+
 def test_overlapped_gradient_sum_schedule_matches_the_sequential_loop(gpu):
     """deploy.OverlappedGradientSum: td part reduced + updated on the communication stream between the
     library's grad-ready and td-weights-ready hooks, att part in-stream.  Four SGD steps must be

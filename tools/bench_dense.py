@@ -39,7 +39,7 @@ def timed(fn, steps, warmup):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--workload', default='cfg003', choices=['cfg003', 'perclass'])
+    ap.add_argument('--workload', default='cfg003', choices=['cfg003', 'perclass', 'eval002'])
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--hw', type=int, default=14)
     ap.add_argument('--classes', type=int, default=None)
@@ -80,6 +80,23 @@ def main():
 
         flops_img = 3 * (2.0 * P * C * Cp + 2.0 * P * Cp * J)          # fwd + 2x bwd
         name = 'cfg003 pose-regularised attention head fwd+bwd (pose head 2048->768->16 + M=1 pooling)'
+    elif args.workload == 'eval002':
+        # BASELINE configs[1]: cfg 002 evaluation, forward + softmax probabilities + argmax (eval.py:181-197)
+        # as one host call; HBM-bound (reads X once): reported against the 8 TB/s peak
+        K = args.classes or 393
+        Wa = (torch.randn(C, 1, generator=g) / C ** 0.5).to(dev); ba = torch.zeros(1, device=dev)
+        Wt = (torch.randn(C, K, generator=g) / C ** 0.5).to(dev); bt = torch.zeros(K, device=dev)
+        ev = cof.HeadEvalStep(X, X, Wa, ba, Wt, bt)
+        step = ev.run
+        sec = timed(step, args.steps, args.warmup)
+        gbs = N * P * C * X.element_size() / sec / 1e9
+        print(json.dumps({
+            'workload': 'cfg002 eval step (attn-pool forward + softmax + argmax, one call); per-GPU batch '
+                        '{} x {}x{}x{} {}, K={}'.format(N, H, H, C, args.dtype, K),
+            'images_per_sec': round(N / sec, 1), 'ms_per_step': round(sec * 1e3, 4),
+            'roofline': {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                         'frac': round(gbs / 8000.0, 4), 'note': 'whole step: P*C*s bytes per image'}}))
+        return
     else:
         K = args.classes or 51
         Wa = (torch.randn(C, K, generator=g) / C ** 0.5).to(dev); ba = torch.zeros(K, device=dev)
@@ -87,15 +104,11 @@ def main():
         labels = torch.randint(0, K, (N,), generator=g).to(dev)
         flags = cof.attn_flags(False, False, True)
         ctr = torch.zeros(1, dtype=torch.int64, device=dev)
-        ws = None
-
-        def step():
-            nonlocal ws
-            logits, att, Ts, _, _, ws = cof.attn_pool_fwd(X, X, Wa, ba, Wt, bt, flags=flags, keep_prob=0.2,
-                                                          seed=42, offset=ctr, workspace=ws)
-            _, G, _, _ = cof.softmax_xent_fwd_bwd(logits, labels)
-            cof.attn_pool_bwd(X, X, Wa, ba, Wt, bt, att, Ts, None, G, flags=flags, keep_prob=0.2,
-                              seed=42, offset=ctr, workspace=ws)
+        grads = (torch.empty_like(X), None, torch.empty_like(Wa), torch.empty_like(ba), torch.empty_like(Wt),
+                 torch.empty_like(bt))
+        st = cof.HeadTrainStep(X, X, Wa, ba, Wt, bt, labels, grads, flags=flags, keep_prob=0.2, seed=42,
+                               offset=ctr)                       # one host call per step
+        step = st.run
 
         flops_img = 3 * (2 * 2.0 * P * C * K)                           # Z and T products, fwd + 2x bwd
         name = 'per-class bottom-up maps (M=K) attention head fwd+bwd'
