@@ -331,7 +331,8 @@ def pose_l2_loss_fwd_bwd(Pl, lbl, valid, *, wt=1.0, grad_scale=1.0, want_grad=Tr
     J = Pl.shape[-1]
     P = Pl.numel() // (N * J)
     dev = Pl.device
-    v8 = valid.to(torch.uint8).contiguous()
+    # a bool tensor already is one 0/1 byte per element: reinterpret, do not launch a conversion
+    v8 = (valid.view(torch.uint8) if valid.dtype == torch.bool else valid.to(torch.uint8)).contiguous()
     loss = torch.empty((1,), dtype=torch.float32, device=dev)
     dPl = torch.empty_like(Pl) if want_grad else None
     need = int(lib.apa_pose_l2_workspace_bytes(N, P, J))
