@@ -7,6 +7,7 @@
 //   B. Per-class bottom-up maps (cfg.NET..._PER_CLASS, nets_factory.py:257): M == K.  Z and T are
 //      two real GEMMs here ([N*P, C] x [C, K]); the activation / spatial mean and their gradients
 //      are small fused elementwise-reduction kernels over the [N,P,K] tensors.
+#include <type_traits>
 #include <math.h>
 
 #include "apa_device.h"
@@ -56,29 +57,23 @@ __global__ __launch_bounds__(512) void pose_dppre_kernel(const float* __restrict
   }
   const int j0 = tid * 4;
   const bool active = j0 < Cp;          // Cp % 4 == 0 (checked on the host)
-  float x[POSE_RB][4], pp[POSE_RB][4];
-  if (active) {
+  // Row loads: raw vectors, no branch between them (an `if (ext)` per row made hipcc emit
+  // load / branch / load / s_waitcnt vmcnt(0) eight times -- eight serial round trips, 17.7 us);
+  // a missing `ext` re-reads Ppre and is multiplied by 0.
+  typedef typename std::conditional<sizeof(T) == 2, uint2, float4>::type rowvec_t;
+  rowvec_t pv[POSE_RB], ev[POSE_RB];
+  const T* extp = ext ? ext : Ppre;
+  const float extm = ext ? 1.f : 0.f;
+  {
+    const int j0c = active ? j0 : 0;   // idle threads (Cp/4 not a multiple of 64) load column 0
 #pragma unroll
     for (int rr = 0; rr < POSE_RB; ++rr) {
-      const size_t off = (size_t)(r0 + min(rr, nrows - 1)) * Cp + j0;   // surplus rows re-read the last
-      if constexpr (sizeof(T) == 2) {
-        const uint2 pv = *reinterpret_cast<const uint2*>(Ppre + off);
-        pp[rr][0] = bf16_lo(pv.x); pp[rr][1] = bf16_hi(pv.x); pp[rr][2] = bf16_lo(pv.y); pp[rr][3] = bf16_hi(pv.y);
-        if (ext) {
-          const uint2 ev = *reinterpret_cast<const uint2*>(ext + off);
-          x[rr][0] = bf16_lo(ev.x); x[rr][1] = bf16_hi(ev.x); x[rr][2] = bf16_lo(ev.y); x[rr][3] = bf16_hi(ev.y);
-        }
-      } else {
-        const float4 pv = *reinterpret_cast<const float4*>(Ppre + off);
-        pp[rr][0] = pv.x; pp[rr][1] = pv.y; pp[rr][2] = pv.z; pp[rr][3] = pv.w;
-        if (ext) {
-          const float4 ev = *reinterpret_cast<const float4*>(ext + off);
-          x[rr][0] = ev.x; x[rr][1] = ev.y; x[rr][2] = ev.z; x[rr][3] = ev.w;
-        }
-      }
-      if (!ext) { x[rr][0] = x[rr][1] = x[rr][2] = x[rr][3] = 0.f; }
+      const size_t off = (size_t)(r0 + min(rr, nrows - 1)) * Cp + j0c;   // surplus rows re-read the last
+      pv[rr] = *reinterpret_cast<const rowvec_t*>(Ppre + off);
+      ev[rr] = *reinterpret_cast<const rowvec_t*>(extp + off);
     }
   }
+  __builtin_amdgcn_sched_barrier(0);
   float w[4][JMAX];
   if (dPl && active && J == JMAX) {   // the 4 x J slice of W2 is one contiguous, 16-byte aligned span
     const float4* wsrc = reinterpret_cast<const float4*>(W2 + (size_t)j0 * J);
@@ -101,15 +96,22 @@ __global__ __launch_bounds__(512) void pose_dppre_kernel(const float* __restrict
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int rr = 0; rr < POSE_RB; ++rr) {
-      float o[4];
+      float o[4], x[4], pp[4];
+      if constexpr (sizeof(T) == 2) {
+        pp[0] = bf16_lo(pv[rr].x); pp[1] = bf16_hi(pv[rr].x); pp[2] = bf16_lo(pv[rr].y); pp[3] = bf16_hi(pv[rr].y);
+        x[0] = bf16_lo(ev[rr].x); x[1] = bf16_hi(ev[rr].x); x[2] = bf16_lo(ev[rr].y); x[3] = bf16_hi(ev[rr].y);
+      } else {
+        pp[0] = pv[rr].x; pp[1] = pv[rr].y; pp[2] = pv[rr].z; pp[3] = pv[rr].w;
+        x[0] = ev[rr].x; x[1] = ev[rr].y; x[2] = ev[rr].z; x[3] = ev[rr].w;
+      }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        float sv = x[rr][c];
+        float sv = x[c] * extm;
         if (dPl) {
 #pragma unroll
           for (int q = 0; q < JMAX; ++q) sv = fmaf(s_dpl[rr * JMAX + q], w[c][q], sv);
         }
-        o[c] = pp[rr][c] > 0.f ? sv : 0.f;
+        o[c] = pp[c] > 0.f ? sv : 0.f;
         acc[c] += rr < nrows ? o[c] : 0.f;
       }
       if (rr < nrows) {
