@@ -406,15 +406,28 @@ __global__ __launch_bounds__(1024) void pc_fwd_act_kernel(const float* __restric
   const float invl = 1.0f / l;
   float acc = 0.f;
   if (ok) {
-    for (int p = pg; p < P; p += PC_PG) {
-      const float z = Z[(rbase + p) * ldz + k];
-      float a = z;
-      if (act == 2) a = expf(z - m) * invl;
-      else if (act == 1) a = fmaxf(z, 0.f);
-      const float t = Tm[(rbase + p) * K + k];
-      att[(rbase + p) * K + k] = a;
-      if (topdown) stf<T>(topdown, (rbase + p) * K + k, t);
-      acc = fmaf(a, t, acc);
+    // four pixels per round, their eight loads issued before the first use (a plain loop is one
+    // dependent round trip per pixel)
+    for (int p0 = pg; p0 < P; p0 += 4 * PC_PG) {
+      float z[4], t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t pr = rbase + min(p0 + u * PC_PG, P - 1);   // surplus slots re-read the last pixel
+        z[u] = Z[pr * ldz + k];
+        t[u] = Tm[pr * K + k];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = p0 + u * PC_PG;
+        if (p < P) {
+          float a = z[u];
+          if (act == 2) a = expf(z[u] - m) * invl;
+          else if (act == 1) a = fmaxf(z[u], 0.f);
+          att[(rbase + p) * K + k] = a;
+          if (topdown) stf<T>(topdown, (rbase + p) * K + k, t[u]);
+          acc = fmaf(a, t[u], acc);
+        }
+      }
     }
   }
   red[pg][kk] = acc;
@@ -454,8 +467,8 @@ __global__ __launch_bounds__(1024) void pc_bwd_act_kernel(const float* __restric
     __syncthreads();
   }
   float sdt = 0.f, sdz = 0.f;
-  for (int p = pg; p < P; p += PC_PG) {
-    if (ok) {
+  for (int p = pg; p < P; p += PC_PG) {   // (batching the loads four pixels deep, as in the forward
+    if (ok) {                               //  pass, measured slower here: 8.9 -> 10.7 us)
       const float a = att[(rbase + p) * K + k];
       const float dA = g * Tm[(rbase + p) * K + k];
       const float dt = g * a;
