@@ -33,8 +33,13 @@ def timed(fn, steps, warmup):
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
+    t1 = time.perf_counter()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps
+    t2 = time.perf_counter()
+    import sys
+    print('host enqueue {:.1f} us/step, wall {:.1f} us/step'.format((t1 - t0) / steps * 1e6, (t2 - t0) / steps * 1e6),
+          file=sys.stderr)
+    return (t2 - t0) / steps
 
 
 def main():
