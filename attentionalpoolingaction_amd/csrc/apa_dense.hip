@@ -47,7 +47,7 @@ __global__ __launch_bounds__(512) void pose_dppre_kernel(const float* __restrict
                                                          T* __restrict__ dPpre,
                                                          float* __restrict__ partial, long R,
                                                          int Cp, int J) {
-  __shared__ float s_dpl[POSE_RB * JMAX];
+  __shared__ __attribute__((aligned(16))) float s_dpl[POSE_RB * JMAX];
   const int tid = threadIdx.x;
   const long r0 = (long)blockIdx.x * POSE_RB;
   const int nrows = (int)min((long)POSE_RB, R - r0);
@@ -107,12 +107,20 @@ __global__ __launch_bounds__(512) void pose_dppre_kernel(const float* __restrict
         pp[0] = pv[rr].x; pp[1] = pv[rr].y; pp[2] = pv[rr].z; pp[3] = pv[rr].w;
         x[0] = ev[rr].x; x[1] = ev[rr].y; x[2] = ev[rr].z; x[3] = ev[rr].w;
       }
+      // the row's dPl values: read from LDS ONCE (4 x ds_read_b128) and kept in registers for the four
+      // columns -- indexed in place hipcc re-read them per column: 128 dependent LDS reads per thread
+      float d[JMAX];
+#pragma unroll
+      for (int q = 0; q < JMAX; q += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(s_dpl + rr * JMAX + q);
+        d[q] = t.x; d[q + 1] = t.y; d[q + 2] = t.z; d[q + 3] = t.w;
+      }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         float sv = x[c] * extm;
         if (dPl) {
 #pragma unroll
-          for (int q = 0; q < JMAX; ++q) sv = fmaf(s_dpl[rr * JMAX + q], w[c][q], sv);
+          for (int q = 0; q < JMAX; ++q) sv = fmaf(d[q], w[c][q], sv);
         }
         o[c] = pp[c] > 0.f ? sv : 0.f;
         acc[c] += rr < nrows ? o[c] : 0.f;
