@@ -1,3 +1,6 @@
+"""Experiment behind DESIGN.md section 5: what each piece of the two-stream gradient-sum schedule costs on ONE
+rank (collectives are no-ops there): library hooks, cross-stream event waits, RCCL calls.  Run through
+gpurun:  python tools/exp_overlap_pieces.py"""
 import sys, time, torch
 sys.path.insert(0, '.')
 from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
