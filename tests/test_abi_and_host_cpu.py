@@ -34,6 +34,26 @@ def test_library_exports_every_declared_symbol():
     assert lib.apa_version() >= 100
 
 
+def test_header_constants_match_the_python_binding():
+    """Every #define of include/apa.h that the ctypes layer mirrors has the same value there."""
+    header = open(os.path.join(ROOT, 'include', 'apa.h')).read()
+    defs = {m.group(1): int(m.group(2).rstrip('uU'), 0)
+            for m in re.finditer(r'#define\s+(APA_[A-Z0-9_]+)\s+(-?(?:0x[0-9a-fA-F]+|\d+)[uU]?)\b', header)}
+    assert {'APA_FLAG_SOFTMAX_ATT', 'APA_FLAG_RELU_ATT', 'APA_FLAG_TRAIN', 'APA_FLAG_RNG_DEVICE',
+            'APA_FLAG_RELU_INPUT', 'APA_DTYPE_F32', 'APA_DTYPE_BF16'} <= set(defs)
+    for name, value in defs.items():
+        if hasattr(cof, name):
+            assert getattr(cof, name) == value, name
+    assert cof.attn_flags(True, True, True, relu_input=True) == 1 | 2 | 4 | 16
+    # the one-call step entry points reject missing outputs before touching the GPU
+    lib = cof.load_library()
+    none = [None] * 7
+    rc = lib.apa_attn_head_train_step(*none, 1.0, 1.0, *([None] * 13), 0, 2, 4, 2048, 2048, 5, 1, 0, 1.0, 0, 0, 0, None)
+    assert rc == -1 and b'null' in lib.apa_last_error()
+    rc = lib.apa_attn_head_eval_step(*([None] * 15), 0, 2, 4, 2048, 2048, 5, 1, 0, 0, None)
+    assert rc == -1 and b'null' in lib.apa_last_error()
+
+
 def test_status_strings_and_error_paths_without_gpu():
     lib = cof.load_library()
     assert lib.apa_status_string(0) == b'APA_OK'
