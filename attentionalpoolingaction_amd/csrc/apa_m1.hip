@@ -595,6 +595,54 @@ __global__ __launch_bounds__(256) void m1_att_gemv_bwd_kernel(
     pdba[blockIdx.x] = (sm[4 * Ca] + sm[4 * Ca + 1]) + (sm[4 * Ca + 2] + sm[4 * Ca + 3]);
 }
 
+// Same outputs, one thread per 16-byte vector of the row (Ca <= 256 vectors): the attention weights
+// and the dwa accumulators of the thread's channels live in registers (the kernel above re-reads Wa
+// from memory and read-modify-writes an LDS accumulator per element and pixel), a block owns a
+// contiguous pixel range and takes it eight pixels per round with the eight row loads in flight.
+template <typename T>
+__global__ __launch_bounds__(256) void m1_att_gemv_bwd2_kernel(
+    const T* __restrict__ Xa, const float* __restrict__ Wa, const float* __restrict__ dZ,
+    T* __restrict__ dXa, float* __restrict__ pdwa, float* __restrict__ pdba, long NP, int Ca) {
+  constexpr int EPV = Vec<T>::EPV;
+  constexpr int PR = 8;
+  const int nvec = Ca / EPV;
+  const int v = threadIdx.x < nvec ? threadIdx.x : nvec - 1;   // idle lanes shadow the last vector
+  const bool active = (int)threadIdx.x < nvec;
+  const long p_begin = (long)blockIdx.x * NP / gridDim.x, p_end = (long)(blockIdx.x + 1) * NP / gridDim.x;
+  float wa[EPV], dwa[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) { wa[e] = Wa[v * EPV + e]; dwa[e] = 0.f; }
+  float dba = 0.f;
+  for (long p0 = p_begin; p0 < p_end; p0 += PR) {
+    uint4 xr[PR];
+    float g[PR];
+#pragma unroll
+    for (int u = 0; u < PR; ++u) {
+      const long px = min(p0 + u, p_end - 1);   // surplus slots re-read the last pixel, weight 0
+      xr[u] = ld16(Xa + (size_t)px * Ca + v * EPV);
+      g[u] = p0 + u < p_end ? dZ[px] : 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < PR; ++u) {
+      float x[EPV], o[EPV];
+      Vec<T>::unpack(xr[u], x);
+      dba += g[u];
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) {
+        o[e] = g[u] * wa[e];
+        dwa[e] = fmaf(g[u], x[e], dwa[e]);
+      }
+      if (active && p0 + u < p_end) st16(dXa + (size_t)(p0 + u) * Ca + v * EPV, Vec<T>::pack(o));
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) pdwa[(size_t)blockIdx.x * Ca + v * EPV + e] = dwa[e];
+  }
+  if (threadIdx.x == 0) pdba[blockIdx.x] = dba;
+}
+
 // ============================================================================================
 // host side
 // ============================================================================================
@@ -895,7 +943,19 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
     if (nb < 1) nb = 1;
     if (nb > pl.nblk) nb = pl.nblk;  // partial buffer is sized for nblk rows
     const size_t shm = ((size_t)4 * Ca + 8) * sizeof(float);
-    if (dtype == APA_DTYPE_F32)
+    const int epv = dtype == APA_DTYPE_F32 ? 4 : 8;
+    static const int use_v2 = env_int("APA_M1_GEMV_BWD2", 1);
+    if (use_v2 && Ca % epv == 0 && Ca / epv <= 256) {   // register-resident form
+      const int nthr = ((Ca / epv + 63) / 64) * 64;
+      if (dtype == APA_DTYPE_F32)
+        hipLaunchKernelGGL(m1_att_gemv_bwd2_kernel<float>, dim3(nb), dim3(nthr), 0, st,
+                           static_cast<const float*>(Xatt), Wa, dZatt, static_cast<float*>(dXatt),
+                           pdwa, pdba, NP, Ca);
+      else
+        hipLaunchKernelGGL(m1_att_gemv_bwd2_kernel<bf16_t>, dim3(nb), dim3(nthr), 0, st,
+                           static_cast<const bf16_t*>(Xatt), Wa, dZatt, static_cast<bf16_t*>(dXatt),
+                           pdwa, pdba, NP, Ca);
+    } else if (dtype == APA_DTYPE_F32)
       hipLaunchKernelGGL(m1_att_gemv_bwd_kernel<float>, dim3(nb), dim3(256), shm, st,
                          static_cast<const float*>(Xatt), Wa, dZatt, static_cast<float*>(dXatt),
                          pdwa, pdba, NP, Ca);
