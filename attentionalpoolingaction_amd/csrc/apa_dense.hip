@@ -39,18 +39,24 @@ constexpr int POSE_RB = 8;   // rows per block of the dPpre kernel
 // Block b owns rows [8b, 8b+8); thread t owns the 4 consecutive columns 4t..4t+3 of all of them
 // (8-byte bf16 / 16-byte fp32 accesses, a wave covers 512 B / 1 KiB of a row), with its 4 x J
 // slice of W2 in registers.  All 16 row loads are issued before the first is used.
-template <typename T, int JMAX>
+// R1 (apa_pose_head_bwd_rank1ext): the external gradient is rank-1, ext[r,j] = ext_row[r] * ext_col[j]
+// (the attention branch of cfg 003: dZ (x) wa) -- formed in registers, no [R,Cp] tensor is read.
+template <typename T, int JMAX, bool R1>
 __global__ __launch_bounds__(512) void pose_dppre_kernel(const float* __restrict__ dPl,
                                                          const float* __restrict__ W2,
                                                          const T* __restrict__ ext,
+                                                         const float* __restrict__ ext_row,
+                                                         const float* __restrict__ ext_col,
                                                          const T* __restrict__ Ppre,
                                                          T* __restrict__ dPpre,
                                                          float* __restrict__ partial, long R,
                                                          int Cp, int J) {
   __shared__ __attribute__((aligned(16))) float s_dpl[POSE_RB * JMAX];
+  __shared__ float s_er[POSE_RB];
   const int tid = threadIdx.x;
   const long r0 = (long)blockIdx.x * POSE_RB;
   const int nrows = (int)min((long)POSE_RB, R - r0);
+  if (R1 && tid < POSE_RB) s_er[tid] = tid < nrows ? ext_row[r0 + tid] : 0.f;
   for (int i = tid; i < POSE_RB * JMAX; i += blockDim.x) {
     const int rr = i / JMAX, q = i - rr * JMAX;
     s_dpl[i] = (dPl && rr < nrows && q < J) ? dPl[(r0 + rr) * J + q] : 0.f;
@@ -61,16 +67,21 @@ __global__ __launch_bounds__(512) void pose_dppre_kernel(const float* __restrict
   // load / branch / load / s_waitcnt vmcnt(0) eight times -- eight serial round trips, 17.7 us);
   // a missing `ext` re-reads Ppre and is multiplied by 0.
   typedef typename std::conditional<sizeof(T) == 2, uint2, float4>::type rowvec_t;
-  rowvec_t pv[POSE_RB], ev[POSE_RB];
+  rowvec_t pv[POSE_RB], ev[R1 ? 1 : POSE_RB];
   const T* extp = ext ? ext : Ppre;
-  const float extm = ext ? 1.f : 0.f;
+  const float extm = (R1 || ext) ? 1.f : 0.f;
+  float ecol[4] = {0.f, 0.f, 0.f, 0.f};
   {
     const int j0c = active ? j0 : 0;   // idle threads (Cp/4 not a multiple of 64) load column 0
 #pragma unroll
     for (int rr = 0; rr < POSE_RB; ++rr) {
       const size_t off = (size_t)(r0 + min(rr, nrows - 1)) * Cp + j0c;   // surplus rows re-read the last
       pv[rr] = *reinterpret_cast<const rowvec_t*>(Ppre + off);
-      ev[rr] = *reinterpret_cast<const rowvec_t*>(extp + off);
+      if (!R1) ev[rr] = *reinterpret_cast<const rowvec_t*>(extp + off);
+    }
+    if (R1) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) ecol[c] = ext_col[j0c + c];
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -102,10 +113,17 @@ __global__ __launch_bounds__(512) void pose_dppre_kernel(const float* __restrict
       float o[4], x[4], pp[4];
       if constexpr (sizeof(T) == 2) {
         pp[0] = bf16_lo(pv[rr].x); pp[1] = bf16_hi(pv[rr].x); pp[2] = bf16_lo(pv[rr].y); pp[3] = bf16_hi(pv[rr].y);
-        x[0] = bf16_lo(ev[rr].x); x[1] = bf16_hi(ev[rr].x); x[2] = bf16_lo(ev[rr].y); x[3] = bf16_hi(ev[rr].y);
+        if constexpr (!R1) {
+          x[0] = bf16_lo(ev[rr].x); x[1] = bf16_hi(ev[rr].x); x[2] = bf16_lo(ev[rr].y); x[3] = bf16_hi(ev[rr].y);
+        }
       } else {
         pp[0] = pv[rr].x; pp[1] = pv[rr].y; pp[2] = pv[rr].z; pp[3] = pv[rr].w;
-        x[0] = ev[rr].x; x[1] = ev[rr].y; x[2] = ev[rr].z; x[3] = ev[rr].w;
+        if constexpr (!R1) { x[0] = ev[rr].x; x[1] = ev[rr].y; x[2] = ev[rr].z; x[3] = ev[rr].w; }
+      }
+      if constexpr (R1) {
+        const float er = s_er[rr];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) x[c] = er * ecol[c];
       }
       // the row's dPl values: read from LDS ONCE (4 x ds_read_b128) and kept in registers for the four
       // columns -- indexed in place hipcc re-read them per column: 128 dependent LDS reads per thread
@@ -237,17 +255,17 @@ extern "C" int apa_pose_head_fwd(const void* X, const float* W1, const float* b1
   return gemm_launch(g2, st);
 }
 
-extern "C" int apa_pose_head_bwd(const void* X, const float* W1, const float* W2, const void* Ppre,
-                                 const float* dPl, const void* dPpre_ext, void* dX, int accumulate_dX,
-                                 float* dW1, float* db1, float* dW2, float* db2, void* ws,
-                                 size_t ws_bytes, int N, int P, int C, int Cp, int J, int dtype,
-                                 void* stream) {
+static int pose_head_bwd_impl(const void* X, const float* W1, const float* W2, const void* Ppre,
+                              const float* dPl, const void* dPpre_ext, const float* ext_row,
+                              const float* ext_col, void* dX, int accumulate_dX, float* dW1, float* db1,
+                              float* dW2, float* db2, void* ws, size_t ws_bytes, int N, int P, int C,
+                              int Cp, int J, int dtype, void* stream) {
   if (!X || !W1 || !W2 || !Ppre || !dX || !dW1 || !db1 || !dW2 || !db2 || N <= 0 || P <= 0 ||
       C <= 0 || Cp <= 0 || J <= 0) {
     set_error("apa_pose_head_bwd: null pointer or non-positive dimension");
     return APA_ERR_INVALID_ARG;
   }
-  if (!dPl && !dPpre_ext) {
+  if (!dPl && !dPpre_ext && !ext_row) {
     set_error("apa_pose_head_bwd: neither dPl nor dPpre_ext given (no gradient to propagate)");
     return APA_ERR_INVALID_ARG;
   }
@@ -274,9 +292,16 @@ extern "C" int apa_pose_head_bwd(const void* X, const float* W1, const float* W2
   }
   const int nthr = ((Cp / 4 + 63) / 64) * 64;   // one thread per 4 columns (<= 512: Cp <= 2048)
 #define APA_DPPRE(T, JM)                                                                            \
-  hipLaunchKernelGGL((pose_dppre_kernel<T, JM>), dim3(pl.nchunks), dim3(nthr), 0, st, dPl, W2,        \
-                     static_cast<const T*>(dPpre_ext), static_cast<const T*>(Ppre),                 \
-                     static_cast<T*>(dPpre), partial, pl.R, Cp, J)
+  do {                                                                                              \
+    if (ext_row)                                                                                    \
+      hipLaunchKernelGGL((pose_dppre_kernel<T, JM, true>), dim3(pl.nchunks), dim3(nthr), 0, st, dPl,  \
+                         W2, static_cast<const T*>(nullptr), ext_row, ext_col,                      \
+                         static_cast<const T*>(Ppre), static_cast<T*>(dPpre), partial, pl.R, Cp, J); \
+    else                                                                                            \
+      hipLaunchKernelGGL((pose_dppre_kernel<T, JM, false>), dim3(pl.nchunks), dim3(nthr), 0, st, dPl, \
+                         W2, static_cast<const T*>(dPpre_ext), ext_row, ext_col,                    \
+                         static_cast<const T*>(Ppre), static_cast<T*>(dPpre), partial, pl.R, Cp, J); \
+  } while (0)
   if (dtype == APA_DTYPE_F32) {
     if (J <= 16) APA_DPPRE(float, 16); else APA_DPPRE(float, 32);
   } else {
@@ -323,6 +348,28 @@ extern "C" int apa_pose_head_bwd(const void* X, const float* W1, const float* W2
     rc = gemm_launch(g, st);
   }
   return rc;
+}
+
+extern "C" int apa_pose_head_bwd(const void* X, const float* W1, const float* W2, const void* Ppre,
+                                 const float* dPl, const void* dPpre_ext, void* dX, int accumulate_dX,
+                                 float* dW1, float* db1, float* dW2, float* db2, void* ws,
+                                 size_t ws_bytes, int N, int P, int C, int Cp, int J, int dtype,
+                                 void* stream) {
+  return pose_head_bwd_impl(X, W1, W2, Ppre, dPl, dPpre_ext, nullptr, nullptr, dX, accumulate_dX, dW1, db1,
+                            dW2, db2, ws, ws_bytes, N, P, C, Cp, J, dtype, stream);
+}
+
+extern "C" int apa_pose_head_bwd_rank1ext(const void* X, const float* W1, const float* W2,
+                                          const void* Ppre, const float* dPl, const float* ext_row,
+                                          const float* ext_col, void* dX, int accumulate_dX, float* dW1,
+                                          float* db1, float* dW2, float* db2, void* ws, size_t ws_bytes,
+                                          int N, int P, int C, int Cp, int J, int dtype, void* stream) {
+  if (!ext_row || !ext_col) {
+    set_error("apa_pose_head_bwd_rank1ext: null ext_row / ext_col");
+    return APA_ERR_INVALID_ARG;
+  }
+  return pose_head_bwd_impl(X, W1, W2, Ppre, dPl, nullptr, ext_row, ext_col, dX, accumulate_dX, dW1, db1,
+                            dW2, db2, ws, ws_bytes, N, P, C, Cp, J, dtype, stream);
 }
 
 // =============================================================================================

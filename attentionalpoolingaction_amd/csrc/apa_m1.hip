@@ -599,7 +599,8 @@ __global__ __launch_bounds__(256) void m1_att_gemv_bwd_kernel(
 // and the dwa accumulators of the thread's channels live in registers (the kernel above re-reads Wa
 // from memory and read-modify-writes an LDS accumulator per element and pixel), a block owns a
 // contiguous pixel range and takes it eight pixels per round with the eight row loads in flight.
-template <typename T>
+// STORE = false (APA_FLAG_DXATT_RANK1): dXa = dZ (x) wa is not materialised, only the dwa / dba partials.
+template <typename T, bool STORE>
 __global__ __launch_bounds__(256) void m1_att_gemv_bwd2_kernel(
     const T* __restrict__ Xa, const float* __restrict__ Wa, const float* __restrict__ dZ,
     T* __restrict__ dXa, float* __restrict__ pdwa, float* __restrict__ pdba, long NP, int Ca) {
@@ -633,7 +634,7 @@ __global__ __launch_bounds__(256) void m1_att_gemv_bwd2_kernel(
         o[e] = g[u] * wa[e];
         dwa[e] = fmaf(g[u], x[e], dwa[e]);
       }
-      if (active && p0 + u < p_end) st16(dXa + (size_t)(p0 + u) * Ca + v * EPV, Vec<T>::pack(o));
+      if (STORE && active && p0 + u < p_end) st16(dXa + (size_t)(p0 + u) * Ca + v * EPV, Vec<T>::pack(o));
     }
   }
   if (active) {
@@ -868,7 +869,9 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
   float* pdwa = reinterpret_cast<float*>(w + pl.off_pdwa);
   float* pdba = reinterpret_cast<float*>(w + pl.off_pdba);
   float* dz = reinterpret_cast<float*>(w + pl.off_dz);
-  float* dZatt = reinterpret_cast<float*>(w + pl.off_dzatt);
+  // APA_FLAG_DXATT_RANK1: the caller's dXatt buffer is fp32 [N*P] and receives dZ itself
+  const bool rank1 = (flags & APA_FLAG_DXATT_RANK1) != 0 && !fused;
+  float* dZatt = rank1 ? static_cast<float*>(dXatt) : reinterpret_cast<float*>(w + pl.off_dzatt);
   float* gemm_ws = reinterpret_cast<float*>(w + pl.off_gemm);
   float* sn_buf = pdba + pl.nblk;   // [N] floats: the pdba region is sized nblk + N
   const RngArgs r = rng_args(train, keep_prob, seed, offset, flags);
@@ -947,14 +950,16 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
     static const int use_v2 = env_int("APA_M1_GEMV_BWD2", 1);
     if (use_v2 && Ca % epv == 0 && Ca / epv <= 256) {   // register-resident form
       const int nthr = ((Ca / epv + 63) / 64) * 64;
-      if (dtype == APA_DTYPE_F32)
-        hipLaunchKernelGGL(m1_att_gemv_bwd2_kernel<float>, dim3(nb), dim3(nthr), 0, st,
-                           static_cast<const float*>(Xatt), Wa, dZatt, static_cast<float*>(dXatt),
-                           pdwa, pdba, NP, Ca);
-      else
-        hipLaunchKernelGGL(m1_att_gemv_bwd2_kernel<bf16_t>, dim3(nb), dim3(nthr), 0, st,
-                           static_cast<const bf16_t*>(Xatt), Wa, dZatt, static_cast<bf16_t*>(dXatt),
-                           pdwa, pdba, NP, Ca);
+#define APA_GB2(T, ST)                                                                        \
+  hipLaunchKernelGGL((m1_att_gemv_bwd2_kernel<T, ST>), dim3(nb), dim3(nthr), 0, st,               \
+                     static_cast<const T*>(Xatt), Wa, dZatt, ST ? static_cast<T*>(dXatt) : nullptr, \
+                     pdwa, pdba, NP, Ca)
+      if (dtype == APA_DTYPE_F32) { if (rank1) APA_GB2(float, false); else APA_GB2(float, true); }
+      else { if (rank1) APA_GB2(bf16_t, false); else APA_GB2(bf16_t, true); }
+#undef APA_GB2
+    } else if (rank1) {
+      set_error("APA_FLAG_DXATT_RANK1: Ca=%d not served by the register-resident GEMV", Ca);
+      return APA_ERR_UNSUPPORTED;
     } else if (dtype == APA_DTYPE_F32)
       hipLaunchKernelGGL(m1_att_gemv_bwd_kernel<float>, dim3(nb), dim3(256), shm, st,
                          static_cast<const float*>(Xatt), Wa, dZatt, static_cast<float*>(dXatt),

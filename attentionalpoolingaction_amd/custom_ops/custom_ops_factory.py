@@ -32,6 +32,7 @@ APA_FLAG_RELU_ATT = 2
 APA_FLAG_TRAIN = 4
 APA_FLAG_RNG_DEVICE = 8
 APA_FLAG_RELU_INPUT = 16  # X in memory is the pre-activation map: relu fused into both passes
+APA_FLAG_DXATT_RANK1 = 32  # attn_pool_bwd returns dZ [N*P] instead of dXatt = dZ (x) Wa
 
 # every symbol include/apa.h declares: name -> (restype, argtypes)
 _SIGNATURES = {
@@ -48,6 +49,8 @@ _SIGNATURES = {
     'apa_pose_head_fwd': (c_int, [c_void_p] * 8 + [c_size_t] + [c_int] * 6 + [c_void_p]),
     'apa_pose_head_bwd': (c_int, [c_void_p] * 7 + [c_int] + [c_void_p] * 5 + [c_size_t] + [c_int] * 6 +
                           [c_void_p]),
+    'apa_pose_head_bwd_rank1ext': (c_int, [c_void_p] * 8 + [c_int] + [c_void_p] * 5 + [c_size_t] + [c_int] * 6 +
+                                   [c_void_p]),
     'apa_softmax_xent_fwd_bwd': (c_int, [c_void_p] * 6 + [c_int, c_int, c_float, c_float, c_void_p]),
     'apa_pose_l2_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'apa_pose_l2_loss_fwd_bwd': (c_int, [c_void_p] * 6 + [c_size_t, c_int, c_int, c_int, c_float,
@@ -203,9 +206,11 @@ def attn_pool_fwd(X, Xatt, Wa, ba, Wt, bt, *, flags=0, keep_prob=1.0, seed=0, of
 
 
 def attn_pool_bwd(X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, *, flags=0, keep_prob=1.0, seed=0,
-                  offset=0, workspace=None, out=None):
+                  offset=0, workspace=None, out=None, dxatt_rank1=False):
     """dX, dXatt, dWa, dba, dWt, dbt = attn_pool_bwd(...).  `out` may supply preallocated
-    (dX, dXatt, dWa, dba, dWt, dbt) buffers (e.g. views into a flat DP gradient bucket)."""
+    (dX, dXatt, dWa, dba, dWt, dbt) buffers (e.g. views into a flat DP gradient bucket).
+    `dxatt_rank1=True` (separate attention input, one bottom-up map): the second result is dZ, f32
+    [N*P], with dXatt = dZ (x) Wa left to the consumer (APA_FLAG_DXATT_RANK1)."""
     lib = load_library()
     N = X.shape[0]
     C = X.shape[-1]
@@ -216,9 +221,16 @@ def attn_pool_bwd(X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, *, flags=0, keep
     dt = _feat_dtype(X)
     dev = X.device
     fused = Xatt is X
+    if dxatt_rank1 and not fused:
+        flags |= APA_FLAG_DXATT_RANK1
     if out is None:
         dX = torch.empty_like(X)
-        dXatt = None if fused else torch.empty_like(Xatt)
+        if fused:
+            dXatt = None
+        elif dxatt_rank1:
+            dXatt = torch.empty((N * P,), dtype=torch.float32, device=dev)
+        else:
+            dXatt = torch.empty_like(Xatt)
         dWa = torch.empty_like(Wa)
         dba = torch.empty_like(ba)
         dWt = torch.empty_like(Wt)
@@ -275,10 +287,13 @@ def pose_head_fwd(X, W1, b1, W2, b2, workspace=None):
     return Ppre, Pl, workspace
 
 
-def pose_head_bwd(X, W1, W2, Ppre, dPl, dPpre_ext, *, dX=None, accumulate_dX=False, workspace=None):
+def pose_head_bwd(X, W1, W2, Ppre, dPl, dPpre_ext, *, dX=None, accumulate_dX=False, workspace=None,
+                  ext_rank1=None):
     """dX, dW1, db1, dW2, db2 = pose_head_bwd(...).  dPl: pose-loss gradient [..,J] f32 or None;
     dPpre_ext: gradient from the attention branch [..,Cp] (dtype of X) or None.  With
-    accumulate_dX the product dPpre.W1^T is ADDED to the given dX buffer."""
+    accumulate_dX the product dPpre.W1^T is ADDED to the given dX buffer.  `ext_rank1=(row, col)`:
+    the attention-branch gradient in rank-1 form row [N*P] (x) col [Cp], both f32
+    (apa_pose_head_bwd_rank1ext; dPpre_ext must then be None)."""
     lib = load_library()
     N, C = X.shape[0], X.shape[-1]
     P = X.numel() // (N * C)
@@ -293,6 +308,21 @@ def pose_head_bwd(X, W1, W2, Ppre, dPl, dPpre_ext, *, dX=None, accumulate_dX=Fal
         dX = torch.empty_like(X)
     dW1, db1 = torch.empty_like(W1), torch.empty((Cp,), dtype=torch.float32, device=X.device)
     dW2, db2 = torch.empty_like(W2), torch.empty((J,), dtype=torch.float32, device=X.device)
+    if ext_rank1 is not None:
+        if dPpre_ext is not None:
+            raise ApaError('give the attention-branch gradient either as a tensor or in rank-1 form')
+        row, col = ext_rank1
+        if row.numel() != N * P or col.numel() != Cp:
+            raise ApaError('ext_rank1: row must have N*P = {} and col Cp = {} elements'.format(N * P, Cp))
+        rc = lib.apa_pose_head_bwd_rank1ext(
+            _dev_ptr(X, 'X'), _dev_ptr(W1, 'W1', torch.float32), _dev_ptr(W2, 'W2', torch.float32),
+            _dev_ptr(Ppre, 'Ppre', X.dtype), _dev_ptr(dPl, 'dPl', torch.float32),
+            _dev_ptr(row, 'ext_row', torch.float32), _dev_ptr(col, 'ext_col', torch.float32),
+            _dev_ptr(dX, 'dX', X.dtype), 1 if accumulate_dX else 0, dW1.data_ptr(), db1.data_ptr(),
+            dW2.data_ptr(), db2.data_ptr(), workspace.data_ptr(), workspace.numel(), N, P, C, Cp, J, dt,
+            _stream_ptr())
+        _check(rc, 'apa_pose_head_bwd_rank1ext')
+        return dX, dW1, db1, dW2, db2
     rc = lib.apa_pose_head_bwd(
         _dev_ptr(X, 'X'), _dev_ptr(W1, 'W1', torch.float32), _dev_ptr(W2, 'W2', torch.float32),
         _dev_ptr(Ppre, 'Ppre', X.dtype), _dev_ptr(dPl, 'dPl', torch.float32),

@@ -106,6 +106,60 @@ class PoseHeadFunction(torch.autograd.Function):
         return dX, dW1, db1, dW2, db2
 
 
+class PoseAttentionFunction(torch.autograd.Function):
+    """cfg 003 in one autograd node: PoseLogits head -> attention map from its pre-logits -> pooling.
+    logits, att, Pl[, topdown] = f(X, W1, b1, W2, b2, Wa, ba, Wt, bt).
+
+    Keeping the two ops in one node lets the backward pass hand the attention-branch gradient to the
+    pose head in rank-1 form (dXatt = dZ (x) Wa: APA_FLAG_DXATT_RANK1 + apa_pose_head_bwd_rank1ext --
+    the [N,P,768] tensor is neither written nor read) and lets the pose head ADD its dX into the
+    pooling op's buffer instead of autograd summing two [N,P,2048] tensors."""
+
+    @staticmethod
+    def forward(ctx, X, W1, b1, W2, b2, Wa, ba, Wt, bt, flags, keep_prob, seed, offset, want_topdown):
+        Xc = X.contiguous()
+        W1c, W2c, Wac, Wtc = W1.contiguous(), W2.contiguous(), Wa.contiguous(), Wt.contiguous()
+        Ppre, Pl, pws = cof.pose_head_fwd(Xc, W1c, b1.contiguous(), W2c, b2.contiguous())
+        logits, att, zsave, abar, topdown, aws = cof.attn_pool_fwd(
+            Xc, Ppre, Wac, ba.contiguous(), Wtc, bt.contiguous(), flags=flags, keep_prob=keep_prob,
+            seed=seed, offset=offset, want_topdown=want_topdown)
+        ctx.save_for_backward(Xc, W1c, W2c, Ppre, Wac, ba, Wtc, bt, att, zsave, abar)
+        ctx.cfg = (flags, keep_prob, seed, offset)
+        ctx.ws = (pws, aws)
+        ctx.xshape = X.shape
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(att)
+        if topdown is not None:
+            ctx.mark_non_differentiable(topdown)
+        return logits, att, Pl, topdown
+
+    @staticmethod
+    def backward(ctx, dlogits, _datt, dPl, _dtd):
+        Xc, W1, W2, Ppre, Wa, ba, Wt, bt, att, zsave, abar = ctx.saved_tensors
+        flags, keep_prob, seed, offset = ctx.cfg
+        pws, aws = ctx.ws
+        dPl_c = None if dPl is None else dPl.contiguous().float()
+        if dlogits is None and dPl_c is None:
+            return (None,) * 14
+        dX = dZ = dWa = dba = dWt = dbt = None
+        if dlogits is not None:
+            epv = 4 if Xc.dtype == torch.float32 else 8
+            rank1 = Wa.shape[0] % epv == 0 and Wa.shape[0] // epv <= 256   # the register-resident GEMV
+            dX, dZ, dWa, dba, dWt, dbt = cof.attn_pool_bwd(
+                Xc, Ppre, Wa, ba.contiguous(), Wt, bt.contiguous(), att, zsave, abar,
+                dlogits.contiguous().float(), flags=flags, keep_prob=keep_prob, seed=seed, offset=offset,
+                workspace=aws, dxatt_rank1=rank1)
+            if rank1:
+                dX, dW1, db1, dW2, db2 = cof.pose_head_bwd(Xc, W1, W2, Ppre, dPl_c, None, dX=dX, accumulate_dX=True,
+                                                           workspace=pws, ext_rank1=(dZ, Wa.reshape(-1)))
+            else:
+                dX, dW1, db1, dW2, db2 = cof.pose_head_bwd(Xc, W1, W2, Ppre, dPl_c, dZ, dX=dX, accumulate_dX=True,
+                                                           workspace=pws)
+        else:
+            dX, dW1, db1, dW2, db2 = cof.pose_head_bwd(Xc, W1, W2, Ppre, dPl_c, None, workspace=pws)
+        return (dX.view(ctx.xshape), dW1, db1, dW2, db2, dWa, dba, dWt, dbt, None, None, None, None, None)
+
+
 def attentional_pooling(X, Xatt, Wa, ba, Wt, bt, *, softmax_att=False, relu_att=False,
                         is_training=False, keep_prob=0.2, seed=0, offset=0, want_topdown=False,
                         relu_input=False):
@@ -142,8 +196,9 @@ class AttentionalPoolingHead(nn.Module):
 
     def __init__(self, num_classes: int, cfg, in_channels: int = 2048, num_pose_keypoints: int = 16,
                  is_training: bool = False, seed: int = 42, with_pose_logits: Optional[bool] = None,
-                 want_topdown: bool = False):
+                 want_topdown: bool = False, fuse_pose_attention: bool = True):
         super().__init__()
+        self.fuse_pose_attention = fuse_pose_attention   # cfg 003: one autograd node for pose head + pooling
         net = cfg.NET
         if not net.USE_POSE_PRELOGITS_BASED_ATTENTION:
             raise ValueError('AttentionalPoolingHead needs cfg.NET.USE_POSE_PRELOGITS_BASED_ATTENTION')
@@ -239,6 +294,24 @@ class AttentionalPoolingHead(nn.Module):
             last_conv, preactivation = torch.relu(last_conv), False
         end_points: Dict[str, torch.Tensor] = {}
         pose_pre = None
+        if (not self.single_layer and self.rank == 1 and not self.per_class and not self.with_pose_feat
+                and self.fuse_pose_attention):
+            # cfg 003: pose head + attention on its pre-logits as one autograd node (rank-1 hand-over)
+            offset = self._step
+            if self.is_training:
+                self._step += 1
+            n, h, w = last_conv.shape[0], last_conv.shape[1], last_conv.shape[2]
+            flags = cof.attn_flags(self.softmax_att, self.relu_att, self.is_training)
+            logits, att, pose_logits, topdown = PoseAttentionFunction.apply(
+                last_conv, self.pose_w1, self.pose_b1, self.pose_w2, self.pose_b2, self.att_weights,
+                self.att_biases, self.td_weights, self.td_biases, flags,
+                self.keep_prob if self.is_training else 1.0, self.seed, offset, self.want_topdown)
+            end_points['PoseLogits'] = pose_logits
+            end_points['PosePrelogitsBasedAttention'] = att.view(n, h, w, -1)
+            if topdown is not None:
+                end_points['TopDownAttention'] = topdown.view(n, h, w, -1)
+            end_points['Logits'] = logits
+            return logits, end_points
         if self.with_pose_logits or not self.single_layer:          # :147-160
             pose_pre, pose_logits = PoseHeadFunction.apply(last_conv, self.pose_w1, self.pose_b1,
                                                            self.pose_w2, self.pose_b2)

@@ -63,6 +63,11 @@ typedef enum apa_status {
                                 /* so the ReLU's own read+write of the map and its backward pass    */
                                 /* (2 + 3 streams of P*C*s bytes) disappear.    */
                                 /* M == 1, Xatt == X, C in {1024,2048,4096} (f32) / 2048 (bf16)     */
+#define APA_FLAG_DXATT_RANK1 32u /* apa_attn_pool_bwd, M == 1 with a separate attention input (cfg   */
+                                /* 003): the gradient w.r.t. Xatt is rank-1, dXatt = dZ (x) Wa; with  */
+                                /* this flag `dXatt` is an fp32 [N*P] buffer that receives dZ and the  */
+                                /* [N,P,Ca] tensor is never written (its consumer,                     */
+                                /* apa_pose_head_bwd_rank1ext, re-forms it in registers)              */
 
 int apa_version(void);
 /* Thread-local, never NULL; describes the last failure on the calling thread. */
@@ -136,6 +141,14 @@ int apa_pose_head_bwd(const void* X, const float* W1, const float* W2, const voi
                       const float* dPl, const void* dPpre_ext, void* dX, int accumulate_dX, float* dW1,
                       float* db1, float* dW2, float* db2, void* ws, size_t ws_bytes, int N, int P, int C,
                       int Cp, int J, int dtype, void* stream);
+/* Same, with the external gradient in rank-1 form: dPpre_ext[r,j] = ext_row[r] * ext_col[j]
+ * (ext_row f32 [N*P] = the dZ that apa_attn_pool_bwd returns under APA_FLAG_DXATT_RANK1, ext_col f32
+ * [Cp] = the attention weights Wa): one write and one read of an [N,P,Cp] tensor less per step. */
+int apa_pose_head_bwd_rank1ext(const void* X, const float* W1, const float* W2, const void* Ppre,
+                               const float* dPl, const float* ext_row, const float* ext_col, void* dX,
+                               int accumulate_dX, float* dW1, float* db1, float* dW2, float* db2,
+                               void* ws, size_t ws_bytes, int N, int P, int C, int Cp, int J, int dtype,
+                               void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Action loss: tf.losses.softmax_cross_entropy(one_hot(labels,K), logits, weights=wt)

@@ -128,15 +128,20 @@ def test_head_module_autograd_matches_oracle_cfg002(gpu):
     apa_config.reset_cfg()
 
 
-def test_head_module_cfg003_pose_attention_with_pose_loss(gpu):
+@pytest.mark.parametrize('fuse,softmax', [(True, False), (False, False), (True, True)])
+def test_head_module_cfg003_pose_attention_with_pose_loss(gpu, fuse, softmax):
     """cfg 003 through the module surface: PoseLogits end point, attention from pose_pre_logits,
-    gen_losses with the pose L2 term; all eight parameter gradients vs the oracle."""
+    gen_losses with the pose L2 term; all eight parameter gradients vs the oracle.  fuse=True: pose head
+    and pooling as ONE autograd node -- the attention-branch gradient reaches the pose head in rank-1
+    form (APA_FLAG_DXATT_RANK1 + apa_pose_head_bwd_rank1ext) and dX is accumulated in place; fuse=False:
+    two nodes, the [N,P,768] gradient tensor in between, autograd sums the two dX."""
     from attentionalpoolingaction_amd import config as apa_config, loss as apa_loss, nets_factory
     cfg = apa_config.reset_cfg()
-    apa_config.cfg_from_dict({'NET': {'USE_POSE_PRELOGITS_BASED_ATTENTION': True},
+    apa_config.cfg_from_dict({'NET': {'USE_POSE_PRELOGITS_BASED_ATTENTION': True,
+                                      'USE_POSE_PRELOGITS_BASED_ATTENTION_SOFTMAX_ATT': softmax},
                               'TRAIN': {'LOSS_FN_POSE': 'l2'}})
     fn = nets_factory.get_network_fn('resnet_v1_101', 51, 16, cfg, is_training=False, device=gpu,
-                                     with_pose_logits=True)
+                                     with_pose_logits=True, fuse_pose_attention=fuse)
     head = fn.head
     g = torch.Generator().manual_seed(8)
     with torch.no_grad():
@@ -159,12 +164,60 @@ def test_head_module_cfg003_pose_attention_with_pose_loss(gpu):
     pre, pl = orc.pose_logits_head(Xr, p['pose_w1'], p['pose_b1'], p['pose_w2'], p['pose_b2'])
     lr, _ = orc.attentional_pooling(Xr, pre, pl, [p['att_weights']], [p['att_biases']],
                                     [p['td_weights']], [p['td_biases']],
-                                    orc.AttnFlags(single_layer_att=False))
+                                    orc.AttnFlags(single_layer_att=False, softmax_att=softmax))
     sum(orc.gen_losses(labels, lr, 'softmax-xentropy', 51, 1.0, pose_lbl.double(), pl, 'l2', valid, 1.0)).backward()
     assert _rel(logits.detach().cpu().numpy(), lr.detach().numpy()) < 2e-5
     assert _rel(Xd.grad.cpu().numpy(), Xr.grad.numpy()) < 1e-4
     for k, v in head.named_parameters():
+        if softmax and k == 'att_biases':      # softmax is shift-invariant: this gradient is exactly 0
+            assert float(v.grad.abs().max()) < 1e-6
+            continue
         assert _rel(v.grad.cpu().numpy(), p[k].grad.numpy()) < 1e-4, k
+    apa_config.reset_cfg()
+
+
+def test_cfg003_fused_node_matches_two_nodes_bf16_and_single_loss_cases(gpu):
+    """PoseAttentionFunction against the two separate autograd nodes, bf16 features: same logits
+    (identical forward kernels), gradients within bf16 resolution (the rank-1 hand-over skips one bf16
+    rounding of the attention-branch gradient); and the two degenerate backward calls -- only the action
+    loss (no dPl) and only the pose loss (no dlogits)."""
+    from attentionalpoolingaction_amd import config as apa_config, nets_factory
+    cfg = apa_config.reset_cfg()
+    apa_config.cfg_from_dict({'NET': {'USE_POSE_PRELOGITS_BASED_ATTENTION': True}, 'TRAIN': {'LOSS_FN_POSE': 'l2'}})
+    heads = []
+    for fuse in (True, False):
+        torch.manual_seed(3)
+        heads.append(nets_factory.get_network_fn('resnet_v1_101', 51, 16, cfg, is_training=False, device=gpu,
+                                                 with_pose_logits=True, fuse_pose_attention=fuse).head)
+    g = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        for name, prm in heads[0].named_parameters():
+            scale = 1.0 / prm.shape[0] ** 0.5 if prm.dim() == 2 else 0.1
+            prm.copy_((torch.randn(prm.shape, generator=g) * scale).to(gpu))
+    heads[1].load_state_dict(heads[0].state_dict())
+    X = torch.relu(torch.randn(3, 7, 7, 2048, generator=g)).bfloat16().to(gpu)
+    labels = torch.tensor([1, 7, 30], device=gpu)
+    for mode in ('both', 'action', 'pose'):
+        grads = []
+        for head in heads:
+            head.zero_grad()
+            Xd = X.clone().requires_grad_(True)
+            logits, ep = head(Xd)
+            loss = 0.0
+            if mode in ('both', 'action'):
+                loss = loss + torch.nn.functional.cross_entropy(logits, labels)
+            if mode in ('both', 'pose'):
+                loss = loss + (ep['PoseLogits'] ** 2).mean()
+            loss.backward()
+            grads.append((logits.detach(), Xd.grad.float(), {k: (None if v.grad is None else v.grad.clone())
+                                                              for k, v in head.named_parameters()}))
+        assert torch.equal(grads[0][0], grads[1][0])
+        assert _rel(grads[0][1].cpu().numpy(), grads[1][1].cpu().numpy()) < 2e-2, mode
+        for k in grads[0][2]:
+            a, b = grads[0][2][k], grads[1][2][k]
+            assert (a is None) == (b is None), (mode, k)
+            if a is not None:
+                assert _rel(a.cpu().numpy(), b.cpu().numpy()) < 2e-2, (mode, k)
     apa_config.reset_cfg()
 
 

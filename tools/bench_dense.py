@@ -49,6 +49,8 @@ def main():
     ap.add_argument('--hw', type=int, default=14)
     ap.add_argument('--classes', type=int, default=None)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-rank1', action='store_true',
+                    help='cfg003: materialise the [N,P,768] attention-branch gradient between the two backward calls')
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
     args = ap.parse_args()
@@ -71,6 +73,7 @@ def main():
         flags = cof.attn_flags(False, False, True)
         ctr = torch.zeros(1, dtype=torch.int64, device=dev)
         pws = aws = None
+        wa_flat = Wa.view(-1)
 
         def step():
             nonlocal pws, aws
@@ -79,9 +82,14 @@ def main():
                                                            seed=42, offset=ctr, workspace=aws)
             _, G, _, _ = cof.softmax_xent_fwd_bwd(logits, labels)
             _, dPl = cof.pose_l2_loss_fwd_bwd(Pl, lbl, valid)
-            dX, dXatt, *_ = cof.attn_pool_bwd(X, Ppre, Wa, ba, Wt, bt, att, zs, ab, G, flags=flags, keep_prob=0.2,
-                                              seed=42, offset=ctr, workspace=aws)
-            cof.pose_head_bwd(X, W1, W2, Ppre, dPl, dXatt, dX=dX, accumulate_dX=True, workspace=pws)
+            # the attention-branch gradient crosses to the pose head in rank-1 form (dZ, wa)
+            dX, dZ, *_ = cof.attn_pool_bwd(X, Ppre, Wa, ba, Wt, bt, att, zs, ab, G, flags=flags, keep_prob=0.2,
+                                           seed=42, offset=ctr, workspace=aws, dxatt_rank1=not args.no_rank1)
+            if args.no_rank1:
+                cof.pose_head_bwd(X, W1, W2, Ppre, dPl, dZ, dX=dX, accumulate_dX=True, workspace=pws)
+            else:
+                cof.pose_head_bwd(X, W1, W2, Ppre, dPl, None, dX=dX, accumulate_dX=True, workspace=pws,
+                                  ext_rank1=(dZ, wa_flat))
 
         flops_img = 3 * (2.0 * P * C * Cp + 2.0 * P * Cp * J)          # fwd + 2x bwd
         name = 'cfg003 pose-regularised attention head fwd+bwd (pose head 2048->768->16 + M=1 pooling)'
