@@ -87,7 +87,10 @@ __global__ __launch_bounds__(512) void pose_dppre_kernel(const float* __restrict
   __builtin_amdgcn_sched_barrier(0);
   // (Two attempts to take W2 off the per-lane path -- more rows per block, and a coalesced read +
   // LDS transposition -- both measured SLOWER (22 / 21 us vs 16 us): they cost occupancy, and this
-  // kernel lives on having ~5 blocks per CU in flight.)
+  // kernel lives on having ~5 blocks per CU in flight.)  Ablation of the rank-1 form (14.1 us): without
+  // the W2 slice loads 10.3, also without the FMA loop 8.1, also without the output stores 6.6 us --
+  // no single phase dominates; each block runs load -> compute -> store once, unpipelined, and only
+  // ~3 blocks per CU exist to overlap them.  A multi-group block with explicit prefetch is the next step.
   float w[4][JMAX];
   if (dPl && active && J == JMAX) {   // the 4 x J slice of W2 is one contiguous, 16-byte aligned span
     const float4* wsrc = reinterpret_cast<const float4*>(W2 + (size_t)j0 * J);
