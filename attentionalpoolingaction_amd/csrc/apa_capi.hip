@@ -259,6 +259,11 @@ static int attn_pool_bwd_impl(const M1Xent* xf, const void* X, const void* Xatt,
     set_error("apa_attn_pool_bwd: APA_FLAG_RELU_INPUT is an M == 1 fast path");
     return APA_ERR_UNSUPPORTED;
   }
+  if ((flags & APA_FLAG_DXATT_RANK1) && M != 1) {
+    set_error("apa_attn_pool_bwd: APA_FLAG_DXATT_RANK1 needs one bottom-up map (M == 1): with per-class "
+              "maps the gradient w.r.t. Xatt has rank K");
+    return APA_ERR_UNSUPPORTED;
+  }
   if (M == 1) {
     if (!zsave || !abar) {
       set_error("apa_attn_pool_bwd: M==1 needs zsave and abar from the forward call");

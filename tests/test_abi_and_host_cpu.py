@@ -52,6 +52,9 @@ def test_header_constants_match_the_python_binding():
     assert rc == -1 and b'null' in lib.apa_last_error()
     rc = lib.apa_attn_head_eval_step(*([None] * 15), 0, 2, 4, 2048, 2048, 5, 1, 0, 0, None)
     assert rc == -1 and b'null' in lib.apa_last_error()
+    rc = lib.apa_pose_head_bwd_rank1ext(*([None] * 8), 0, *([None] * 5), 0, 2, 4, 2048, 768, 16, 0, None)
+    assert rc == -1 and b'null' in lib.apa_last_error()
+    assert cof.APA_FLAG_DXATT_RANK1 == defs['APA_FLAG_DXATT_RANK1'] == 32
 
 
 def test_status_strings_and_error_paths_without_gpu():

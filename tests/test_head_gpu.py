@@ -526,6 +526,21 @@ def test_relu_input_flag_equals_explicit_relu(gpu, C, dtype, softmax, train):
         assert torch.equal(ref[i], got[i]), name
 
 
+def test_dxatt_rank1_flag_is_rejected_for_per_class_maps(gpu):
+    """APA_FLAG_DXATT_RANK1 only exists for one bottom-up map: with M = K the gradient w.r.t. the attention
+    input has rank K and the caller's [N*P] buffer would be overrun -- the call must fail loudly."""
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    N, P, C, K = 2, 9, 2048, 8
+    X = torch.randn(N, P, C, device=gpu)
+    Xatt = torch.randn(N, P, 768, device=gpu)
+    Wa, ba = torch.randn(768, K, device=gpu) * 0.03, torch.zeros(K, device=gpu)
+    Wt, bt = torch.randn(C, K, device=gpu) * 0.03, torch.zeros(K, device=gpu)
+    logits, att, zsave, abar, _, ws = cof.attn_pool_fwd(X, Xatt, Wa, ba, Wt, bt)
+    G = torch.randn(N, K, device=gpu)
+    with pytest.raises(cof.ApaError):
+        cof.attn_pool_bwd(X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, workspace=ws, dxatt_rank1=True)
+
+
 def test_relu_input_flag_rejects_paths_without_the_fused_kernels(gpu):
     from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
     N, P, K = 2, 9, 8
