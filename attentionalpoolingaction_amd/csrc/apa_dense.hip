@@ -313,9 +313,7 @@ static int pose_head_bwd_impl(const void* X, const float* W1, const float* W2, c
 #undef APA_DPPRE
   APA_LAUNCH_CHECK("pose_dppre_kernel");
   // db1 = column sums of dPpre, db2 = column sums of dPl (fixed-order reduce of the block partials)
-  int rc = m1_colsum(partial, nullptr, db1, nullptr, pl.nchunks, Cp, Cp + J, nullptr, st);
-  if (rc != APA_OK) return rc;
-  rc = m1_colsum(partial + Cp, nullptr, db2, nullptr, pl.nchunks, J, Cp + J, nullptr, st);
+  int rc = m1_colsum(partial, nullptr, db1, nullptr, pl.nchunks, Cp + J, Cp + J, nullptr, st, db2, Cp);
   if (rc != APA_OK) return rc;
 
   if (dPl) {  // dW2[j,q] = sum_r Ppre[r,j] dPl[r,q]
@@ -549,8 +547,8 @@ __global__ __launch_bounds__(1024) void pc_bwd_act_kernel(const float* __restric
   red2[pg][kk] = sdz;
   __syncthreads();
   if (pg == 0 && ok) {
-    pdbt[(size_t)n * K + k] = pc_colsum(red, kk);
-    pdba[(size_t)n * K + k] = pc_colsum(red2, kk);
+    pdbt[(size_t)n * 2 * K + k] = pc_colsum(red, kk);       // one [N][2K] partial matrix: dbt | dba
+    pdba[(size_t)n * 2 * K + k] = pc_colsum(red2, kk);
   }
 }
 
@@ -571,8 +569,8 @@ static PcPlan pc_plan(int N, int P, int C, int Ca, int K, int dtype) {
   pl.off_z = off;    off += align_up((size_t)pl.R * pl.Kp * 4, 256);
   pl.off_dt = off;   off += align_up((size_t)pl.R * pl.Kp * dt_size(dtype), 256);
   pl.off_dz = off;   off += align_up((size_t)pl.R * pl.Kp * dt_size(dtype), 256);
-  pl.off_pdbt = off; off += align_up((size_t)N * K * 4, 256);
-  pl.off_pdba = off; off += align_up((size_t)N * K * 4, 256);
+  pl.off_pdbt = off; off += align_up((size_t)N * 2 * K * 4, 256);   // [N][2K]: dbt | dba partials
+  pl.off_pdba = pl.off_pdbt + (size_t)K * 4;
   const int cm = C > Ca ? C : Ca;
   {
     size_t g = gemm_ws_bytes(cm, K, 32);
@@ -740,9 +738,7 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
                        static_cast<bf16_t*>(dT), static_cast<bf16_t*>(dZ), pdbt, pdba, P, K, Kp,
                        act_code(flags));
   APA_LAUNCH_CHECK("pc_bwd_act_kernel");
-  int rc = m1_colsum(pdbt, nullptr, dbt, nullptr, N, K, K, nullptr, st);
-  if (rc != APA_OK) return rc;
-  rc = m1_colsum(pdba, nullptr, dba, nullptr, N, K, K, nullptr, st);
+  int rc = m1_colsum(pdbt, nullptr, dbt, nullptr, N, 2 * K, 2 * K, nullptr, st, dba, K);
   if (rc != APA_OK) return rc;
   {  // dWt[c,k] = sum_r Xt[r,c] dT[r,k]
     GemmDesc g;

@@ -178,8 +178,9 @@ bool m1_logits_xent_supported(int N, int C, int K, bool eval);
 int m1_logits2_xent(const float* z, const float* Wt, const float* abar, const float* bt,
                     const int64_t* labels, float* logits, float* loss, float* G, float gscale,
                     float* probs, int64_t* pred, float* part_ws, int N, int C, int K, hipStream_t st);
+// dwa2 != nullptr: columns [C1, C) of the partial matrix are summed into dwa2 instead (one launch, two outputs)
 int m1_colsum(const float* pdwa, const float* pdba, float* dwa, float* dba, int nblk, int C, int ld,
-              uint64_t* rng_bump, hipStream_t st);
+              uint64_t* rng_bump, hipStream_t st, float* dwa2 = nullptr, int C1 = 0);
 
 // apa_dense.hip: per-class bottom-up maps (M == K); Tsave = fp32 [N,P,K] top-down map saved for bwd
 size_t pc_workspace_bytes(int N, int P, int C, int Ca, int K, int dtype);

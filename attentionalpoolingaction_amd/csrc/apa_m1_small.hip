@@ -675,11 +675,14 @@ __global__ __launch_bounds__(256) void m1_bwd_head_kernel(
 // grid = ceil(C/32) blocks of 1024 threads: 32 row groups x 32 columns, 128-byte row segments.
 // The last kernel of the backward call: optionally advances the HBM dropout counter.
 // --------------------------------------------------------------------------------------------
+// Columns [0, C1) go to dwa, columns [C1, C) to dwa2 (two outputs from one partial matrix, e.g.
+// db1 | db2 of the pose head); C1 == C for a single output.
 __global__ __launch_bounds__(1024) void m1_colsum_kernel(const float* __restrict__ pdwa,
                                                          const float* __restrict__ pdba,
                                                          float* __restrict__ dwa,
                                                          float* __restrict__ dba, int nblk, int C,
-                                                         int ld, uint64_t* __restrict__ rng_bump) {
+                                                         int ld, uint64_t* __restrict__ rng_bump,
+                                                         float* __restrict__ dwa2, int C1) {
   __shared__ float red[32][33];
   const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + col;
@@ -708,7 +711,8 @@ __global__ __launch_bounds__(1024) void m1_colsum_kernel(const float* __restrict
     float s = 0.f;
 #pragma unroll
     for (int g = 0; g < 32; ++g) s += red[g][col];
-    dwa[c] = s;
+    if (c < C1) dwa[c] = s;
+    else dwa2[c - C1] = s;
   }
   if (blockIdx.x == 0 && pdba) {
     __syncthreads();
@@ -862,9 +866,10 @@ int m1_bwd_head(const float* G, const float* Wt, const float* zsave, const float
 }
 
 int m1_colsum(const float* pdwa, const float* pdba, float* dwa, float* dba, int nblk, int C, int ld,
-              uint64_t* rng_bump, hipStream_t st) {
+              uint64_t* rng_bump, hipStream_t st, float* dwa2, int C1) {
+  if (!dwa2) C1 = C;
   hipLaunchKernelGGL(m1_colsum_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, pdwa, pdba, dwa, dba,
-                     nblk, C, ld, rng_bump);
+                     nblk, C, ld, rng_bump, dwa2, C1);
   APA_LAUNCH_CHECK("m1_colsum_kernel");
   return APA_OK;
 }
