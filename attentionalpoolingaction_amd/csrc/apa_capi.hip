@@ -21,21 +21,6 @@ int hip_fail(hipError_t e, const char* what) {
   return APA_ERR_HIP;
 }
 
-static thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
-static thread_local hipEvent_t g_null_start = nullptr, g_null_stop = nullptr;
-void prof_kernel_events(hipEvent_t* start, hipEvent_t* stop) {
-  *start = g_prof_start;
-  *stop = g_prof_stop;
-}
-static thread_local hipEvent_t g_grad_ready = nullptr;
-hipEvent_t grad_ready_event() { return g_grad_ready; }
-static thread_local hipEvent_t g_td_ready = nullptr;
-hipEvent_t td_weights_ready_event() { return g_td_ready; }
-void prof_null_events(hipEvent_t* start, hipEvent_t* stop) {
-  *start = g_null_start;
-  *stop = g_null_stop;
-}
-
 #ifdef APA_ABLATION
 int g_dbg_skip = [] { const char* e = getenv("APA_DBG_SKIP"); return e ? atoi(e) : 0; }();
 #endif
@@ -51,18 +36,9 @@ extern "C" void apa_debug_set_skip(int mask) { apa::g_dbg_skip = mask; }
 
 extern "C" int apa_prof_event_create(void** event) {
   if (!event) { set_error("apa_prof_event_create: null"); return APA_ERR_INVALID_ARG; }
-  // Timing-only events: no system-scope fence at the record (hip_runtime_api.h,
-  // hipEventDisableSystemFence: "can improve the accuracy of timing measurements by avoiding the
-  // cost of cache writeback and invalidation"); APA_PROF_EVENT_FLAGS overrides (0 = hipEventDefault).
-  static const unsigned flags = [] {
-    const char* e = getenv("APA_PROF_EVENT_FLAGS");
-    return e ? (unsigned)strtoul(e, nullptr, 0) : (unsigned)hipEventDisableSystemFence;
-  }();
+  // default flags: timing enabled; the events are stamped by hipExtLaunchKernel (dispatch begin / end)
   hipEvent_t e;
-  if (hipEventCreateWithFlags(&e, flags) != hipSuccess) {
-    (void)hipGetLastError();
-    APA_HIP_CHECK(hipEventCreate(&e));
-  }
+  APA_HIP_CHECK(hipEventCreate(&e));
   *event = e;
   return APA_OK;
 }
@@ -80,28 +56,6 @@ extern "C" int apa_prof_event_elapsed_ms(void* start, void* stop, float* ms) {
   APA_HIP_CHECK(hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)));
   return APA_OK;
 }
-extern "C" int apa_prof_set_kernel_events(void* start, void* stop) {
-  g_prof_start = static_cast<hipEvent_t>(start);
-  g_prof_stop = static_cast<hipEvent_t>(stop);
-  return APA_OK;
-}
-
-extern "C" int apa_set_grad_ready_event(void* event) {
-  g_grad_ready = static_cast<hipEvent_t>(event);
-  return APA_OK;
-}
-
-extern "C" int apa_set_td_weights_ready_event(void* event) {
-  g_td_ready = static_cast<hipEvent_t>(event);
-  return APA_OK;
-}
-
-extern "C" int apa_prof_set_null_events(void* start, void* stop) {
-  g_null_start = static_cast<hipEvent_t>(start);
-  g_null_stop = static_cast<hipEvent_t>(stop);
-  return APA_OK;
-}
-
 extern "C" int apa_version(void) { return APA_VERSION; }
 
 extern "C" const char* apa_last_error(void) { return g_err; }
@@ -146,7 +100,7 @@ extern "C" size_t apa_attn_pool_workspace_bytes(int N, int P, int C, int Ca, int
   return 0;
 }
 
-static int attn_pool_fwd_impl(M1Xent* xf, const void* X, const void* Xatt, const float* Wa, const float* ba,
+static int attn_pool_fwd_impl(const Hooks& hk, M1Xent* xf, const void* X, const void* Xatt, const float* Wa, const float* ba,
                                  const float* Wt, const float* bt, float* logits, float* att,
                                  float* zsave, float* abar, void* topdown, void* ws,
                                  size_t ws_bytes, int N, int P, int C, int Ca, int K, int M,
@@ -188,7 +142,7 @@ static int attn_pool_fwd_impl(M1Xent* xf, const void* X, const void* Xatt, const
       return APA_ERR_WORKSPACE;
     }
     rc = m1_forward(X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar, ws, N, P, C, Ca, K, flags,
-                    keep_prob, seed, offset, dtype, st, xf);
+                    keep_prob, seed, offset, dtype, st, xf, hk);
     if (rc != APA_OK || !topdown) return rc;
     // end_points['TopDownAttention'] = dropout(X).Wt + bt  (nets_factory.py:296-309): the factorised
     // path never needs it; it is materialised only on request (eval.py --ept dumps) by one GEMM.
@@ -218,7 +172,7 @@ static int attn_pool_fwd_impl(M1Xent* xf, const void* X, const void* Xatt, const
     set_error("apa_attn_pool_fwd: workspace too small (%zu < %zu)", ws_bytes, need);
     return APA_ERR_WORKSPACE;
   }
-  if (td_weights_ready_event()) APA_HIP_CHECK(hipStreamWaitEvent(st, td_weights_ready_event(), 0));
+  if (hk.td_ready) APA_HIP_CHECK(hipStreamWaitEvent(st, hk.td_ready, 0));
   return pc_forward(X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, topdown, ws, N, P, C, Ca, K, flags,
                     keep_prob, seed, offset, dtype, st);
 }
@@ -229,11 +183,21 @@ extern "C" int apa_attn_pool_fwd(const void* X, const void* Xatt, const float* W
                                  size_t ws_bytes, int N, int P, int C, int Ca, int K, int M,
                                  unsigned flags, float keep_prob, uint64_t seed, uint64_t offset,
                                  int dtype, void* stream) {
-  return attn_pool_fwd_impl(nullptr, X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar, topdown, ws,
+  return attn_pool_fwd_impl(Hooks(), nullptr, X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar, topdown, ws,
                             ws_bytes, N, P, C, Ca, K, M, flags, keep_prob, seed, offset, dtype, stream);
 }
 
-static int attn_pool_bwd_impl(const M1Xent* xf, const void* X, const void* Xatt, const float* Wa, const float* ba,
+extern "C" int apa_attn_pool_fwd_ex(const apa_hooks* hooks, const void* X, const void* Xatt,
+                                    const float* Wa, const float* ba, const float* Wt, const float* bt,
+                                    float* logits, float* att, float* zsave, float* abar, void* topdown,
+                                    void* ws, size_t ws_bytes, int N, int P, int C, int Ca, int K, int M,
+                                    unsigned flags, float keep_prob, uint64_t seed, uint64_t offset,
+                                    int dtype, void* stream) {
+  return attn_pool_fwd_impl(Hooks(hooks), nullptr, X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar, topdown,
+                            ws, ws_bytes, N, P, C, Ca, K, M, flags, keep_prob, seed, offset, dtype, stream);
+}
+
+static int attn_pool_bwd_impl(const Hooks& hk, const M1Xent* xf, const void* X, const void* Xatt, const float* Wa, const float* ba,
                                  const float* Wt, const float* bt, const float* att,
                                  const float* zsave, const float* abar, const float* G, void* dX,
                                  void* dXatt, float* dWa, float* dba, float* dWt, float* dbt,
@@ -279,7 +243,7 @@ static int attn_pool_bwd_impl(const M1Xent* xf, const void* X, const void* Xatt,
       return APA_ERR_WORKSPACE;
     }
     return m1_backward(X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, dX, dXatt, dWa, dba, dWt, dbt,
-                       ws, N, P, C, Ca, K, flags, keep_prob, seed, offset, dtype, st, xf);
+                       ws, N, P, C, Ca, K, flags, keep_prob, seed, offset, dtype, st, xf, hk);
   }
   if (!zsave) {
     set_error("apa_attn_pool_bwd: M==K needs zsave (the fp32 [N,P,K] top-down map from forward)");
@@ -292,7 +256,7 @@ static int attn_pool_bwd_impl(const M1Xent* xf, const void* X, const void* Xatt,
   }
   rc = pc_backward(X, Xatt, Wa, Wt, att, zsave, G, dX, dXatt, dWa, dba, dWt, dbt, ws, N, P, C, Ca, K,
                    flags, keep_prob, seed, offset, dtype, st);
-  if (rc == APA_OK && grad_ready_event()) APA_HIP_CHECK(hipEventRecord(grad_ready_event(), st));
+  if (rc == APA_OK && hk.grad_ready) APA_HIP_CHECK(hipEventRecord(hk.grad_ready, st));
   return rc;
 }
 
@@ -303,20 +267,33 @@ extern "C" int apa_attn_pool_bwd(const void* X, const void* Xatt, const float* W
                                  void* ws, size_t ws_bytes, int N, int P, int C, int Ca, int K,
                                  int M, unsigned flags, float keep_prob, uint64_t seed,
                                  uint64_t offset, int dtype, void* stream) {
-  return attn_pool_bwd_impl(nullptr, X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, dX, dXatt, dWa, dba,
+  return attn_pool_bwd_impl(Hooks(), nullptr, X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, dX, dXatt, dWa, dba,
                             dWt, dbt, ws, ws_bytes, N, P, C, Ca, K, M, flags, keep_prob, seed, offset,
                             dtype, stream);
 }
 
-extern "C" int apa_attn_head_train_step(const void* X, const void* Xatt, const float* Wa,
-                                        const float* ba, const float* Wt, const float* bt,
-                                        const int64_t* labels, float loss_wt, float grad_scale,
-                                        float* logits, float* att, float* zsave, float* abar,
-                                        float* loss, float* G, void* dX, void* dXatt, float* dWa,
-                                        float* dba, float* dWt, float* dbt, void* ws, size_t ws_bytes,
-                                        int N, int P, int C, int Ca, int K, int M, unsigned flags,
-                                        float keep_prob, uint64_t seed, uint64_t offset, int dtype,
-                                        void* stream) {
+extern "C" int apa_attn_pool_bwd_ex(const apa_hooks* hooks, const void* X, const void* Xatt,
+                                    const float* Wa, const float* ba, const float* Wt, const float* bt,
+                                    const float* att, const float* zsave, const float* abar,
+                                    const float* G, void* dX, void* dXatt, float* dWa, float* dba,
+                                    float* dWt, float* dbt, void* ws, size_t ws_bytes, int N, int P,
+                                    int C, int Ca, int K, int M, unsigned flags, float keep_prob,
+                                    uint64_t seed, uint64_t offset, int dtype, void* stream) {
+  return attn_pool_bwd_impl(Hooks(hooks), nullptr, X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, dX, dXatt,
+                            dWa, dba, dWt, dbt, ws, ws_bytes, N, P, C, Ca, K, M, flags, keep_prob, seed,
+                            offset, dtype, stream);
+}
+
+extern "C" int apa_attn_head_train_step_ex(const apa_hooks* hooks, const void* X, const void* Xatt,
+                                           const float* Wa, const float* ba, const float* Wt,
+                                           const float* bt, const int64_t* labels, float loss_wt,
+                                           float grad_scale, float* logits, float* att, float* zsave,
+                                           float* abar, float* loss, float* G, void* dX, void* dXatt,
+                                           float* dWa, float* dba, float* dWt, float* dbt, void* ws,
+                                           size_t ws_bytes, int N, int P, int C, int Ca, int K, int M,
+                                           unsigned flags, float keep_prob, uint64_t seed,
+                                           uint64_t offset, int dtype, void* stream) {
+  const Hooks hk(hooks);
   if (!labels || !loss || !G) {
     apa::set_error("apa_attn_head_train_step: null labels / loss / G pointer");
     return APA_ERR_INVALID_ARG;
@@ -329,7 +306,7 @@ extern "C" int apa_attn_head_train_step(const void* X, const void* Xatt, const f
   xf.lscale = N > 0 ? loss_wt / (float)N : 0.f;
   xf.gscale = N > 0 ? loss_wt * grad_scale / (float)N : 0.f;
   xf.done = false;
-  int rc = attn_pool_fwd_impl(M == 1 ? &xf : nullptr, X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar,
+  int rc = attn_pool_fwd_impl(hk, M == 1 ? &xf : nullptr, X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar,
                               nullptr, ws, ws_bytes, N, P, C, Ca, K, M, flags, keep_prob, seed, offset,
                               dtype, stream);
   if (rc != APA_OK) return rc;
@@ -338,9 +315,23 @@ extern "C" int apa_attn_head_train_step(const void* X, const void* Xatt, const f
                                   stream);
     if (rc != APA_OK) return rc;
   }
-  return attn_pool_bwd_impl(xf.done ? &xf : nullptr, X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, dX,
+  return attn_pool_bwd_impl(hk, xf.done ? &xf : nullptr, X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, dX,
                             dXatt, dWa, dba, dWt, dbt, ws, ws_bytes, N, P, C, Ca, K, M, flags, keep_prob,
                             seed, offset, dtype, stream);
+}
+
+extern "C" int apa_attn_head_train_step(const void* X, const void* Xatt, const float* Wa,
+                                        const float* ba, const float* Wt, const float* bt,
+                                        const int64_t* labels, float loss_wt, float grad_scale,
+                                        float* logits, float* att, float* zsave, float* abar,
+                                        float* loss, float* G, void* dX, void* dXatt, float* dWa,
+                                        float* dba, float* dWt, float* dbt, void* ws, size_t ws_bytes,
+                                        int N, int P, int C, int Ca, int K, int M, unsigned flags,
+                                        float keep_prob, uint64_t seed, uint64_t offset, int dtype,
+                                        void* stream) {
+  return apa_attn_head_train_step_ex(nullptr, X, Xatt, Wa, ba, Wt, bt, labels, loss_wt, grad_scale, logits,
+                                     att, zsave, abar, loss, G, dX, dXatt, dWa, dba, dWt, dbt, ws, ws_bytes,
+                                     N, P, C, Ca, K, M, flags, keep_prob, seed, offset, dtype, stream);
 }
 
 extern "C" int apa_attn_head_eval_step(const void* X, const void* Xatt, const float* Wa, const float* ba,
@@ -362,7 +353,7 @@ extern "C" int apa_attn_head_eval_step(const void* X, const void* Xatt, const fl
   M1Xent xf;
   xf.labels = nullptr; xf.loss = nullptr; xf.G = nullptr; xf.gscale = 0.f; xf.lscale = 0.f; xf.done = false;
   xf.probs = probs; xf.pred = pred;
-  int rc = attn_pool_fwd_impl((M == 1 && !labels) ? &xf : nullptr, X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar, nullptr, ws,
+  int rc = attn_pool_fwd_impl(Hooks(), (M == 1 && !labels) ? &xf : nullptr, X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar, nullptr, ws,
                               ws_bytes, N, P, C, Ca, K, M, eval_flags, 1.0f, 0, 0, dtype, stream);
   if (rc != APA_OK || xf.done) return rc;
   if (labels)

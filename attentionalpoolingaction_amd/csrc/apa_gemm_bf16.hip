@@ -708,7 +708,8 @@ int launch_layout(const FastParams& p, bool a_km, bool b_km, int splits, hipStre
 // Eligibility: bf16 A, bf16 or fp32 B, no fused dropout, 16-byte addressable rows, K a multiple of 8,
 // at least one full vector of rows for k-major operands.
 bool gemm_bf16_eligible(const GemmDesc& d) {
-  if (getenv("APA_GEMM_FAST") && atoi(getenv("APA_GEMM_FAST")) == 0) return false;
+  static const int fast = [] { const char* e = getenv("APA_GEMM_FAST"); return e ? atoi(e) : 1; }();
+  if (!fast) return false;
   if (d.ta != 1 || d.drop_a) return false;
   if (d.drop_c && (d.n_valid > 0 && d.n_valid != d.N)) return false;   // mask index uses the row length
   if (d.K % 8 != 0 || d.K < 8 || d.M < 8 || d.N < 8) return false;

@@ -1,6 +1,7 @@
 // apa_internal.h -- host-side declarations shared by the translation units of libapa_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -25,13 +26,19 @@ int hip_fail(hipError_t e, const char* what);
     if (_e != hipSuccess) return ::apa::hip_fail(_e, "launch " name); \
   } while (0)
 
-// Optional per-thread event pair recorded around the dominant kernel (apa_prof_set_kernel_events).
-void prof_kernel_events(hipEvent_t* start, hipEvent_t* stop);
-void prof_null_events(hipEvent_t* start, hipEvent_t* stop);
-// apa_set_grad_ready_event: recorded once dWt / dbt are final (nullptr when unset)
-hipEvent_t grad_ready_event();
-// apa_set_td_weights_ready_event: waited for before the first kernel that reads Wt / bt
-hipEvent_t td_weights_ready_event();
+// apa_hooks members as typed events (all nullptr when the caller passed no hooks)
+struct Hooks {
+  hipEvent_t grad_ready = nullptr, td_ready = nullptr;
+  hipEvent_t fwd0 = nullptr, fwd1 = nullptr, bwd0 = nullptr, bwd1 = nullptr;
+  Hooks() {}
+  explicit Hooks(const apa_hooks* h) {
+    if (!h) return;
+    grad_ready = static_cast<hipEvent_t>(h->grad_ready_event);
+    td_ready = static_cast<hipEvent_t>(h->td_weights_ready_event);
+    fwd0 = static_cast<hipEvent_t>(h->prof_fwd_start); fwd1 = static_cast<hipEvent_t>(h->prof_fwd_stop);
+    bwd0 = static_cast<hipEvent_t>(h->prof_bwd_start); bwd1 = static_cast<hipEvent_t>(h->prof_bwd_stop);
+  }
+};
 
 // Ablation hook for profiling experiments only (make ABLATE=1): a bit mask of kernels NOT to launch
 // (results are then wrong by construction).  Compiled out of the product build.
@@ -45,6 +52,17 @@ inline int dbg_skip() { return g_dbg_skip; }
 #define APA_TS(i) do {} while (0)
 constexpr int dbg_skip() { return 0; }
 #endif
+
+// Launch `kernel`; with a start / stop event the launch goes through hipExtLaunchKernel, which stamps the
+// events with the dispatch's own begin / end timestamps (the pair rocprofv3 --kernel-trace reports).
+template <typename... KArgs, typename... Args>
+inline void launch_ev(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shm, hipStream_t st,
+                      hipEvent_t e0, hipEvent_t e1, Args... args) {
+  if (e0 || e1)
+    hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)shm, st, e0, e1, 0u, static_cast<KArgs>(args)...);
+  else
+    hipLaunchKernelGGL(kernel, grid, block, shm, st, static_cast<KArgs>(args)...);
+}
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -131,13 +149,14 @@ M1Plan m1_plan(int N, int P, int C, int Ca, int K);
 int m1_forward(const void* X, const void* Xatt, const float* Wa, const float* ba, const float* Wt,
                const float* bt, float* logits, float* att, float* zsave, float* abar, void* ws,
                int N, int P, int C, int Ca, int K, unsigned flags, float keep_prob, uint64_t seed,
-               uint64_t offset, int dtype, hipStream_t stream, M1Xent* xf = nullptr);
+               uint64_t offset, int dtype, hipStream_t stream, M1Xent* xf = nullptr,
+               const Hooks& hk = Hooks());
 int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* ba, const float* Wt,
                 const float* bt, const float* att, const float* zsave, const float* abar,
                 const float* G, void* dX, void* dXatt, float* dWa, float* dba, float* dWt,
                 float* dbt, void* ws, int N, int P, int C, int Ca, int K, unsigned flags,
                 float keep_prob, uint64_t seed, uint64_t offset, int dtype, hipStream_t stream,
-                const M1Xent* xf = nullptr);
+                const M1Xent* xf = nullptr, const Hooks& hk = Hooks());
 bool m1_supported(int C, int Ca, int dtype, bool fused);
 
 // apa_m1_stream.hip: "pixel tile x channel split" streaming passes for wide maps
@@ -147,6 +166,7 @@ struct M1Rng {
   uint64_t seed, offset;
   const uint64_t* offset_dev;
   bool relu_input = false;   // APA_FLAG_RELU_INPUT
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;   // apa_hooks prof_*: dispatch begin / end timestamps
 };
 bool m1s_supported(int C, int dtype);
 int m1s_launch_pool_fwd(int dtype, int C, bool fused, bool train, int nblk, hipStream_t st,

@@ -40,9 +40,12 @@ __global__ __launch_bounds__(256) void pose_labels_kernel(
   __shared__ int s_ok[LBL_MAX_PEOPLE * LBL_MAX_J];
   __shared__ int s_flag[2];
   const int n = blockIdx.x, tid = threadIdx.x;
-  const int32_t* g = geom + (size_t)n * 7;
+  // two frames (preprocess_pipeline.py:155-157 vs :29-36): keypoints are scaled with the ORIGINAL image
+  // size, the crop with the size of the image the augmentation recorded it on (preproc_info['image_shape'])
+  const int32_t* g = geom + (size_t)n * 9;
   const long long im_ht = g[0], im_wd = g[1];
-  const int crop_y = g[2], crop_x = g[3], crop_h = g[4], crop_w = g[5], flip = g[6];
+  const int aug_ht = g[2], aug_wd = g[3];
+  const int crop_y = g[4], crop_x = g[5], crop_h = g[6], crop_w = g[7], flip = g[8];
   const int nv = n_vals[n];
   const int n_rects = nv / (3 * J);
   float* out = labels + (size_t)n * S * S * J;
@@ -52,10 +55,10 @@ __global__ __launch_bounds__(256) void pose_labels_kernel(
   const int out_ht = im_wd > 0 ? (int)((double)(im_ht * out_wd) / (double)im_wd) : -1;
   const int radius = (int)((float)out_wd * ratio);
   // crop rescaled to the canvas with the reference's float32 ratios and truncation
-  const float ratio_x = __fdiv_rn((float)out_wd, (float)im_wd), ratio_y = __fdiv_rn((float)out_ht, (float)im_ht);
+  const float ratio_x = __fdiv_rn((float)out_wd, (float)aug_wd), ratio_y = __fdiv_rn((float)out_ht, (float)aug_ht);
   const int y0 = (int)mul_2r((float)crop_y, ratio_y), x0 = (int)mul_2r((float)crop_x, ratio_x);
   const int ch = (int)mul_2r((float)crop_h, ratio_y), cw = (int)mul_2r((float)crop_w, ratio_x);
-  const bool bad = im_ht <= 0 || im_wd <= 0 || out_ht <= 0 || nv < 0 || nv % (3 * J) != 0 ||
+  const bool bad = im_ht <= 0 || im_wd <= 0 || aug_ht <= 0 || aug_wd <= 0 || out_ht <= 0 || nv < 0 || nv % (3 * J) != 0 ||
                    n_rects > LBL_MAX_PEOPLE || nv > max_vals || y0 < 0 || x0 < 0 || ch <= 0 || cw <= 0 ||
                    y0 + ch > out_ht || x0 + cw > out_wd;
   if (bad) {   // the host path returns an error here (tf.slice / the op's assert would fail)

@@ -674,7 +674,8 @@ M1Plan m1_plan(int N, int P, int C, int Ca, int K) {
   const int target = env_int("APA_M1_TARGET_BLOCKS", 512);
   int S = (target + N / 2) / N;
   if (S < 1) S = 1;
-  const int maxS = P >= 8 ? P / 4 : 1;
+  int maxS = P >= 8 ? P / 4 : 1;
+  if (maxS > 256) maxS = 256;   // m1_finalize_fwd_kernel: one split per thread of a 256-thread block
   if (S > maxS) S = maxS;
   pl.S = S;
   pl.ppb = (P + S - 1) / S;
@@ -712,7 +713,7 @@ static int launch_pool_fwd(bool fused, bool train, int nblk, hipStream_t st, con
                            int P, int S, int act, RngArgs r) {
   const T* x = static_cast<const T*>(X);
 #define APA_GO(F, TR)                                                                          \
-  hipLaunchKernelGGL((m1_pool_fwd_kernel<T, VEC, F, TR>), dim3(nblk), dim3(256), 0, st, x, Wa, \
+  launch_ev(m1_pool_fwd_kernel<T, VEC, F, TR>, dim3(nblk), dim3(256), 0, st, r.ev0, r.ev1, x, Wa, \
                      ba, att, pacc, pstat, P, S, act, r.inv_keep, r.thresh, r.seed, r.offset,  \
                      r.offset_dev)
   if (fused) { if (train) APA_GO(true, true); else APA_GO(true, false); }
@@ -732,7 +733,7 @@ static int launch_bwd_main(bool fused, bool train, int nblk, hipStream_t st, con
   const T* x = static_cast<const T*>(X);
   T* dx = static_cast<T*>(dX);
 #define APA_GO(F, TR)                                                                            \
-  hipLaunchKernelGGL((m1_bwd_main_kernel<T, VEC, F, TR>), dim3(nblk), dim3(256), 0, st, x, Wa,   \
+  launch_ev(m1_bwd_main_kernel<T, VEC, F, TR>, dim3(nblk), dim3(256), 0, st, r.ev0, r.ev1, x, Wa,   \
                      att, dz, zsave, abar, G, bt, sn_pre, dx, dZout, pdwa, pdba, P, S, K, act,   \
                      r.inv_keep, r.thresh, r.seed, r.offset, r.offset_dev)
   if (fused) { if (train) APA_GO(true, true); else APA_GO(true, false); }
@@ -784,7 +785,7 @@ static RngArgs rng_args(bool train, float keep_prob, uint64_t seed, uint64_t off
 int m1_forward(const void* X, const void* Xatt, const float* Wa, const float* ba, const float* Wt,
                const float* bt, float* logits, float* att, float* zsave, float* abar, void* ws,
                int N, int P, int C, int Ca, int K, unsigned flags, float keep_prob, uint64_t seed,
-               uint64_t offset, int dtype, hipStream_t st, M1Xent* xf) {
+               uint64_t offset, int dtype, hipStream_t st, M1Xent* xf, const Hooks& hk) {
   const bool fused = (Xatt == X);
   const bool train = (flags & APA_FLAG_TRAIN) && keep_prob < 1.0f;
   const int act = act_of(flags);
@@ -793,7 +794,8 @@ int m1_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
   float* pacc = reinterpret_cast<float*>(w + pl.off_pacc);
   float* pstat = reinterpret_cast<float*>(w + pl.off_pstat);
   float* gemm_ws = reinterpret_cast<float*>(w + pl.off_gemm);
-  const RngArgs r = rng_args(train, keep_prob, seed, offset, flags);
+  RngArgs r = rng_args(train, keep_prob, seed, offset, flags);
+  r.ev0 = hk.fwd0; r.ev1 = hk.fwd1;
 
   if (r.relu_input && !(fused && use_stream_kernels(C, dtype))) {
     set_error("APA_FLAG_RELU_INPUT: needs Xatt == X and C in {1024,2048,4096} (f32) / 2048 (bf16)");
@@ -831,8 +833,8 @@ int m1_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
                        pstat, zsave, abar, att, P, pl.S, C, online);
     APA_LAUNCH_CHECK("m1_finalize_fwd_kernel");
   }
-  // logits = z . Wt + abar (x) bt -- the first reader of Wt / bt (apa_set_td_weights_ready_event)
-  if (td_weights_ready_event()) APA_HIP_CHECK(hipStreamWaitEvent(st, td_weights_ready_event(), 0));
+  // logits = z . Wt + abar (x) bt -- the first reader of Wt / bt (apa_hooks.td_weights_ready_event)
+  if (hk.td_ready) APA_HIP_CHECK(hipStreamWaitEvent(st, hk.td_ready, 0));
   static const int use_l2 = env_int("APA_M1_LOGITS2", 1);
   static const int use_lx = env_int("APA_M1_LOGITS_XENT", 1);
   static const int use_bh = env_int("APA_M1_BWD_HEAD", 1);
@@ -859,7 +861,7 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
                 const float* G, void* dX, void* dXatt, float* dWa, float* dba, float* dWt,
                 float* dbt, void* ws, int N, int P, int C, int Ca, int K, unsigned flags,
                 float keep_prob, uint64_t seed, uint64_t offset, int dtype, hipStream_t st,
-                const M1Xent* xf) {
+                const M1Xent* xf, const Hooks& hk) {
   (void)ba;
   const bool fused = (Xatt == X);
   const bool train = (flags & APA_FLAG_TRAIN) && keep_prob < 1.0f;
@@ -874,7 +876,8 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
   float* dZatt = rank1 ? static_cast<float*>(dXatt) : reinterpret_cast<float*>(w + pl.off_dzatt);
   float* gemm_ws = reinterpret_cast<float*>(w + pl.off_gemm);
   float* sn_buf = pdba + pl.nblk;   // [N] floats: the pdba region is sized nblk + N
-  const RngArgs r = rng_args(train, keep_prob, seed, offset, flags);
+  RngArgs r = rng_args(train, keep_prob, seed, offset, flags);
+  r.ev0 = hk.bwd0; r.ev1 = hk.bwd1;
   if (r.relu_input && !(fused && use_stream_kernels(C, dtype))) {
     set_error("APA_FLAG_RELU_INPUT: needs Xatt == X and C in {1024,2048,4096} (f32) / 2048 (bf16)");
     return APA_ERR_UNSUPPORTED;
@@ -912,19 +915,8 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
   }
 
   // dWt / dbt are final here (fast path): let a data-parallel caller start their all-reduce now
-  if (small_ok && grad_ready_event()) APA_HIP_CHECK(hipEventRecord(grad_ready_event(), st));
+  if (small_ok && hk.grad_ready) APA_HIP_CHECK(hipEventRecord(hk.grad_ready, st));
 
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  prof_kernel_events(&ev0, &ev1);
-  {
-    hipEvent_t n0 = nullptr, n1 = nullptr;   // calibration pair: nothing in between
-    prof_null_events(&n0, &n1);
-    if (n0 && n1) {
-      APA_HIP_CHECK(hipEventRecord(n0, st));
-      APA_HIP_CHECK(hipEventRecord(n1, st));
-    }
-  }
-  if (ev0) APA_HIP_CHECK(hipEventRecord(ev0, st));
   if (dbg_skip() & 64) {}
   else if (use_stream_kernels(C, dtype))
     rc = m1s_launch_bwd_main(dtype, C, fused, train, pl.nblk, st, X, Wa, att, dz, zsave, abar, G,
@@ -935,7 +927,6 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
                           zsave, abar, G, bt, small_ok ? sn_buf : nullptr, dX, dZatt, pdwa, pdba,
                           P, pl.S, K, act, r);
   if (rc != APA_OK) return rc;
-  if (ev1) APA_HIP_CHECK(hipEventRecord(ev1, st));
 
   int nred = pl.nblk;
   int cred = C;
@@ -980,7 +971,7 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
   hipLaunchKernelGGL(m1_bwd_reduce_kernel, dim3((cred + 63) / 64 + 1), dim3(256), 0, st, pdwa, pdba,
                      dWa, dba, abar, G, dbt, nred, cred, N, K, 1, bump);
   APA_LAUNCH_CHECK("m1_bwd_reduce_kernel");
-  if (grad_ready_event()) APA_HIP_CHECK(hipEventRecord(grad_ready_event(), st));   // dbt comes last here
+  if (hk.grad_ready) APA_HIP_CHECK(hipEventRecord(hk.grad_ready, st));   // dbt comes last here
   return APA_OK;
 }
 

@@ -521,19 +521,17 @@ static int launch_fwd_t(bool fused, bool train, int nblk, hipStream_t st, const 
     }
     if constexpr (PIX == 2) {
       if (train)
-        hipLaunchKernelGGL((m1s_pool_fwd_kernel<T, VW, 2, true, true, true>), dim3(nblk), dim3(256), 0,
-                           st, x, Wa, ba, att, pacc, pstat, P, S, act, r.inv_keep, r.thresh, r.seed,
+        launch_ev(m1s_pool_fwd_kernel<T, VW, 2, true, true, true>, dim3(nblk), dim3(256), 0, st, r.ev0, r.ev1, x, Wa, ba, att, pacc, pstat, P, S, act, r.inv_keep, r.thresh, r.seed,
                            r.offset, r.offset_dev);
       else
-        hipLaunchKernelGGL((m1s_pool_fwd_kernel<T, VW, 2, true, false, true>), dim3(nblk), dim3(256), 0,
-                           st, x, Wa, ba, att, pacc, pstat, P, S, act, r.inv_keep, r.thresh, r.seed,
+        launch_ev(m1s_pool_fwd_kernel<T, VW, 2, true, false, true>, dim3(nblk), dim3(256), 0, st, r.ev0, r.ev1, x, Wa, ba, att, pacc, pstat, P, S, act, r.inv_keep, r.thresh, r.seed,
                            r.offset, r.offset_dev);
     }
     APA_LAUNCH_CHECK("m1s_pool_fwd_kernel");
     return APA_OK;
   }
 #define APA_GO(F, TR)                                                                            \
-  hipLaunchKernelGGL((m1s_pool_fwd_kernel<T, VW, PIX, F, TR>), dim3(nblk), dim3(256), 0, st, x,  \
+  launch_ev(m1s_pool_fwd_kernel<T, VW, PIX, F, TR>, dim3(nblk), dim3(256), 0, st, r.ev0, r.ev1, x,  \
                      Wa, ba, att, pacc, pstat, P, S, act, r.inv_keep, r.thresh, r.seed,          \
                      r.offset, r.offset_dev)
   if (fused) { if (train) APA_GO(true, true); else APA_GO(true, false); }
@@ -558,19 +556,17 @@ static int launch_bwd_t(bool fused, bool train, int nblk, hipStream_t st, const 
     }
     if constexpr (PIX == 2) {
       if (train)
-        hipLaunchKernelGGL((m1s_bwd_main_kernel<T, VW, 2, true, true, true>), dim3(nblk), dim3(256), 0,
-                           st, x, Wa, att, dz, zsave, abar, G, bt, sn_pre, dx, dZout, pdwa, pdba, P, S, K,
+        launch_ev(m1s_bwd_main_kernel<T, VW, 2, true, true, true>, dim3(nblk), dim3(256), 0, st, r.ev0, r.ev1, x, Wa, att, dz, zsave, abar, G, bt, sn_pre, dx, dZout, pdwa, pdba, P, S, K,
                            act, r.inv_keep, r.thresh, r.seed, r.offset, r.offset_dev);
       else
-        hipLaunchKernelGGL((m1s_bwd_main_kernel<T, VW, 2, true, false, true>), dim3(nblk), dim3(256), 0,
-                           st, x, Wa, att, dz, zsave, abar, G, bt, sn_pre, dx, dZout, pdwa, pdba, P, S, K,
+        launch_ev(m1s_bwd_main_kernel<T, VW, 2, true, false, true>, dim3(nblk), dim3(256), 0, st, r.ev0, r.ev1, x, Wa, att, dz, zsave, abar, G, bt, sn_pre, dx, dZout, pdwa, pdba, P, S, K,
                            act, r.inv_keep, r.thresh, r.seed, r.offset, r.offset_dev);
     }
     APA_LAUNCH_CHECK("m1s_bwd_main_kernel");
     return APA_OK;
   }
 #define APA_GO(F, TR)                                                                            \
-  hipLaunchKernelGGL((m1s_bwd_main_kernel<T, VW, PIX, F, TR>), dim3(nblk), dim3(256), 0, st, x,  \
+  launch_ev(m1s_bwd_main_kernel<T, VW, PIX, F, TR>, dim3(nblk), dim3(256), 0, st, r.ev0, r.ev1, x,  \
                      Wa, att, dz, zsave, abar, G, bt, sn_pre, dx, dZout, pdwa, pdba, P, S, K,    \
                      act, r.inv_keep, r.thresh, r.seed, r.offset, r.offset_dev)
   if (fused) { if (train) APA_GO(true, true); else APA_GO(true, false); }

@@ -44,6 +44,11 @@ _SIGNATURES = {
                           [c_uint, c_float, c_uint64, c_uint64, c_int, c_void_p]),
     'apa_attn_pool_bwd': (c_int, [c_void_p] * 17 + [c_size_t] + [c_int] * 6 +
                           [c_uint, c_float, c_uint64, c_uint64, c_int, c_void_p]),
+    # the *_ex forms take a `const apa_hooks*` first (NULL = no hooks)
+    'apa_attn_pool_fwd_ex': (c_int, [c_void_p] * 13 + [c_size_t] + [c_int] * 6 +
+                             [c_uint, c_float, c_uint64, c_uint64, c_int, c_void_p]),
+    'apa_attn_pool_bwd_ex': (c_int, [c_void_p] * 18 + [c_size_t] + [c_int] * 6 +
+                             [c_uint, c_float, c_uint64, c_uint64, c_int, c_void_p]),
     'apa_dropout_mask': (c_int, [c_void_p, c_size_t, c_float, c_uint64, c_uint64, c_void_p]),
     'apa_pose_head_workspace_bytes': (c_size_t, [c_int] * 6),
     'apa_pose_head_fwd': (c_int, [c_void_p] * 8 + [c_size_t] + [c_int] * 6 + [c_void_p]),
@@ -67,17 +72,16 @@ _SIGNATURES = {
     'apa_attn_head_train_step': (c_int, [c_void_p] * 7 + [c_float, c_float] + [c_void_p] * 13 +
                                  [c_size_t] + [c_int] * 6 + [c_uint, c_float, c_uint64, c_uint64, c_int,
                                                              c_void_p]),
+    'apa_attn_head_train_step_ex': (c_int, [c_void_p] * 8 + [c_float, c_float] + [c_void_p] * 13 +
+                                    [c_size_t] + [c_int] * 6 + [c_uint, c_float, c_uint64, c_uint64, c_int,
+                                                                c_void_p]),
     'apa_attn_head_eval_step': (c_int, [c_void_p] * 15 + [c_size_t] + [c_int] * 6 + [c_uint, c_int, c_void_p]),
-    'apa_set_grad_ready_event': (c_int, [c_void_p]),
-    'apa_set_td_weights_ready_event': (c_int, [c_void_p]),
     'apa_momentum_sgd_step': (c_int, [c_int, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_float),
                                       c_void_p, c_void_p, c_float, c_float, c_float, c_void_p]),
     'apa_prof_event_create': (c_int, [POINTER(c_void_p)]),
     'apa_prof_event_destroy': (c_int, [c_void_p]),
     'apa_prof_event_record': (c_int, [c_void_p, c_void_p]),
     'apa_prof_event_elapsed_ms': (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
-    'apa_prof_set_kernel_events': (c_int, [c_void_p, c_void_p]),
-    'apa_prof_set_null_events': (c_int, [c_void_p, c_void_p]),
 }
 
 _lib = None
@@ -155,6 +159,44 @@ def _rng_offset(offset, flags):
     return int(offset), flags
 
 
+class ApaHooks(ctypes.Structure):
+    """`apa_hooks` of include/apa.h: per-call ordering / timing aids, passed explicitly to the *_ex
+    entry points (the library keeps no per-thread or global state)."""
+    _fields_ = [('grad_ready_event', c_void_p), ('td_weights_ready_event', c_void_p),
+                ('prof_fwd_start', c_void_p), ('prof_fwd_stop', c_void_p),
+                ('prof_bwd_start', c_void_p), ('prof_bwd_stop', c_void_p)]
+
+
+def _event_handle(event):
+    """torch.cuda.Event (recorded at least once, so that its handle exists), raw hipEvent_t or None."""
+    if event is None:
+        return None
+    if isinstance(event, torch.cuda.Event):
+        return event.cuda_event
+    if isinstance(event, c_void_p):
+        return event.value
+    return int(event)
+
+
+def make_hooks(grad_ready=None, td_weights_ready=None, prof_fwd=None, prof_bwd=None) -> ApaHooks:
+    """Build an apa_hooks struct.  grad_ready / td_weights_ready: events (see include/apa.h);
+    prof_fwd / prof_bwd: (start, stop) event pairs that receive the dispatch timestamps of the two
+    streaming kernels.  Keep the returned object (and the events) alive while calls that use it are in
+    flight."""
+    h = ApaHooks()
+    h.grad_ready_event = _event_handle(grad_ready)
+    h.td_weights_ready_event = _event_handle(td_weights_ready)
+    if prof_fwd is not None:
+        h.prof_fwd_start, h.prof_fwd_stop = _event_handle(prof_fwd[0]), _event_handle(prof_fwd[1])
+    if prof_bwd is not None:
+        h.prof_bwd_start, h.prof_bwd_stop = _event_handle(prof_bwd[0]), _event_handle(prof_bwd[1])
+    return h
+
+
+def _hooks_ptr(hooks):
+    return None if hooks is None else ctypes.addressof(hooks)
+
+
 def attn_flags(softmax_att=False, relu_att=False, is_training=False, relu_input=False) -> int:
     return ((APA_FLAG_SOFTMAX_ATT if softmax_att else 0) | (APA_FLAG_RELU_ATT if relu_att else 0) |
             (APA_FLAG_TRAIN if is_training else 0) | (APA_FLAG_RELU_INPUT if relu_input else 0))
@@ -168,7 +210,7 @@ def attn_pool_workspace_bytes(N, P, C, Ca, K, M, flags=0) -> int:
 
 
 def attn_pool_fwd(X, Xatt, Wa, ba, Wt, bt, *, flags=0, keep_prob=1.0, seed=0, offset=0,
-                  workspace=None, want_topdown=False):
+                  workspace=None, want_topdown=False, hooks=None):
     """logits, att, zsave, abar, topdown, workspace = attn_pool_fwd(...)
 
     X [N,P,C] (or [N,H,W,C]) f32/bf16; Xatt same tensor object as X (cfg 002) or [N,P,Ca];
@@ -194,8 +236,8 @@ def attn_pool_fwd(X, Xatt, Wa, ba, Wt, bt, *, flags=0, keep_prob=1.0, seed=0, of
         workspace = torch.empty((max(need, 16),), dtype=torch.uint8, device=dev)
     xatt_ptr = _dev_ptr(X, 'X') if Xatt is X else _dev_ptr(Xatt, 'Xatt', X.dtype)
     offset, flags = _rng_offset(offset, flags)
-    rc = lib.apa_attn_pool_fwd(
-        _dev_ptr(X, 'X'), xatt_ptr, _dev_ptr(Wa, 'Wa', torch.float32),
+    rc = lib.apa_attn_pool_fwd_ex(
+        _hooks_ptr(hooks), _dev_ptr(X, 'X'), xatt_ptr, _dev_ptr(Wa, 'Wa', torch.float32),
         _dev_ptr(ba, 'ba', torch.float32), _dev_ptr(Wt, 'Wt', torch.float32),
         _dev_ptr(bt, 'bt', torch.float32), logits.data_ptr(), att.data_ptr(),
         _dev_ptr(zsave, 'zsave'), _dev_ptr(abar, 'abar'), _dev_ptr(topdown, 'topdown'),
@@ -206,7 +248,7 @@ def attn_pool_fwd(X, Xatt, Wa, ba, Wt, bt, *, flags=0, keep_prob=1.0, seed=0, of
 
 
 def attn_pool_bwd(X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, *, flags=0, keep_prob=1.0, seed=0,
-                  offset=0, workspace=None, out=None, dxatt_rank1=False):
+                  offset=0, workspace=None, out=None, dxatt_rank1=False, hooks=None):
     """dX, dXatt, dWa, dba, dWt, dbt = attn_pool_bwd(...).  `out` may supply preallocated
     (dX, dXatt, dWa, dba, dWt, dbt) buffers (e.g. views into a flat DP gradient bucket).
     `dxatt_rank1=True` (separate attention input, one bottom-up map): the second result is dZ, f32
@@ -242,8 +284,8 @@ def attn_pool_bwd(X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, *, flags=0, keep
         workspace = torch.empty((max(need, 16),), dtype=torch.uint8, device=dev)
     xatt_ptr = _dev_ptr(X, 'X') if fused else _dev_ptr(Xatt, 'Xatt', X.dtype)
     offset, flags = _rng_offset(offset, flags)
-    rc = lib.apa_attn_pool_bwd(
-        _dev_ptr(X, 'X'), xatt_ptr, _dev_ptr(Wa, 'Wa', torch.float32),
+    rc = lib.apa_attn_pool_bwd_ex(
+        _hooks_ptr(hooks), _dev_ptr(X, 'X'), xatt_ptr, _dev_ptr(Wa, 'Wa', torch.float32),
         _dev_ptr(ba, 'ba', torch.float32), _dev_ptr(Wt, 'Wt', torch.float32),
         _dev_ptr(bt, 'bt', torch.float32), _dev_ptr(att, 'att', torch.float32),
         _dev_ptr(zsave, 'zsave'), _dev_ptr(abar, 'abar'), _dev_ptr(G, 'G', torch.float32),
@@ -449,7 +491,10 @@ def pose_label_replay_resize(hm_u8: np.ndarray, orig_hw, crop_info, whether_flip
 def pose_labels_device(poses, geoms, out_wd=200, J=16, marker_wd_ratio=0.1, out_side=15, device='cuda'):
     """The whole label path of src/preprocess_pipeline.py:150-214 for a batch on the device.
     poses: list of int64 arrays (x, y, vis triples, n_people*J of them); geoms: list of
-    (im_ht, im_wd, crop_y, crop_x, crop_h, crop_w, flip).  Returns (labels f32 [N,S,S,J] device,
+    (im_ht, im_wd, aug_ht, aug_wd, crop_y, crop_x, crop_h, crop_w, flip) -- im_* = the ORIGINAL image
+    size (keypoint scaling, preprocess_pipeline.py:155-157), aug_* = preproc_info['image_shape'], the
+    size after the aspect-preserving resize, on which crop_* was recorded (:29-36); a 7-tuple
+    (im_ht, im_wd, crop...) means aug == im (no resize).  Returns (labels f32 [N,S,S,J] device,
     valid bool [N,J] device, status int32 [N] device)."""
     lib = load_library()
     N = len(poses)
@@ -461,7 +506,15 @@ def pose_labels_device(poses, geoms, out_wd=200, J=16, marker_wd_ratio=0.1, out_
     dev = torch.device(device)
     pose_d = torch.from_numpy(pose_h).to(dev)
     nv_d = torch.tensor([f.size for f in flat], dtype=torch.int32, device=dev)
-    geom_d = torch.tensor([[int(v) for v in g] for g in geoms], dtype=torch.int32, device=dev)
+    g9 = []
+    for g in geoms:
+        g = [int(v) for v in g]
+        if len(g) == 7:
+            g = g[:2] + g[:2] + g[2:]
+        if len(g) != 9:
+            raise ValueError('geom needs 9 (or 7) integers, got {}'.format(len(g)))
+        g9.append(g)
+    geom_d = torch.tensor(g9, dtype=torch.int32, device=dev)
     labels = torch.empty((N, out_side, out_side, J), dtype=torch.float32, device=dev)
     valid = torch.empty((N, J), dtype=torch.uint8, device=dev)
     status = torch.empty((N,), dtype=torch.int32, device=dev)
@@ -515,7 +568,7 @@ class HeadTrainStep:
     (device-side dropout counter, advanced by the backward pass)."""
 
     def __init__(self, X, Xatt, Wa, ba, Wt, bt, labels, grads, *, flags=0, keep_prob=1.0, seed=0,
-                 offset=0, loss_wt=1.0, grad_scale=1.0, workspace=None):
+                 offset=0, loss_wt=1.0, grad_scale=1.0, workspace=None, hooks=None):
         self.lib = load_library()
         N, C = X.shape[0], X.shape[-1]
         P = X.numel() // (N * C)
@@ -523,6 +576,7 @@ class HeadTrainStep:
         dev = X.device
         fused = Xatt is X
         dX, dXatt, dWa, dba, dWt, dbt = grads
+        self.hooks = hooks            # default apa_hooks of run(); kept alive here
         self.logits = torch.empty((N, K), dtype=torch.float32, device=dev)
         self.att = torch.empty((N, P, M), dtype=torch.float32, device=dev)
         self.zsave = torch.empty((N, C) if M == 1 else (N, P, K), dtype=torch.float32, device=dev)
@@ -546,11 +600,13 @@ class HeadTrainStep:
             _dev_ptr(dba, 'dba', torch.float32), _dev_ptr(dWt, 'dWt', torch.float32),
             _dev_ptr(dbt, 'dbt', torch.float32), workspace.data_ptr(), workspace.numel(), N, P, C, Ca, K, M,
             flags, float(keep_prob), int(seed), off, _feat_dtype(X)]
-        self._fn = self.lib.apa_attn_head_train_step
+        self._fn = self.lib.apa_attn_head_train_step_ex
 
-    def run(self, stream: Optional[int] = None) -> None:
-        """Enqueue one step on `stream` (a raw hipStream_t) or torch's current stream."""
-        rc = self._fn(*self._args, _stream_ptr() if stream is None else stream)
+    def run(self, stream: Optional[int] = None, hooks=None) -> None:
+        """Enqueue one step on `stream` (a raw hipStream_t) or torch's current stream; `hooks`
+        (an ApaHooks) overrides the instance's for this call."""
+        h = self.hooks if hooks is None else hooks
+        rc = self._fn(_hooks_ptr(h), *self._args, _stream_ptr() if stream is None else stream)
         if rc != 0:
             _check(rc, 'apa_attn_head_train_step')
 
@@ -595,34 +651,6 @@ class HeadEvalStep:
             _check(rc, 'apa_attn_head_eval_step')
 
 
-def set_grad_ready_event(event) -> None:
-    """Register (or clear, with None) the event apa_attn_pool_bwd records as soon as dWt / dbt are
-    final.  `event`: a torch.cuda.Event that has been recorded at least once (so its handle
-    exists) or a raw hipEvent_t."""
-    lib = load_library()
-    if event is None:
-        handle = None
-    elif isinstance(event, torch.cuda.Event):
-        handle = c_void_p(event.cuda_event)
-    else:
-        handle = c_void_p(event)
-    _check(lib.apa_set_grad_ready_event(handle), 'apa_set_grad_ready_event')
-
-
-def set_td_weights_ready_event(event) -> None:
-    """Register (or clear, with None) the event apa_attn_pool_fwd waits for right before its first
-    kernel that reads td_weights / td_biases (include/apa.h): record it on the communication stream
-    after the all-reduce / update of those tensors.  Same handle rules as set_grad_ready_event."""
-    lib = load_library()
-    if event is None:
-        handle = None
-    elif isinstance(event, torch.cuda.Event):
-        handle = c_void_p(event.cuda_event)
-    else:
-        handle = c_void_p(event)
-    _check(lib.apa_set_td_weights_ready_event(handle), 'apa_set_td_weights_ready_event')
-
-
 def momentum_sgd_step(weights, weight_decay, grad_flat, acc_flat, lr, momentum=0.9, grad_scale=1.0):
     """One fused launch: acc = m*acc + (grad_scale*g + wd_i*w_i); w_i -= lr*acc for every parameter.
     `weights`: list of fp32 device tensors in bucket order; `weight_decay`: one float per tensor."""
@@ -644,17 +672,24 @@ def momentum_sgd_step(weights, weight_decay, grad_flat, acc_flat, lr, momentum=0
 # measurement hooks (bench.py)
 # --------------------------------------------------------------------------------------------
 class KernelTimer:
-    """HIP-event pairs recorded by the library around its dominant streaming kernel
-    (m1_bwd_main_kernel) on the launch stream; see apa_prof_set_kernel_events in include/apa.h."""
+    """Per-step event pairs for the two streaming kernels of the M == 1 head (m1s_pool_fwd_kernel,
+    m1s_bwd_main_kernel).  `hooks(i)` is the apa_hooks struct to pass to step i: the library launches
+    those kernels through hipExtLaunchKernel with the pair attached, so the events carry the
+    dispatch's own begin / end timestamps (what rocprofv3 --kernel-trace reports) and
+    elapsed(start, stop) is the kernel duration itself -- nothing to calibrate away."""
 
-    def __init__(self, n_pairs: int):
+    def __init__(self, n_steps: int, base: Optional[ApaHooks] = None):
         lib = load_library()
         self._lib = lib
-        self.pairs = []
-        self.null_pairs = []      # recorded back to back just before the kernel pair (calibration)
-        for _ in range(n_pairs):
-            self.pairs.append(self._new_pair())
-            self.null_pairs.append(self._new_pair())
+        self.fwd, self.bwd, self._hooks = [], [], []
+        for _ in range(n_steps):
+            f, b = self._new_pair(), self._new_pair()
+            self.fwd.append(f)
+            self.bwd.append(b)
+            h = make_hooks(prof_fwd=f, prof_bwd=b)
+            if base is not None:
+                h.grad_ready_event, h.td_weights_ready_event = base.grad_ready_event, base.td_weights_ready_event
+            self._hooks.append(h)
 
     def _new_pair(self):
         a, b = c_void_p(), c_void_p()
@@ -662,15 +697,8 @@ class KernelTimer:
         _check(self._lib.apa_prof_event_create(ctypes.byref(b)), 'apa_prof_event_create')
         return a, b
 
-    def arm(self, i: int) -> None:
-        a, b = self.pairs[i]
-        self._lib.apa_prof_set_kernel_events(a, b)
-        a, b = self.null_pairs[i]
-        self._lib.apa_prof_set_null_events(a, b)
-
-    def disarm(self) -> None:
-        self._lib.apa_prof_set_kernel_events(None, None)
-        self._lib.apa_prof_set_null_events(None, None)
+    def hooks(self, i: int) -> ApaHooks:
+        return self._hooks[i]
 
     def _elapsed(self, pairs):
         out = []
@@ -680,15 +708,14 @@ class KernelTimer:
             out.append(ms.value)
         return out
 
-    def elapsed_ms(self):
-        return self._elapsed(self.pairs)
+    def fwd_elapsed_ms(self):
+        return self._elapsed(self.fwd)
 
-    def null_elapsed_ms(self):
-        return self._elapsed(self.null_pairs)
+    def bwd_elapsed_ms(self):
+        return self._elapsed(self.bwd)
 
     def close(self) -> None:
-        for a, b in self.pairs + self.null_pairs:
+        for a, b in self.fwd + self.bwd:
             self._lib.apa_prof_event_destroy(a)
             self._lib.apa_prof_event_destroy(b)
-        self.pairs = []
-        self.null_pairs = []
+        self.fwd, self.bwd, self._hooks = [], [], []

@@ -101,8 +101,11 @@ class OverlappedGradientSum:
                          all-reduce(att part)                          <- only exposed collective
         comm stream      [wait ready(k)] all-reduce(td part) -> update -> record td_done(k)
 
-    The two waits are the library hooks `apa_set_grad_ready_event` / `apa_set_td_weights_ready_event`
-    (include/apa.h).  Each stream drives its own communicator: two collectives of one communicator
+    The two waits are the `grad_ready_event` / `td_weights_ready_event` members of `apa_hooks`
+    (include/apa.h): `self.hooks` is that struct and has to be handed to every forward / backward call
+    of the head explicitly (`cof.attn_pool_fwd(..., hooks=ogs.hooks)`, `cof.attn_pool_bwd(..., hooks=
+    ogs.hooks)`, `cof.HeadTrainStep(..., hooks=ogs.hooks)`) -- nothing is registered per thread, so the
+    schedule also holds when autograd runs the backward on its engine thread.  Each stream drives its own communicator: two collectives of one communicator
     must not be in flight at the same time.  Every rank enqueues them in the same order.  Same sums
     as `sum_clone_gradients` (model_deploy.py:421-451), only the schedule differs."""
 
@@ -117,8 +120,7 @@ class OverlappedGradientSum:
         self.ready.record(self.compute)          # materialise the handles; both start out signalled
         self.td_done.record(self.compute)
         torch.cuda.synchronize(device)
-        cof.set_grad_ready_event(self.ready)
-        cof.set_td_weights_ready_event(self.td_done)
+        self.hooks = cof.make_hooks(grad_ready=self.ready, td_weights_ready=self.td_done)
 
     def after_backward(self, update_td=None, update_att=None) -> None:
         """Call right after `attn_pool_bwd` was enqueued on the compute stream.  `update_td()` /
@@ -135,8 +137,6 @@ class OverlappedGradientSum:
             update_att()
 
     def close(self) -> None:
-        self._cof.set_grad_ready_event(None)
-        self._cof.set_td_weights_ready_event(None)
         self.side.synchronize()
 
 

@@ -12,9 +12,24 @@ class-agnostic bottom-up map (M=1), training-mode dropout keep=0.2 (nets_factory
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (m1_bwd_main_kernel: reads X
-once, writes dX once); `cpu_baseline` is the literal op-by-op PyTorch-CPU restatement of the
-reference graph (oracle/, a *port* -- TF1 cannot run here) timed on this box's host cores.
+What is timed, and how:
+  * The feature map and its gradient are ROTATED over R buffer sets with R * (X + dX) > 256 MiB (the
+    Infinity Cache), so a step never finds its X in cache from the previous step: the forward pass
+    reads X from HBM.  (Inside one step the backward pass re-reads the X its own forward pass streamed
+    a few microseconds earlier; what the cache keeps of it is part of the real workload.)
+  * The K-step timed loop (barrier + synchronize on both sides, max over ranks) is repeated until at
+    least --min-ms of device time AND --repeats loops have run; `ms_per_step` / `value` are the MEDIAN
+    loop.  `steps`, `warmup` echo the flags; `repeats` says how many K-step loops were timed.
+  * `roofline`: the dominant kernel (m1s_bwd_main_kernel: reads X once, writes dX once).  Its
+    duration is read live from HIP events that the library attaches to that dispatch itself
+    (hipExtLaunchKernel start/stop events = the dispatch's begin / end timestamps, the pair
+    rocprofv3 --kernel-trace reports; profiles/ holds the rocprofv3 summary of this same command).
+    No calibration constant is subtracted.
+  * `extra`: the other BASELINE configs on the same driver-timed line (cfg 002 eval step, cfg 003
+    bf16 training step, HMDB-51 per-class bf16 training step, and the headline step at N = 512,
+    1.6 GB of features per pass: far outside every cache).
+  * `cpu_baseline`: the literal op-by-op PyTorch-CPU restatement of the reference graph (oracle/, a
+    *port* -- TF1 cannot run here) timed on this box's host cores.
 """
 import argparse
 import json
@@ -29,6 +44,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
+L3_BYTES = 256 << 20    # Infinity Cache
 
 
 def parse_args():
@@ -44,16 +60,20 @@ def parse_args():
     ap.add_argument('--keep-prob', type=float, default=0.2)
     ap.add_argument('--eval-mode', action='store_true', help='no dropout (is_training=False)')
     ap.add_argument('--softmax-att', action='store_true')
+    ap.add_argument('--rotate', type=int, default=0,
+                    help='number of (X, dX) buffer sets the steps cycle through; 0 = smallest R >= 3 with '
+                         'R * (X + dX) >= 1.5 x 256 MiB (Infinity Cache); 1 = the same buffers every step')
+    ap.add_argument('--min-ms', type=float, default=50.0,
+                    help='repeat the --steps-long timed loop until this much device time has been measured')
+    ap.add_argument('--repeats', type=int, default=5, help='minimum number of timed loops (median reported)')
     ap.add_argument('--graph', action='store_true',
-                    help='capture the step in a hipGraph (measured: replay overhead makes it ~5%% '
-                         'slower than eager launches for this 8-kernel step, so off by default)')
+                    help='capture the step in a hipGraph (measured: replay overhead makes it slower than '
+                         'eager launches for this step, so off by default); implies --rotate 1')
     ap.add_argument('--overlap', default='auto', choices=['auto', 'on', 'off'],
                     help='N > 1: reduce dWt|dbt (99.7 %% of the bytes) on a communication stream with its own '
-                         'RCCL communicator, between the library\'s grad-ready and td-weights-ready hooks '
-                         '(hidden under the streaming backward pass and the next pooling pass), and only '
-                         'dWa|dba (8 KB) on the compute stream (deploy.OverlappedGradientSum).  auto = on '
-                         'with --comm rccl, off (one in-stream bucket) with --comm torch, whose extra host '
-                         'calls cost more than the overlap buys at this step size')
+                         'RCCL communicator, between the grad-ready and td-weights-ready hooks (apa_hooks), '
+                         'and only dWa|dba (8 KB) on the compute stream (deploy.OverlappedGradientSum).  auto = on '
+                         'with --comm rccl, off (one in-stream bucket) with --comm torch')
     ap.add_argument('--comm', default='rccl', choices=['rccl', 'torch', 'gloo'],
                     help='N > 1 gradient sum: direct in-stream ncclAllReduce through librccl (default), '
                          'torch.distributed.all_reduce over RCCL, or over gloo (host-staged; lets two ranks '
@@ -62,12 +82,12 @@ def parse_args():
     ap.add_argument('--force-dist', action='store_true',
                     help='run the N > 1 code path (RCCL group, side stream, split all-reduce) on one GPU')
     ap.add_argument('--relu-input', action='store_true',
-                    help='APA_FLAG_RELU_INPUT: feed the pre-activation map (randn, not rectified) and let the '
-                         'op apply the backbone\'s last ReLU on the fly in both passes')
+                    help='APA_FLAG_RELU_INPUT: feed the pre-activation map and let the op apply the backbone\'s '
+                         'last ReLU on the fly in both passes')
     ap.add_argument('--per-op-calls', action='store_true',
-                    help='drive the step as three separately marshalled calls (apa_attn_pool_fwd, '
-                         'apa_softmax_xent_fwd_bwd, apa_attn_pool_bwd) with per-step output allocation instead '
-                         'of one apa_attn_head_train_step call: same kernels, more host time per step')
+                    help='drive the step as three separately marshalled calls instead of one '
+                         'apa_attn_head_train_step call: same kernels, more host time per step')
+    ap.add_argument('--no-extra', action='store_true', help='skip the `extra` workloads')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=10.0)
     ap.add_argument('--traffic-bytes', type=float, default=None,
@@ -99,14 +119,17 @@ def cpu_baseline(args, seconds):
         orc.action_softmax_xent(logits, labels, K).backward()
 
     # 256 MKL threads on a 256-core box thrash on this problem size: probe a few thread counts
-    # and keep the fastest (the count actually used is what `cores` reports)
-    best_t, best_thr = None, None
+    # (best of 3 iterations each, after one untimed) and keep the fastest; `cores` reports that count
+    best_t, best_thr, probes = None, None, 3
     for thr in sorted({min(os.cpu_count(), c) for c in (8, 16, 32, 64, 128)}):
         torch.set_num_threads(thr)
         it()
-        t0 = time.perf_counter()
-        it()
-        dt = time.perf_counter() - t0
+        dt = None
+        for _ in range(probes):
+            t0 = time.perf_counter()
+            it()
+            d = time.perf_counter() - t0
+            dt = d if dt is None else min(dt, d)
         if best_t is None or dt < best_t:
             best_t, best_thr = dt, thr
     torch.set_num_threads(best_thr)
@@ -120,9 +143,9 @@ def cpu_baseline(args, seconds):
     return {'value': round(N * n / el, 2), 'unit': 'images/sec', 'cores': best_thr,
             'kind': 'port',
             'sample': '{} iterations ({:.1f} s) of the same workload (N={}, {}x{}x{}, K={}, fp32, '
-                      'literal [N,P,K] top-down formulation, torch {} CPU, best of 8..128 threads = {} on a '
-                      '{}-core host)'.format(n, el, N, H, H, C, K, torch.__version__, best_thr,
-                                             os.cpu_count())}
+                      'literal [N,P,K] top-down formulation, torch {} CPU); {} threads chosen by a best-of-{} '
+                      'probe over 8..128 threads on a {}-core host'.format(
+                          n, el, N, H, H, C, K, torch.__version__, best_thr, probes, os.cpu_count())}
 
 
 def _claim_stdout():
@@ -134,6 +157,115 @@ def _claim_stdout():
     real = os.fdopen(os.dup(1), 'w')
     os.dup2(2, 1)
     return real
+
+
+def _median(v):
+    v = sorted(v)
+    return v[len(v) // 2]
+
+
+class HeadWorkload:
+    """The cfg 002 training step on `rotate` buffer sets: one HeadTrainStep per (X, dX) set, every
+    other buffer (weights, gradient bucket, workspace, dropout counter) shared."""
+
+    def __init__(self, cof, args, dev, rank, world, N, rotate, hooks=None):
+        H, C, K = args.hw, args.channels, args.classes
+        P = H * H
+        self.N, self.P, self.C, self.K = N, P, C, K
+        tdtype = torch.float32 if args.dtype == 'f32' else torch.bfloat16
+        self.esz = 4 if args.dtype == 'f32' else 2
+        if rotate <= 0:
+            per_set = 2 * N * P * C * self.esz
+            rotate = max(3, -(-int(1.5 * L3_BYTES) // per_set))
+        self.rotate = rotate
+        g = torch.Generator(device=dev).manual_seed(42 + rank)    # cfg.RNG_SEED = 42
+        gw = torch.Generator(device='cpu').manual_seed(42)         # replicated weights
+        self.Wa = (torch.randn(C, 1, generator=gw) / C ** 0.5).to(dev)
+        self.ba = torch.zeros(1, device=dev)
+        self.Wt = (torch.randn(C, K, generator=gw) / C ** 0.5).to(dev)
+        self.bt = torch.zeros(K, device=dev)
+        self.labels = torch.randint(0, K, (N,), generator=gw).to(dev)
+        train = not args.eval_mode
+        self.flags = cof.attn_flags(args.softmax_att, False, train, relu_input=args.relu_input)
+        self.keep = args.keep_prob if train else 1.0
+        # flat fp32 gradient bucket [dWa | dba | dWt | dbt]: one all-reduce per step, no packing copy
+        sizes = [C * 1, 1, C * K, K]
+        self.bucket = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        views, o = [], 0
+        for s in sizes:
+            views.append(self.bucket[o:o + s])
+            o += s
+        self.dWa, self.dba, self.dWt, self.dbt = views[0].view(C, 1), views[1], views[2].view(C, K), views[3]
+        self.ws = torch.empty((cof.attn_pool_workspace_bytes(N, P, C, C, K, 1, self.flags),),
+                              dtype=torch.uint8, device=dev)
+        self.grad_scale = 1.0 / world               # model_deploy.py:223-225: clone loss / num_clones
+        # dropout step counter in HBM: read by the kernels, advanced by the backward call, so every
+        # step (and every hipGraph replay) draws a fresh mask like a fresh tf.nn.dropout per sess.run
+        self.rng_ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.X, self.dX, self.steppers = [], [], []
+        for _ in range(rotate):
+            x = torch.randn(N, P, C, generator=g, device=dev)
+            x = (x if args.relu_input else torch.relu(x)).to(tdtype)
+            dx = torch.empty_like(x)
+            self.X.append(x)
+            self.dX.append(dx)
+            # one foreign call per step (apa_attn_head_train_step = the three entry points back to
+            # back, arguments marshalled once): keeps the host ahead of the ~50 us step on any CPU
+            self.steppers.append(None if args.per_op_calls else cof.HeadTrainStep(
+                x, x, self.Wa, self.ba, self.Wt, self.bt, self.labels,
+                (dx, None, self.dWa, self.dba, self.dWt, self.dbt), flags=self.flags, keep_prob=self.keep,
+                seed=42, offset=self.rng_ctr, grad_scale=self.grad_scale, workspace=self.ws, hooks=hooks))
+        self.cof = cof
+        self.hooks = hooks
+        self.i = 0
+
+    def compute(self, hooks=None):
+        r = self.i % self.rotate
+        self.i += 1
+        st = self.steppers[r]
+        if st is not None:
+            st.run(hooks=hooks)
+            return
+        cof, X, h = self.cof, self.X[r], (hooks if hooks is not None else self.hooks)
+        logits, att, zsave, abar, _, _ = cof.attn_pool_fwd(X, X, self.Wa, self.ba, self.Wt, self.bt,
+                                                           flags=self.flags, keep_prob=self.keep, seed=42,
+                                                           offset=self.rng_ctr, workspace=self.ws, hooks=h)
+        _, G, _, _ = cof.softmax_xent_fwd_bwd(logits, self.labels, grad_scale=self.grad_scale)
+        cof.attn_pool_bwd(X, X, self.Wa, self.ba, self.Wt, self.bt, att, zsave, abar, G, flags=self.flags,
+                          keep_prob=self.keep, seed=42, offset=self.rng_ctr, workspace=self.ws,
+                          out=(self.dX[r], None, self.dWa, self.dba, self.dWt, self.dbt), hooks=h)
+
+
+def timed_loops(step, barrier, steps, min_ms, repeats, reduce_max):
+    """>= `repeats` loops of `steps` steps, each bracketed by barrier(); until >= min_ms in total.
+    Every rank takes the same number of loops (the per-loop time is MAX-reduced over ranks)."""
+    per, total, enq = [], 0.0, []
+    while True:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        t_enq = time.perf_counter() - t0        # host time to enqueue the steps (no device wait)
+        barrier()
+        dt = reduce_max(time.perf_counter() - t0)
+        per.append(dt / steps)
+        enq.append(t_enq / steps)
+        total += dt
+        if (len(per) >= repeats and total >= min_ms * 1e-3) or len(per) >= 400:
+            break
+    return per, enq
+
+
+def kernel_times(cof, work, step_with_hooks, barrier, n, base_hooks=None):
+    """Durations of the two streaming kernels over n live steps: dispatch begin -> end timestamps
+    attached by hipExtLaunchKernel (see include/apa.h, apa_hooks.prof_*)."""
+    timer = cof.KernelTimer(n, base=base_hooks)
+    for i in range(n):
+        step_with_hooks(timer.hooks(i))
+    barrier()
+    f, b = timer.fwd_elapsed_ms(), timer.bwd_elapsed_ms()
+    timer.close()
+    return f, b
 
 
 def main():
@@ -170,72 +302,11 @@ def main():
 
     N, H, C, K = args.batch, args.hw, args.channels, args.classes
     P = H * H
-    tdtype = torch.float32 if args.dtype == 'f32' else torch.bfloat16
-    g = torch.Generator(device='cpu').manual_seed(42 + rank)     # cfg.RNG_SEED = 42
-    X = torch.randn(N, P, C, generator=g)
-    X = (X if args.relu_input else torch.relu(X)).to(tdtype).to(dev)
-    gw = torch.Generator(device='cpu').manual_seed(42)            # replicated weights
-    Wa = (torch.randn(C, 1, generator=gw) / C ** 0.5).to(dev)
-    ba = torch.zeros(1, device=dev)
-    Wt = (torch.randn(C, K, generator=gw) / C ** 0.5).to(dev)
-    bt = torch.zeros(K, device=dev)
-    labels = torch.randint(0, K, (N,), generator=g).to(dev)
-
-    train = not args.eval_mode
-    flags = cof.attn_flags(args.softmax_att, False, train, relu_input=args.relu_input)
-    keep = args.keep_prob if train else 1.0
-
-    # flat fp32 gradient bucket [dWa | dba | dWt | dbt]: one all-reduce per step, no packing copy
-    sizes = [C * 1, 1, C * K, K]
-    bucket = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
-    views, o = [], 0
-    for s in sizes:
-        views.append(bucket[o:o + s])
-        o += s
-    dWa, dba, dWt, dbt = views[0].view(C, 1), views[1], views[2].view(C, K), views[3]
-    dX = torch.empty_like(X)
-    ws = torch.empty((cof.attn_pool_workspace_bytes(N, P, C, C, K, 1, flags),), dtype=torch.uint8,
-                     device=dev)
-    grad_scale = 1.0 / world                    # model_deploy.py:223-225: clone loss / num_clones
-    # dropout step counter in HBM: read by the kernels, advanced by the backward call, so every
-    # step (and every hipGraph replay) draws a fresh mask like a fresh tf.nn.dropout per sess.run
-    rng_ctr = torch.zeros(1, dtype=torch.int64, device=dev)
-
-    # one foreign call per step (apa_attn_head_train_step = the three entry points back to back,
-    # arguments marshalled once): keeps the host ahead of the ~55 us step on any CPU
-    stepper = None if args.per_op_calls else cof.HeadTrainStep(
-        X, X, Wa, ba, Wt, bt, labels, (dX, None, dWa, dba, dWt, dbt), flags=flags, keep_prob=keep, seed=42,
-        offset=rng_ctr, grad_scale=grad_scale, workspace=ws)
-
-    def compute():
-        if stepper is not None:
-            stepper.run()
-            return
-        logits, att, zsave, abar, _, _ = cof.attn_pool_fwd(X, X, Wa, ba, Wt, bt, flags=flags,
-                                                           keep_prob=keep, seed=42, offset=rng_ctr,
-                                                           workspace=ws)
-        _, G, _, _ = cof.softmax_xent_fwd_bwd(logits, labels, grad_scale=grad_scale)
-        cof.attn_pool_bwd(X, X, Wa, ba, Wt, bt, att, zsave, abar, G, flags=flags, keep_prob=keep,
-                          seed=42, offset=rng_ctr, workspace=ws,
-                          out=(dX, None, dWa, dba, dWt, dbt))
-
-    graph = None
     if args.graph:
-        # the launches of a step are stream-ordered, allocation-free and argument-stable (the
-        # dropout counter lives in HBM), so the whole step can be captured once in a hipGraph
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                compute()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            compute()
+        args.rotate = 1
 
     # Data-parallel gradient sum (model_deploy.py:421-451).  dWt|dbt (99.7 % of the payload) are final
-    # after the first kernel of the backward call: the library records `ready` there and their
+    # after the first kernel of the backward call: the library records `grad_ready` there and their
     # all-reduce starts on a side stream underneath the streaming pass; dWa|dba (8 KB) follow on the
     # main stream once the call is done.
     comm = comm_td = None
@@ -263,24 +334,47 @@ def main():
             dist.destroy_process_group()
             dist.init_process_group('nccl', device_id=dev)
 
+    # the overlapped schedule needs the bucket views before the workload exists: build the workload
+    # first without hooks, then attach them to its steppers
+    work = HeadWorkload(cof, args, dev, rank, world, N, args.rotate)
+    bucket = work.bucket
+    overlap = None
+    bucket_att, bucket_td = bucket[:C + 1], bucket[C + 1:]
+    if dist is not None and not args.graph and comm_td is not None:
+        from attentionalpoolingaction_amd import deploy
+        overlap = deploy.OverlappedGradientSum(bucket_att, bucket_td, comm, comm_td, dev)
+        work.hooks = overlap.hooks
+        for st in work.steppers:
+            if st is not None:
+                st.hooks = overlap.hooks
+    torch_overlap = dist is not None and not args.graph and comm is None and args.overlap == 'on'
+
     def allreduce(t, stream=None, async_op=False):
         if comm is not None:
             comm.all_reduce_(t, stream)
             return None
         return dist.all_reduce(t, async_op=async_op)
 
-    overlap = None
-    bucket_att, bucket_td = bucket[:C + 1], bucket[C + 1:]
-    if dist is not None and graph is None and comm_td is not None:
-        from attentionalpoolingaction_amd import deploy
-        overlap = deploy.OverlappedGradientSum(bucket_att, bucket_td, comm, comm_td, dev)
-    torch_overlap = dist is not None and graph is None and comm is None and args.overlap == 'on'
+    graph = None
+    if args.graph:
+        # the launches of a step are stream-ordered, allocation-free and argument-stable (the
+        # dropout counter lives in HBM), so the whole step can be captured once in a hipGraph
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                work.compute()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            work.compute()
 
-    def step(eager=False):
-        if graph is not None and not eager:
+    def step(hooks=None):
+        if graph is not None and hooks is None:
             graph.replay()
         else:
-            compute()
+            work.compute(hooks)
         if overlap is not None:
             overlap.after_backward()
         elif torch_overlap:
@@ -297,53 +391,42 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def reduce_max(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     for _ in range(args.warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    t_enq = time.perf_counter() - t0            # host time to enqueue the K steps (no device wait)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    print('host enqueue {:.1f} us/step, wall {:.1f} us/step'.format(t_enq / args.steps * 1e6,
-                                                                 elapsed / args.steps * 1e6), file=sys.stderr)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    per, enq = timed_loops(step, barrier, args.steps, args.min_ms, args.repeats, reduce_max)
+    sec = _median(per)
+    print('host enqueue {:.1f} us/step, wall {:.1f} us/step (median of {} loops, min {:.1f} max {:.1f})'.format(
+        _median(enq) * 1e6, sec * 1e6, len(per), min(per) * 1e6, max(per) * 1e6), file=sys.stderr)
 
-    # ---- dominant-kernel duration, HIP events on the launch stream, live over the same steps ----
-    kt_steps = min(args.steps, 100)
-    timer = cof.KernelTimer(kt_steps)
-    for i in range(kt_steps):
-        timer.arm(i)
-        step(eager=True)        # event records are host calls: run the same launches un-captured
-    timer.disarm()
-    barrier()
-    kms = sorted(timer.elapsed_ms())
-    nms = sorted(timer.null_elapsed_ms())
-    timer.close()
-    # A HIP event pair costs ~3 us by itself (two timestamp packets + the dispatch gap); the library
-    # records a second, empty pair right before the kernel's pair on the same stream, and the
-    # kernel duration is the difference of the two averages.  rocprofv3 --kernel-trace (profiles/)
-    # measures the same kernel begin->end on the GPU clock and must agree with it.
-    k_raw_ms = sum(kms) / len(kms)
-    k_null_ms = sum(nms) / len(nms)
-    k_avg_ms = max(k_raw_ms - k_null_ms, 1e-6)
-    esz = 4 if args.dtype == 'f32' else 2
+    # ---- streaming-kernel durations: dispatch timestamps, live over the same steps (eager launches) ----
+    kt_steps = max(20, min(args.steps, 200))
+    kf, kb = kernel_times(cof, work, step, barrier, kt_steps,
+                          base_hooks=overlap.hooks if overlap is not None else None)
+    esz = work.esz
+    kb_avg_ms, kf_avg_ms = sum(kb) / len(kb), sum(kf) / len(kf)
     alg_bytes = 2.0 * N * P * C * esz           # bwd main kernel: read X once + write dX once
-    achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9
+    achieved = alg_bytes / (kb_avg_ms * 1e-3) / 1e9
+    fwd_bytes = 1.0 * N * P * C * esz
+    fwd_achieved = fwd_bytes / (kf_avg_ms * 1e-3) / 1e9
 
-    # HBM traffic of the dominant kernel from the separate rocprofv3 --pmc passes (profiles/):
-    # only valid for the exact workload it was collected on
-    traffic = args.traffic_bytes
+    train = not args.eval_mode
     workload = ('cfg002 attentional-pooling head fwd + softmax-xent + bwd, per-GPU batch {} '
-                'x {}x{}x{} {} features, K={}, M=1 (class-agnostic bottom-up map), '
-                '{}'.format(N, H, H, C, args.dtype, K,
-                            'dropout keep={}'.format(keep) if train else 'eval (no dropout)'))
+                'x {}x{}x{} {} features, K={}, M=1 (class-agnostic bottom-up map), {}; X/dX rotated over {} '
+                'buffer sets ({:.0f} MB live)'.format(
+                    N, H, H, C, args.dtype, K,
+                    'dropout keep={}'.format(work.keep) if train else 'eval (no dropout)', work.rotate,
+                    work.rotate * 2.0 * N * P * C * esz / 1e6))
+    # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (they cannot run
+    # inside this process): the newest committed summary collected on exactly this workload
+    traffic, traffic_source = args.traffic_bytes, ('--traffic-bytes' if args.traffic_bytes is not None else None)
     if traffic is None and not args.softmax_att:
-        # newest committed PMC summary whose workload string is exactly this run's
         import glob
         for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')), reverse=True):
             try:
@@ -354,23 +437,27 @@ def main():
                    and v.get('workload') == workload]
             if hit:
                 traffic = hit[0]['hbm_bytes_per_launch']
+                traffic_source = 'profiles/' + os.path.basename(f) + ' (rocprofv3 --pmc passes of this command)'
                 break
 
+    out = None
     if rank == 0:
-        total_images = N * world * args.steps
+        stream_kernel = (C % 1024 == 0 and args.dtype == 'f32') or (C == 2048)
         out = {
             'metric': 'images/sec attn-pool fwd+bwd, Nx14x14x2048, 393 classes',
-            'value': round(total_images / elapsed, 1),
+            'value': round(N * world / sec, 1),
             'unit': 'images/sec',
             'n_gpus': world,
             'steps': args.steps,
             'warmup': args.warmup,
-            'ms_per_step': round(elapsed / args.steps * 1e3, 5),
+            'ms_per_step': round(sec * 1e3, 5),
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
             'dtype': args.dtype,
             'data': 'synthetic',
+            'repeats': len(per),
+            'ms_per_step_min_max': [round(min(per) * 1e3, 5), round(max(per) * 1e3, 5)],
             'config': {
                 'workload': workload,
                 'global_batch': N * world,
@@ -387,19 +474,75 @@ def main():
             },
             'roofline': {
                 'bound': 'hbm',
-                'kernel': 'm1s_bwd_main_kernel' if (C % 1024 == 0 and args.dtype == 'f32') or (C == 2048) else 'm1_bwd_main_kernel',
+                'kernel': 'm1s_bwd_main_kernel' if stream_kernel else 'm1_bwd_main_kernel',
                 'achieved': round(achieved, 1),
                 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 4),
                 'traffic': traffic,
+                'traffic_source': traffic_source,
                 'alg_bytes_per_launch': alg_bytes,
-                'kernel_avg_us': round(k_avg_ms * 1e3, 3),
-                'event_pair_raw_us': round(k_raw_ms * 1e3, 3),
-                'event_pair_null_us': round(k_null_ms * 1e3, 3),
+                'kernel_avg_us': round(kb_avg_ms * 1e3, 3),
+                'kernel_median_us': round(_median(kb) * 1e3, 3),
+                'timer': 'hipExtLaunchKernel start/stop events (dispatch begin -> end), {} live steps'.format(len(kb)),
             },
-            'step_roofline_frac': round((3.0 * N * P * C * esz) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+            'roofline_fwd': {
+                'bound': 'hbm',
+                'kernel': 'm1s_pool_fwd_kernel' if stream_kernel else 'm1_pool_fwd_kernel',
+                'achieved': round(fwd_achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(fwd_achieved / HBM_PEAK_GBS, 4), 'alg_bytes_per_launch': fwd_bytes,
+                'kernel_avg_us': round(kf_avg_ms * 1e3, 3), 'kernel_median_us': round(_median(kf) * 1e3, 3),
+            },
+            'step_roofline_frac': round((3.0 * N * P * C * esz) / sec / 1e9 / HBM_PEAK_GBS, 4),
         }
+
+    # ---- the other BASELINE configs, same process, same timing discipline (N = 1 only) ----
+    if world == 1 and dist is None and not args.no_extra and out is not None:
+        from tools import bench_dense as bd
+        extra = {}
+        del work
+        torch.cuda.empty_cache()
+
+        def run_extra(key, builder, **kw):
+            try:
+                fn, info = builder(cof, dev, **kw)
+                s, reps = bd.timed(fn, 50, 5, min_ms=args.min_ms, repeats=args.repeats)
+                extra[key] = bd.report(info, s, reps)
+            except Exception as e:                             # noqa: BLE001 -- report, do not lose the headline
+                extra[key] = {'error': '{}: {}'.format(type(e).__name__, e)}
+            torch.cuda.empty_cache()
+
+        run_extra('cfg002_eval', bd.build_eval002, N=32, H=14, K=393, dtype='f32')
+        run_extra('cfg003_bf16_train', bd.build_cfg003, N=32, H=14, K=393, dtype='bf16')
+        run_extra('hmdb51_perclass_bf16_train', bd.build_perclass, N=32, H=14, K=51, dtype='bf16')
+        # the headline step far outside every cache: N = 512 (1.6 GB of features per pass, no rotation needed)
+        try:
+            big = HeadWorkload(cof, args, dev, rank, world, 512, 1)
+            for _ in range(3):
+                big.compute()
+            bper, _ = timed_loops(big.compute, torch.cuda.synchronize, 20, args.min_ms, args.repeats, lambda x: x)
+            bf, bb = kernel_times(cof, big, big.compute, torch.cuda.synchronize, 20)
+            bsec = _median(bper)
+            bb_avg, bf_avg = sum(bb) / len(bb), sum(bf) / len(bf)
+            extra['cfg002_train_n512'] = {
+                'workload': 'the headline step at per-GPU batch 512 (1.6 GB of features per pass)',
+                'images_per_sec': round(512 / bsec, 1), 'ms_per_step': round(bsec * 1e3, 5), 'repeats': len(bper),
+                'step_roofline_frac': round(3.0 * 512 * P * C * esz / bsec / 1e9 / HBM_PEAK_GBS, 4),
+                'roofline': {'bound': 'hbm', 'kernel': 'm1s_bwd_main_kernel', 'kernel_avg_us': round(bb_avg * 1e3, 2),
+                             'achieved': round(2.0 * 512 * P * C * esz / (bb_avg * 1e-3) / 1e9, 1),
+                             'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                             'frac': round(2.0 * 512 * P * C * esz / (bb_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                'roofline_fwd': {'bound': 'hbm', 'kernel': 'm1s_pool_fwd_kernel', 'kernel_avg_us': round(bf_avg * 1e3, 2),
+                                 'achieved': round(1.0 * 512 * P * C * esz / (bf_avg * 1e-3) / 1e9, 1),
+                                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                 'frac': round(1.0 * 512 * P * C * esz / (bf_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+            del big
+        except Exception as e:                                 # noqa: BLE001
+            extra['cfg002_train_n512'] = {'error': '{}: {}'.format(type(e).__name__, e)}
+        torch.cuda.empty_cache()
+        out['extra'] = extra
+
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N = 1 only
             out['cpu_baseline'] = cpu_baseline(args, args.cpu_seconds)
         print(json.dumps(out), file=real_stdout, flush=True)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define APA_VERSION 100 /* major*10000 + minor*100 + patch */
+#define APA_VERSION 200 /* major*10000 + minor*100 + patch */
 
 typedef enum apa_status {
   APA_OK = 0,
@@ -230,8 +230,13 @@ int apa_pose_label_replay_resize(const uint8_t* hm_host, int h, int w, int J, in
  * cfg.EPS = 1e-14, gives the same result on a binary canvas).
  *   pose    int64 [N][max_vals]  (x, y, is_visible) triples, n_vals[n] of them used (multiple of 3*J,
  *           at most 32 people)
- *   geom    int32 [N][7] = im_ht, im_wd, crop_y, crop_x, crop_h, crop_w, flip   (crop in the
- *           coordinates of the im_ht x im_wd image, like the host function's orig_h x orig_w)
+ *   geom    int32 [N][9] = im_ht, im_wd, aug_ht, aug_wd, crop_y, crop_x, crop_h, crop_w, flip.
+ *           TWO frames, as in the reference: the keypoints are scaled onto the canvas with the size
+ *           of the ORIGINAL image (im_ht x im_wd, preprocess_pipeline.py:155-157), while the crop
+ *           was recorded on the image AFTER the aspect-preserving resize to RESIZE_SIDE (aug_ht x
+ *           aug_wd = preproc_info['image_shape'], vgg_preprocessing.py:325) and is rescaled to the
+ *           canvas with ratio = canvas / aug size (_replay_augmentation, :29-36) -- the orig_h x
+ *           orig_w of apa_pose_label_replay_resize
  *   labels  f32 [N, out_side, out_side, J];  valid uint8 [N, J];  status int32 [N]: 0 = ok, 1 = the
  *           host path would have failed for this image (bad crop / sizes): its label is all zero. */
 int apa_pose_labels_device(const int64_t* pose, const int32_t* n_vals, const int32_t* geom, int N,
@@ -257,25 +262,60 @@ int apa_zero_out_channels(const float* in, const uint8_t* channels, float* out, 
                           int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Gradient-ready hook (communication / compute overlap).  The classifier gradients dWt / dbt --
- * 99.7 % of the all-reduce payload -- are final after the FIRST kernel of apa_attn_pool_bwd, before
- * the streaming pass starts.  If an event is registered (per host thread), apa_attn_pool_bwd
- * records it on its stream at that point, so a data-parallel trainer can start the RCCL
- * all-reduce of that part of the bucket on a second stream while dX / dWa are still being
- * produced (bench.py, deploy.py).  NULL clears.  Purely an ordering aid: results are unaffected.
+ * Per-call hooks (communication / compute overlap, measurement).  The library keeps NO state
+ * between calls and none per thread: a caller that wants one of the aids below passes this struct
+ * to the *_ex form of an entry point; NULL (or the plain entry points) means "no hooks".  Every
+ * member is a hipEvent_t created by the caller (or NULL).  Purely ordering / timing aids: results
+ * are unaffected.
+ *
+ *   grad_ready_event        recorded on the call's stream as soon as the classifier gradients
+ *                           dWt / dbt -- 99.7 % of the all-reduce payload -- are final, i.e. after the
+ *                           FIRST kernel of the backward pass, before the streaming pass starts: a
+ *                           data-parallel trainer starts the RCCL all-reduce of that part of the
+ *                           bucket on a second stream while dX / dWa are still being produced
+ *                           (deploy.OverlappedGradientSum, bench.py --gpus N).
+ *   td_weights_ready_event  the mirror image on the forward side: the stream waits for it
+ *                           (hipStreamWaitEvent) immediately before the first kernel that reads
+ *                           td_weights / td_biases -- on the M == 1 path that is the logits product,
+ *                           AFTER the pooling pass, which only needs the attention weights.  The
+ *                           trainer records it on its communication stream once the all-reduce (and
+ *                           optimizer update) of td_weights of the previous step is done, so that
+ *                           collective hides under the streaming backward pass of step k AND the
+ *                           pooling pass of step k+1.
+ *   prof_fwd_start/stop     the M == 1 streaming kernels (m1s_pool_fwd_kernel / m1s_bwd_main_kernel) are
+ *   prof_bwd_start/stop     launched with hipExtLaunchKernel(start, stop): the events then carry the
+ *                           dispatch's own begin / end timestamps -- the same clock and the same two
+ *                           points rocprofv3 --kernel-trace reports -- and hipEventElapsedTime(start,
+ *                           stop) is the kernel's duration with no event-packet overhead to subtract.
  */
-int apa_set_grad_ready_event(void* event);
+typedef struct apa_hooks {
+  void* grad_ready_event;
+  void* td_weights_ready_event;
+  void* prof_fwd_start;
+  void* prof_fwd_stop;
+  void* prof_bwd_start;
+  void* prof_bwd_stop;
+} apa_hooks;
 
-/* The mirror-image hook on the forward side.  If an event is registered (per host thread),
- * apa_attn_pool_fwd makes its stream wait for it (hipStreamWaitEvent) immediately before the first
- * kernel that reads td_weights / td_biases -- on the M == 1 path that is the logits product, AFTER
- * the pooling and finalize passes, which only need the attention weights.  A data-parallel
- * trainer records the event on its communication stream once the all-reduce (and the optimizer
- * update) of td_weights / td_biases of the previous step is done: that collective is then hidden
- * under the streaming backward pass of step k AND the pooling pass of step k+1, and only the 8 KB
- * attention-weight all-reduce stays on the critical path (bench.py --gpus N).
- * On the other paths the wait is placed at the start of the call.  NULL clears. */
-int apa_set_td_weights_ready_event(void* event);
+int apa_attn_pool_fwd_ex(const apa_hooks* hooks, const void* X, const void* Xatt, const float* Wa,
+                         const float* ba, const float* Wt, const float* bt, float* logits, float* att,
+                         float* zsave, float* abar, void* topdown, void* ws, size_t ws_bytes, int N,
+                         int P, int C, int Ca, int K, int M, unsigned flags, float keep_prob,
+                         uint64_t seed, uint64_t offset, int dtype, void* stream);
+int apa_attn_pool_bwd_ex(const apa_hooks* hooks, const void* X, const void* Xatt, const float* Wa,
+                         const float* ba, const float* Wt, const float* bt, const float* att,
+                         const float* zsave, const float* abar, const float* G, void* dX, void* dXatt,
+                         float* dWa, float* dba, float* dWt, float* dbt, void* ws, size_t ws_bytes,
+                         int N, int P, int C, int Ca, int K, int M, unsigned flags, float keep_prob,
+                         uint64_t seed, uint64_t offset, int dtype, void* stream);
+int apa_attn_head_train_step_ex(const apa_hooks* hooks, const void* X, const void* Xatt,
+                                const float* Wa, const float* ba, const float* Wt, const float* bt,
+                                const int64_t* labels, float loss_wt, float grad_scale, float* logits,
+                                float* att, float* zsave, float* abar, float* loss, float* G, void* dX,
+                                void* dXatt, float* dWa, float* dba, float* dWt, float* dbt, void* ws,
+                                size_t ws_bytes, int N, int P, int C, int Ca, int K, int M,
+                                unsigned flags, float keep_prob, uint64_t seed, uint64_t offset,
+                                int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused optimizer step (src/train.py:90-94 tf.train.MomentumOptimizer + the slim L2 regulariser of
@@ -292,19 +332,13 @@ int apa_momentum_sgd_step(int nseg, float* const* weights, const size_t* sizes,
                           float lr, float momentum, float grad_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Measurement hooks (bench.py): HIP events owned by the library's HIP runtime, and a per-thread
- * pair that the next apa_attn_pool_bwd call records immediately before / after its dominant
- * streaming kernel (m1_bwd_main_kernel), on the call's stream.  Pass NULL, NULL to clear.
+ * Measurement helpers (bench.py): HIP events owned by the library's HIP runtime, for the prof_*
+ * members of apa_hooks.
  */
 int apa_prof_event_create(void** event);
 int apa_prof_event_destroy(void* event);
 int apa_prof_event_record(void* event, void* stream);
 int apa_prof_event_elapsed_ms(void* start, void* stop, float* ms); /* both must have completed */
-int apa_prof_set_kernel_events(void* start, void* stop);
-/* Calibration: a second per-thread pair that the same call records BACK TO BACK (nothing between
- * them) right before the first pair, i.e. under the same stream conditions.  Its elapsed time is
- * what an event pair costs by itself (~3-4 us on MI355X); bench.py subtracts it.  NULL, NULL clears. */
-int apa_prof_set_null_events(void* start, void* stop);
 
 #ifdef __cplusplus
 }

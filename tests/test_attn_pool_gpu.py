@@ -98,6 +98,21 @@ def test_m1_fused_fp32_parity(gpu, H, C, K, softmax, relu):
     _grads_close(got, ref, ('dX', 'dWa', 'dba', 'dWt', 'dbt'))
 
 
+@pytest.mark.parametrize('H,C,softmax', [(36, 256, True), (36, 256, False), (34, 1024, True)])
+def test_m1_batch_one_large_map_split_count_is_clamped(gpu, H, C, softmax):
+    """The shipped eval config runs batch 1; with P > 1024 pixels the per-image split count
+    (target 512 blocks / N) would exceed the 256 splits m1_finalize_fwd_kernel merges -- m1_plan clamps
+    it.  Both kernel families (per-pixel C = 256, channel-split C = 1024), softmax statistics included."""
+    inp = make_head_inputs(N=1, H=H, W=H, C=C, K=10, seed=5 + H)
+    flags = orc.AttnFlags(single_layer_att=True, softmax_att=softmax)
+    ref = _oracle(inp, flags)
+    got = _run_hip(inp, gpu, softmax=softmax)
+    _close(got['logits'], ref['logits'], TIGHT, 'logits')
+    _close(got['att'].reshape(ref['att'].shape), ref['att'], TIGHT, 'attention map')
+    assert torch.equal(got['pred'], ref['logits'].argmax(dim=1))
+    _grads_close(got, ref, ('dX', 'dWa', 'dba', 'dWt', 'dbt'))
+
+
 @pytest.mark.parametrize('softmax,relu', [(False, False), (True, False), (False, True)])
 def test_m1_separate_attention_input_cfg003(gpu, softmax, relu):
     # cfg 003: bottom-up map from pose_pre_logits (768 channels), top-down from conv5

@@ -764,13 +764,14 @@ def test_overlapped_gradient_sum_schedule_matches_the_sequential_loop(gpu):
             Wa.add_(dWa, alpha=-lr)
             ba.add_(dba, alpha=-lr)
         losses = []
+        hooks = sync.hooks if overlapped else None       # apa_hooks: passed per call, no library state
         for _ in range(4):
             logits, att, zsave, abar, _, _ = cof.attn_pool_fwd(X, X, Wa, ba, Wt, bt, flags=flags, keep_prob=0.5,
-                                                               seed=42, offset=ctr, workspace=ws)
+                                                               seed=42, offset=ctr, workspace=ws, hooks=hooks)
             loss, G, _, _ = cof.softmax_xent_fwd_bwd(logits, labels)
             losses.append(loss.clone())
             cof.attn_pool_bwd(X, X, Wa, ba, Wt, bt, att, zsave, abar, G, flags=flags, keep_prob=0.5, seed=42,
-                              offset=ctr, workspace=ws, out=(dX, None, dWa, dba, dWt, dbt))
+                              offset=ctr, workspace=ws, out=(dX, None, dWa, dba, dWt, dbt), hooks=hooks)
             if overlapped:
                 sync.after_backward(update_td, update_att)
             else:
@@ -840,20 +841,30 @@ def test_device_label_path_bit_exact_vs_host_functions(gpu):
                 p[..., 0], p[..., 1], p[..., 2] = im_wd // 2, im_ht // 2, 1
                 crop_h = crop_w = max(8, min(im_ht, im_wd) // 40)
                 crop_y, crop_x = im_ht // 2 - crop_h // 2, im_wd // 2 - crop_w // 2
+            # the crop is recorded on the image AFTER the aspect-preserving resize to RESIZE_SIDE
+            # (vgg_preprocessing.py:325): a different frame from the keypoints' (original) one
+            scale = 480.0 / min(im_ht, im_wd) if i % 3 else 1.0
+            aug_ht, aug_wd = int(im_ht * scale), int(im_wd * scale)
+            crop_y, crop_x = int(crop_y * scale), int(crop_x * scale)
+            crop_h, crop_w = max(1, int(crop_h * scale)), max(1, int(crop_w * scale))
+            if i == 1:
+                aug_ht, aug_wd = im_ht, im_wd
+                crop_h = crop_w = max(8, min(im_ht, im_wd) // 40)
+                crop_y, crop_x = im_ht // 2 - crop_h // 2, im_wd // 2 - crop_w // 2
             poses.append(p.reshape(-1))
-            geoms.append((im_ht, im_wd, crop_y, crop_x, crop_h, crop_w, int(rng.rand() < 0.5)))
+            geoms.append((im_ht, im_wd, aug_ht, aug_wd, crop_y, crop_x, crop_h, crop_w, int(rng.rand() < 0.5)))
         labels, valid, status = cof.pose_labels_device(poses, geoms, marker_wd_ratio=ratio, device=gpu)
         labels, valid, status = labels.cpu().numpy(), valid.cpu().numpy(), status.cpu().numpy()
         assert (status == 0).all()
         for i, (p, g) in enumerate(zip(poses, geoms)):
             hm, v = cof.pose_to_heatmap(p, g[0], g[1], 200, out_channels=J, marker_wd_ratio=ratio,
                                         do_gauss_blur=False)
-            ref = cof.pose_label_replay_resize(hm, (g[0], g[1]), [g[2], g[3], g[4], g[5]], bool(g[6]), 15)
+            ref = cof.pose_label_replay_resize(hm, (g[2], g[3]), [g[4], g[5], g[6], g[7]], bool(g[8]), 15)
             assert np.array_equal(valid[i], v), i
             assert np.array_equal(labels[i], ref), (i, float(np.abs(labels[i] - ref).max()))
         assert labels[0].max() == 0.0 and labels[2:].max() == 1.0
     # a crop outside the image is reported, not silently accepted
-    _, _, st = cof.pose_labels_device([poses[3]], [(300, 300, 250, 0, 100, 100, 0)], device=gpu)
+    _, _, st = cof.pose_labels_device([poses[3]], [(300, 300, 300, 300, 250, 0, 100, 100, 0)], device=gpu)
     assert int(st[0]) == 1
 
 
@@ -997,6 +1008,13 @@ def test_bench_prints_one_json_line_with_the_contract_fields(gpu):
         r = d['roofline']
         assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
         assert 0.2 < r['frac'] < 1.0 and d['value'] > 2000          # BASELINE target: >= 2000 img/s
+        assert d['repeats'] >= 5 and d['repeats'] * 20 * d['ms_per_step'] >= 45.0     # >= 50 ms measured, median
+        assert 'rotated over' in d['config']['workload'] and r['timer'].startswith('hipExtLaunchKernel')
+        assert d['roofline_fwd']['kernel'] == 'm1s_pool_fwd_kernel' and 0.2 < d['roofline_fwd']['frac'] < 1.0
         if '--no-cpu-baseline' not in extra:
             c = d['cpu_baseline']
             assert c['kind'] == 'port' and c['unit'] == 'images/sec' and c['cores'] >= 1 and c['value'] > 0
+            # the other BASELINE configs ride on the same line
+            for k in ('cfg002_eval', 'cfg003_bf16_train', 'hmdb51_perclass_bf16_train', 'cfg002_train_n512'):
+                assert 'error' not in d['extra'][k], d['extra'][k]
+                assert d['extra'][k]['ms_per_step'] > 0 and 0.0 < d['extra'][k]['roofline']['frac'] < 1.0
