@@ -28,7 +28,10 @@ def main():
         w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage'])
         for r in rows:
             w.writerow([r['Name'], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage']])
-    bench_line = [l for l in open(os.path.join(out_dir, 'bench_under_rocprof.log')).read().splitlines()
+    log = os.path.join(out_dir, 'bench_under_rocprof.log')
+    if not os.path.exists(log):
+        log = os.path.join(out_dir, 'bench.log')
+    bench_line = [l for l in open(log).read().splitlines()
                   if l.startswith('{"metric"')][-1]
     open(os.path.join(prof, tag + '_bench_under_rocprof.log'), 'w').write(bench_line + '\n')
     bench = json.loads(bench_line)
@@ -42,7 +45,7 @@ def main():
         return {k: sum(v) / len(v) for k, v in acc.items() if len(v) >= 10}
     fetch, write = pmc('pmc_fetch', 'FETCH_SIZE'), pmc('pmc_write', 'WRITE_SIZE')
     traffic = {'_how': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, two separate passes over '
-                       '`python bench.py --steps 30 --warmup 5 --no-cpu-baseline ' + bench_args + '`; per-dispatch '
+                       '`python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extra ' + bench_args + '`; per-dispatch '
                        'averages. Units: KB (x1024). gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts '
                        '64 B per 128-B request of a wide coalesced stream -> doubled; the forward pooling pass '
                        '(reads exactly X) is the calibration row.'}
@@ -59,11 +62,23 @@ def main():
     with open(os.path.join(prof, tag + '_summary.md'), 'w') as f:
         f.write('# {} rocprofv3 summary (MI355X, gfx950)\n\n'.format(tag))
         f.write('Command (inside gpurun): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py '
-                '--steps 200 --warmup 20 --no-cpu-baseline {}`\n\n(workload: {})\n\n'.format(bench_args, cfg))
+                '--steps 200 --warmup 20 --no-cpu-baseline --no-extra {}`\n\n(workload: {})\n\n'.format(bench_args, cfg))
         f.write('bench line under the profiler: {} img/s, {:.2f} us/step\n\n'.format(bench['value'], bench['ms_per_step'] * 1e3))
         f.write('| kernel | calls | avg us | % |\n|---|---|---|---|\n')
         for r in per_step:
             f.write('| `{}` | {} | {:.2f} | {} |\n'.format(r['Name'].replace('(anonymous namespace)::', '').split('(')[0], r['Calls'], float(r['AverageNs']) / 1e3, r['Percentage']))
+        rl, rf = bench.get('roofline', {}), bench.get('roofline_fwd', {})
+        f.write('\nCross-check of bench.py\'s own kernel timer (hipExtLaunchKernel start/stop events) against the '
+                'rocprofv3 averages above, same run:\n\n| kernel | bench.py avg us | rocprofv3 avg us | ratio |\n|---|---|---|---|\n')
+        for r in per_step:
+            for tag_, blk in (('bwd_main', rl), ('pool_fwd', rf)):
+                if tag_ in r['Name'] and blk.get('kernel_avg_us'):
+                    ra = float(r['AverageNs']) / 1e3
+                    f.write('| `{}` | {:.2f} | {:.2f} | {:.3f} |\n'.format(blk['kernel'], blk['kernel_avg_us'], ra,
+                                                                         blk['kernel_avg_us'] / ra))
+        if rl:
+            f.write('\nroofline (bench line): {} GB/s = {} of {} GB/s on {} B per launch\n'.format(
+                rl.get('achieved'), rl.get('frac'), rl.get('peak'), rl.get('alg_bytes_per_launch')))
         f.write('\nrocprofv3 kernel durations include ~1.5 us of dispatch overhead per kernel (an empty kernel '
                 'reads 1.5 us min / 4.6 us median under the profiler, tools/ubench.hip), so the small kernels look '
                 'bigger here than their marginal cost in the un-profiled step (tools/kbench.cpp ablation).\n\n')
