@@ -100,7 +100,22 @@ extern "C" size_t apa_attn_pool_workspace_bytes(int N, int P, int C, int Ca, int
   return 0;
 }
 
-static int attn_pool_fwd_impl(const Hooks& hk, M1Xent* xf, const void* X, const void* Xatt, const float* Wa, const float* ba,
+static int check_cat(const char* fn, const apa_concat_feat* c, int M, unsigned flags, bool topdown,
+                     bool backward, CatFeat* out) {
+  if (!c->Xext || !c->zext || (backward && !c->dXext)) {
+    set_error("%s: apa_concat_feat needs Xext, zext%s", fn, backward ? " and dXext" : "");
+    return APA_ERR_INVALID_ARG;
+  }
+  if (M != 1 || (flags & APA_FLAG_RELU_INPUT) || topdown || !m1_cat_supported(c->J)) {
+    set_error("%s: the concatenated pose channels are built for M == 1, 1 <= J <= 64, without "
+              "APA_FLAG_RELU_INPUT and without the TopDownAttention dump (J=%d M=%d)", fn, c->J, M);
+    return APA_ERR_UNSUPPORTED;
+  }
+  out->Xext = c->Xext; out->J = c->J; out->zext = c->zext; out->dXext = c->dXext;
+  return APA_OK;
+}
+
+static int attn_pool_fwd_impl(const Hooks& hk, const apa_concat_feat* catp, M1Xent* xf, const void* X, const void* Xatt, const float* Wa, const float* ba,
                                  const float* Wt, const float* bt, float* logits, float* att,
                                  float* zsave, float* abar, void* topdown, void* ws,
                                  size_t ws_bytes, int N, int P, int C, int Ca, int K, int M,
@@ -121,6 +136,11 @@ static int attn_pool_fwd_impl(const Hooks& hk, M1Xent* xf, const void* X, const 
     return APA_ERR_INVALID_ARG;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
+  CatFeat cat;
+  if (catp) {
+    rc = check_cat("apa_attn_pool_fwd_cat", catp, M, flags, topdown != nullptr, false, &cat);
+    if (rc != APA_OK) return rc;
+  }
   if ((flags & APA_FLAG_RELU_INPUT) && (M != 1 || topdown)) {
     set_error("apa_attn_pool_fwd: APA_FLAG_RELU_INPUT is an M == 1 fast path without the "
               "TopDownAttention dump");
@@ -142,7 +162,7 @@ static int attn_pool_fwd_impl(const Hooks& hk, M1Xent* xf, const void* X, const 
       return APA_ERR_WORKSPACE;
     }
     rc = m1_forward(X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar, ws, N, P, C, Ca, K, flags,
-                    keep_prob, seed, offset, dtype, st, xf, hk);
+                    keep_prob, seed, offset, dtype, st, xf, hk, catp ? &cat : nullptr);
     if (rc != APA_OK || !topdown) return rc;
     // end_points['TopDownAttention'] = dropout(X).Wt + bt  (nets_factory.py:296-309): the factorised
     // path never needs it; it is materialised only on request (eval.py --ept dumps) by one GEMM.
@@ -183,7 +203,7 @@ extern "C" int apa_attn_pool_fwd(const void* X, const void* Xatt, const float* W
                                  size_t ws_bytes, int N, int P, int C, int Ca, int K, int M,
                                  unsigned flags, float keep_prob, uint64_t seed, uint64_t offset,
                                  int dtype, void* stream) {
-  return attn_pool_fwd_impl(Hooks(), nullptr, X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar, topdown, ws,
+  return attn_pool_fwd_impl(Hooks(), nullptr, nullptr, X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar, topdown, ws,
                             ws_bytes, N, P, C, Ca, K, M, flags, keep_prob, seed, offset, dtype, stream);
 }
 
@@ -193,11 +213,11 @@ extern "C" int apa_attn_pool_fwd_ex(const apa_hooks* hooks, const void* X, const
                                     void* ws, size_t ws_bytes, int N, int P, int C, int Ca, int K, int M,
                                     unsigned flags, float keep_prob, uint64_t seed, uint64_t offset,
                                     int dtype, void* stream) {
-  return attn_pool_fwd_impl(Hooks(hooks), nullptr, X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar, topdown,
+  return attn_pool_fwd_impl(Hooks(hooks), nullptr, nullptr, X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar, topdown,
                             ws, ws_bytes, N, P, C, Ca, K, M, flags, keep_prob, seed, offset, dtype, stream);
 }
 
-static int attn_pool_bwd_impl(const Hooks& hk, const M1Xent* xf, const void* X, const void* Xatt, const float* Wa, const float* ba,
+static int attn_pool_bwd_impl(const Hooks& hk, const apa_concat_feat* catp, const M1Xent* xf, const void* X, const void* Xatt, const float* Wa, const float* ba,
                                  const float* Wt, const float* bt, const float* att,
                                  const float* zsave, const float* abar, const float* G, void* dX,
                                  void* dXatt, float* dWa, float* dba, float* dWt, float* dbt,
@@ -219,6 +239,11 @@ static int attn_pool_bwd_impl(const Hooks& hk, const M1Xent* xf, const void* X, 
     return APA_ERR_INVALID_ARG;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
+  CatFeat cat;
+  if (catp) {
+    rc = check_cat("apa_attn_pool_bwd_cat", catp, M, flags, false, true, &cat);
+    if (rc != APA_OK) return rc;
+  }
   if ((flags & APA_FLAG_RELU_INPUT) && M != 1) {
     set_error("apa_attn_pool_bwd: APA_FLAG_RELU_INPUT is an M == 1 fast path");
     return APA_ERR_UNSUPPORTED;
@@ -243,7 +268,8 @@ static int attn_pool_bwd_impl(const Hooks& hk, const M1Xent* xf, const void* X, 
       return APA_ERR_WORKSPACE;
     }
     return m1_backward(X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, dX, dXatt, dWa, dba, dWt, dbt,
-                       ws, N, P, C, Ca, K, flags, keep_prob, seed, offset, dtype, st, xf, hk);
+                       ws, N, P, C, Ca, K, flags, keep_prob, seed, offset, dtype, st, xf, hk,
+                       catp ? &cat : nullptr);
   }
   if (!zsave) {
     set_error("apa_attn_pool_bwd: M==K needs zsave (the fp32 [N,P,K] top-down map from forward)");
@@ -267,7 +293,7 @@ extern "C" int apa_attn_pool_bwd(const void* X, const void* Xatt, const float* W
                                  void* ws, size_t ws_bytes, int N, int P, int C, int Ca, int K,
                                  int M, unsigned flags, float keep_prob, uint64_t seed,
                                  uint64_t offset, int dtype, void* stream) {
-  return attn_pool_bwd_impl(Hooks(), nullptr, X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, dX, dXatt, dWa, dba,
+  return attn_pool_bwd_impl(Hooks(), nullptr, nullptr, X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, dX, dXatt, dWa, dba,
                             dWt, dbt, ws, ws_bytes, N, P, C, Ca, K, M, flags, keep_prob, seed, offset,
                             dtype, stream);
 }
@@ -279,9 +305,32 @@ extern "C" int apa_attn_pool_bwd_ex(const apa_hooks* hooks, const void* X, const
                                     float* dWt, float* dbt, void* ws, size_t ws_bytes, int N, int P,
                                     int C, int Ca, int K, int M, unsigned flags, float keep_prob,
                                     uint64_t seed, uint64_t offset, int dtype, void* stream) {
-  return attn_pool_bwd_impl(Hooks(hooks), nullptr, X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, dX, dXatt,
+  return attn_pool_bwd_impl(Hooks(hooks), nullptr, nullptr, X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, dX, dXatt,
                             dWa, dba, dWt, dbt, ws, ws_bytes, N, P, C, Ca, K, M, flags, keep_prob, seed,
                             offset, dtype, stream);
+}
+
+extern "C" int apa_attn_pool_fwd_cat(const apa_concat_feat* cat, const apa_hooks* hooks, const void* X,
+                                     const void* Xatt, const float* Wa, const float* ba, const float* Wt,
+                                     const float* bt, float* logits, float* att, float* zsave,
+                                     float* abar, void* topdown, void* ws, size_t ws_bytes, int N, int P,
+                                     int C, int Ca, int K, int M, unsigned flags, float keep_prob,
+                                     uint64_t seed, uint64_t offset, int dtype, void* stream) {
+  return attn_pool_fwd_impl(Hooks(hooks), cat, nullptr, X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar,
+                            topdown, ws, ws_bytes, N, P, C, Ca, K, M, flags, keep_prob, seed, offset, dtype,
+                            stream);
+}
+
+extern "C" int apa_attn_pool_bwd_cat(const apa_concat_feat* cat, const apa_hooks* hooks, const void* X,
+                                     const void* Xatt, const float* Wa, const float* ba, const float* Wt,
+                                     const float* bt, const float* att, const float* zsave,
+                                     const float* abar, const float* G, void* dX, void* dXatt, float* dWa,
+                                     float* dba, float* dWt, float* dbt, void* ws, size_t ws_bytes, int N,
+                                     int P, int C, int Ca, int K, int M, unsigned flags, float keep_prob,
+                                     uint64_t seed, uint64_t offset, int dtype, void* stream) {
+  return attn_pool_bwd_impl(Hooks(hooks), cat, nullptr, X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, dX,
+                            dXatt, dWa, dba, dWt, dbt, ws, ws_bytes, N, P, C, Ca, K, M, flags, keep_prob,
+                            seed, offset, dtype, stream);
 }
 
 extern "C" int apa_attn_head_train_step_ex(const apa_hooks* hooks, const void* X, const void* Xatt,
@@ -306,7 +355,7 @@ extern "C" int apa_attn_head_train_step_ex(const apa_hooks* hooks, const void* X
   xf.lscale = N > 0 ? loss_wt / (float)N : 0.f;
   xf.gscale = N > 0 ? loss_wt * grad_scale / (float)N : 0.f;
   xf.done = false;
-  int rc = attn_pool_fwd_impl(hk, M == 1 ? &xf : nullptr, X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar,
+  int rc = attn_pool_fwd_impl(hk, nullptr, M == 1 ? &xf : nullptr, X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar,
                               nullptr, ws, ws_bytes, N, P, C, Ca, K, M, flags, keep_prob, seed, offset,
                               dtype, stream);
   if (rc != APA_OK) return rc;
@@ -315,7 +364,7 @@ extern "C" int apa_attn_head_train_step_ex(const apa_hooks* hooks, const void* X
                                   stream);
     if (rc != APA_OK) return rc;
   }
-  return attn_pool_bwd_impl(hk, xf.done ? &xf : nullptr, X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, dX,
+  return attn_pool_bwd_impl(hk, nullptr, xf.done ? &xf : nullptr, X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, dX,
                             dXatt, dWa, dba, dWt, dbt, ws, ws_bytes, N, P, C, Ca, K, M, flags, keep_prob,
                             seed, offset, dtype, stream);
 }
@@ -353,7 +402,7 @@ extern "C" int apa_attn_head_eval_step(const void* X, const void* Xatt, const fl
   M1Xent xf;
   xf.labels = nullptr; xf.loss = nullptr; xf.G = nullptr; xf.gscale = 0.f; xf.lscale = 0.f; xf.done = false;
   xf.probs = probs; xf.pred = pred;
-  int rc = attn_pool_fwd_impl(Hooks(), (M == 1 && !labels) ? &xf : nullptr, X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar, nullptr, ws,
+  int rc = attn_pool_fwd_impl(Hooks(), nullptr, (M == 1 && !labels) ? &xf : nullptr, X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar, nullptr, ws,
                               ws_bytes, N, P, C, Ca, K, M, eval_flags, 1.0f, 0, 0, dtype, stream);
   if (rc != APA_OK || xf.done) return rc;
   if (labels)

@@ -136,13 +136,21 @@ struct M1Xent {
   int64_t* pred = nullptr;    // [N]
 };
 
+// ..._WITH_POSE_FEAT (nets_factory.py:289-295): J extra top-down channels (apa_m1_cat.hip)
+struct CatFeat {
+  const float* Xext = nullptr;   // [N,P,J] f32
+  int J = 0;
+  float* zext = nullptr;         // [N,J] f32: forward output, backward input
+  float* dXext = nullptr;        // [N,P,J] f32 (backward)
+};
+
 struct M1Plan {
   int S;        // pixel splits per image
   int ppb;      // pixels per block
   int nblk;     // N * S
   int lsplits;  // split-K factor of the logits GEMM
   // workspace carve (byte offsets)
-  size_t off_pacc, off_pstat, off_pdwa, off_pdba, off_dz, off_gemm, off_dzatt, total;
+  size_t off_pacc, off_pstat, off_pdwa, off_pdba, off_dz, off_gemm, off_dzatt, off_cat_e, total;
 };
 M1Plan m1_plan(int N, int P, int C, int Ca, int K);
 
@@ -150,13 +158,13 @@ int m1_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
                const float* bt, float* logits, float* att, float* zsave, float* abar, void* ws,
                int N, int P, int C, int Ca, int K, unsigned flags, float keep_prob, uint64_t seed,
                uint64_t offset, int dtype, hipStream_t stream, M1Xent* xf = nullptr,
-               const Hooks& hk = Hooks());
+               const Hooks& hk = Hooks(), const CatFeat* cat = nullptr);
 int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* ba, const float* Wt,
                 const float* bt, const float* att, const float* zsave, const float* abar,
                 const float* G, void* dX, void* dXatt, float* dWa, float* dba, float* dWt,
                 float* dbt, void* ws, int N, int P, int C, int Ca, int K, unsigned flags,
                 float keep_prob, uint64_t seed, uint64_t offset, int dtype, hipStream_t stream,
-                const M1Xent* xf = nullptr, const Hooks& hk = Hooks());
+                const M1Xent* xf = nullptr, const Hooks& hk = Hooks(), const CatFeat* cat = nullptr);
 bool m1_supported(int C, int Ca, int dtype, bool fused);
 
 // apa_m1_stream.hip: "pixel tile x channel split" streaming passes for wide maps
@@ -168,6 +176,12 @@ struct M1Rng {
   bool relu_input = false;   // APA_FLAG_RELU_INPUT
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // apa_hooks prof_*: dispatch begin / end timestamps
 };
+// apa_m1_cat.hip
+bool m1_cat_supported(int J);
+int m1_cat_forward(const CatFeat& cat, const float* att, const float* Wt, float* logits, int N, int P,
+                   int C, int K, bool train, const M1Rng& r, hipStream_t st);
+int m1_cat_backward(const CatFeat& cat, const float* att, const float* G, const float* Wt, float* dWt,
+                    float* e_out, int N, int P, int C, int K, bool train, const M1Rng& r, hipStream_t st);
 bool m1s_supported(int C, int dtype);
 int m1s_launch_pool_fwd(int dtype, int C, bool fused, bool train, int nblk, hipStream_t st,
                         const void* X, const float* Wa, const float* ba, float* att, float* pacc,
@@ -176,7 +190,7 @@ int m1s_launch_bwd_main(int dtype, int C, bool fused, bool train, int nblk, hipS
                         const void* X, const float* Wa, const float* att, const float* dz,
                         const float* zsave, const float* abar, const float* G, const float* bt,
                         const float* sn_pre, void* dX, float* dZout, float* pdwa, float* pdba,
-                        int P, int S, int K, int act, const M1Rng& r);
+                        int P, int S, int K, int act, const M1Rng& r, const float* dA_extra);
 
 // apa_m1_small.hip: LDS-tiled f32-MFMA kernels for the small products of the M == 1 path
 bool m1_small_supported(int C, int K);

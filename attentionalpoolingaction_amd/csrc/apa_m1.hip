@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void m1_bwd_main_kernel(
     const float* __restrict__ sn_pre, T* __restrict__ dX,
     float* __restrict__ dZout, float* __restrict__ pdwa, float* __restrict__ pdba, int P, int S,
     int K, int act, float inv_keep, uint32_t thresh, uint64_t seed, uint64_t offset,
-    const uint64_t* __restrict__ offset_dev) {
+    const uint64_t* __restrict__ offset_dev, const float* __restrict__ dA_extra, float extra_scale) {
   constexpr int EPV = Vec<T>::EPV;
   constexpr int EPL = VEC * EPV;
   constexpr int C = EPL * 64;
@@ -453,7 +453,8 @@ __global__ __launch_bounds__(256) void m1_bwd_main_kernel(
         d1 = fmaf(x[i + 1], dzr[i + 1], d1);
       }
     }
-    const float dA = (wave_sum(d0 + d1) + sn) * invP;
+    // + the concatenated pose channels' share (apa_m1_cat.hip); callers without them pass att, scale 0
+    const float dA = (wave_sum(d0 + d1) + sn + dA_extra[(size_t)n * P + p] * extra_scale) * invP;
     float dZ;
     if (act == ACT_SOFTMAX) dZ = a * (dA - corr);
     else if (act == ACT_RELU) dZ = a > 0.f ? dA : 0.f;
@@ -694,6 +695,7 @@ M1Plan m1_plan(int N, int P, int C, int Ca, int K) {
     if (C % 64 == 0 && m1_logits2_ws_bytes(N, C, K) > g) g = m1_logits2_ws_bytes(N, C, K);
     pl.off_gemm = off;  off += align_up(g, 256);
   }
+  pl.off_cat_e = off; off += align_up((size_t)N * P * 4, 256);   // e[n,p] of apa_m1_cat.hip
   pl.total = off;
   return pl;
 }
@@ -729,13 +731,15 @@ static int launch_bwd_main(bool fused, bool train, int nblk, hipStream_t st, con
                            const float* abar, const float* G, const float* bt,
                            const float* sn_pre, void* dX,
                            float* dZout, float* pdwa, float* pdba, int P, int S, int K, int act,
-                           RngArgs r) {
+                           RngArgs r, const float* dA_extra) {
   const T* x = static_cast<const T*>(X);
   T* dx = static_cast<T*>(dX);
+  const float* ex = dA_extra ? dA_extra : att;
+  const float exs = dA_extra ? 1.0f : 0.0f;
 #define APA_GO(F, TR)                                                                            \
   launch_ev(m1_bwd_main_kernel<T, VEC, F, TR>, dim3(nblk), dim3(256), 0, st, r.ev0, r.ev1, x, Wa,   \
                      att, dz, zsave, abar, G, bt, sn_pre, dx, dZout, pdwa, pdba, P, S, K, act,   \
-                     r.inv_keep, r.thresh, r.seed, r.offset, r.offset_dev)
+                     r.inv_keep, r.thresh, r.seed, r.offset, r.offset_dev, ex, exs)
   if (fused) { if (train) APA_GO(true, true); else APA_GO(true, false); }
   else       { if (train) APA_GO(false, true); else APA_GO(false, false); }
 #undef APA_GO
@@ -785,7 +789,8 @@ static RngArgs rng_args(bool train, float keep_prob, uint64_t seed, uint64_t off
 int m1_forward(const void* X, const void* Xatt, const float* Wa, const float* ba, const float* Wt,
                const float* bt, float* logits, float* att, float* zsave, float* abar, void* ws,
                int N, int P, int C, int Ca, int K, unsigned flags, float keep_prob, uint64_t seed,
-               uint64_t offset, int dtype, hipStream_t st, M1Xent* xf, const Hooks& hk) {
+               uint64_t offset, int dtype, hipStream_t st, M1Xent* xf, const Hooks& hk,
+               const CatFeat* cat) {
   const bool fused = (Xatt == X);
   const bool train = (flags & APA_FLAG_TRAIN) && keep_prob < 1.0f;
   const int act = act_of(flags);
@@ -839,6 +844,7 @@ int m1_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
   static const int use_lx = env_int("APA_M1_LOGITS_XENT", 1);
   static const int use_bh = env_int("APA_M1_BWD_HEAD", 1);
   const bool xeval = xf && xf->probs;
+  if (cat) xf = nullptr;   // the extra channels add to the logits after the reduction: no fused loss
   if (xf && use_l2 && use_lx && (xeval || use_bh) && m1_logits_xent_supported(N, C, K, xeval) &&
       (xeval || m1_small_supported(C, K)) &&
       ((reinterpret_cast<uintptr_t>(zsave) | reinterpret_cast<uintptr_t>(Wt) |
@@ -850,10 +856,14 @@ int m1_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
     return rc;
   }
   if (use_l2 && m1_logits2_supported(C, K) && (reinterpret_cast<uintptr_t>(zsave) & 15) == 0)
-    return m1_logits2(zsave, Wt, abar, bt, logits, gemm_ws, N, C, K, st);
-  if (m1_small_supported(C, K) && (reinterpret_cast<uintptr_t>(zsave) & 15) == 0)
-    return m1_logits(zsave, Wt, abar, bt, logits, gemm_ws, N, C, K, st);
-  return sgemm_small(zsave, C, 1, Wt, K, 1, logits, K, N, K, C, pl.lsplits, abar, bt, gemm_ws, st);
+    rc = m1_logits2(zsave, Wt, abar, bt, logits, gemm_ws, N, C, K, st);
+  else if (m1_small_supported(C, K) && (reinterpret_cast<uintptr_t>(zsave) & 15) == 0)
+    rc = m1_logits(zsave, Wt, abar, bt, logits, gemm_ws, N, C, K, st);
+  else
+    rc = sgemm_small(zsave, C, 1, Wt, K, 1, logits, K, N, K, C, pl.lsplits, abar, bt, gemm_ws, st);
+  if (rc != APA_OK || !cat) return rc;
+  // ..._WITH_POSE_FEAT: logits += zext . Wt[C:C+J]
+  return m1_cat_forward(*cat, att, Wt, logits, N, P, C, K, train, r, st);
 }
 
 int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* ba, const float* Wt,
@@ -861,7 +871,7 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
                 const float* G, void* dX, void* dXatt, float* dWa, float* dba, float* dWt,
                 float* dbt, void* ws, int N, int P, int C, int Ca, int K, unsigned flags,
                 float keep_prob, uint64_t seed, uint64_t offset, int dtype, hipStream_t st,
-                const M1Xent* xf, const Hooks& hk) {
+                const M1Xent* xf, const Hooks& hk, const CatFeat* cat) {
   (void)ba;
   const bool fused = (Xatt == X);
   const bool train = (flags & APA_FLAG_TRAIN) && keep_prob < 1.0f;
@@ -914,6 +924,13 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
     if (rc != APA_OK) return rc;
   }
 
+  const float* dA_extra = nullptr;
+  if (cat) {   // dWt rows C..C+J-1, dXext, and the extra channels' per-pixel share of dA
+    float* e = reinterpret_cast<float*>(w + pl.off_cat_e);
+    rc = m1_cat_backward(*cat, att, G, Wt, dWt, e, N, P, C, K, train, r, st);
+    if (rc != APA_OK) return rc;
+    dA_extra = e;
+  }
   // dWt / dbt are final here (fast path): let a data-parallel caller start their all-reduce now
   if (small_ok && hk.grad_ready) APA_HIP_CHECK(hipEventRecord(hk.grad_ready, st));
 
@@ -921,11 +938,11 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
   else if (use_stream_kernels(C, dtype))
     rc = m1s_launch_bwd_main(dtype, C, fused, train, pl.nblk, st, X, Wa, att, dz, zsave, abar, G,
                              bt, small_ok ? sn_buf : nullptr, dX, dZatt, pdwa, pdba, P, pl.S, K,
-                             act, r);
+                             act, r, dA_extra);
   else
     rc = APA_DISPATCH_VEC(launch_bwd_main, dtype, C, fused, train, pl.nblk, st, X, Wa, att, dz,
                           zsave, abar, G, bt, small_ok ? sn_buf : nullptr, dX, dZatt, pdwa, pdba,
-                          P, pl.S, K, act, r);
+                          P, pl.S, K, act, r, dA_extra);
   if (rc != APA_OK) return rc;
 
   int nred = pl.nblk;

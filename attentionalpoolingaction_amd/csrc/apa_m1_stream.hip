@@ -295,8 +295,8 @@ struct BwdState {
 
 template <typename T, int VW, int PIX, bool FUSED, bool TRAIN, bool RIN>
 __device__ __forceinline__ void bwd_chunk(BwdState<T, VW, PIX, FUSED, TRAIN>& st,
-                                          const uint4 (&xr)[PIX][VW], float a_l, ChunkRange cr,
-                                          float* sm, T* __restrict__ dxim,
+                                          const uint4 (&xr)[PIX][VW], float a_l, float e_l,
+                                          ChunkRange cr, float* sm, T* __restrict__ dxim,
                                           float* __restrict__ dZout_im, int n, int P, int C,
                                           int cbase, int wave, int lane, int act, float invP,
                                           float inv_keep, uint32_t thresh, uint32_t k0,
@@ -340,7 +340,7 @@ __device__ __forceinline__ void bwd_chunk(BwdState<T, VW, PIX, FUSED, TRAIN>& st
   }
   float tot = block_dots<PIX>(d, sm, wave, lane);
   if (TRAIN) tot *= inv_keep;
-  const float dA = (tot + st.sn) * invP;
+  const float dA = (tot + st.sn + e_l) * invP;   // e_l: extra channels' share (apa_m1_cat.hip), else 0
   float dZl;
   if (act == S_ACT_SOFTMAX) dZl = a_l * (dA - st.corr);
   else if (act == S_ACT_RELU) dZl = a_l > 0.f ? dA : 0.f;
@@ -393,7 +393,10 @@ __global__ __launch_bounds__(256, 2) void m1s_bwd_main_kernel(
     const float* __restrict__ G, const float* __restrict__ bt, const float* __restrict__ sn_pre,
     T* __restrict__ dX, float* __restrict__ dZout, float* __restrict__ pdwa,
     float* __restrict__ pdba, int P, int S, int K, int act, float inv_keep, uint32_t thresh,
-    uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev) {
+    uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev,
+    const float* __restrict__ dA_extra, float extra_scale) {
+  // dA_extra [N,P]: per-pixel additive term of dA * P from the concatenated pose channels; callers
+  // without them pass `att` and extra_scale = 0, so the load is unconditional (straight-line code)
   constexpr int EPV = Vec<T>::EPV;
   constexpr int EPL = VW * EPV;
   constexpr int CW = EPL * 64;
@@ -421,7 +424,9 @@ __global__ __launch_bounds__(256, 2) void m1s_bwd_main_kernel(
   const int p_last = p_end - 1;
   uint4 xa[PIX][VW], xb[PIX][VW];
   load_chunk<T, VW, PIX, APA_BWD_NT_LOAD>(xa, xim, p_begin, p_last, C, cbase);
+  const float* ex_im = dA_extra + (size_t)n * P;
   float a_a = att_im[min(p_begin + l16, p_last)], a_b = 0.f;
+  float e_a = ex_im[min(p_begin + l16, p_last)] * extra_scale, e_b = 0.f;
 
   // per-image constants: L2 hits issued behind the first chunk's HBM loads
   BwdState<T, VW, PIX, FUSED, TRAIN> st;
@@ -466,13 +471,15 @@ __global__ __launch_bounds__(256, 2) void m1s_bwd_main_kernel(
   for (int ch = 0; ch < nchunk; ch += 2) {
     load_chunk<T, VW, PIX, APA_BWD_NT_LOAD>(xb, xim, p_begin + (ch + 1) * PIX, p_last, C, cbase);
     a_b = att_im[min(p_begin + (ch + 1) * PIX + l16, p_last)];
-    bwd_chunk<T, VW, PIX, FUSED, TRAIN, RIN>(st, xa, a_a, chunk_range<PIX>(p_begin, p_end, ch), sm_x[0],
+    e_b = ex_im[min(p_begin + (ch + 1) * PIX + l16, p_last)] * extra_scale;
+    bwd_chunk<T, VW, PIX, FUSED, TRAIN, RIN>(st, xa, a_a, e_a, chunk_range<PIX>(p_begin, p_end, ch), sm_x[0],
                                         dxim, dZout_im, n, P, C, cbase, wave, lane, act, invP,
                                         inv_keep, thresh, k0, k1);
     if (ch + 1 >= nchunk) break;
     load_chunk<T, VW, PIX, APA_BWD_NT_LOAD>(xa, xim, p_begin + (ch + 2) * PIX, p_last, C, cbase);
     a_a = att_im[min(p_begin + (ch + 2) * PIX + l16, p_last)];
-    bwd_chunk<T, VW, PIX, FUSED, TRAIN, RIN>(st, xb, a_b, chunk_range<PIX>(p_begin, p_end, ch + 1),
+    e_a = ex_im[min(p_begin + (ch + 2) * PIX + l16, p_last)] * extra_scale;
+    bwd_chunk<T, VW, PIX, FUSED, TRAIN, RIN>(st, xb, a_b, e_b, chunk_range<PIX>(p_begin, p_end, ch + 1),
                                         sm_x[1], dxim, dZout_im, n, P, C, cbase, wave, lane, act,
                                         invP, inv_keep, thresh, k0, k1);
   }
@@ -546,9 +553,11 @@ static int launch_bwd_t(bool fused, bool train, int nblk, hipStream_t st, const 
                         const float* Wa, const float* att, const float* dz, const float* zsave,
                         const float* abar, const float* G, const float* bt, const float* sn_pre,
                         void* dX, float* dZout, float* pdwa, float* pdba, int P, int S, int K,
-                        int act, const M1Rng& r) {
+                        int act, const M1Rng& r, const float* dA_extra) {
   const T* x = static_cast<const T*>(X);
   T* dx = static_cast<T*>(dX);
+  const float* ex = dA_extra ? dA_extra : att;
+  const float exs = dA_extra ? 1.0f : 0.0f;
   if (r.relu_input) {
     if (!fused || PIX != 2) {
       set_error("APA_FLAG_RELU_INPUT needs Xatt == X (and the default APA_M1S_PIX)");
@@ -557,10 +566,10 @@ static int launch_bwd_t(bool fused, bool train, int nblk, hipStream_t st, const 
     if constexpr (PIX == 2) {
       if (train)
         launch_ev(m1s_bwd_main_kernel<T, VW, 2, true, true, true>, dim3(nblk), dim3(256), 0, st, r.ev0, r.ev1, x, Wa, att, dz, zsave, abar, G, bt, sn_pre, dx, dZout, pdwa, pdba, P, S, K,
-                           act, r.inv_keep, r.thresh, r.seed, r.offset, r.offset_dev);
+                           act, r.inv_keep, r.thresh, r.seed, r.offset, r.offset_dev, ex, exs);
       else
         launch_ev(m1s_bwd_main_kernel<T, VW, 2, true, false, true>, dim3(nblk), dim3(256), 0, st, r.ev0, r.ev1, x, Wa, att, dz, zsave, abar, G, bt, sn_pre, dx, dZout, pdwa, pdba, P, S, K,
-                           act, r.inv_keep, r.thresh, r.seed, r.offset, r.offset_dev);
+                           act, r.inv_keep, r.thresh, r.seed, r.offset, r.offset_dev, ex, exs);
     }
     APA_LAUNCH_CHECK("m1s_bwd_main_kernel");
     return APA_OK;
@@ -568,7 +577,7 @@ static int launch_bwd_t(bool fused, bool train, int nblk, hipStream_t st, const 
 #define APA_GO(F, TR)                                                                            \
   launch_ev(m1s_bwd_main_kernel<T, VW, PIX, F, TR>, dim3(nblk), dim3(256), 0, st, r.ev0, r.ev1, x,  \
                      Wa, att, dz, zsave, abar, G, bt, sn_pre, dx, dZout, pdwa, pdba, P, S, K,    \
-                     act, r.inv_keep, r.thresh, r.seed, r.offset, r.offset_dev)
+                     act, r.inv_keep, r.thresh, r.seed, r.offset, r.offset_dev, ex, exs)
   if (fused) { if (train) APA_GO(true, true); else APA_GO(true, false); }
   else       { if (train) APA_GO(false, true); else APA_GO(false, false); }
 #undef APA_GO
@@ -610,9 +619,9 @@ int m1s_launch_bwd_main(int dtype, int C, bool fused, bool train, int nblk, hipS
                         const void* X, const float* Wa, const float* att, const float* dz,
                         const float* zsave, const float* abar, const float* G, const float* bt,
                         const float* sn_pre, void* dX, float* dZout, float* pdwa, float* pdba,
-                        int P, int S, int K, int act, const M1Rng& r) {
+                        int P, int S, int K, int act, const M1Rng& r, const float* dA_extra) {
   return APA_S_DISPATCH(launch_bwd_t, dtype, C, fused, train, nblk, st, X, Wa, att, dz, zsave,
-                        abar, G, bt, sn_pre, dX, dZout, pdwa, pdba, P, S, K, act, r);
+                        abar, G, bt, sn_pre, dX, dZout, pdwa, pdba, P, S, K, act, r, dA_extra);
 }
 
 }  // namespace apa

@@ -60,6 +60,9 @@ _SIGNATURES = {
     'apa_pose_l2_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'apa_pose_l2_loss_fwd_bwd': (c_int, [c_void_p] * 6 + [c_size_t, c_int, c_int, c_int, c_float,
                                                           c_float, c_void_p]),
+    'apa_action_loss_fwd_bwd': (c_int, [c_int] + [c_void_p] * 4 + [c_int, c_int, c_float, c_float, c_float, c_void_p]),
+    'apa_pose_sampled_loss_fwd_bwd': (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_float, c_float, c_void_p]),
+    'apa_resize_bilinear_tf1': (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     'apa_pose_to_heatmap_out_ht': (c_int64, [c_int64, c_int64, c_int64]),
     'apa_pose_to_heatmap': (c_int, [POINTER(c_int64), c_int64, c_int64, c_int64, c_int64, c_int,
                                     c_float, c_int, POINTER(c_float), POINTER(c_uint8)]),
@@ -72,6 +75,11 @@ _SIGNATURES = {
     'apa_attn_head_train_step': (c_int, [c_void_p] * 7 + [c_float, c_float] + [c_void_p] * 13 +
                                  [c_size_t] + [c_int] * 6 + [c_uint, c_float, c_uint64, c_uint64, c_int,
                                                              c_void_p]),
+    # ..._WITH_POSE_FEAT: `const apa_concat_feat*`, `const apa_hooks*`, then the plain arguments
+    'apa_attn_pool_fwd_cat': (c_int, [c_void_p] * 14 + [c_size_t] + [c_int] * 6 +
+                              [c_uint, c_float, c_uint64, c_uint64, c_int, c_void_p]),
+    'apa_attn_pool_bwd_cat': (c_int, [c_void_p] * 19 + [c_size_t] + [c_int] * 6 +
+                              [c_uint, c_float, c_uint64, c_uint64, c_int, c_void_p]),
     'apa_attn_head_train_step_ex': (c_int, [c_void_p] * 8 + [c_float, c_float] + [c_void_p] * 13 +
                                     [c_size_t] + [c_int] * 6 + [c_uint, c_float, c_uint64, c_uint64, c_int,
                                                                 c_void_p]),
@@ -296,6 +304,76 @@ def attn_pool_bwd(X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, *, flags=0, keep
     return dX, dXatt, dWa, dba, dWt, dbt
 
 
+class ApaConcatFeat(ctypes.Structure):
+    """`apa_concat_feat` of include/apa.h (..._WITH_POSE_FEAT, nets_factory.py:289-295)."""
+    _fields_ = [('Xext', c_void_p), ('J', c_int), ('zext', c_void_p), ('dXext', c_void_p)]
+
+
+def attn_pool_fwd_cat(X, Xatt, Xext, Wa, ba, Wt, bt, *, flags=0, keep_prob=1.0, seed=0, offset=0,
+                      workspace=None, hooks=None):
+    """logits, att, zsave, abar, zext, workspace = attn_pool_fwd_cat(...): attentional pooling over
+    concat(X, Xext) without forming it (include/apa.h: apa_attn_pool_fwd_cat).  Xext [N,P,J] (or
+    [N,H,W,J]) f32; Wt is the full [C+J, K] td_weights; M == 1."""
+    lib = load_library()
+    N, C = X.shape[0], X.shape[-1]
+    P = X.numel() // (N * C)
+    Ca, M, K, J = Xatt.shape[-1], Wa.shape[1], Wt.shape[1], Xext.shape[-1]
+    if Wt.shape[0] != C + J or Xext.numel() != N * P * J:
+        raise ApaError('attn_pool_fwd_cat: Wt must be [C+J, K] and Xext [N,P,J]')
+    dev = X.device
+    logits = torch.empty((N, K), dtype=torch.float32, device=dev)
+    att = torch.empty((N, P, M), dtype=torch.float32, device=dev)
+    zsave = torch.empty((N, C), dtype=torch.float32, device=dev)
+    abar = torch.empty((N,), dtype=torch.float32, device=dev)
+    zext = torch.empty((N, J), dtype=torch.float32, device=dev)
+    need = int(lib.apa_attn_pool_workspace_bytes(N, P, C, Ca, K, M, flags))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty((max(need, 16),), dtype=torch.uint8, device=dev)
+    cat = ApaConcatFeat(_dev_ptr(Xext, 'Xext', torch.float32), J, zext.data_ptr(), None)
+    xatt_ptr = _dev_ptr(X, 'X') if Xatt is X else _dev_ptr(Xatt, 'Xatt', X.dtype)
+    offset, flags = _rng_offset(offset, flags)
+    rc = lib.apa_attn_pool_fwd_cat(
+        ctypes.addressof(cat), _hooks_ptr(hooks), _dev_ptr(X, 'X'), xatt_ptr, _dev_ptr(Wa, 'Wa', torch.float32),
+        _dev_ptr(ba, 'ba', torch.float32), _dev_ptr(Wt, 'Wt', torch.float32),
+        _dev_ptr(bt, 'bt', torch.float32), logits.data_ptr(), att.data_ptr(), zsave.data_ptr(),
+        abar.data_ptr(), None, workspace.data_ptr(), workspace.numel(), N, P, C, Ca, K, M, flags,
+        float(keep_prob), int(seed), offset, _feat_dtype(X), _stream_ptr())
+    _check(rc, 'apa_attn_pool_fwd_cat')
+    return logits, att, zsave, abar, zext, workspace
+
+
+def attn_pool_bwd_cat(X, Xatt, Xext, zext, Wa, ba, Wt, bt, att, zsave, abar, G, *, flags=0, keep_prob=1.0,
+                      seed=0, offset=0, workspace=None, hooks=None):
+    """dX, dXatt, dXext, dWa, dba, dWt, dbt = attn_pool_bwd_cat(...); dWt is [C+J, K]."""
+    lib = load_library()
+    N, C = X.shape[0], X.shape[-1]
+    P = X.numel() // (N * C)
+    Ca, M, K, J = Xatt.shape[-1], Wa.shape[1], Wt.shape[1], Xext.shape[-1]
+    dev = X.device
+    fused = Xatt is X
+    dX = torch.empty_like(X)
+    dXatt = None if fused else torch.empty_like(Xatt)
+    dXext = torch.empty_like(Xext)
+    dWa, dba, dWt, dbt = torch.empty_like(Wa), torch.empty_like(ba), torch.empty_like(Wt), torch.empty_like(bt)
+    need = int(lib.apa_attn_pool_workspace_bytes(N, P, C, Ca, K, M, flags))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty((max(need, 16),), dtype=torch.uint8, device=dev)
+    cat = ApaConcatFeat(_dev_ptr(Xext, 'Xext', torch.float32), J, _dev_ptr(zext, 'zext', torch.float32),
+                        dXext.data_ptr())
+    xatt_ptr = _dev_ptr(X, 'X') if fused else _dev_ptr(Xatt, 'Xatt', X.dtype)
+    offset, flags = _rng_offset(offset, flags)
+    rc = lib.apa_attn_pool_bwd_cat(
+        ctypes.addressof(cat), _hooks_ptr(hooks), _dev_ptr(X, 'X'), xatt_ptr, _dev_ptr(Wa, 'Wa', torch.float32),
+        _dev_ptr(ba, 'ba', torch.float32), _dev_ptr(Wt, 'Wt', torch.float32),
+        _dev_ptr(bt, 'bt', torch.float32), _dev_ptr(att, 'att', torch.float32), _dev_ptr(zsave, 'zsave'),
+        _dev_ptr(abar, 'abar'), _dev_ptr(G, 'G', torch.float32), dX.data_ptr(), _dev_ptr(dXatt, 'dXatt'),
+        dWa.data_ptr(), dba.data_ptr(), dWt.data_ptr(), dbt.data_ptr(), workspace.data_ptr(),
+        workspace.numel(), N, P, C, Ca, K, M, flags, float(keep_prob), int(seed), offset, _feat_dtype(X),
+        _stream_ptr())
+    _check(rc, 'apa_attn_pool_bwd_cat')
+    return dX, dXatt, dXext, dWa, dba, dWt, dbt
+
+
 def dropout_mask(shape, keep_prob, seed, offset, device='cuda') -> torch.Tensor:
     """The exact {0,1} mask APA_FLAG_TRAIN applies to X (uint8, `shape` = X.shape)."""
     lib = load_library()
@@ -415,6 +493,54 @@ def pose_l2_loss_fwd_bwd(Pl, lbl, valid, *, wt=1.0, grad_scale=1.0, want_grad=Tr
         N, P, J, float(wt), float(grad_scale), _stream_ptr())
     _check(rc, 'apa_pose_l2_loss_fwd_bwd')
     return loss, dPl
+
+
+ACTION_LOSS_KINDS = {'l2': 1, 'multi-label': 2, 'multi-label-2': 3}
+
+
+def action_loss_fwd_bwd(kind: str, logits, labels, *, wt=1.0, grad_scale=1.0, pos_weight=10.0, want_grad=True):
+    """loss [1], G [N,K] for the action losses of src/loss.py:81-101 other than softmax cross-entropy
+    ('l2': labels int64 [N]; 'multi-label' / 'multi-label-2': labels f32 [N,K] multi-hot)."""
+    lib = load_library()
+    N, K = logits.shape
+    dev = logits.device
+    loss = torch.empty((1,), dtype=torch.float32, device=dev)
+    G = torch.empty((N, K), dtype=torch.float32, device=dev) if want_grad else None
+    ldt = torch.int64 if kind == 'l2' else torch.float32
+    rc = lib.apa_action_loss_fwd_bwd(ACTION_LOSS_KINDS[kind], _dev_ptr(logits, 'logits', torch.float32),
+                                     _dev_ptr(labels, 'labels', ldt), loss.data_ptr(), _dev_ptr(G, 'G'), N, K,
+                                     float(wt), float(grad_scale), float(pos_weight), _stream_ptr())
+    _check(rc, 'apa_action_loss_fwd_bwd')
+    return loss, G
+
+
+def pose_sampled_loss_fwd_bwd(Pl, lbl, valid, uniform, *, wt=1.0, grad_scale=1.0, want_grad=True):
+    """loss [1], dPl, mask = LOSS_FN_POSE_SAMPLED (src/loss.py:36-52); `uniform` = the caller's
+    uniform [0,1) draws, same shape as Pl."""
+    lib = load_library()
+    N, J = Pl.shape[0], Pl.shape[-1]
+    P = Pl.numel() // (N * J)
+    dev = Pl.device
+    loss = torch.empty((1,), dtype=torch.float32, device=dev)
+    dPl = torch.empty_like(Pl) if want_grad else None
+    mask = torch.empty_like(Pl)
+    v8 = valid.to(torch.uint8).contiguous()
+    rc = lib.apa_pose_sampled_loss_fwd_bwd(_dev_ptr(Pl, 'Pl', torch.float32), _dev_ptr(lbl, 'lbl', torch.float32),
+                                           _dev_ptr(v8, 'valid'), _dev_ptr(uniform, 'uniform', torch.float32),
+                                           loss.data_ptr(), _dev_ptr(dPl, 'dPl'), mask.data_ptr(), N, P, J,
+                                           float(wt), float(grad_scale), _stream_ptr())
+    _check(rc, 'apa_pose_sampled_loss_fwd_bwd')
+    return loss, dPl, mask
+
+
+def resize_bilinear_tf1(img, out_h: int, out_w: int):
+    """tf.image.resize_images (TF 1.1 legacy bilinear) of an f32 [N,h,w,C] device tensor."""
+    lib = load_library()
+    N, h, w, C = img.shape
+    out = torch.empty((N, out_h, out_w, C), dtype=torch.float32, device=img.device)
+    _check(lib.apa_resize_bilinear_tf1(_dev_ptr(img, 'img', torch.float32), out.data_ptr(), N, h, w, C,
+                                       int(out_h), int(out_w), _stream_ptr()), 'apa_resize_bilinear_tf1')
+    return out
 
 
 # --------------------------------------------------------------------------------------------

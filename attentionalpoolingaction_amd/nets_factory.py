@@ -81,6 +81,43 @@ class AttentionalPoolingFunction(torch.autograd.Function):
         return dX, dXatt, dWa, dba, dWt, dbt, None, None, None, None, None
 
 
+class AttentionalPoolingCatFunction(torch.autograd.Function):
+    """logits, att = f(X, Xatt, Xext, Wa, ba, Wt, bt): ..._WITH_POSE_FEAT (nets_factory.py:289-296) --
+    attentional pooling over concat(X, Xext) with Wt [C+J, K], the concatenation never formed
+    (apa_attn_pool_fwd_cat / apa_attn_pool_bwd_cat); `Xatt is None` = attention from X itself."""
+
+    @staticmethod
+    def forward(ctx, X, Xatt, Xext, Wa, ba, Wt, bt, flags, keep_prob, seed, offset):
+        Xc = X.contiguous()
+        fused = Xatt is None
+        Xa = Xc if fused else Xatt.contiguous()
+        Xe = Xext.contiguous().float()
+        logits, att, zsave, abar, zext, ws = cof.attn_pool_fwd_cat(
+            Xc, Xa, Xe, Wa.contiguous(), ba.contiguous(), Wt.contiguous(), bt.contiguous(), flags=flags,
+            keep_prob=keep_prob, seed=seed, offset=offset)
+        ctx.save_for_backward(Xc, Xa, Xe, Wa, ba, Wt, bt, att, zsave, abar, zext)
+        ctx.fused = fused
+        ctx.cfg = (flags, keep_prob, seed, offset)
+        ctx.ws = ws
+        ctx.shapes = (X.shape, None if fused else Xatt.shape, Xext.shape)
+        ctx.mark_non_differentiable(att)
+        return logits, att
+
+    @staticmethod
+    def backward(ctx, dlogits, _datt):
+        Xc, Xa, Xe, Wa, ba, Wt, bt, att, zsave, abar, zext = ctx.saved_tensors
+        flags, keep_prob, seed, offset = ctx.cfg
+        if ctx.fused:
+            Xa = Xc
+        dX, dXatt, dXext, dWa, dba, dWt, dbt = cof.attn_pool_bwd_cat(
+            Xc, Xa, Xe, zext, Wa.contiguous(), ba.contiguous(), Wt.contiguous(), bt.contiguous(), att, zsave,
+            abar, dlogits.contiguous().float(), flags=flags, keep_prob=keep_prob, seed=seed, offset=offset,
+            workspace=ctx.ws)
+        xs, xas, xes = ctx.shapes
+        return (dX.view(xs), None if dXatt is None else dXatt.view(xas), dXext.view(xes), dWa, dba, dWt, dbt,
+                None, None, None, None)
+
+
 class PoseHeadFunction(torch.autograd.Function):
     """Ppre, Pl = f(X, W1, b1, W2, b2): the PoseLogits head (nets_factory.py:147-160) on MFMA."""
 
@@ -214,12 +251,12 @@ class AttentionalPoolingHead(nn.Module):
             # the affine collapse used below and no shipped config selects them
             raise NotImplementedError('rank > 1 is built for the class-agnostic map without '
                                       'softmax/relu (nets_factory.py:258-274,298-309,322-328)')
-        if net.USE_POSE_PRELOGITS_BASED_ATTENTION_WITH_POSE_FEAT_2LAYER:
-            # that conv inherits batch-norm + relu from the resnet arg-scope (nets_factory.py:291-294
-            # passes neither normalizer_fn nor activation_fn): not built
-            raise NotImplementedError('..._WITH_POSE_FEAT_2LAYER is off in all shipped configs and not built')
-        if self.with_pose_feat and (net.USE_POSE_PRELOGITS_BASED_ATTENTION_PER_CLASS or self.rank > 1):
-            raise NotImplementedError('..._WITH_POSE_FEAT is built for the class-agnostic rank-1 map')
+        self.pose_feat_2layer = bool(self.with_pose_feat and
+                                     net.USE_POSE_PRELOGITS_BASED_ATTENTION_WITH_POSE_FEAT_2LAYER)
+        if self.with_pose_feat and (net.USE_POSE_PRELOGITS_BASED_ATTENTION_PER_CLASS or self.rank > 1
+                                    or want_topdown):
+            raise NotImplementedError('..._WITH_POSE_FEAT is built for the class-agnostic rank-1 map '
+                                      '(without the TopDownAttention dump)')
         self.num_classes = num_classes
         self.single_layer = bool(net.USE_POSE_PRELOGITS_BASED_ATTENTION_SINGLE_LAYER_ATT)
         self.softmax_att = bool(net.USE_POSE_PRELOGITS_BASED_ATTENTION_SOFTMAX_ATT)
@@ -239,8 +276,8 @@ class AttentionalPoolingHead(nn.Module):
         self.pose_w1 = nn.Parameter(torch.randn(in_channels, cp) * 0.001)
         self.pose_b1 = nn.Parameter(torch.zeros(cp))
         # slim.variance_scaling_initializer(): truncated normal, std = sqrt(1.3 * 2 / fan_in)
-        self.pose_w2 = nn.Parameter(torch.randn(cp, max(num_pose_keypoints, 1)).clamp_(-2, 2) *
-                                    (2.6 / cp) ** 0.5)
+        self.pose_w2 = nn.Parameter(torch.nn.init.trunc_normal_(
+            torch.empty(cp, max(num_pose_keypoints, 1)), 0.0, 1.0, -2.0, 2.0) * (2.6 / cp) ** 0.5)
         self.pose_b2 = nn.Parameter(torch.zeros(max(num_pose_keypoints, 1)))
         self.att_weights = nn.Parameter(torch.randn(cin, n_maps) * 0.001)
         self.att_biases = nn.Parameter(torch.zeros(n_maps))
@@ -249,6 +286,20 @@ class AttentionalPoolingHead(nn.Module):
         self.in_channels = in_channels
         self.td_weights = nn.Parameter(torch.randn(td_in, num_classes) * 0.001)
         self.td_biases = nn.Parameter(torch.zeros(num_classes))
+        if self.pose_feat_2layer:
+            # :290-294: slim.conv2d(pose_logits, J, [1,1], N(0,1e-3)) with neither normalizer_fn nor
+            # activation_fn given, so the resnet arg-scope's batch-norm (decay 0.997, eps 1e-5, scale)
+            # + relu apply and there is no bias; the batch-norm sits OUTSIDE resnet_v1()'s own
+            # `arg_scope([slim.batch_norm], is_training=...)`, so it keeps slim's default
+            # is_training=True: batch statistics in training AND in evaluation (reproduced literally).
+            # Unnamed conv created before the top-down conv -> it is scope 'Conv' and the top-down
+            # conv becomes 'Conv_1' (tf_variable_names()).  [N,P,J]-sized: torch ops on the device.
+            J = max(num_pose_keypoints, 1)
+            self.pose_feat_weights = nn.Parameter(torch.randn(J, J) * 0.001)
+            self.pose_feat_bn_gamma = nn.Parameter(torch.ones(J))
+            self.pose_feat_bn_beta = nn.Parameter(torch.zeros(J))
+            self.register_buffer('pose_feat_bn_moving_mean', torch.zeros(J))
+            self.register_buffer('pose_feat_bn_moving_variance', torch.ones(J))
         # rank > 1 (:258-274, :298-309): the r-th attention conv consumes the OUTPUT of conv r-1
         # ([M,M] = [1,1] weights, scopes Conv2d_PrePose_Attn1, ...); one more top-down conv per rank
         # (scopes Conv_1, ...)
@@ -264,6 +315,14 @@ class AttentionalPoolingHead(nn.Module):
     def tf_variable_names(self):
         """attribute -> TF variable name, including the per-rank scopes."""
         names = dict(self.TF_NAMES)
+        if getattr(self, 'pose_feat_2layer', False):
+            pre = 'PosePrelogitsBasedAttention/'
+            names.update({'pose_feat_weights': pre + 'Conv/weights',
+                          'pose_feat_bn_gamma': pre + 'Conv/BatchNorm/gamma',
+                          'pose_feat_bn_beta': pre + 'Conv/BatchNorm/beta',
+                          'pose_feat_bn_moving_mean': pre + 'Conv/BatchNorm/moving_mean',
+                          'pose_feat_bn_moving_variance': pre + 'Conv/BatchNorm/moving_variance',
+                          'td_weights': pre + 'Conv_1/weights', 'td_biases': pre + 'Conv_1/biases'})
         for r in range(1, self.rank):
             pre = 'PosePrelogitsBasedAttention/'
             names['att_weights_r.%d' % (r - 1)] = pre + 'Conv2d_PrePose_Attn%d/weights' % r
@@ -272,12 +331,22 @@ class AttentionalPoolingHead(nn.Module):
             names['td_biases_r.%d' % (r - 1)] = pre + 'Conv_%d/biases' % r
         return names
 
+    def get_extra_state(self):
+        # the dropout step counter keys the mask stream: checkpoint it, so a resumed run does not
+        # replay the masks of steps 0, 1, ...
+        return {'dropout_step': int(self._step)}
+
+    def set_extra_state(self, state):
+        self._step = int(state.get('dropout_step', 0)) if state else 0
+
     def regularized_weights(self):
         """conv weights carry slim.l2_regularizer from the resnet arg-scope (resnet_utils.py:241);
         biases do not.  Pose-head weights only count when the pose head is in the graph."""
         ws = [self.att_weights, self.td_weights] + list(self.att_weights_r) + list(self.td_weights_r)
         if self.with_pose_logits or not self.single_layer:
             ws += [self.pose_w1, self.pose_w2]
+        if getattr(self, 'pose_feat_2layer', False):
+            ws.append(self.pose_feat_weights)
         return ws
 
     def can_fuse_input_relu(self, dtype=torch.float32) -> bool:
@@ -325,31 +394,31 @@ class AttentionalPoolingHead(nn.Module):
         kw = dict(softmax_att=self.softmax_att, relu_att=self.relu_att, is_training=self.is_training,
                   keep_prob=self.keep_prob, seed=self.seed, offset=offset)
 
-        if self.rank == 1:
-            wt_x = self.td_weights[:C] if self.with_pose_feat else self.td_weights
-            logits, att, topdown = attentional_pooling(
-                last_conv, xatt, self.att_weights, self.att_biases, wt_x, self.td_biases,
-                want_topdown=self.want_topdown and not self.with_pose_feat, relu_input=preactivation, **kw)
+        if self.rank == 1 and self.with_pose_feat:
+            # :289-296: concat(last_conv, pose_logits) -> dropout -> top-down conv.  The J extra channels
+            # run through the same HIP op (apa_attn_pool_*_cat): same dropout stream, same attention-
+            # weighted mean, their share of dA fed to the streaming backward kernel.
+            xext = end_points['PoseLogits']
+            if self.pose_feat_2layer:
+                y = xext.float() @ self.pose_feat_weights
+                mean = y.mean(dim=(0, 1, 2))
+                var = y.var(dim=(0, 1, 2), unbiased=False)           # tf.nn.moments
+                if self.is_training:
+                    with torch.no_grad():                             # UPDATE_OPS, decay 0.997
+                        self.pose_feat_bn_moving_mean.mul_(0.997).add_(mean.detach(), alpha=0.003)
+                        self.pose_feat_bn_moving_variance.mul_(0.997).add_(var.detach(), alpha=0.003)
+                y = (y - mean) * torch.rsqrt(var + 1e-5) * self.pose_feat_bn_gamma + self.pose_feat_bn_beta
+                xext = torch.relu(y)
+            flags = cof.attn_flags(self.softmax_att, self.relu_att, self.is_training)
+            logits, att = AttentionalPoolingCatFunction.apply(
+                last_conv, xatt, xext, self.att_weights, self.att_biases, self.td_weights, self.td_biases,
+                flags, self.keep_prob if self.is_training else 1.0, self.seed, offset)
             end_points['PosePrelogitsBasedAttention'] = att.view(n, h, w, -1)    # :287
-            if self.with_pose_feat:
-                # :289-296: the J extra channels of concat(last_conv, pose_logits) go through the
-                # same dropout and the same attention-weighted mean.  [N,P,16] is plumbing-sized, so
-                # this side term is torch ops on the device (the 2048-channel part above is the HIP
-                # op); the op's attention end point is non-differentiable, so the map is re-formed
-                # here for autograd (one GEMV over the attention input)
-                xa = (last_conv if self.single_layer else pose_pre).reshape(n, h * w, -1).float()
-                a_t = (xa @ self.att_weights).squeeze(-1) + self.att_biases
-                if self.softmax_att:
-                    a_t = torch.softmax(a_t, dim=1)
-                if self.relu_att:
-                    a_t = torch.relu(a_t)
-                pl = end_points['PoseLogits'].reshape(n, h * w, -1).float()
-                if self.is_training and self.keep_prob < 1.0:
-                    g = torch.Generator(device=pl.device).manual_seed(self.seed * 1000003 + offset)
-                    keep = torch.rand(pl.shape, generator=g, device=pl.device) < self.keep_prob
-                    pl = pl * keep / self.keep_prob
-                zp = torch.einsum('np,npj->nj', a_t, pl) / float(h * w)
-                logits = logits + zp @ self.td_weights[C:]
+        elif self.rank == 1:
+            logits, att, topdown = attentional_pooling(
+                last_conv, xatt, self.att_weights, self.att_biases, self.td_weights, self.td_biases,
+                want_topdown=self.want_topdown, relu_input=preactivation, **kw)
+            end_points['PosePrelogitsBasedAttention'] = att.view(n, h, w, -1)    # :287
             if topdown is not None:
                 end_points['TopDownAttention'] = topdown.view(n, h, w, -1)       # :309
         else:
@@ -405,9 +474,15 @@ class BaselineHead(nn.Module):
         self.seed = seed
         self._step = 0
         # slim.variance_scaling_initializer(): truncated normal, std = sqrt(1.3 * 2 / fan_in)
-        self.logits_weights = nn.Parameter(torch.randn(in_channels, num_classes).clamp_(-2, 2) *
-                                           (2.6 / in_channels) ** 0.5)
+        self.logits_weights = nn.Parameter(torch.nn.init.trunc_normal_(
+            torch.empty(in_channels, num_classes), 0.0, 1.0, -2.0, 2.0) * (2.6 / in_channels) ** 0.5)
         self.logits_biases = nn.Parameter(torch.zeros(num_classes))
+
+    def get_extra_state(self):
+        return {'dropout_step': int(self._step)}
+
+    def set_extra_state(self, state):
+        self._step = int(state.get('dropout_step', 0)) if state else 0
 
     def regularized_weights(self):
         return [self.logits_weights]
@@ -472,7 +547,7 @@ def get_network_fn(name: str, num_classes: int, num_pose_keypoints: int, cfg,
                    weight_decay: float = 0.0, is_training: bool = False,
                    backbone: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
                    device='cuda', with_backbone: bool = False, backbone_dtype=None,
-                   fuse_final_relu: bool = False, **head_kwargs):
+                   fuse_final_relu: bool = False, clone_index: Optional[int] = None, **head_kwargs):
     """Same signature as nets_factory.py:94-95 (+ optional backbone/device).
 
     Returns `network_fn(images) -> (logits, end_points)`; `network_fn.head` exposes the module
@@ -489,12 +564,27 @@ def get_network_fn(name: str, num_classes: int, num_pose_keypoints: int, cfg,
     if name not in last_conv_map:
         raise ValueError('Name of network unknown %s' % name)
     channels = last_conv_map[name][1]
+    if clone_index is None:      # one clone per data-parallel rank (model_deploy.py:189-197)
+        import torch.distributed as dist
+        clone_index = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    # the reference's towers draw independent dropout masks: fold the clone index into the key
+    head_seed = int(cfg.RNG_SEED) + 1000003 * int(clone_index)
     if with_backbone and backbone is None:
         from . import resnet_v1
         if name not in resnet_v1.BLOCKS:
             raise ValueError('no built-in backbone for %s (pass backbone=callable)' % name)
         net = resnet_v1.ResNetV1(name, final_relu=not fuse_final_relu).to(device)
         net.train(is_training)
+        if cfg.NET.TRAIN_TOP_BN:
+            # resnet_v1.py:191-204: every batch-norm but the root block's runs with is_training=False
+            # and trainable=False (moving statistics, frozen gamma / beta)
+            root_bn = net.conv1.bn if net.conv1 is not None else None
+            for m in net.modules():
+                if isinstance(m, nn.BatchNorm2d) and m is not root_bn:
+                    m.eval()
+                    m.train = lambda mode=True, _m=m: _m      # stays frozen through later .train() calls
+                    for p_ in m.parameters():
+                        p_.requires_grad_(False)
 
         def backbone(images, _net=net, _dt=backbone_dtype):
             if _dt is None:
@@ -507,10 +597,10 @@ def get_network_fn(name: str, num_classes: int, num_pose_keypoints: int, cfg,
     if cfg.NET.USE_POSE_PRELOGITS_BASED_ATTENTION:
         head = AttentionalPoolingHead(num_classes, cfg, in_channels=channels,
                                       num_pose_keypoints=num_pose_keypoints, is_training=is_training,
-                                      seed=cfg.RNG_SEED, **head_kwargs).to(device)
+                                      seed=head_seed, **head_kwargs).to(device)
     else:   # cfg 001: the backbone's own average-pool + logits head
         head = BaselineHead(num_classes, cfg, in_channels=channels, is_training=is_training,
-                            seed=cfg.RNG_SEED).to(device)
+                            seed=head_seed).to(device)
     temporal = None
     if cfg.NET.USE_TEMPORAL_ATT:
         # 'TemporalAttention/Conv/{weights,biases}': 1x1 conv K->1, N(0,1e-3) weights; the bias is
@@ -543,7 +633,16 @@ def get_network_fn(name: str, num_classes: int, num_pose_keypoints: int, cfg,
             logits = frame_pooling(logits, frames_per_video, end_points, tw, tb)
         return logits, end_points
 
+    def regularized_weights():
+        """every tensor slim's arg-scope puts the L2 regulariser on (resnet_utils.py:241): the head's conv
+        weights and the TemporalAttention conv weights (biases are not regularised)."""
+        ws = list(head.regularized_weights())
+        if temporal is not None:
+            ws.append(temporal['weights'])
+        return ws
+
     network_fn.head = head
+    network_fn.regularized_weights = regularized_weights
     network_fn.backbone = getattr(backbone, 'module', backbone)
     network_fn.temporal = temporal
     network_fn.weight_decay = weight_decay

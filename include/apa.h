@@ -201,6 +201,37 @@ int apa_pose_l2_loss_fwd_bwd(const float* Pl, const float* lbl, const uint8_t* v
                              float* dPl, void* ws, size_t ws_bytes, int N, int P, int J, float wt,
                              float grad_scale, void* stream);
 
+/* The other action losses gen_losses accepts (src/loss.py:81-101), value + gradient in one launch:
+ *   APA_ACTION_LOSS_L2             tf.losses.mean_squared_error(one_hot(labels,K), logits, weights=wt):
+ *                                  loss = wt * mean_{n,k} (logits - onehot)^2;  labels int64 [N]
+ *   APA_ACTION_LOSS_MULTI_LABEL    mean(tf.nn.weighted_cross_entropy_with_logits(targets, logits,
+ *                                  pos_weight)) added with tf.losses.add_loss -- action_loss_wt is NOT
+ *                                  applied by the reference (loss.py:93-97), so `wt` is ignored;
+ *                                  labels f32 [N,K] multi-hot; the reference passes pos_weight = 10
+ *   APA_ACTION_LOSS_MULTI_LABEL_2  tf.losses.sigmoid_cross_entropy(labels, logits) * wt; labels f32 [N,K]
+ * loss f32 [1]; G f32 [N,K] or NULL = grad_scale * dloss/dlogits. */
+#define APA_ACTION_LOSS_L2 1
+#define APA_ACTION_LOSS_MULTI_LABEL 2
+#define APA_ACTION_LOSS_MULTI_LABEL_2 3
+int apa_action_loss_fwd_bwd(int kind, const float* logits, const void* labels, float* loss, float* G,
+                            int N, int K, float wt, float grad_scale, float pos_weight, void* stream);
+
+/* Pose loss with cfg.TRAIN.LOSS_FN_POSE_SAMPLED (src/loss.py:36-52), literally -- including the
+ * loop header's swapped names, by which "keep all positive pixels" tests the LOGITS:
+ *   ratio_j = #(lbl[..,j] > 0) / (N*P);  sel = (uniform < ratio_j) * (lbl == 0)
+ *   mask = (sel + (Pl > 0)) > 0;         loss = wt * sum_j mean_n( valid ? 0.5 * mean_p (mask*(Pl-lbl))^2 : 0 )
+ * uniform f32 [N,P,J]: the caller's tf.random_uniform draws in [0,1) (passed in like a dropout mask:
+ * TF's stream cannot be reproduced); mask_out f32 [N,P,J] or NULL = end_points['PoseLossMask'];
+ * dPl [N,P,J] or NULL (the mask is a constant of the differentiation, as in TF). */
+int apa_pose_sampled_loss_fwd_bwd(const float* Pl, const float* lbl, const uint8_t* valid,
+                                  const float* uniform, float* loss, float* dPl, float* mask_out, int N,
+                                  int P, int J, float wt, float grad_scale, void* stream);
+
+/* tf.image.resize_images(BILINEAR) as of TF 1.1 (legacy rule: src = dst * in/out, no half-pixel
+ * offset; src/loss.py:14-22 on the label map, device tensors): in f32 [N,h,w,C] -> out [N,oh,ow,C]. */
+int apa_resize_bilinear_tf1(const float* in, float* out, int N, int h, int w, int C, int out_h, int out_w,
+                            void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Label generator: PoseToHeatmapOp::Compute, src/custom_ops/pose_to_heatmap.cc:35-96.
  * HOST function (the reference op is DEVICE_CPU and runs inside the input pipeline).
@@ -316,6 +347,39 @@ int apa_attn_head_train_step_ex(const apa_hooks* hooks, const void* X, const voi
                                 size_t ws_bytes, int N, int P, int C, int Ca, int K, int M,
                                 unsigned flags, float keep_prob, uint64_t seed, uint64_t offset,
                                 int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * ..._WITH_POSE_FEAT (nets_factory.py:289-295): `last_conv = tf.concat([last_conv, pose_logits], -1)`
+ * before the dropout and the top-down conv, i.e. J extra fp32 channels Xext [N,P,J] (the PoseLogits
+ * output, after the optional ..._2LAYER conv) next to the C channels of X.  The concatenated tensor is
+ * never formed: the *_cat entry points take the two parts separately.  With `cat` given
+ *   Wt / dWt are the full td_weights [C+J, K] (rows C.. belong to the extra channels),
+ *   the dropout mask of the extra channels continues X's flat element stream at index N*P*C
+ *   (apa_dropout_mask over N*P*C + N*P*J elements returns both parts),
+ *   zext [N,J] is written by the forward call and must be passed unchanged to the backward call,
+ *   dXext [N,P,J] receives the gradient w.r.t. Xext (backward call only).
+ * M == 1 only, no APA_FLAG_RELU_INPUT, no TopDownAttention dump; cat == NULL is the plain call.
+ */
+typedef struct apa_concat_feat {
+  const float* Xext;
+  int J;
+  float* zext;
+  float* dXext;
+} apa_concat_feat;
+
+int apa_attn_pool_fwd_cat(const apa_concat_feat* cat, const apa_hooks* hooks, const void* X,
+                          const void* Xatt, const float* Wa, const float* ba, const float* Wt,
+                          const float* bt, float* logits, float* att, float* zsave, float* abar,
+                          void* topdown, void* ws, size_t ws_bytes, int N, int P, int C, int Ca, int K,
+                          int M, unsigned flags, float keep_prob, uint64_t seed, uint64_t offset,
+                          int dtype, void* stream);
+int apa_attn_pool_bwd_cat(const apa_concat_feat* cat, const apa_hooks* hooks, const void* X,
+                          const void* Xatt, const float* Wa, const float* ba, const float* Wt,
+                          const float* bt, const float* att, const float* zsave, const float* abar,
+                          const float* G, void* dX, void* dXatt, float* dWa, float* dba, float* dWt,
+                          float* dbt, void* ws, size_t ws_bytes, int N, int P, int C, int Ca, int K,
+                          int M, unsigned flags, float keep_prob, uint64_t seed, uint64_t offset,
+                          int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused optimizer step (src/train.py:90-94 tf.train.MomentumOptimizer + the slim L2 regulariser of

@@ -112,7 +112,7 @@ def attentional_pooling(last_conv: torch.Tensor,
                         keep_prob: float = 0.2,
                         dropout_mask: Optional[torch.Tensor] = None,
                         pose_feat_w: Optional[torch.Tensor] = None,
-                        pose_feat_b: Optional[torch.Tensor] = None,
+                        pose_feat_bn: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
                         ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
     """Literal restatement of the `USE_POSE_PRELOGITS_BASED_ATTENTION` branch.
 
@@ -141,8 +141,17 @@ def attentional_pooling(last_conv: torch.Tensor,
     if flags.with_pose_feat:                                                # :289-295
         pl = pose_logits
         if flags.with_pose_feat_2layer:
-            # slim.conv2d default activation_fn is relu (not overridden at :291-294)
-            pl = torch.relu(conv1x1(pl, pose_feat_w, pose_feat_b))
+            # :291-294 passes neither activation_fn nor normalizer_fn, so the resnet arg-scope
+            # (resnet_utils.py:236-245) supplies relu AND slim.batch_norm (eps 1e-5, scale=True; a conv
+            # with a normalizer has no bias).  This batch-norm sits outside resnet_v1()'s own
+            # arg_scope([slim.batch_norm], is_training=...) (resnet_v1.py:191-194), so it runs with
+            # slim's default is_training=True: batch statistics (tf.nn.moments, biased variance) in
+            # training and in evaluation alike.  pose_feat_bn = (gamma, beta).
+            y = conv1x1(pl, pose_feat_w, None)
+            mean = y.mean(dim=(0, 1, 2))
+            var = y.var(dim=(0, 1, 2), unbiased=False)
+            gamma, beta = pose_feat_bn
+            pl = torch.relu((y - mean) / torch.sqrt(var + 1e-5) * gamma + beta)
         feats = torch.cat([feats, pl], dim=-1)
     feats = dropout(feats, keep_prob, dropout_mask, is_training)            # :296
 
@@ -256,6 +265,60 @@ def action_l2(logits: torch.Tensor, labels: torch.Tensor, num_classes: int,
     return action_loss_wt * ((logits - onehot) ** 2).mean()
 
 
+def action_multi_label(logits: torch.Tensor, labels: torch.Tensor, pos_weight: float = 10.0) -> torch.Tensor:
+    """src/loss.py:88-97: labels cast to float (multi-hot [N,K]);
+    loss = reduce_mean(tf.nn.weighted_cross_entropy_with_logits(targets, logits, pos_weight=10)),
+    registered with tf.losses.add_loss -- action_loss_wt is NOT applied by the reference.
+    TF 1.x documents the op as  targets * -log(sigmoid(x)) * pos_weight + (1-targets) * -log(1-sigmoid(x))."""
+    t = labels.to(logits.dtype)
+    logsig = torch.nn.functional.logsigmoid
+    per = t * -logsig(logits) * pos_weight + (1 - t) * -logsig(-logits)
+    return per.mean()
+
+
+def action_multi_label_2(logits: torch.Tensor, labels: torch.Tensor, weight: float = 1.0) -> torch.Tensor:
+    """src/loss.py:98-101: tf.losses.sigmoid_cross_entropy(multi_class_labels, logits), default
+    weights=1.0: mean over all N*K elements of  max(x,0) - x*z + log(1 + exp(-|x|))."""
+    t = labels.to(logits.dtype)
+    per = torch.clamp(logits, min=0) - logits * t + torch.log1p(torch.exp(-logits.abs()))
+    return weight * per.mean()
+
+
+def pose_l2_sampled_loss(logits_pose: torch.Tensor, labels_pose: torch.Tensor,
+                         labels_pose_valid: torch.Tensor, uniform: torch.Tensor,
+                         pose_loss_wt: float = 1.0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """src/loss.py:29-70 with cfg.TRAIN.LOSS_FN_POSE_SAMPLED, line by line.  `uniform` [N,H,W,J] stands
+    for the tf.random_uniform(tf.shape(lgt), 0, 1.0) draws of :43-45 (channel j of it for keypoint j).
+    Returns (loss, PoseLossMask [N,H,W,J]).
+
+    The loop header (:35) is `for v, lbl, lgt in zip(channels_valid, channels_logits, channels_labels)`:
+    `lbl` holds the LOGITS channel and `lgt` the LABEL channel.  Restated with those names so that every
+    line reads like the reference -- in particular `tf.greater(lbl, 0)` (:49) tests the logits."""
+    if labels_pose.shape != logits_pose.shape:
+        labels_pose = tf1_resize_bilinear(labels_pose, logits_pose.shape[1], logits_pose.shape[2])
+    n, h, w, j = logits_pose.shape
+    total = logits_pose.new_zeros(())
+    masks = []
+    for ch in range(j):
+        v = labels_pose_valid[:, ch].to(torch.bool)
+        lbl = logits_pose[..., ch]                                              # :35 (swapped names)
+        lgt = labels_pose[..., ch]
+        neg_areas = (lgt == 0)                                                  # :38
+        pos_areas = (lgt > 0)                                                   # :39
+        total_area = float(lgt.numel())                                         # :40  N*H*W
+        pos_area_ratio = pos_areas.to(lgt.dtype).sum() / total_area             # :41
+        neg_areas_selected = (uniform[..., ch].to(lgt.dtype) < pos_area_ratio).to(lgt.dtype) * \
+            neg_areas.to(lgt.dtype)                                             # :43-46
+        mask = ((neg_areas_selected + (lbl > 0).to(lgt.dtype)) > 0).to(lgt.dtype)   # :48-50
+        lgt_m = lgt * mask                                                      # :51
+        lbl_m = lbl * mask                                                      # :52
+        loss_val = 0.5 * ((lbl_m - lgt_m) ** 2).mean(dim=(1, 2))                # :53
+        masks.append(mask.unsqueeze(-1))                                        # :57
+        L = torch.where(v, loss_val, torch.zeros_like(loss_val)).mean()         # :58-62
+        total = total + L
+    return total * pose_loss_wt, torch.cat(masks, dim=-1)                       # :68-70
+
+
 def l2_regularizer(weights: Sequence[torch.Tensor], weight_decay: float) -> torch.Tensor:
     """slim.l2_regularizer(wd)(W) = wd * tf.nn.l2_loss(W) = wd * 0.5 * sum(W^2), conv weights
     only (models/slim/nets/resnet_utils.py:241); biases are not regularised."""
@@ -274,11 +337,21 @@ def gen_losses(labels_action, logits_action, loss_type_action, num_action_classe
     if loss_type_pose and logits_pose is not None and logits_pose.shape[-1] > 0:
         if loss_type_pose != 'l2':
             raise ValueError('Invalid loss {}'.format(loss_type_pose))
-        losses.append(pose_l2_loss(logits_pose, labels_pose, labels_pose_valid, pose_loss_wt))
+        if cfg is not None and cfg.TRAIN.LOSS_FN_POSE_SAMPLED:                      # loss.py:36-52
+            loss_p, mask = pose_l2_sampled_loss(logits_pose, labels_pose, labels_pose_valid,
+                                                end_points['PoseLossUniform'], pose_loss_wt)
+            end_points['PoseLossMask'] = mask
+            losses.append(loss_p)
+        else:
+            losses.append(pose_l2_loss(logits_pose, labels_pose, labels_pose_valid, pose_loss_wt))
     if loss_type_action == 'softmax-xentropy':
         losses.append(action_softmax_xent(logits_action, labels_action, num_action_classes, action_loss_wt))
     elif loss_type_action == 'l2':
         losses.append(action_l2(logits_action, labels_action, num_action_classes, action_loss_wt))
+    elif loss_type_action == 'multi-label':                                         # loss.py:88-97
+        losses.append(action_multi_label(logits_action, labels_action))
+    elif loss_type_action == 'multi-label-2':                                       # loss.py:98-101
+        losses.append(action_multi_label_2(logits_action, labels_action))
     elif loss_type_action == '':
         pass
     else:

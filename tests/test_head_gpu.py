@@ -263,6 +263,75 @@ def test_pose_loss_through_gen_losses_with_label_resize(gpu):
     assert _rel(Pd.grad.cpu().numpy(), Pr.grad.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize('shape', [((2, 10, 10, 16), (5, 5)), ((3, 15, 15, 16), (14, 14)), ((1, 7, 9, 3), (15, 15)),
+                                   ((2, 14, 14, 16), (15, 15))])
+def test_label_resize_kernel_matches_tf1_legacy_rule(gpu, shape):
+    """apa_resize_bilinear_tf1 (gather form, f32) vs the oracle's float64 restatement of TF 1.1's
+    legacy bilinear rule (Appendix B): down- and up-sampling, non-square, the clamped last row / column."""
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    (n, h, w, c), (oh, ow) = shape
+    img = torch.rand(n, h, w, c, generator=torch.Generator().manual_seed(h * 31 + ow))
+    got = cof.resize_bilinear_tf1(img.to(gpu), oh, ow).cpu()
+    want = orc.tf1_resize_bilinear(img.double(), oh, ow)
+    assert got.shape == (n, oh, ow, c)
+    assert float((got.double() - want).abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize('kind', ['l2', 'multi-label', 'multi-label-2'])
+def test_other_action_losses_through_gen_losses(gpu, kind):
+    """src/loss.py:81-101 through the 12-argument gen_losses: value and gradient vs the oracle."""
+    from attentionalpoolingaction_amd import loss as apa_loss
+    g = torch.Generator().manual_seed(21)
+    N, K, wt = 9, 157, 0.7
+    logits = torch.randn(N, K, generator=g) * 2.5
+    if kind == 'l2':
+        labels = torch.randint(0, K, (N,), generator=g)
+    else:
+        labels = (torch.rand(N, K, generator=g) < 0.08).long()       # multi-hot, int like the tfrecord field
+    Ld = logits.to(gpu).requires_grad_(True)
+    (la,) = apa_loss.gen_losses(labels.to(gpu), Ld, kind, K, wt, None, None, '', None, 1.0)
+    la.backward()
+    Lr = logits.double().requires_grad_(True)
+    if kind == 'l2':
+        want = orc.action_l2(Lr, labels, K, wt)
+    elif kind == 'multi-label':
+        want = orc.action_multi_label(Lr, labels)                     # the reference ignores the weight here
+    else:
+        want = orc.action_multi_label_2(Lr, labels)
+    want.backward()
+    assert abs(float(la) - float(want)) < 2e-6 * max(1.0, abs(float(want)))
+    assert _rel(Ld.grad.cpu().numpy(), Lr.grad.numpy()) < 5e-6
+
+
+def test_sampled_pose_loss_through_gen_losses(gpu):
+    """cfg.TRAIN.LOSS_FN_POSE_SAMPLED (src/loss.py:36-52) with the label resize in front: value, gradient and
+    the PoseLossMask end point vs the literal oracle, fed the same uniform draws.  Labels are sparse
+    blobs (zeros elsewhere) like real heat-maps, so both the "selected negatives" and the "positive
+    logits" parts of the mask are populated."""
+    from attentionalpoolingaction_amd import config as apa_config, loss as apa_loss
+    cfg = apa_config.reset_cfg()
+    apa_config.cfg_from_dict({'TRAIN': {'LOSS_FN_POSE_SAMPLED': True}})
+    g = torch.Generator().manual_seed(8)
+    N, H, J = 4, 15, 16
+    Pl = torch.randn(N, H, H, J, generator=g) * 0.5
+    lbl = torch.rand(N, H, H, J, generator=g)
+    lbl = torch.where(lbl > 0.8, lbl, torch.zeros_like(lbl))
+    valid = torch.rand(N, J, generator=g) > 0.3
+    u = torch.rand(N, H, H, J, generator=g)
+    Pd = Pl.to(gpu).requires_grad_(True)
+    ep = {'PoseLossUniform': u.to(gpu)}
+    (lp,) = apa_loss.gen_losses(None, None, '', 0, 1.0, lbl.to(gpu), Pd, 'l2', valid.to(gpu), 3.0, ep, cfg)
+    lp.backward()
+    Pr = Pl.double().requires_grad_(True)
+    want, wmask = orc.pose_l2_sampled_loss(Pr, lbl.double(), valid, u.double(), 3.0)
+    want.backward()
+    assert torch.equal(ep['PoseLossMask'].cpu().double(), wmask)
+    assert 0.2 < float(wmask.mean()) < 0.9
+    assert abs(float(lp) - float(want)) < 2e-6 * float(want)
+    assert _rel(Pd.grad.cpu().numpy(), Pr.grad.numpy()) < 5e-6
+    apa_config.reset_cfg()
+
+
 def test_zero_out_channels_reference_case(gpu):
     """src/custom_ops/test/zero_out_channels_op_test.py:10-18: ones((1,3,3,5)), mask [T,F,T,T,T]
     -> channel 1 zero, the others one."""
@@ -417,35 +486,69 @@ def test_head_module_rank3_matches_oracle(gpu, single_layer):
     apa_config.reset_cfg()
 
 
-def test_head_module_with_pose_feat_matches_oracle(gpu):
-    """..._WITH_POSE_FEAT (nets_factory.py:289-295): the top-down conv sees concat(last_conv,
-    pose_logits); eval mode (the extra channels' dropout mask is an independent stream)."""
+@pytest.mark.parametrize('single_layer,two_layer,train', [(False, False, False), (False, False, True),
+                                                          (True, False, True), (False, True, True),
+                                                          (True, True, False)])
+def test_head_module_with_pose_feat_matches_oracle(gpu, single_layer, two_layer, train):
+    """..._WITH_POSE_FEAT[_2LAYER] (nets_factory.py:289-296): the top-down conv sees concat(last_conv,
+    pose_logits) -- here through apa_attn_pool_{fwd,bwd}_cat, the concatenation never formed.  Training
+    mode hands the oracle the kernel's own keep-mask of the [N,P,2048+16] tensor (X part = the flat
+    stream, extra channels = its continuation at N*P*C); the 2-layer variant adds conv + batch-norm
+    (batch statistics) + relu in front of the concatenation."""
     from attentionalpoolingaction_amd import config as apa_config
-    fn, _ = _make_head(gpu, {'USE_POSE_PRELOGITS_BASED_ATTENTION_SINGLE_LAYER_ATT': False,
-                             'USE_POSE_PRELOGITS_BASED_ATTENTION_WITH_POSE_FEAT': True})
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    fn, _ = _make_head(gpu, {'USE_POSE_PRELOGITS_BASED_ATTENTION_SINGLE_LAYER_ATT': single_layer,
+                             'USE_POSE_PRELOGITS_BASED_ATTENTION_WITH_POSE_FEAT': True,
+                             'USE_POSE_PRELOGITS_BASED_ATTENTION_WITH_POSE_FEAT_2LAYER': two_layer},
+                       is_training=train)
     head = fn.head
     assert head.td_weights.shape == (2048 + 16, 51)
+    with torch.no_grad():
+        if two_layer:
+            head.pose_feat_weights.copy_(torch.randn(16, 16, generator=torch.Generator().manual_seed(3)) * 0.3)
+            head.pose_feat_bn_gamma.copy_(torch.rand(16, generator=torch.Generator().manual_seed(4)) + 0.5)
+            head.pose_feat_bn_beta.copy_(torch.randn(16, generator=torch.Generator().manual_seed(5)) * 0.2)
+    N, H, C, J = 3, 14, 2048, 16
     g = torch.Generator().manual_seed(19)
-    X = torch.relu(torch.randn(2, 14, 14, 2048, generator=g))
-    labels = torch.randint(0, 51, (2,), generator=g)
+    X = torch.relu(torch.randn(N, H, H, C, generator=g))
+    labels = torch.randint(0, 51, (N,), generator=g)
     Xd = X.to(gpu).requires_grad_(True)
+    step0 = head._step
     logits, ep = fn(Xd)
     torch.nn.functional.cross_entropy(logits, labels.to(gpu)).backward()
+    mask = None
+    if train:
+        m = cof.dropout_mask((N * H * H * (C + J),), head.keep_prob, head.seed, step0).cpu()
+        mx = m[:N * H * H * C].view(N, H, H, C)
+        me = m[N * H * H * C:].view(N, H, H, J)
+        mask = torch.cat([mx, me], dim=-1)
+        assert abs(float(me.float().mean()) - head.keep_prob) < 0.03
     p = {k: v.detach().cpu().double().requires_grad_(True) for k, v in head.named_parameters()}
     Xr = X.double().requires_grad_(True)
     pre, pl = orc.pose_logits_head(Xr, p['pose_w1'], p['pose_b1'], p['pose_w2'], p['pose_b2'])
-    lr, _ = orc.attentional_pooling(Xr, pre, pl, [p['att_weights']], [p['att_biases']],
-                                    [p['td_weights']], [p['td_biases']],
-                                    orc.AttnFlags(single_layer_att=False, with_pose_feat=True))
+    lr, _ = orc.attentional_pooling(
+        Xr, pre, pl, [p['att_weights']], [p['att_biases']], [p['td_weights']], [p['td_biases']],
+        orc.AttnFlags(single_layer_att=single_layer, with_pose_feat=True, with_pose_feat_2layer=two_layer),
+        is_training=train, keep_prob=head.keep_prob, dropout_mask=mask,
+        pose_feat_w=p.get('pose_feat_weights'),
+        pose_feat_bn=(p['pose_feat_bn_gamma'], p['pose_feat_bn_beta']) if two_layer else None)
     torch.nn.functional.cross_entropy(lr, labels).backward()
     assert _rel(logits.detach().cpu().numpy(), lr.detach().numpy()) < 2e-5
+    assert _rel(ep['PoseLogits'].detach().cpu().numpy(), pl.detach().numpy()) < 2e-5
     assert _rel(Xd.grad.cpu().numpy(), Xr.grad.numpy()) < 2e-4
-    for k in ('pose_w1', 'pose_b1', 'pose_w2', 'pose_b2', 'att_weights', 'att_biases', 'td_weights', 'td_biases'):
+    names = ['pose_w1', 'pose_b1', 'pose_w2', 'pose_b2', 'att_weights', 'att_biases', 'td_weights', 'td_biases']
+    if two_layer:
+        names += ['pose_feat_weights', 'pose_feat_bn_gamma', 'pose_feat_bn_beta']
+        tfn = head.tf_variable_names()
+        assert tfn['pose_feat_weights'].endswith('Attention/Conv/weights') and tfn['td_weights'].endswith('Conv_1/weights')
+    for k in names:
+        if two_layer and k == 'pose_b2':
+            # batch-norm removes any per-channel shift of its input: d/d(pose_b2) of the attention branch
+            # is exactly 0 (only rounding noise on both sides)
+            assert float(getattr(head, k).grad.abs().max()) < 1e-6 * float(head.pose_w2.grad.abs().max())
+            continue
         assert _rel(getattr(head, k).grad.cpu().numpy(), p[k].grad.numpy()) < 2e-4, k
-    apa_config.reset_cfg()
-    with pytest.raises(NotImplementedError):
-        _make_head(gpu, {'USE_POSE_PRELOGITS_BASED_ATTENTION_WITH_POSE_FEAT': True,
-                         'USE_POSE_PRELOGITS_BASED_ATTENTION_WITH_POSE_FEAT_2LAYER': True})
+    assert float(getattr(head, 'td_weights').grad[C:].abs().max()) > 0      # the extra rows do get a gradient
     apa_config.reset_cfg()
 
 
