@@ -364,8 +364,10 @@ extern "C" int apa_attn_head_train_step_ex(const apa_hooks* hooks, const void* X
                                   stream);
     if (rc != APA_OK) return rc;
   }
+  // same workspace, nothing in between: the backward may reuse what the forward prepared in it
   return attn_pool_bwd_impl(hk, nullptr, xf.done ? &xf : nullptr, X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, dX,
-                            dXatt, dWa, dba, dWt, dbt, ws, ws_bytes, N, P, C, Ca, K, M, flags, keep_prob,
+                            dXatt, dWa, dba, dWt, dbt, ws, ws_bytes, N, P, C, Ca, K, M,
+                            flags | APA_FLAG_WS_FROM_FWD, keep_prob,
                             seed, offset, dtype, stream);
 }
 

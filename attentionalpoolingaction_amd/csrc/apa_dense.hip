@@ -504,7 +504,9 @@ __global__ __launch_bounds__(1024) void pc_bwd_act_kernel(const float* __restric
                                                          T* __restrict__ dT, T* __restrict__ dZ,
                                                          float* __restrict__ pdbt,
                                                          float* __restrict__ pdba, int P, int K,
-                                                         int Kp, int act) {
+                                                         int Kp, int act, int ldg) {
+  // dT / dZ: [R][ldg] with Kp written columns each (ldg = Kp, or 2*Kp when the two are interleaved as
+  // one [R][dT | dZ] operand for apa_pc_fused.hip)
   __shared__ float red[PC_PG][64];
   __shared__ float red2[PC_PG][64];
   const int n = blockIdx.x;
@@ -534,13 +536,13 @@ __global__ __launch_bounds__(1024) void pc_bwd_act_kernel(const float* __restric
       float dz = dA;
       if (act == 2) dz = a * (dA - corr);
       else if (act == 1) dz = a > 0.f ? dA : 0.f;
-      stf<T>(dT, (rbase + p) * Kp + k, dt);
-      stf<T>(dZ, (rbase + p) * Kp + k, dz);
+      stf<T>(dT, (rbase + p) * ldg + k, dt);
+      stf<T>(dZ, (rbase + p) * ldg + k, dz);
       sdt += dt;
       sdz += dz;
     } else if (pad) {
-      stf<T>(dT, (rbase + p) * Kp + k, 0.f);
-      stf<T>(dZ, (rbase + p) * Kp + k, 0.f);
+      stf<T>(dT, (rbase + p) * ldg + k, 0.f);
+      stf<T>(dZ, (rbase + p) * ldg + k, 0.f);
     }
   }
   red[pg][kk] = sdt;
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(1024) void pc_bwd_act_kernel(const float* __restric
 struct PcPlan {
   long R;
   int Kp;
-  size_t off_wap, off_wtp, off_bap, off_z, off_dt, off_dz, off_pdbt, off_pdba, off_gemm, off_xd, total;
+  size_t off_wap, off_wtp, off_bap, off_z, off_dt, off_dz, off_pdbt, off_pdba, off_gemm, off_xd, off_fused, total;
 };
 static PcPlan pc_plan(int N, int P, int C, int Ca, int K, int dtype) {
   PcPlan pl;
@@ -581,6 +583,8 @@ static PcPlan pc_plan(int N, int P, int C, int Ca, int K, int dtype) {
   // bf16 training: dropout(X) materialised once per call, so the MFMA GEMMs that consume it can DMA
   // their operands (the generic kernel applies the mask while staging through registers)
   pl.off_xd = off;   off += dtype == APA_DTYPE_BF16 ? align_up((size_t)pl.R * C * 2, 256) : 0;
+  // K <= 64, bf16: operands of the HBM-bound fused kernels (apa_pc_fused.hip)
+  pl.off_fused = off; off += (dtype == APA_DTYPE_BF16 && K <= 64 && Ca == C) ? pc_fused_ws_bytes(N, P, C) : 0;
   pl.total = off;
   return pl;
 }
@@ -654,6 +658,21 @@ int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
   const int tdt = dt_code(dtype);
   const bool wb16 = dtype == APA_DTYPE_BF16;   // padded weights stored as bf16
   const bool fast = dtype == APA_DTYPE_BF16 && C % 8 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+  if (pc_fused_supported(N, P, C, Ca, K, dtype, X, Xatt)) {
+    // K <= 64 (HMDB-51): Z | T in ONE pass over X, dropout applied on the way into LDS (apa_pc_fused.hip)
+    const PcFusedWs f = pc_fused_carve(w + pl.off_fused, N, P, C);
+    int rc = pc_fused_prep(f, Wa, Wt, ba, bt, C, K, st);
+    if (rc != APA_OK) return rc;
+    const bool devctr = flags & APA_FLAG_RNG_DEVICE;
+    rc = pc_fused_forward(f, X, Z, Tsave, R, C, K, train, keep_prob, seed, devctr ? 0 : offset,
+                          devctr ? reinterpret_cast<const uint64_t*>(static_cast<uintptr_t>(offset)) : nullptr, st);
+    if (rc != APA_OK) return rc;
+    dim3 grid(N, (K + 63) / 64);
+    hipLaunchKernelGGL(pc_fwd_act_kernel<bf16_t>, grid, dim3(64 * PC_PG), 0, st, Z, Kp, Tsave, att, logits,
+                       static_cast<bf16_t*>(topdown), P, K, act_code(flags));
+    APA_LAUNCH_CHECK("pc_fwd_act_kernel");
+    return APA_OK;
+  }
   {
     PcPadList pads;
     pads.add(Wa, WaP, Ca, Kp, wb16);
@@ -721,6 +740,40 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
   const bool fused = (Xatt == X);
   const int tdt = dt_code(dtype);
   const bool wb16 = dtype == APA_DTYPE_BF16;
+  if (pc_fused_supported(N, P, C, Ca, K, dtype, X, Xatt)) {
+    const PcFusedWs f = pc_fused_carve(w + pl.off_fused, N, P, C);
+    int rc = APA_OK;
+    const bool devctr = flags & APA_FLAG_RNG_DEVICE;
+    const uint64_t off = devctr ? 0 : offset;
+    const uint64_t* offd = devctr ? reinterpret_cast<const uint64_t*>(static_cast<uintptr_t>(offset)) : nullptr;
+    if (!(flags & APA_FLAG_WS_FROM_FWD)) {   // else the forward call left the operands and the mask bits in place
+      rc = pc_fused_prep(f, Wa, Wt, nullptr, nullptr, C, K, st);
+      if (rc != APA_OK) return rc;
+      if (train) {
+        rc = pc_fused_maskbits(f, (size_t)R * C, keep_prob, seed, off, offd, st);
+        if (rc != APA_OK) return rc;
+      }
+    }
+    bf16_t* dTc = static_cast<bf16_t*>(f.dTdZ);              // [R][dT (64) | dZ (64)]
+    dim3 grid(N, (Kp + 63) / 64);
+    hipLaunchKernelGGL(pc_bwd_act_kernel<bf16_t>, grid, dim3(64 * PC_PG), 0, st, G, att, Tsave, dTc, dTc + 64,
+                       pdbt, pdba, P, K, Kp, act_code(flags), 128);
+    APA_LAUNCH_CHECK("pc_bwd_act_kernel");
+    rc = m1_colsum(pdbt, nullptr, dbt, nullptr, N, 2 * K, 2 * K, nullptr, st, dba, K);
+    if (rc != APA_OK) return rc;
+    rc = pc_fused_dw(f, X, dWt, dWa, R, C, K, train, keep_prob, st);
+    if (rc != APA_OK) return rc;
+    // dX = (dT . Wt^T) * mask/keep + dZ . Wa^T: one launch over the concatenated k = 128
+    static const int exp_mask = [] { const char* e = getenv("APA_PC_EXP"); return e ? atoi(e) : 0; }();
+    if (train && !(exp_mask & 1))
+      return gemm_bf16_mid_dropout(f.dTdZ, 128, f.Wcat2, 128, dX, C, R, C, 128, 1.0f / keep_prob, f.maskbits, st);
+    GemmDesc g;
+    g.A = f.dTdZ; g.lda = 128; g.ta = 1; g.a_kc = true;
+    g.B = f.Wcat2; g.ldb = 128; g.tb = 1; g.b_kc = true;
+    g.C = dX; g.ldc = C; g.tc = 1;
+    g.M = R; g.N = C; g.K = 128;
+    return gemm_launch(g, st);
+  }
   {
     PcPadList pads;
     pads.add(Wa, WaP, Ca, Kp, wb16);
@@ -732,11 +785,11 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
   if (dtype == APA_DTYPE_F32)
     hipLaunchKernelGGL(pc_bwd_act_kernel<float>, grid, dim3(64 * PC_PG), 0, st, G, att, Tsave,
                        static_cast<float*>(dT), static_cast<float*>(dZ), pdbt, pdba, P, K, Kp,
-                       act_code(flags));
+                       act_code(flags), Kp);
   else
     hipLaunchKernelGGL(pc_bwd_act_kernel<bf16_t>, grid, dim3(64 * PC_PG), 0, st, G, att, Tsave,
                        static_cast<bf16_t*>(dT), static_cast<bf16_t*>(dZ), pdbt, pdba, P, K, Kp,
-                       act_code(flags));
+                       act_code(flags), Kp);
   APA_LAUNCH_CHECK("pc_bwd_act_kernel");
   int rc = m1_colsum(pdbt, nullptr, dbt, nullptr, N, 2 * K, 2 * K, nullptr, st, dba, K);
   if (rc != APA_OK) return rc;

@@ -114,6 +114,10 @@ struct FastParams {
   int Nout;      // columns that exist in C / partial (N may cover zero-padded columns of B)
   int drop_c; float inv_keep; uint32_t thresh; uint64_t seed, offset; const uint64_t* offset_dev;
   int vec_epi;   // N % 8 == 0 and C / bias / partial rows 16-byte addressable
+  int drop_mid;  // >= 0 (gemm_bf16_glds_kernel<.., MID>): after k tile `drop_mid` the accumulators are
+                 // multiplied by the dropout mask / keep of their output element (flat index row*Nout+col):
+                 // C = (A[:, :k1] . B[:, :k1]^T) * mask/keep + A[:, k1:] . B[:, k1:]^T in one launch
+  const uint8_t* maskbits;   // the keep decisions as bits ([M*Nout/8] bytes); Nout % 64 == 0
 };
 
 // 8 consecutive output columns of one row: split-K partial, or bias / relu / output dropout /
@@ -419,7 +423,7 @@ __device__ __forceinline__ bf16x8 fragment_sw(const short* img, int rbase, int k
   }
 }
 
-template <typename TC, bool A_KM, bool B_KM>
+template <typename TC, bool A_KM, bool B_KM, bool MID = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(FastParams p) {
   extern __shared__ __attribute__((aligned(16))) short smem[];   // [2 buffers][A image | B image], + epilogue
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -464,6 +468,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(FastParams p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (nk > 0) issue(0);
+  // MID: the keep-bits of this wave's 16 rows x 64 columns are fetched up front (their latency hides under
+  // the first operand tile): one 8-byte word per (row tile i, register r)
+  uint64_t mbits[MID ? 16 : 1];
+  if (MID) {
+    const int kbm = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = min(m0 + wm * 64 + i * 16 + 4 * kbm + r, p.M - 1);
+        mbits[i * 4 + r] = *reinterpret_cast<const uint64_t*>(
+            p.maskbits + (((size_t)row * p.Nout + n0 + wn * 64) >> 3));
+      }
+  }
   __syncthreads();
   for (int t = 0; t < nk; ++t) {
     const short* a_img = smem + (t & 1) * 2 * IMG;
@@ -482,6 +500,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(FastParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (MID && t == p.drop_mid) {   // mask what has been accumulated so far (D layout: row = 4*(lane>>4)+reg)
+      const int l16 = lane & 15;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint64_t bits = mbits[i * 4 + r];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j][r] *= ((bits >> (j * 16 + l16)) & 1ull) ? p.inv_keep : 0.f;
+        }
     }
     __syncthreads();
   }
@@ -705,6 +735,36 @@ int launch_layout(const FastParams& p, bool a_km, bool b_km, int splits, hipStre
 }
 }  // namespace
 
+// C [M][N] bf16 = (A[:, :k1] . B[:, :k1]^T) * mask/keep + A[:, k1:] . B[:, k1:]^T, all operands bf16 with k
+// contiguous, k1 = 64 (one k tile), K a multiple of 64, N a multiple of 8 (apa_pc_fused.hip: dX).
+int gemm_bf16_mid_dropout(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N,
+                          int K, float inv_keep, const uint8_t* maskbits, hipStream_t st) {
+  if (N % 128 != 0 || K % TK != 0) {
+    set_error("gemm_bf16_mid_dropout: N=%d must be a multiple of 128 and K=%d of 64", N, K);
+    return APA_ERR_UNSUPPORTED;
+  }
+  FastParams p;
+  p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K; p.bias = nullptr; p.beta = 0.f; p.act = 0;
+  p.k_per_split = K; p.partial = nullptr; p.Nout = N;
+  p.drop_c = 0; p.inv_keep = inv_keep; p.thresh = 0; p.seed = 0; p.offset = 0;
+  p.offset_dev = nullptr;
+  p.vec_epi = N % 8 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && (ldc * 2) % 16 == 0;
+  p.drop_mid = 0;
+  p.maskbits = maskbits;
+  const size_t shm = (size_t)2 * 2 * OP_ELEMS * sizeof(short);
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_glds_kernel<bf16_t, false, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    attr_set = true;
+  }
+  const int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
+  hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, false, false, true>), dim3(tiles, 1, 1), dim3(256), shm, st, p);
+  APA_LAUNCH_CHECK("gemm_bf16_glds_kernel<mid>");
+  return APA_OK;
+}
+
 // Eligibility: bf16 A, bf16 or fp32 B, no fused dropout, 16-byte addressable rows, K a multiple of 8,
 // at least one full vector of rows for k-major operands.
 bool gemm_bf16_eligible(const GemmDesc& d) {
@@ -731,6 +791,8 @@ int gemm_bf16_launch(const GemmDesc& d, int splits, int k_per_split, hipStream_t
   p.Nout = d.n_valid > 0 ? d.n_valid : d.N;
   p.drop_c = d.drop_c; p.inv_keep = d.inv_keep; p.thresh = d.thresh; p.seed = d.seed; p.offset = d.offset;
   p.offset_dev = d.offset_dev;
+  p.drop_mid = -1;
+  p.maskbits = nullptr;
   const int ec = d.tc == 1 ? 2 : 4;
   p.vec_epi = p.Nout % 8 == 0 && (!d.drop_c || p.Nout % 2 == 0) && (reinterpret_cast<uintptr_t>(d.C) & 15) == 0 && (d.ldc * ec) % 16 == 0 &&
               (!d.bias || (reinterpret_cast<uintptr_t>(d.bias) & 15) == 0) &&

@@ -216,6 +216,32 @@ int m1_logits2_xent(const float* z, const float* Wt, const float* abar, const fl
 int m1_colsum(const float* pdwa, const float* pdba, float* dwa, float* dba, int nblk, int C, int ld,
               uint64_t* rng_bump, hipStream_t st, float* dwa2 = nullptr, int C1 = 0);
 
+// apa_gemm_bf16.hip: C = (A[:, :64] . B[:, :64]^T) * mask/keep + A[:, 64:] . B[:, 64:]^T  (all bf16, k contiguous)
+int gemm_bf16_mid_dropout(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N,
+                          int K, float inv_keep, const uint8_t* maskbits, hipStream_t st);
+
+// apa_pc_fused.hip: per-class maps with K <= 64 (HMDB-51), bf16, Xatt == X: the HBM-bound form
+constexpr int PC_DW_MAX_SPLITS = 32;
+struct PcFusedWs {
+  void* WcatT;      // bf16 [C/64][128][64]: Wa | Wt transposed (zero padded to 64 columns each), k-tile-major
+  void* Wcat2;      // bf16 [C][128]: Wt | Wa
+  float* bcat;      // f32 [128]: ba | bt
+  void* dTdZ;       // bf16 [R][128]: dT | dZ
+  float* partial;   // f32 [splits][C][128]
+  uint8_t* maskbits;  // [R*C/8]: keep decisions of the dropout mask, bit (e & 7) of byte e >> 3
+};
+bool pc_fused_supported(int N, int P, int C, int Ca, int K, int dtype, const void* X, const void* Xatt);
+size_t pc_fused_ws_bytes(int N, int P, int C);
+PcFusedWs pc_fused_carve(void* base, int N, int P, int C);
+int pc_fused_prep(const PcFusedWs& f, const float* Wa, const float* Wt, const float* ba, const float* bt, int C,
+                  int K, hipStream_t st);
+int pc_fused_forward(const PcFusedWs& f, const void* X, float* Z, float* T, int R, int C, int K, bool train,
+                     float keep_prob, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, hipStream_t st);
+int pc_fused_maskbits(const PcFusedWs& f, size_t n_elems, float keep_prob, uint64_t seed, uint64_t offset,
+                      const uint64_t* offset_dev, hipStream_t st);
+int pc_fused_dw(const PcFusedWs& f, const void* X, float* dWt, float* dWa, int R, int C, int K, bool train,
+                float keep_prob, hipStream_t st);
+
 // apa_dense.hip: per-class bottom-up maps (M == K); Tsave = fp32 [N,P,K] top-down map saved for bwd
 size_t pc_workspace_bytes(int N, int P, int C, int Ca, int K, int dtype);
 int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba, const float* Wt,

@@ -1,0 +1,493 @@
+// apa_pc_fused.hip -- per-class bottom-up maps (M == K, cfg.NET..._PER_CLASS, nets_factory.py:257) for
+// SMALL class counts (K <= 64: the HMDB-51 configuration of BASELINE.json), bf16 features, attention
+// computed from the feature map itself (Xatt == X).
+//
+// With K = 51 the two 1x1 convs (Z = X.Wa, T = dropout(X).Wt) are 128 output columns over a 2048-deep
+// contraction: 0.25 GFLOP per image against 3 * P * C * 2 bytes -- the products are HBM-bound, not
+// MFMA-bound, and what matters is how often the 25.7 MB feature map crosses the memory system.  The
+// generic path (apa_dense.hip) materialises dropout(X) (read + write of the map), runs Z and T as two
+// split-K GEMMs (two more reads), and in backward materialises it again, runs dWa / dWt as two more
+// GEMMs and dX as two GEMMs with a read-modify-write in between: ten passes over map-sized tensors.
+// Here the map is read ONCE per product group and dX is written once:
+//
+//   pc_fwd_zt_kernel   Z | T  = X . [Wa | Wt]        one pass over X.  The A tile goes through registers on
+//                                                    its way to LDS and is stored TWICE: as it is (the Z
+//                                                    columns read this image) and with the dropped
+//                                                    elements zeroed (the T columns read that one); the
+//                                                    1/keep scale is applied to the fp32 accumulators.
+//   pc_bwd_dw_kernel   dWt | dWa = [Xd | X]^T . [dT | dZ]   one pass over X (k-major operand, transposing
+//                                                    LDS reads), same two-image trick, split over the rows.
+//   dX                 = (dT . Wt^T) * mask/keep + dZ . Wa^T   ONE launch of the DMA-staged GEMM
+//                                                    (apa_gemm_bf16.hip) over the concatenated operands
+//                                                    [dT | dZ] . [Wt | Wa]^T: the accumulators are masked
+//                                                    in registers between the two 64-deep k tiles.
+// The dropout mask is the library's counter-based one (flat element index r*C + c), regenerated where it
+// is needed -- never stored.
+#include "apa_device.h"
+#include "apa_internal.h"
+
+namespace apa {
+
+namespace {
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int FK = 64;          // k tile
+constexpr int LDK = FK + 8;     // [row][k] image: 144-byte rows, conflict-free ds_read_b128
+constexpr int LDM = 128 + 8;    // [k][row] image: 272-byte rows (transposing reads)
+
+// keep decisions of 8 consecutive elements (flat element index e, a multiple of 8) as bits 0..7
+__device__ __forceinline__ uint32_t keep_bits8(uint64_t e, uint32_t k0, uint32_t k1, uint32_t thresh) {
+  uint32_t bits = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint64_t q = (e >> 1) + i;
+    const uint32_t h = rng_hash((uint32_t)q, k0, k1 ^ __umul24((uint32_t)(q >> 32), 0x9E3779u));
+    bits |= ((h & 0xffffu) < thresh ? 1u : 0u) << (2 * i);
+    bits |= ((h >> 16) < thresh ? 1u : 0u) << (2 * i + 1);
+  }
+  return bits;
+}
+// zero the dropped elements of 8 consecutive bf16
+__device__ __forceinline__ uint4 apply_bits8(uint4 v, uint32_t bits) {
+  uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    w[i] &= ((bits >> (2 * i)) & 1u ? 0x0000ffffu : 0u) | ((bits >> (2 * i + 1)) & 1u ? 0xffff0000u : 0u);
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// The keep-mask of the whole map as bits ([R*C/8] bytes, 1/16 of the bf16 map): the forward pass writes it
+// while it masks its A tiles; the backward kernels read it instead of hashing again (the mask-in-registers
+// step of the dX product cost as much as the product itself with 64 hashes per lane).  A backward call
+// that cannot rely on the forward call's workspace regenerates it with this kernel.
+__global__ __launch_bounds__(256) void pc_maskbits_kernel(uint8_t* __restrict__ bits, size_t n8, uint32_t thresh,
+                                                          uint64_t seed, uint64_t offset,
+                                                          const uint64_t* __restrict__ offset_dev) {
+  uint32_t k0, k1;
+  rng_key_dev(seed, offset_dev ? *offset_dev : offset, k0, k1);
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n8; v += (size_t)gridDim.x * 256)
+    bits[v] = (uint8_t)keep_bits8(v * 8, k0, k1, thresh);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight preparation: the padded, concatenated bf16 operands of the three products (one launch).
+//   WcatT [C/64][128][64]  k-tile-major: tile t holds rows n < 64: Wa[64t.., n], rows 64 + n: Wt[64t.., n]
+//                    (n >= K: zero) -- the forward B operand; each 64-deep k tile is ONE contiguous
+//                    16 KB run (a [128][C] layout puts the 128 row segments of a tile 4 KB apart)
+//   Wcat2 [C][128]   cols 0..63: Wt[c, :] ; cols 64..127: Wa[c, :]                     -- dX B operand
+//   bcat  [128] f32  ba | bt (zero padded)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pc_prep_kernel(const float* __restrict__ Wa, const float* __restrict__ Wt,
+                                                      const float* __restrict__ ba, const float* __restrict__ bt,
+                                                      bf16_t* __restrict__ WcatT, bf16_t* __restrict__ Wcat2,
+                                                      float* __restrict__ bcat, int C, int K) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx < (long)C * 128) {
+    const int c = (int)(idx >> 7), col = (int)(idx & 127);
+    const int k = col & 63;
+    const bool is_a = col < 64;        // WcatT order: Wa | Wt
+    const float v = k < K ? (is_a ? Wa : Wt)[(size_t)c * K + k] : 0.f;
+    const uint16_t b = (uint16_t)f32_to_bf16_bits(v);
+    WcatT[((size_t)(c >> 6) * 128 + col) * 64 + (c & 63)].v = b;
+    Wcat2[(size_t)c * 128 + (is_a ? 64 + k : k)].v = b;   // Wcat2 order: Wt | Wa
+  }
+  if (idx < 128 && ba && bt) {   // (the backward call does not need the biases)
+    const int k = (int)idx & 63;
+    bcat[idx] = k < K ? (idx < 64 ? ba[k] : bt[k]) : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Forward: Z[r, 0:64] = X[r,:] . Wa + ba (fp32, ld 64);  T[r, 0:K] = (X*mask/keep)[r,:] . Wt + bt (fp32, ld K).
+// Block = BM rows x 128 columns, 4 waves: wave w -> column half (w >> 1: 0 = Z, 1 = T) x 32 columns
+// (w & 1), all BM rows.  Two LDS stages; the next tile's global loads fly under this tile's MFMAs.
+// ---------------------------------------------------------------------------------------------
+constexpr int KA = 256;          // k extent of one A load (512 contiguous bytes per row)
+constexpr int LDA = KA + 8;      // A image row stride: 528 B = 132 dwords -> 16 rows cover the 64 banks once
+
+template <int BM, bool TRAIN>
+__global__ __launch_bounds__(256) void pc_fwd_zt_kernel(
+    const bf16_t* __restrict__ X, const bf16_t* __restrict__ WcatT, const float* __restrict__ bcat,
+    float* __restrict__ Z, float* __restrict__ T, uint8_t* __restrict__ maskbits, int R, int C, int K,
+    float inv_keep, uint32_t thresh, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev) {
+  // X is streamed from HBM exactly once, and HBM wants long contiguous bursts: a block owns BM whole rows
+  // (BM * C * 2 contiguous bytes) and fetches them KA = 256 channels at a time -- 512 contiguous bytes per
+  // row and wave-instruction pair -- while the weight slab (L2-resident, re-read by every block) moves
+  // in 64-deep k tiles.  (Fetching A in the same 64-deep tiles, 128 B per row, measured 21 us for the
+  // 25.7 MB map: every request opened a different DRAM page.)
+  extern __shared__ __attribute__((aligned(16))) short smem[];
+  constexpr int A_EL = BM * LDA, B_EL = 128 * LDK;
+  constexpr int NA = TRAIN ? 2 : 1;             // A images per buffer: plain [, masked]
+  constexpr int AV = BM * (KA / 8) / 256;       // 16-byte vectors of an A load per thread
+  constexpr int MT = BM / 16;                   // MFMA row tiles per wave
+  constexpr int D = 4;                          // B tiles in flight (register sets); also KA / FK
+  static_assert(KA / FK == D, "one A load spans D sub-steps");
+  short* const a_base = smem;                   // [2][NA][BM][LDA]
+  short* const b_base = smem + 2 * NA * A_EL;   // [2][128][LDK]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int half = wave >> 1, wn = wave & 1;
+  const int l16 = lane & 15, kb = lane >> 4;
+  const int m0 = blockIdx.x * BM;
+  const int nk = C / FK, nsuper = C / KA;
+  uint32_t k0 = 0, k1 = 0;
+  if (TRAIN) rng_key_dev(seed, offset_dev ? *offset_dev : offset, k0, k1);
+
+  uint4 av[AV], bv[D][4];
+  auto load_a = [&](int sidx) {
+    const int sc = min(sidx, nsuper - 1);       // past the end: re-load the last one (never stored)
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      const int vi = tid + i * 256;
+      const int grow = min(m0 + (vi >> 5), R - 1);
+      av[i] = ld16(X + (size_t)grow * C + sc * KA + (vi & 31) * 8);
+    }
+  };
+  auto store_a = [&](int buf, int sidx) {
+    short* a0 = a_base + buf * NA * A_EL;
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      const int vi = tid + i * 256;
+      const int row = vi >> 5, kc = (vi & 31) * 8;
+      *reinterpret_cast<uint4*>(a0 + row * LDA + kc) = av[i];
+      if (TRAIN) {
+        const uint64_t e = (uint64_t)min(m0 + row, R - 1) * C + sidx * KA + kc;
+        const uint32_t kb8 = keep_bits8(e, k0, k1, thresh);
+        *reinterpret_cast<uint4*>(a0 + A_EL + row * LDA + kc) = apply_bits8(av[i], kb8);
+        // the bytes of 4 neighbouring lanes (32 consecutive channels of one row) leave as ONE dword
+        // (byte stores from every lane cost 4 us on the 1.6 MB bit map)
+        const uint32_t b1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)kb8, 0x39, 0xf, 0xf, true);   // lane + 1
+        const uint32_t b2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)kb8, 0x4E, 0xf, 0xf, true);   // lane + 2
+        const uint32_t b3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)kb8, 0x93, 0xf, 0xf, true);   // lane + 3
+        if ((lane & 3) == 0 && m0 + row < R)
+          *reinterpret_cast<uint32_t*>(maskbits + (e >> 3)) = kb8 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+      }
+    }
+  };
+  auto load_b = [&](uint4 (&b)[4], int t) {
+    const int tc = min(t, nk - 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int vi = tid + i * 256;
+      b[i] = ld16(WcatT + (size_t)tc * (128 * FK) + vi * 8);   // tile-major: 1 KiB per wave-instruction
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto store_b = [&](const uint4 (&b)[4], int buf) {
+    short* bi = b_base + buf * B_EL;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int vi = tid + i * 256;
+      *reinterpret_cast<uint4*>(bi + (vi >> 3) * LDK + (vi & 7) * 8) = b[i];
+    }
+  };
+
+  f32x4 acc[MT][2];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto compute = [&](int abuf, int sub, int bbuf) {
+    const short* a_img = a_base + (abuf * NA + ((TRAIN && half) ? 1 : 0)) * A_EL + sub * FK;
+    const short* b_img = b_base + bbuf * B_EL;
+#pragma unroll
+    for (int ks = 0; ks < FK / 32; ++ks) {
+      bf16x8 af[MT], bf[2];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(a_img + (i * 16 + l16) * LDA + ks * 32 + kb * 8);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        bf[j] = *reinterpret_cast<const bf16x8*>(b_img + (half * 64 + wn * 32 + j * 16 + l16) * LDK + ks * 32 + kb * 8);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  load_a(0);
+#pragma unroll
+  for (int d = 0; d < D; ++d) load_b(bv[d], d);
+  store_a(0, 0);
+  load_a(1);
+  store_b(bv[0], 0);
+  __syncthreads();
+  for (int sidx = 0; sidx < nsuper; ++sidx) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int t = sidx * D + d;
+      load_b(bv[d], t + D);                   // set d went to LDS in the previous sub-step: free again
+      compute(sidx & 1, d, t & 1);
+      if (t + 1 < nk) store_b(bv[(d + 1) % D], (t + 1) & 1);
+      if (d == D - 1 && sidx + 1 < nsuper) {  // the next A load has had D sub-steps to arrive
+        store_a((sidx + 1) & 1, sidx + 1);
+        load_a(sidx + 2);
+      }
+      __syncthreads();
+    }
+  }
+  // D layout of the 16x16 MFMA: row = 4 * (lane >> 4) + reg, col = lane & 15
+  const float scale = (TRAIN && half) ? inv_keep : 1.0f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = wn * 32 + j * 16 + l16;       // within the half
+    const float bias = bcat[half * 64 + col];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + i * 16 + 4 * kb + r;
+        if (row >= R) continue;
+        const float v = fmaf(acc[i][j][r], scale, bias);
+        if (half == 0) Z[(size_t)row * 64 + col] = v;
+        else if (col < K) T[(size_t)row * K + col] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward weights: partial[s][c][0:64] = sum_r Xd[r,c] dT[r,:]   (unscaled: 1/keep at the reduce)
+//                   partial[s][c][64:128] = sum_r X[r,c] dZ[r,:]
+// over the rows of split s.  Block = 128 channels x 128 columns; both operands are k-major ([r][.]):
+// [k][row] LDS images read with ds_read_b64_tr_b16 (see apa_gemm_bf16.hip for the lane mapping).
+// 4 waves: column half (w >> 1: 0 = dT with the masked image, 1 = dZ with the plain one) x 64 channels.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8 frag_km(const short* img, int rbase, int ks, int lane) {
+  typedef bf16x4 __attribute__((address_space(3))) * lds_v4;
+  const int l16 = lane & 15, kb = lane >> 4;
+  const short* s0 = img + (ks * 32 + kb * 8 + (l16 >> 2)) * LDM + rbase + 4 * (l16 & 3);
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(s0));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(s0 + 4 * LDM));
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <bool TRAIN>
+__global__ __launch_bounds__(256) void pc_bwd_dw_kernel(
+    const bf16_t* __restrict__ X, const bf16_t* __restrict__ dTdZ, const uint8_t* __restrict__ maskbits,
+    float* __restrict__ partial, int R, int C, int rows_per_split) {
+  extern __shared__ __attribute__((aligned(16))) short smem[];
+  constexpr int IMG = FK * LDM;
+  constexpr int STAGE = (TRAIN ? 3 : 2) * IMG;     // A plain | [A masked] | B
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int half = wave >> 1, wm = wave & 1;
+  const int l16 = lane & 15, kb = lane >> 4;
+  const int c0 = blockIdx.x * 128;
+  const int rbeg = blockIdx.y * rows_per_split, rend = min(R, rbeg + rows_per_split);
+  const int nk = (rend - rbeg + FK - 1) / FK;
+
+  uint4 av[4], bv[4];
+  uint32_t mb[TRAIN ? 4 : 1];
+  auto load = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int vi = tid + i * 256;
+      const int r = rbeg + t * FK + (vi >> 4), m = (vi & 15) * 8;
+      const int rc = min(r, rend - 1);
+      const uint4 a = ld16(X + (size_t)rc * C + c0 + m);
+      const uint4 b = ld16(dTdZ + (size_t)rc * 128 + m);
+      if (TRAIN) mb[i] = maskbits[((size_t)rc * C + c0 + m) >> 3];
+      const bool ok = r < rend;
+      av[i] = ok ? a : make_uint4(0u, 0u, 0u, 0u);
+      bv[i] = ok ? b : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto store = [&](int buf, int t) {
+    short* a0 = smem + buf * STAGE;
+    short* a1 = a0 + IMG;
+    short* b = a0 + (TRAIN ? 2 : 1) * IMG;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int vi = tid + i * 256;
+      const int kk = vi >> 4, m = (vi & 15) * 8;
+      *reinterpret_cast<uint4*>(a0 + kk * LDM + m) = av[i];
+      if (TRAIN) *reinterpret_cast<uint4*>(a1 + kk * LDM + m) = apply_bits8(av[i], mb[i]);
+      *reinterpret_cast<uint4*>(b + kk * LDM + m) = bv[i];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) {
+    load(0);
+    store(0, 0);
+  }
+  __syncthreads();
+  for (int t = 0; t < nk; ++t) {
+    // half 0 (dT columns) contracts against the MASKED features, half 1 (dZ) against the plain ones
+    const short* a_img = smem + (t & 1) * STAGE + ((TRAIN && half == 0) ? IMG : 0);
+    const short* b_img = smem + (t & 1) * STAGE + (TRAIN ? 2 : 1) * IMG;
+    const bool more = t + 1 < nk;
+    if (more) load(t + 1);
+#pragma unroll
+    for (int ks = 0; ks < FK / 32; ++ks) {
+      bf16x8 af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = frag_km(a_img, wm * 64 + i * 16, ks, lane);
+        bf[i] = frag_km(b_img, half * 64 + i * 16, ks, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store((t + 1) & 1, t + 1);
+    __syncthreads();
+  }
+  float* out = partial + ((size_t)blockIdx.y * C + c0) * 128;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        out[(size_t)(wm * 64 + i * 16 + 4 * kb + r) * 128 + half * 64 + j * 16 + l16] = acc[i][j][r];
+}
+
+// dWt[c,k] = inv_keep * sum_s partial[s][c][k];  dWa[c,k] = sum_s partial[s][c][64 + k]   (fixed order)
+__global__ __launch_bounds__(256) void pc_dw_reduce_kernel(const float* __restrict__ partial,
+                                                           float* __restrict__ dWt, float* __restrict__ dWa,
+                                                           int C, int K, int S, float inv_keep) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)C * 128) return;
+  const int c = (int)(idx >> 7), col = (int)(idx & 127), k = col & 63;
+  if (k >= K) return;
+  float acc = 0.f;
+  for (int s = 0; s < S; ++s) acc += partial[((size_t)s * C + c) * 128 + col];
+  if (col < 64) dWt[(size_t)c * K + k] = acc * inv_keep;
+  else dWa[(size_t)c * K + k] = acc;
+}
+}  // namespace
+
+bool pc_fused_supported(int N, int P, int C, int Ca, int K, int dtype, const void* X, const void* Xatt) {
+  static const int enabled = [] { const char* e = getenv("APA_PC_FUSED"); return e ? atoi(e) : 1; }();
+  (void)N; (void)P;
+  return enabled && dtype == APA_DTYPE_BF16 && Xatt == X && Ca == C && K >= 1 && K <= 64 && C % 256 == 0 &&
+         (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+}
+
+size_t pc_fused_ws_bytes(int N, int P, int C) {
+  const size_t R = (size_t)N * P;
+  size_t off = 0;
+  off += align_up((size_t)128 * C * 2, 256);          // WcatT
+  off += align_up((size_t)C * 128 * 2, 256);          // Wcat2
+  off += align_up((size_t)128 * 4, 256);              // bcat
+  off += align_up(R * 128 * 2, 256);                  // dT | dZ
+  off += align_up((size_t)PC_DW_MAX_SPLITS * C * 128 * 4, 256);   // dW partials
+  off += align_up(R * C / 8, 256);                    // keep-mask bits
+  return off;
+}
+
+PcFusedWs pc_fused_carve(void* base, int N, int P, int C) {
+  const size_t R = (size_t)N * P;
+  char* w = static_cast<char*>(base);
+  PcFusedWs f;
+  f.WcatT = w;   w += align_up((size_t)128 * C * 2, 256);
+  f.Wcat2 = w;   w += align_up((size_t)C * 128 * 2, 256);
+  f.bcat = reinterpret_cast<float*>(w);  w += align_up((size_t)128 * 4, 256);
+  f.dTdZ = w;    w += align_up(R * 128 * 2, 256);
+  f.partial = reinterpret_cast<float*>(w);  w += align_up((size_t)PC_DW_MAX_SPLITS * C * 128 * 4, 256);
+  f.maskbits = reinterpret_cast<uint8_t*>(w);
+  return f;
+}
+
+int pc_fused_prep(const PcFusedWs& f, const float* Wa, const float* Wt, const float* ba, const float* bt, int C,
+                  int K, hipStream_t st) {
+  hipLaunchKernelGGL(pc_prep_kernel, dim3((unsigned)(((long)C * 128 + 255) / 256)), dim3(256), 0, st, Wa, Wt, ba,
+                     bt, static_cast<bf16_t*>(f.WcatT), static_cast<bf16_t*>(f.Wcat2), f.bcat, C, K);
+  APA_LAUNCH_CHECK("pc_prep_kernel");
+  return APA_OK;
+}
+
+int pc_fused_forward(const PcFusedWs& f, const void* X, float* Z, float* T, int R, int C, int K, bool train,
+                     float keep_prob, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, hipStream_t st) {
+  static const int bm_env = [] { const char* e = getenv("APA_PC_BM"); return e ? atoi(e) : 0; }();
+  // 64-row tiles re-read the 512 KB weight slab half as often; 32-row tiles cover more CUs when the
+  // batch is small (R / 64 < 200 blocks)
+  const int bm = bm_env ? bm_env : ((R + 63) / 64 >= 200 ? 64 : 32);
+  static const int exp_mask = [] { const char* e = getenv("APA_PC_EXP"); return e ? atoi(e) : 0; }();
+  if (exp_mask & 2) train = false;    // timing experiments only (wrong results)
+  const float inv_keep = train ? 1.0f / keep_prob : 1.0f;
+  const uint32_t thresh = keep_thresh(keep_prob);
+  const bf16_t* x = static_cast<const bf16_t*>(X);
+  const bf16_t* wb = static_cast<const bf16_t*>(f.WcatT);
+#define APA_ZT(BM, TR)                                                                                   \
+  do {                                                                                                   \
+    const size_t shm = (size_t)2 * ((TR ? 2 : 1) * BM * LDA + 128 * LDK) * sizeof(short);                \
+    static thread_local bool attr_set = false;                                                           \
+    if (!attr_set) {                                                                                     \
+      APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_fwd_zt_kernel<BM, TR>),           \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));          \
+      attr_set = true;                                                                                   \
+    }                                                                                                    \
+    hipLaunchKernelGGL((pc_fwd_zt_kernel<BM, TR>), dim3((R + BM - 1) / BM), dim3(256), shm, st, x, wb,     \
+                       f.bcat, Z, T, f.maskbits, R, C, K, inv_keep, thresh, seed, offset, offset_dev);    \
+  } while (0)
+  if (bm == 64) { if (train) APA_ZT(64, true); else APA_ZT(64, false); }
+  else          { if (train) APA_ZT(32, true); else APA_ZT(32, false); }
+#undef APA_ZT
+  APA_LAUNCH_CHECK("pc_fwd_zt_kernel");
+  return APA_OK;
+}
+
+int pc_fused_maskbits(const PcFusedWs& f, size_t n_elems, float keep_prob, uint64_t seed, uint64_t offset,
+                      const uint64_t* offset_dev, hipStream_t st) {
+  const size_t n8 = n_elems / 8;
+  size_t nb = (n8 + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(pc_maskbits_kernel, dim3((unsigned)nb), dim3(256), 0, st, f.maskbits, n8,
+                     keep_thresh(keep_prob), seed, offset, offset_dev);
+  APA_LAUNCH_CHECK("pc_maskbits_kernel");
+  return APA_OK;
+}
+
+int pc_fused_dw(const PcFusedWs& f, const void* X, float* dWt, float* dWa, int R, int C, int K, bool train,
+                float keep_prob, hipStream_t st) {
+  static const int s_env = [] { const char* e = getenv("APA_PC_DW_SPLITS"); return e ? atoi(e) : 0; }();
+  const int ctiles = C / 128;
+  int S = s_env ? s_env : (256 + ctiles - 1) / ctiles;            // one block per CU
+  if (S > PC_DW_MAX_SPLITS) S = PC_DW_MAX_SPLITS;
+  int ktiles = (R + FK - 1) / FK;
+  if (S > ktiles) S = ktiles;
+  const int rows_per_split = ((ktiles + S - 1) / S) * FK;
+  S = (R + rows_per_split - 1) / rows_per_split;
+  static const int exp_mask = [] { const char* e = getenv("APA_PC_EXP"); return e ? atoi(e) : 0; }();
+  if (exp_mask & 4) train = false;    // timing experiments only (wrong results)
+  const size_t shm = (size_t)2 * (train ? 3 : 2) * FK * LDM * sizeof(short);
+  const bf16_t* x = static_cast<const bf16_t*>(X);
+  const bf16_t* g = static_cast<const bf16_t*>(f.dTdZ);
+  if (train) {
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+      APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_bwd_dw_kernel<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(pc_bwd_dw_kernel<true>, dim3(ctiles, S), dim3(256), shm, st, x, g, f.maskbits, f.partial,
+                       R, C, rows_per_split);
+  } else {
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+      APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_bwd_dw_kernel<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(pc_bwd_dw_kernel<false>, dim3(ctiles, S), dim3(256), shm, st, x, g, f.maskbits, f.partial,
+                       R, C, rows_per_split);
+  }
+  APA_LAUNCH_CHECK("pc_bwd_dw_kernel");
+  hipLaunchKernelGGL(pc_dw_reduce_kernel, dim3((unsigned)(((long)C * 128 + 255) / 256)), dim3(256), 0, st,
+                     f.partial, dWt, dWa, C, K, S, train ? 1.0f / keep_prob : 1.0f);
+  APA_LAUNCH_CHECK("pc_dw_reduce_kernel");
+  return APA_OK;
+}
+
+}  // namespace apa

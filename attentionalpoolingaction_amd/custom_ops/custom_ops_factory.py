@@ -110,7 +110,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get('APA_LIB_PATH') or LIB_PATH      # APA_LIB_PATH: A/B experiments (tools/)
     if not os.path.exists(p):
         raise ApaError(
             '{} not found. Build it with `python -c "import __graft_entry__ as g; g.build()"` or '

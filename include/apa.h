@@ -69,6 +69,11 @@ typedef enum apa_status {
                                 /* [N,P,Ca] tensor is never written (its consumer,                     */
                                 /* apa_pose_head_bwd_rank1ext, re-forms it in registers)              */
 
+#define APA_FLAG_WS_FROM_FWD 64u /* apa_attn_pool_bwd only: `ws` is the workspace of the matching forward   */
+                                /* call and has not been written since -- prepared operands the forward  */
+                                /* left there (padded bf16 weights of the per-class path) are reused      */
+                                /* instead of rebuilt.  apa_attn_head_train_step sets it by itself.       */
+
 int apa_version(void);
 /* Thread-local, never NULL; describes the last failure on the calling thread. */
 const char* apa_last_error(void);

@@ -250,3 +250,66 @@ def test_hmdb51_per_class_bf16_vs_float64_oracle(gpu, N):
         rel = float((got.detach().cpu().double().reshape(ref.shape) - ref).abs().max() / ref.abs().max())
         print('   {} rel err {:.2e} (= {:.2f} u)'.format(name, rel, rel / U))
         assert rel <= (2.0 + KAPPA) * U, name
+
+
+@pytest.mark.parametrize('N,K,softmax', [(32, 51, False), (5, 51, True), (3, 64, False), (4, 10, False)])
+def test_per_class_small_k_bf16_training_fused_kernels(gpu, N, K, softmax):
+    """The HBM-bound per-class path for K <= 64 (apa_pc_fused.hip: Z | T in one pass over X with the dropout
+    applied on the way into LDS, dWt | dWa in one pass, dX in one launch) in TRAINING mode, keep = 0.2:
+    against the float64 oracle fed the kernel's own mask -- logits vs the rounding-aware oracle (Wa, Wt
+    -> bf16), gradients in units of u -- and the one-call train step (which lets the backward reuse the
+    operands the forward prepared, APA_FLAG_WS_FROM_FWD) bit-identical to the three separate calls."""
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    H, C, P = 14, 2048, 196
+    g = torch.Generator().manual_seed(7 * N + K)
+    X = torch.relu(torch.randn(N, H, H, C, generator=g)).bfloat16()
+    Wa = torch.randn(C, K, generator=g) / C ** 0.5
+    ba = torch.randn(K, generator=g) * 0.1
+    Wt = torch.randn(C, K, generator=g) / C ** 0.5
+    bt = torch.randn(K, generator=g) * 0.1
+    labels = torch.randint(0, K, (N,), generator=g)
+    keep, seed, offset = 0.2, 11, 3
+    d = lambda t: t.to(gpu).contiguous()
+    Xd, Wad, bad, Wtd, btd, lab = d(X), d(Wa), d(ba), d(Wt), d(bt), d(labels)
+    flags = cof.attn_flags(softmax, False, True)
+    logits, att, Ts, _, _, ws = cof.attn_pool_fwd(Xd, Xd, Wad, bad, Wtd, btd, flags=flags, keep_prob=keep, seed=seed,
+                                                  offset=offset)
+    loss, G, _, pred = cof.softmax_xent_fwd_bwd(logits, lab, want_pred=True)
+    dX, _, dWa, dba, dWt, dbt = cof.attn_pool_bwd(Xd, Xd, Wad, bad, Wtd, btd, att, Ts, None, G, flags=flags,
+                                                  keep_prob=keep, seed=seed, offset=offset)   # fresh workspace
+    mask = cof.dropout_mask((N, H, H, C), keep, seed, offset).cpu()
+    # the one-call step on the same inputs
+    grads = (torch.empty_like(Xd), None, torch.empty_like(Wad), torch.empty_like(bad), torch.empty_like(Wtd),
+             torch.empty_like(btd))
+    st = cof.HeadTrainStep(Xd, Xd, Wad, bad, Wtd, btd, lab, grads, flags=flags, keep_prob=keep, seed=seed,
+                           offset=offset)
+    st.run()
+    torch.cuda.synchronize()
+    assert torch.equal(st.logits, logits) and torch.equal(st.G, G)
+    for a, b, name in zip(grads, (dX, None, dWa, dba, dWt, dbt), ('dX', '', 'dWa', 'dba', 'dWt', 'dbt')):
+        if a is not None:
+            assert torch.equal(a, b), name
+
+    leaf = lambda t: t.double().clone().requires_grad_(True)
+    Xr, War, bar, Wtr, btr = map(leaf, (X, Wa, ba, Wt, bt))
+    oflags = orc.AttnFlags(per_class=True, softmax_att=softmax)
+    lg, ep = orc.attentional_pooling(Xr, None, None, [War], [bar], [Wtr], [btr], oflags, is_training=True,
+                                     keep_prob=keep, dropout_mask=mask)
+    orc.action_softmax_xent(lg, labels, K).backward()
+    with torch.no_grad():
+        lg_q, _ = orc.attentional_pooling(Xr, None, None, [_bf16(War)], [bar], [_bf16(Wtr)], [btr], oflags,
+                                          is_training=True, keep_prob=keep, dropout_mask=mask)
+    e_kernel = float((logits.cpu().double() - lg_q).abs().max())
+    e_full = float((logits.cpu().double() - lg.detach()).abs().max())
+    print('N={} K={}: logits kernel vs rounding-aware oracle {:.2e}, vs unrounded {:.2e}'.format(N, K, e_kernel, e_full))
+    assert e_kernel < 3e-4 and e_full < 2 * LOGIT_TOL_BF16        # keep = 0.2 scales T (and its error) by 5
+    assert torch.equal(pred.cpu(), logits.argmax(1).cpu())
+    for name, got, ref in (('dWt', dWt, Wtr.grad), ('dWa', dWa, War.grad), ('dbt', dbt, btr.grad),
+                           ('dba', dba, bar.grad), ('dX', dX.float().view(N, H, H, C), Xr.grad)):
+        scale = max(float(ref.abs().max()), 1e-30)
+        rel = float((got.detach().cpu().double().reshape(ref.shape) - ref).abs().max()) / scale
+        print('   {} rel err {:.2e} (= {:.2f} u)'.format(name, rel, rel / U))
+        if softmax and name == 'dba':
+            assert float(got.abs().max()) < 1e-6        # d(ba) == 0 under the spatial softmax
+            continue
+        assert rel <= (2.0 + KAPPA) * U, name
