@@ -164,6 +164,74 @@ __global__ __launch_bounds__(512) void pose_dppre_kernel(const float* __restrict
   }
 }
 
+// Pl = Ppre . W2 + b2 for bf16 features: [R, Cp] x [Cp, J <= 16] -- 16 output columns, so a 128-wide GEMM
+// tile wastes 7/8 of its MFMAs and needs split-K plus a reduce launch (11.6 + 5.2 us at R = 6272).  Here
+// a wave owns 16 rows: its A fragments come straight from global memory (one 16-byte load per lane and
+// k step, all KS of them in flight at once), the whole W2 sits in registers as bf16 B fragments (staged
+// once per block through LDS), KS MFMAs later the 16 x 16 result leaves with the bias added.  HBM-bound
+// on the 9.6 MB pre-logit map.
+template <int KS>   // k steps of 32: Cp = 32 * KS
+__global__ __launch_bounds__(256) void pose_pl_kernel(const bf16_t* __restrict__ Ppre,
+                                                      const float* __restrict__ W2,
+                                                      const float* __restrict__ b2, float* __restrict__ Pl,
+                                                      int R, int J) {
+  typedef short bf16x8 __attribute__((ext_vector_type(8)));
+  constexpr int Cp = 32 * KS, LDW = Cp + 8;
+  __shared__ __attribute__((aligned(16))) short w2s[16 * LDW];   // [n][k] bf16, zero rows for n >= J
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int l16 = lane & 15, kb = lane >> 4;
+  const int r0 = (blockIdx.x * 4 + wave) * 16;
+  // A fragments first: they are the long-latency loads
+  bf16x8 af[KS];
+  const bf16_t* arow = Ppre + (size_t)min(r0 + l16, R - 1) * Cp + kb * 8;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const uint4 v = ld16(arow + ks * 32);
+    af[ks] = __builtin_bit_cast(bf16x8, v);
+  }
+  if (J == 16) {   // W2 rows are 64 B: 4 float4 each, every load of the block issued before the first use
+    constexpr int NV = Cp * 4 / 256;             // Cp is a multiple of 256 / 4
+    float4 wv[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) wv[u] = *reinterpret_cast<const float4*>(W2 + (size_t)(tid + u * 256) * 4);
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int v = tid + u * 256, k = v >> 2, n = (v & 3) * 4;
+      w2s[(n + 0) * LDW + k] = (short)f32_to_bf16_bits(wv[u].x);
+      w2s[(n + 1) * LDW + k] = (short)f32_to_bf16_bits(wv[u].y);
+      w2s[(n + 2) * LDW + k] = (short)f32_to_bf16_bits(wv[u].z);
+      w2s[(n + 3) * LDW + k] = (short)f32_to_bf16_bits(wv[u].w);
+    }
+  } else {
+    for (int i = tid; i < 16 * Cp; i += 256) {
+      const int k = i >> 4, n = i & 15;          // W2 is [Cp][J]: consecutive threads read consecutive n
+      const float v = n < J ? W2[(size_t)k * J + n] : 0.f;
+      w2s[n * LDW + k] = (short)f32_to_bf16_bits(v);
+    }
+  }
+  __syncthreads();
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const bf16x8 bf = *reinterpret_cast<const bf16x8*>(w2s + l16 * LDW + ks * 32 + kb * 8);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], bf, acc, 0, 0, 0);
+  }
+  if (l16 < J) {
+    const float bias = b2[l16];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = r0 + 4 * kb + r;
+      if (row < R) Pl[(size_t)row * J + l16] = acc[r] + bias;
+    }
+  }
+}
+
+static bool pose_pl_fast(int Cp, int J, int dtype, const void* Ppre) {
+  static const int enabled = [] { const char* e = getenv("APA_POSE_PL_FAST"); return e ? atoi(e) : 1; }();
+  return enabled && dtype == APA_DTYPE_BF16 && J <= 16 && (Cp == 256 || Cp == 512 || Cp == 768 || Cp == 1024) &&
+         (reinterpret_cast<uintptr_t>(Ppre) & 15) == 0;
+}
+
 struct PosePlan {
   long R;
   int nchunks;
@@ -199,10 +267,14 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
 
 // W1 as the bf16 operand of the pose-head GEMMs (only when its size allows whole 16-byte vectors)
 static const void* pose_w1_operand(const float* W1, void* ws_w1b, int C, int Cp, int dtype, int* tb,
-                                   hipStream_t st) {
+                                   hipStream_t st, bool reuse = false) {
   *tb = 0;
   if (dtype != APA_DTYPE_BF16 || ((size_t)C * Cp) % 8 != 0 || (reinterpret_cast<uintptr_t>(W1) & 15))
     return W1;
+  if (reuse) {   // APA_POSE_WS_FROM_FWD: the forward call's copy is still in the workspace
+    *tb = 1;
+    return ws_w1b;
+  }
   const size_t n8 = (size_t)C * Cp / 8;
   size_t nb = (n8 + 255) / 256;
   if (nb > 2048) nb = 2048;
@@ -249,6 +321,18 @@ extern "C" int apa_pose_head_fwd(const void* X, const float* W1, const float* b1
   g1.M = R; g1.N = Cp; g1.K = C; g1.bias = b1; g1.act = 1;
   int rc = gemm_launch(g1, st);
   if (rc != APA_OK) return rc;
+  if (pose_pl_fast(Cp, J, dtype, Ppre)) {   // Pl = Ppre.W2 + b2: skinny product, one wave per 16 rows
+    const dim3 grid((R + 63) / 64);
+    const bf16_t* pp = static_cast<const bf16_t*>(Ppre);
+    switch (Cp / 32) {
+      case 8: hipLaunchKernelGGL(pose_pl_kernel<8>, grid, dim3(256), 0, st, pp, W2, b2, Pl, R, J); break;
+      case 16: hipLaunchKernelGGL(pose_pl_kernel<16>, grid, dim3(256), 0, st, pp, W2, b2, Pl, R, J); break;
+      case 24: hipLaunchKernelGGL(pose_pl_kernel<24>, grid, dim3(256), 0, st, pp, W2, b2, Pl, R, J); break;
+      default: hipLaunchKernelGGL(pose_pl_kernel<32>, grid, dim3(256), 0, st, pp, W2, b2, Pl, R, J); break;
+    }
+    APA_LAUNCH_CHECK("pose_pl_kernel");
+    return APA_OK;
+  }
   GemmDesc g2;  // Pl = Ppre.W2 + b2
   g2.A = Ppre; g2.lda = Cp; g2.ta = dt_code(dtype); g2.a_kc = true;
   g2.B = W2; g2.ldb = J; g2.tb = 0; g2.b_kc = false;
@@ -342,10 +426,11 @@ static int pose_head_bwd_impl(const void* X, const float* W1, const float* W2, c
     GemmDesc g;
     g.A = dPpre; g.lda = Cp; g.ta = tdt; g.a_kc = true;
     int w1_tb = 0;
-    const void* W1op = pose_w1_operand(W1, w + pl.off_w1b, C, Cp, dtype, &w1_tb, st);
+    const void* W1op = pose_w1_operand(W1, w + pl.off_w1b, C, Cp, dtype, &w1_tb, st,
+                                       (accumulate_dX & APA_POSE_WS_FROM_FWD) != 0);
     g.B = W1op; g.ldb = Cp; g.tb = w1_tb; g.b_kc = true;   // W1 [C][Cp]: n = c rows, k contiguous
     g.C = dX; g.ldc = C; g.tc = tdt;
-    g.M = R; g.N = C; g.K = Cp; g.beta = accumulate_dX ? 1.f : 0.f;
+    g.M = R; g.N = C; g.K = Cp; g.beta = (accumulate_dX & 1) ? 1.f : 0.f;
     rc = gemm_launch(g, st);
   }
   return rc;

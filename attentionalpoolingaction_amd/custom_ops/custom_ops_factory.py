@@ -407,13 +407,15 @@ def pose_head_fwd(X, W1, b1, W2, b2, workspace=None):
     return Ppre, Pl, workspace
 
 
-def pose_head_bwd(X, W1, W2, Ppre, dPl, dPpre_ext, *, dX=None, accumulate_dX=False, workspace=None,
+def pose_head_bwd(X, W1, W2, Ppre, dPl, dPpre_ext, *, dX=None, accumulate_dX=False, workspace=None, ws_from_fwd=False,
                   ext_rank1=None):
     """dX, dW1, db1, dW2, db2 = pose_head_bwd(...).  dPl: pose-loss gradient [..,J] f32 or None;
     dPpre_ext: gradient from the attention branch [..,Cp] (dtype of X) or None.  With
     accumulate_dX the product dPpre.W1^T is ADDED to the given dX buffer.  `ext_rank1=(row, col)`:
     the attention-branch gradient in rank-1 form row [N*P] (x) col [Cp], both f32
-    (apa_pose_head_bwd_rank1ext; dPpre_ext must then be None)."""
+    (apa_pose_head_bwd_rank1ext; dPpre_ext must then be None).  `ws_from_fwd=True`: `workspace` is
+    the one pose_head_fwd returned and nothing has written to it since (APA_POSE_WS_FROM_FWD: the bf16
+    copy of W1 in it is reused)."""
     lib = load_library()
     N, C = X.shape[0], X.shape[-1]
     P = X.numel() // (N * C)
@@ -421,7 +423,10 @@ def pose_head_bwd(X, W1, W2, Ppre, dPl, dPpre_ext, *, dX=None, accumulate_dX=Fal
     dt = _feat_dtype(X)
     need = int(lib.apa_pose_head_workspace_bytes(N, P, C, Cp, J, dt))
     if workspace is None or workspace.numel() < need:
+        if ws_from_fwd:
+            raise ApaError('ws_from_fwd needs the workspace of the forward call')
         workspace = torch.empty((max(need, 16),), dtype=torch.uint8, device=X.device)
+    acc_flag = (1 if accumulate_dX else 0) | (2 if ws_from_fwd else 0)
     if dX is None:
         if accumulate_dX:
             raise ApaError('accumulate_dX needs an existing dX buffer')
@@ -438,7 +443,7 @@ def pose_head_bwd(X, W1, W2, Ppre, dPl, dPpre_ext, *, dX=None, accumulate_dX=Fal
             _dev_ptr(X, 'X'), _dev_ptr(W1, 'W1', torch.float32), _dev_ptr(W2, 'W2', torch.float32),
             _dev_ptr(Ppre, 'Ppre', X.dtype), _dev_ptr(dPl, 'dPl', torch.float32),
             _dev_ptr(row, 'ext_row', torch.float32), _dev_ptr(col, 'ext_col', torch.float32),
-            _dev_ptr(dX, 'dX', X.dtype), 1 if accumulate_dX else 0, dW1.data_ptr(), db1.data_ptr(),
+            _dev_ptr(dX, 'dX', X.dtype), acc_flag, dW1.data_ptr(), db1.data_ptr(),
             dW2.data_ptr(), db2.data_ptr(), workspace.data_ptr(), workspace.numel(), N, P, C, Cp, J, dt,
             _stream_ptr())
         _check(rc, 'apa_pose_head_bwd_rank1ext')
@@ -447,7 +452,7 @@ def pose_head_bwd(X, W1, W2, Ppre, dPl, dPpre_ext, *, dX=None, accumulate_dX=Fal
         _dev_ptr(X, 'X'), _dev_ptr(W1, 'W1', torch.float32), _dev_ptr(W2, 'W2', torch.float32),
         _dev_ptr(Ppre, 'Ppre', X.dtype), _dev_ptr(dPl, 'dPl', torch.float32),
         _dev_ptr(dPpre_ext, 'dPpre_ext', X.dtype), _dev_ptr(dX, 'dX', X.dtype),
-        1 if accumulate_dX else 0, dW1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), db2.data_ptr(),
+        acc_flag, dW1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), db2.data_ptr(),
         workspace.data_ptr(), workspace.numel(), N, P, C, Cp, J, dt, _stream_ptr())
     _check(rc, 'apa_pose_head_bwd')
     return dX, dW1, db1, dW2, db2

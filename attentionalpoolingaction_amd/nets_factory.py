@@ -139,7 +139,7 @@ class PoseHeadFunction(torch.autograd.Function):
         dPl_c = None if dPl is None else dPl.contiguous().float()
         dPpre_c = None if dPpre is None else dPpre.contiguous().to(Xc.dtype)
         dX, dW1, db1, dW2, db2 = cof.pose_head_bwd(Xc, W1.contiguous(), W2.contiguous(), Ppre, dPl_c,
-                                                   dPpre_c, workspace=ctx.ws)
+                                                   dPpre_c, workspace=ctx.ws, ws_from_fwd=True)
         return dX, dW1, db1, dW2, db2
 
 
@@ -188,12 +188,14 @@ class PoseAttentionFunction(torch.autograd.Function):
                 workspace=aws, dxatt_rank1=rank1)
             if rank1:
                 dX, dW1, db1, dW2, db2 = cof.pose_head_bwd(Xc, W1, W2, Ppre, dPl_c, None, dX=dX, accumulate_dX=True,
-                                                           workspace=pws, ext_rank1=(dZ, Wa.reshape(-1)))
+                                                           workspace=pws, ws_from_fwd=True,
+                                                           ext_rank1=(dZ, Wa.reshape(-1)))
             else:
                 dX, dW1, db1, dW2, db2 = cof.pose_head_bwd(Xc, W1, W2, Ppre, dPl_c, dZ, dX=dX, accumulate_dX=True,
-                                                           workspace=pws)
+                                                           workspace=pws, ws_from_fwd=True)
         else:
-            dX, dW1, db1, dW2, db2 = cof.pose_head_bwd(Xc, W1, W2, Ppre, dPl_c, None, workspace=pws)
+            dX, dW1, db1, dW2, db2 = cof.pose_head_bwd(Xc, W1, W2, Ppre, dPl_c, None, workspace=pws,
+                                                       ws_from_fwd=True)
         return (dX.view(ctx.xshape), dW1, db1, dW2, db2, dWa, dba, dWt, dbt, None, None, None, None, None)
 
 

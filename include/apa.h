@@ -136,8 +136,11 @@ int apa_dropout_mask(uint8_t* mask, size_t n_elems, float keep_prob, uint64_t se
  * Backward (TF autodiff in the reference):  dPl [N,P,J] f32 = gradient of the pose loss (or NULL);
  * dPpre_ext [N,P,Cp] dtype = gradient arriving at Ppre from the attention branch of cfg 003 (the
  * dXatt of apa_attn_pool_bwd) or NULL.  Outputs dW1 [C,Cp], db1 [Cp], dW2 [Cp,J], db2 [J] f32 and
- * dX [N,P,C] dtype, overwritten or (accumulate_dX != 0) added to what the buffer already holds.
+ * dX [N,P,C] dtype, overwritten or (accumulate_dX & 1) added to what the buffer already holds.
+ * accumulate_dX & APA_POSE_WS_FROM_FWD: `ws` is the workspace of the matching apa_pose_head_fwd call and has
+ * not been written since -- the bf16 copy of W1 the forward call left there is reused, not rebuilt.
  */
+#define APA_POSE_WS_FROM_FWD 2
 size_t apa_pose_head_workspace_bytes(int N, int P, int C, int Cp, int J, int dtype);
 int apa_pose_head_fwd(const void* X, const float* W1, const float* b1, const float* W2,
                       const float* b2, void* Ppre, float* Pl, void* ws, size_t ws_bytes, int N, int P,

@@ -62,10 +62,11 @@ def build_cfg003(cof, dev, N=32, H=14, K=393, dtype='bf16', rank1=True):
         dX, dZ, *_ = cof.attn_pool_bwd(X, Ppre, Wa, ba, Wt, bt, att, zs, ab, G, flags=flags, keep_prob=0.2,
                                        seed=42, offset=ctr, workspace=state['aws'], dxatt_rank1=rank1)
         if not rank1:
-            cof.pose_head_bwd(X, W1, W2, Ppre, dPl, dZ, dX=dX, accumulate_dX=True, workspace=state['pws'])
+            cof.pose_head_bwd(X, W1, W2, Ppre, dPl, dZ, dX=dX, accumulate_dX=True, workspace=state['pws'],
+                              ws_from_fwd=True)
         else:
             cof.pose_head_bwd(X, W1, W2, Ppre, dPl, None, dX=dX, accumulate_dX=True, workspace=state['pws'],
-                              ext_rank1=(dZ, wa_flat))
+                              ws_from_fwd=True, ext_rank1=(dZ, wa_flat))
 
     info = {'workload': 'cfg003 pose-regularised attention head fwd+bwd (pose head 2048->768->16 + M=1 '
                         'pooling + pose L2 + softmax-xent); per-GPU batch {} x {}x{}x{} {}, K={}, dropout '

@@ -43,7 +43,7 @@ def bench(name, after, steps=200):
     print('%-46s wall %6.1f us/step   host %5.1f us/step' % (name, (t2 - t0) / steps * 1e6, (t4 - t3) / 30 * 1e6))
 
 bench('plain', lambda: None)
-cof.set_grad_ready_event(ready)
+st.hooks = cof.make_hooks(grad_ready=ready)
 bench('+ready record', lambda: None)
 def a1():
     side.wait_event(ready)
@@ -51,7 +51,7 @@ bench('+side.wait_event(ready)', a1)
 def a2():
     side.wait_event(ready); done.record(side)
 bench('+done.record(side)', a2)
-cof.set_td_weights_ready_event(done)
+st.hooks = cof.make_hooks(grad_ready=ready, td_weights_ready=done)
 bench('+fwd waits done', a2)
 def a3():
     side.wait_event(ready); c2.all_reduce_(b_td, side); done.record(side)
@@ -59,7 +59,7 @@ bench('+AR td on side', a3)
 def a4():
     side.wait_event(ready); c2.all_reduce_(b_td, side); done.record(side); c1.all_reduce_(b_att, main)
 bench('+AR att on main (full schedule)', a4)
-cof.set_grad_ready_event(None); cof.set_td_weights_ready_event(None)
+st.hooks = None
 bench('plain again', lambda: None)
 def a5():
     c1.all_reduce_(bucket, main)
