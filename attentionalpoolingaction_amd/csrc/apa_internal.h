@@ -150,7 +150,7 @@ struct M1Plan {
   int nblk;     // N * S
   int lsplits;  // split-K factor of the logits GEMM
   // workspace carve (byte offsets)
-  size_t off_pacc, off_pstat, off_pdwa, off_pdba, off_dz, off_gemm, off_dzatt, off_cat_e, total;
+  size_t off_pacc, off_pstat, off_pdwa, off_pdba, off_dz, off_gemm, off_dzatt, off_cat_e, off_maskbits, total;
 };
 M1Plan m1_plan(int N, int P, int C, int Ca, int K);
 
@@ -175,6 +175,8 @@ struct M1Rng {
   const uint64_t* offset_dev;
   bool relu_input = false;   // APA_FLAG_RELU_INPUT
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // apa_hooks prof_*: dispatch begin / end timestamps
+  uint8_t* maskbits_out = nullptr;           // forward (training): where the keep-bits go
+  const uint8_t* maskbits_in = nullptr;      // backward: the forward call's keep-bits, or nullptr (hash again)
 };
 // apa_m1_cat.hip
 bool m1_cat_supported(int J);

@@ -696,6 +696,8 @@ M1Plan m1_plan(int N, int P, int C, int Ca, int K) {
     pl.off_gemm = off;  off += align_up(g, 256);
   }
   pl.off_cat_e = off; off += align_up((size_t)N * P * 4, 256);   // e[n,p] of apa_m1_cat.hip
+  // keep-bits of the dropout mask, forward -> backward (apa_m1_stream.hip): 256 * ceil(C / 2048) B per pixel
+  pl.off_maskbits = off; off += align_up((size_t)N * P * 256 * ((C / 256 + 7) / 8), 256);
   pl.total = off;
   return pl;
 }
@@ -801,6 +803,7 @@ int m1_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
   float* gemm_ws = reinterpret_cast<float*>(w + pl.off_gemm);
   RngArgs r = rng_args(train, keep_prob, seed, offset, flags);
   r.ev0 = hk.fwd0; r.ev1 = hk.fwd1;
+  r.maskbits_out = reinterpret_cast<uint8_t*>(w + pl.off_maskbits);
 
   if (r.relu_input && !(fused && use_stream_kernels(C, dtype))) {
     set_error("APA_FLAG_RELU_INPUT: needs Xatt == X and C in {1024,2048,4096} (f32) / 2048 (bf16)");
@@ -888,6 +891,9 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
   float* sn_buf = pdba + pl.nblk;   // [N] floats: the pdba region is sized nblk + N
   RngArgs r = rng_args(train, keep_prob, seed, offset, flags);
   r.ev0 = hk.bwd0; r.ev1 = hk.bwd1;
+  static const int use_bits = env_int("APA_M1_KEEP_BITS", 1);
+  if ((flags & APA_FLAG_WS_FROM_FWD) && use_bits)   // same workspace, untouched since the forward call
+    r.maskbits_in = reinterpret_cast<const uint8_t*>(w + pl.off_maskbits);
   if (r.relu_input && !(fused && use_stream_kernels(C, dtype))) {
     set_error("APA_FLAG_RELU_INPUT: needs Xatt == X and C in {1024,2048,4096} (f32) / 2048 (bf16)");
     return APA_ERR_UNSUPPORTED;

@@ -127,12 +127,30 @@ struct FwdState {
   float bias, m_run, l_run, a_sum;
 };
 
+// Keep-bits hand-off.  The forward pass has to hash every element anyway; it also leaves the decisions
+// behind as bits -- byte (n*P + p) * C/8 + (cbase - j-part)/EPL.. : ONE byte (two for EPL = 16) per lane and
+// pixel, bit j*EPV + e = channel cbase + j*64*EPV + e, i.e. exactly the lane's own channels -- and a backward
+// call that is handed the same workspace (APA_FLAG_WS_FROM_FWD) reads them back instead of hashing again:
+// the hash was 2.1 us of VALU work in the dominant kernel (profiles/r01_hot_pmc.md), the bits are 1/32
+// of the fp32 map's bytes.  Layout per pixel: [C / EPL] lanes-worth of BPL bytes, lane-major.
+// Measured (bench.py, N = 32 / 512): bf16 features, where a lane hashes 8 elements per 16-byte load and the
+// backward pass is VALU-bound on it, gain 15.6 -> 13.2 us in the backward kernel for +0.1 us in the
+// forward one; fp32 features (4 elements per load, memory-bound either way) gain nothing in backward and
+// pay for the extra store instructions in forward (13.9 -> 14.1 us at N = 32, 150 -> 183 us at N = 512:
+// memory-instruction issue, not bytes) -- so the hand-off is compiled in for bf16 only.
+template <typename T> struct KeepBits { static constexpr bool ON = sizeof(T) == 2; };
+template <int EPL> struct MaskBytes {
+  static constexpr int BPL = (EPL + 7) / 8;   // bytes per lane and pixel
+  static constexpr int BPP = 256 * BPL;       // bytes per pixel (4 waves x 64 lanes)
+};
+
 template <typename T, int VW, int PIX, bool FUSED, bool TRAIN, bool RIN>
 __device__ __forceinline__ void fwd_chunk(FwdState<T, VW, PIX, FUSED, TRAIN>& st,
                                           const uint4 (&xr)[PIX][VW], ChunkRange cr, float* sm,
                                           float* __restrict__ att_im, int n, int P, int C, int cbase,
                                           int wave, int lane, int act, float inv_keep,
-                                          uint32_t thresh, uint32_t k0, uint32_t k1) {
+                                          uint32_t thresh, uint32_t k0, uint32_t k1,
+                                          uint8_t* __restrict__ bits_im) {
   constexpr int EPV = Vec<T>::EPV;
   constexpr int EPL = VW * EPV;
   const int l16 = lane & 15;
@@ -180,7 +198,10 @@ __device__ __forceinline__ void fwd_chunk(FwdState<T, VW, PIX, FUSED, TRAIN>& st
     const float a = readlane_f(av, i);   // 0 for surplus slots
     st.a_sum += a;
     const float ak = TRAIN ? a * inv_keep : a;
-    const uint64_t ebase = ((uint64_t)n * P + (q0 + i)) * C + cbase;
+    // surplus slots repeat the block's last pixel (data, element index and therefore mask bits alike)
+    const int pi = min(q0 + i, q0 + np - 1);
+    const uint64_t ebase = ((uint64_t)n * P + pi) * C + cbase;
+    uint32_t lbits = 0;
 #pragma unroll
     for (int j = 0; j < VW; ++j) {
       float x[EPV];
@@ -189,14 +210,30 @@ __device__ __forceinline__ void fwd_chunk(FwdState<T, VW, PIX, FUSED, TRAIN>& st
       if (TRAIN) {
 #pragma unroll
         for (int e = 0; e < EPV; e += 2) {
-          float m0, m1;
-          rng_keep2(ebase + j * 64 * EPV + e, k0, k1, thresh, m0, m1);
-          st.acc[j * EPV + e] = fmaf(ak * m0, x[e], st.acc[j * EPV + e]);
-          st.acc[j * EPV + e + 1] = fmaf(ak * m1, x[e + 1], st.acc[j * EPV + e + 1]);
+          const uint32_t b = rng_keep2_bits(ebase + j * 64 * EPV + e, k0, k1, thresh);
+          lbits |= b << (j * EPV + e);
+          st.acc[j * EPV + e] = fmaf((b & 1u) ? ak : 0.f, x[e], st.acc[j * EPV + e]);
+          st.acc[j * EPV + e + 1] = fmaf((b & 2u) ? ak : 0.f, x[e + 1], st.acc[j * EPV + e + 1]);
         }
       } else {
 #pragma unroll
         for (int e = 0; e < EPV; ++e) st.acc[j * EPV + e] = fmaf(ak, x[e], st.acc[j * EPV + e]);
+      }
+    }
+    if (TRAIN && KeepBits<T>::ON) {
+      // BPL bytes per lane; the bytes of 4 (BPL = 1) / 2 (BPL = 2) neighbouring lanes leave as one dword
+      constexpr int BPL = MaskBytes<EPL>::BPL;
+      uint8_t* dst = bits_im + (size_t)pi * MaskBytes<EPL>::BPP + (size_t)(wave * 64 + lane) * BPL;
+      if (BPL == 1) {
+        const uint32_t b1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)lbits, 0x39, 0xf, 0xf, true);   // lane + 1
+        const uint32_t b2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)lbits, 0x4E, 0xf, 0xf, true);   // lane + 2
+        const uint32_t b3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)lbits, 0x93, 0xf, 0xf, true);   // lane + 3
+        const uint32_t w = (lbits & 0xffu) | ((b1 & 0xffu) << 8) | ((b2 & 0xffu) << 16) | (b3 << 24);
+        if ((lane & 3) == 0) *reinterpret_cast<uint32_t*>(dst) = w;
+      } else {
+        const uint32_t b1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)lbits, 0xB1, 0xf, 0xf, true);   // lane ^ 1
+        const uint32_t w = (lbits & 0xffffu) | (b1 << 16);
+        if ((lane & 1) == 0) *reinterpret_cast<uint32_t*>(dst) = w;
       }
     }
   }
@@ -207,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void m1s_pool_fwd_kernel(
     const T* __restrict__ X, const float* __restrict__ Wa, const float* __restrict__ ba,
     float* __restrict__ att, float* __restrict__ pacc, float* __restrict__ pstat, int P, int S,
     int act, float inv_keep, uint32_t thresh, uint64_t seed, uint64_t offset,
-    const uint64_t* __restrict__ offset_dev) {
+    const uint64_t* __restrict__ offset_dev, uint8_t* __restrict__ maskbits) {
   constexpr int EPV = Vec<T>::EPV;
   constexpr int EPL = VW * EPV;   // channels per lane
   constexpr int CW = EPL * 64;    // channels per wave
@@ -227,6 +264,7 @@ __global__ __launch_bounds__(256, 2) void m1s_pool_fwd_kernel(
 
   const T* xim = X + (size_t)n * P * C;
   float* att_im = att + (size_t)n * P;
+  uint8_t* bits_im = TRAIN ? maskbits + (size_t)n * P * MaskBytes<EPL>::BPP : nullptr;
 
   const int p_last = p_end - 1;
   uint4 xa[PIX][VW], xb[PIX][VW];
@@ -253,12 +291,12 @@ __global__ __launch_bounds__(256, 2) void m1s_pool_fwd_kernel(
     load_chunk<T, VW, PIX>(xb, xim, p_begin + (ch + 1) * PIX, p_last, C, cbase);
     fwd_chunk<T, VW, PIX, FUSED, TRAIN, RIN>(st, xa, chunk_range<PIX>(p_begin, p_end, ch), sm_x[0],
                                         att_im, n, P, C, cbase, wave, lane, act, inv_keep, thresh,
-                                        k0, k1);
+                                        k0, k1, bits_im);
     if (ch + 1 >= nchunk) break;
     load_chunk<T, VW, PIX>(xa, xim, p_begin + (ch + 2) * PIX, p_last, C, cbase);
     fwd_chunk<T, VW, PIX, FUSED, TRAIN, RIN>(st, xb, chunk_range<PIX>(p_begin, p_end, ch + 1), sm_x[1],
                                         att_im, n, P, C, cbase, wave, lane, act, inv_keep, thresh,
-                                        k0, k1);
+                                        k0, k1, bits_im);
   }
 
   float* pa = pacc + (size_t)blk * C + cbase;
@@ -293,9 +331,10 @@ struct BwdState {
   float dba_acc, sn, corr;
 };
 
-template <typename T, int VW, int PIX, bool FUSED, bool TRAIN, bool RIN>
+template <typename T, int VW, int PIX, bool FUSED, bool TRAIN, bool RIN, bool BITS>
 __device__ __forceinline__ void bwd_chunk(BwdState<T, VW, PIX, FUSED, TRAIN>& st,
                                           const uint4 (&xr)[PIX][VW], float a_l, float e_l,
+                                          const uint32_t (&kbits)[PIX],
                                           ChunkRange cr, float* sm, T* __restrict__ dxim,
                                           float* __restrict__ dZout_im, int n, int P, int C,
                                           int cbase, int wave, int lane, int act, float invP,
@@ -325,7 +364,8 @@ __device__ __forceinline__ void bwd_chunk(BwdState<T, VW, PIX, FUSED, TRAIN>& st
       for (int e = 0; e < EPV; e += 2) {
         const int c = j * EPV + e;
         if (TRAIN) {
-          const uint32_t b = rng_keep2_bits(ebase + j * 64 * EPV + e, k0, k1, thresh);
+          const uint32_t b = BITS ? ((kbits[i] >> c) & 3u)
+                                  : rng_keep2_bits(ebase + j * 64 * EPV + e, k0, k1, thresh);
           const int bit = i * EPL + c;
           mb[bit >> 5] |= b << (bit & 31);
           d0 = fmaf((b & 1u) ? x[e] : 0.f, st.dzr[c], d0);
@@ -386,7 +426,12 @@ __device__ __forceinline__ void bwd_chunk(BwdState<T, VW, PIX, FUSED, TRAIN>& st
   }
 }
 
-template <typename T, int VW, int PIX, bool FUSED, bool TRAIN, bool RIN = false>
+template <int BPL> __device__ __forceinline__ uint32_t ld_keep_bits(const uint8_t* p) {
+  if (BPL == 1) return *p;
+  return *reinterpret_cast<const uint16_t*>(p);
+}
+
+template <typename T, int VW, int PIX, bool FUSED, bool TRAIN, bool RIN = false, bool BITS = false>
 __global__ __launch_bounds__(256, 2) void m1s_bwd_main_kernel(
     const T* __restrict__ X, const float* __restrict__ Wa, const float* __restrict__ att,
     const float* __restrict__ dz, const float* __restrict__ zsave, const float* __restrict__ abar,
@@ -394,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void m1s_bwd_main_kernel(
     T* __restrict__ dX, float* __restrict__ dZout, float* __restrict__ pdwa,
     float* __restrict__ pdba, int P, int S, int K, int act, float inv_keep, uint32_t thresh,
     uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev,
-    const float* __restrict__ dA_extra, float extra_scale) {
+    const float* __restrict__ dA_extra, float extra_scale, const uint8_t* __restrict__ maskbits) {
   // dA_extra [N,P]: per-pixel additive term of dA * P from the concatenated pose channels; callers
   // without them pass `att` and extra_scale = 0, so the load is unconditional (straight-line code)
   constexpr int EPV = Vec<T>::EPV;
@@ -427,6 +472,16 @@ __global__ __launch_bounds__(256, 2) void m1s_bwd_main_kernel(
   const float* ex_im = dA_extra + (size_t)n * P;
   float a_a = att_im[min(p_begin + l16, p_last)], a_b = 0.f;
   float e_a = ex_im[min(p_begin + l16, p_last)] * extra_scale, e_b = 0.f;
+  // BITS: the forward pass left the keep decisions of this lane's channels behind, BPL bytes per pixel
+  constexpr int BPL = MaskBytes<EPL>::BPL;
+  constexpr int BPP = MaskBytes<EPL>::BPP;
+  const uint8_t* kb_im = BITS ? maskbits + (size_t)n * P * BPP + (size_t)(wave * 64 + lane) * BPL : nullptr;
+  uint32_t kb_a[PIX], kb_b[PIX];
+#pragma unroll
+  for (int i = 0; i < PIX; ++i) {
+    kb_a[i] = BITS ? ld_keep_bits<BPL>(kb_im + (size_t)min(p_begin + i, p_last) * BPP) : 0u;
+    kb_b[i] = 0u;
+  }
 
   // per-image constants: L2 hits issued behind the first chunk's HBM loads
   BwdState<T, VW, PIX, FUSED, TRAIN> st;
@@ -472,14 +527,24 @@ __global__ __launch_bounds__(256, 2) void m1s_bwd_main_kernel(
     load_chunk<T, VW, PIX, APA_BWD_NT_LOAD>(xb, xim, p_begin + (ch + 1) * PIX, p_last, C, cbase);
     a_b = att_im[min(p_begin + (ch + 1) * PIX + l16, p_last)];
     e_b = ex_im[min(p_begin + (ch + 1) * PIX + l16, p_last)] * extra_scale;
-    bwd_chunk<T, VW, PIX, FUSED, TRAIN, RIN>(st, xa, a_a, e_a, chunk_range<PIX>(p_begin, p_end, ch), sm_x[0],
+    if (BITS) {
+#pragma unroll
+      for (int i = 0; i < PIX; ++i)
+        kb_b[i] = ld_keep_bits<BPL>(kb_im + (size_t)min(p_begin + (ch + 1) * PIX + i, p_last) * BPP);
+    }
+    bwd_chunk<T, VW, PIX, FUSED, TRAIN, RIN, BITS>(st, xa, a_a, e_a, kb_a, chunk_range<PIX>(p_begin, p_end, ch), sm_x[0],
                                         dxim, dZout_im, n, P, C, cbase, wave, lane, act, invP,
                                         inv_keep, thresh, k0, k1);
     if (ch + 1 >= nchunk) break;
     load_chunk<T, VW, PIX, APA_BWD_NT_LOAD>(xa, xim, p_begin + (ch + 2) * PIX, p_last, C, cbase);
     a_a = att_im[min(p_begin + (ch + 2) * PIX + l16, p_last)];
     e_a = ex_im[min(p_begin + (ch + 2) * PIX + l16, p_last)] * extra_scale;
-    bwd_chunk<T, VW, PIX, FUSED, TRAIN, RIN>(st, xb, a_b, e_b, chunk_range<PIX>(p_begin, p_end, ch + 1),
+    if (BITS) {
+#pragma unroll
+      for (int i = 0; i < PIX; ++i)
+        kb_a[i] = ld_keep_bits<BPL>(kb_im + (size_t)min(p_begin + (ch + 2) * PIX + i, p_last) * BPP);
+    }
+    bwd_chunk<T, VW, PIX, FUSED, TRAIN, RIN, BITS>(st, xb, a_b, e_b, kb_b, chunk_range<PIX>(p_begin, p_end, ch + 1),
                                         sm_x[1], dxim, dZout_im, n, P, C, cbase, wave, lane, act,
                                         invP, inv_keep, thresh, k0, k1);
   }
@@ -521,6 +586,7 @@ static int launch_fwd_t(bool fused, bool train, int nblk, hipStream_t st, const 
                         const float* Wa, const float* ba, float* att, float* pacc, float* pstat,
                         int P, int S, int act, const M1Rng& r) {
   const T* x = static_cast<const T*>(X);
+  uint8_t* mbits = r.maskbits_out;
   if (r.relu_input) {   // instantiated for the default chunk width and the fused map only
     if (!fused || PIX != 2) {
       set_error("APA_FLAG_RELU_INPUT needs Xatt == X (and the default APA_M1S_PIX)");
@@ -529,10 +595,10 @@ static int launch_fwd_t(bool fused, bool train, int nblk, hipStream_t st, const 
     if constexpr (PIX == 2) {
       if (train)
         launch_ev(m1s_pool_fwd_kernel<T, VW, 2, true, true, true>, dim3(nblk), dim3(256), 0, st, r.ev0, r.ev1, x, Wa, ba, att, pacc, pstat, P, S, act, r.inv_keep, r.thresh, r.seed,
-                           r.offset, r.offset_dev);
+                           r.offset, r.offset_dev, mbits);
       else
         launch_ev(m1s_pool_fwd_kernel<T, VW, 2, true, false, true>, dim3(nblk), dim3(256), 0, st, r.ev0, r.ev1, x, Wa, ba, att, pacc, pstat, P, S, act, r.inv_keep, r.thresh, r.seed,
-                           r.offset, r.offset_dev);
+                           r.offset, r.offset_dev, mbits);
     }
     APA_LAUNCH_CHECK("m1s_pool_fwd_kernel");
     return APA_OK;
@@ -540,7 +606,7 @@ static int launch_fwd_t(bool fused, bool train, int nblk, hipStream_t st, const 
 #define APA_GO(F, TR)                                                                            \
   launch_ev(m1s_pool_fwd_kernel<T, VW, PIX, F, TR>, dim3(nblk), dim3(256), 0, st, r.ev0, r.ev1, x,  \
                      Wa, ba, att, pacc, pstat, P, S, act, r.inv_keep, r.thresh, r.seed,          \
-                     r.offset, r.offset_dev)
+                     r.offset, r.offset_dev, mbits)
   if (fused) { if (train) APA_GO(true, true); else APA_GO(true, false); }
   else       { if (train) APA_GO(false, true); else APA_GO(false, false); }
 #undef APA_GO
@@ -558,6 +624,7 @@ static int launch_bwd_t(bool fused, bool train, int nblk, hipStream_t st, const 
   T* dx = static_cast<T*>(dX);
   const float* ex = dA_extra ? dA_extra : att;
   const float exs = dA_extra ? 1.0f : 0.0f;
+  const uint8_t* mbits = r.maskbits_in;    // non-null: the forward call's keep-bits (APA_FLAG_WS_FROM_FWD)
   if (r.relu_input) {
     if (!fused || PIX != 2) {
       set_error("APA_FLAG_RELU_INPUT needs Xatt == X (and the default APA_M1S_PIX)");
@@ -566,20 +633,29 @@ static int launch_bwd_t(bool fused, bool train, int nblk, hipStream_t st, const 
     if constexpr (PIX == 2) {
       if (train)
         launch_ev(m1s_bwd_main_kernel<T, VW, 2, true, true, true>, dim3(nblk), dim3(256), 0, st, r.ev0, r.ev1, x, Wa, att, dz, zsave, abar, G, bt, sn_pre, dx, dZout, pdwa, pdba, P, S, K,
-                           act, r.inv_keep, r.thresh, r.seed, r.offset, r.offset_dev, ex, exs);
+                           act, r.inv_keep, r.thresh, r.seed, r.offset, r.offset_dev, ex, exs, nullptr);
       else
         launch_ev(m1s_bwd_main_kernel<T, VW, 2, true, false, true>, dim3(nblk), dim3(256), 0, st, r.ev0, r.ev1, x, Wa, att, dz, zsave, abar, G, bt, sn_pre, dx, dZout, pdwa, pdba, P, S, K,
-                           act, r.inv_keep, r.thresh, r.seed, r.offset, r.offset_dev, ex, exs);
+                           act, r.inv_keep, r.thresh, r.seed, r.offset, r.offset_dev, ex, exs, nullptr);
     }
     APA_LAUNCH_CHECK("m1s_bwd_main_kernel");
     return APA_OK;
   }
-#define APA_GO(F, TR)                                                                            \
-  launch_ev(m1s_bwd_main_kernel<T, VW, PIX, F, TR>, dim3(nblk), dim3(256), 0, st, r.ev0, r.ev1, x,  \
-                     Wa, att, dz, zsave, abar, G, bt, sn_pre, dx, dZout, pdwa, pdba, P, S, K,    \
-                     act, r.inv_keep, r.thresh, r.seed, r.offset, r.offset_dev, ex, exs)
-  if (fused) { if (train) APA_GO(true, true); else APA_GO(true, false); }
-  else       { if (train) APA_GO(false, true); else APA_GO(false, false); }
+#define APA_GO(F, TR, BT)                                                                         \
+  launch_ev(m1s_bwd_main_kernel<T, VW, PIX, F, TR, false, BT>, dim3(nblk), dim3(256), 0, st, r.ev0, r.ev1, x, \
+            Wa, att, dz, zsave, abar, G, bt, sn_pre, dx, dZout, pdwa, pdba, P, S, K, act, r.inv_keep,   \
+            r.thresh, r.seed, r.offset, r.offset_dev, ex, exs, mbits)
+  bool bits_done = false;
+  if constexpr (PIX == 2 && KeepBits<T>::ON) {   // the keep-bits variant: default chunk width, bf16 features
+    if (train && mbits) {
+      if (fused) APA_GO(true, true, true); else APA_GO(false, true, true);
+      bits_done = true;
+    }
+  }
+  if (!bits_done) {
+    if (fused) { if (train) APA_GO(true, true, false); else APA_GO(true, false, false); }
+    else       { if (train) APA_GO(false, true, false); else APA_GO(false, false, false); }
+  }
 #undef APA_GO
   APA_LAUNCH_CHECK("m1s_bwd_main_kernel");
   return APA_OK;
