@@ -202,10 +202,14 @@ int m1_logits(const float* z, const float* Wt, const float* abar, const float* b
 int m1_bwd_small(const float* G, const float* Wt, const float* zsave, const float* abar,
                  const float* bt, float* dz, float* dWt, float* dbt, float* sn, int N, int C, int K,
                  hipStream_t st);
+// the finalize step folded into the logits kernel (m1_logits2_kernel<.., FIN>): the pooling pass's partials
+struct M1Partials {
+  const float* pacc; const float* pstat; float* z_out; float* abar_out; int S, P;
+};
 bool m1_logits2_supported(int C, int K);
 size_t m1_logits2_ws_bytes(int N, int C, int K);
 int m1_logits2(const float* z, const float* Wt, const float* abar, const float* bt, float* logits,
-               float* part_ws, int N, int C, int K, hipStream_t st);
+               float* part_ws, int N, int C, int K, hipStream_t st, const M1Partials* fp = nullptr);
 bool m1_bwd_head_supported(int N, int C, int K);
 int m1_bwd_head(const float* G, const float* Wt, const float* zsave, const float* abar,
                 const float* bt, float* dz, float* dWt, float* dbt, float* sn, int N, int C, int K,
@@ -213,7 +217,8 @@ int m1_bwd_head(const float* G, const float* Wt, const float* zsave, const float
 bool m1_logits_xent_supported(int N, int C, int K, bool eval);
 int m1_logits2_xent(const float* z, const float* Wt, const float* abar, const float* bt,
                     const int64_t* labels, float* logits, float* loss, float* G, float gscale,
-                    float* probs, int64_t* pred, float* part_ws, int N, int C, int K, hipStream_t st);
+                    float* probs, int64_t* pred, float* part_ws, int N, int C, int K, hipStream_t st,
+                    const M1Partials* fp = nullptr);
 // dwa2 != nullptr: columns [C1, C) of the partial matrix are summed into dwa2 instead (one launch, two outputs)
 int m1_colsum(const float* pdwa, const float* pdba, float* dwa, float* dba, int nblk, int C, int ld,
               uint64_t* rng_bump, hipStream_t st, float* dwa2 = nullptr, int C1 = 0);

@@ -836,7 +836,19 @@ int m1_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
                           pacc, pstat, P, pl.S, pool_act, r);
   if (rc != APA_OK) return rc;
   const int online = (fused && act == ACT_SOFTMAX) ? 1 : 0;
-  if (!(dbg_skip() & 2)) {
+  // A/B arm, OFF by default: without an on-line softmax to merge, the finalize step (z = (1/P) sum of the S
+  // partial rows, abar) can ride in the prologue of the logits kernel (m1_logits2_kernel<.., FIN>).  Measured
+  // on MI355X (round 2, bench.py, N = 32): one launch fewer but SLOWER -- training step 51.7 -> 54.1 us,
+  // evaluation step 23.2 -> 25.5 us: 128 logits blocks each gather a 128 KB slab of partials (16 MB of L2
+  // traffic, 32 dependent-free but wide loads per thread ahead of the MFMAs) where the stand-alone kernel
+  // moves 4 MB once, and a dependent kernel boundary on this chip costs only ~1.7 us.
+  static const int fuse_fin = env_int("APA_M1_FUSE_FINALIZE", 0);
+  static const int use_l2f = env_int("APA_M1_LOGITS2", 1);
+  const bool fin_in_logits = fuse_fin && use_l2f && !online && m1_logits2_supported(C, K) &&
+                             (reinterpret_cast<uintptr_t>(zsave) & 15) == 0 && pl.S <= 256;
+  M1Partials fpart{pacc, pstat, zsave, abar, pl.S, P};
+  const M1Partials* fp = fin_in_logits ? &fpart : nullptr;
+  if (!fin_in_logits && !(dbg_skip() & 2)) {
     hipLaunchKernelGGL(m1_finalize_fwd_kernel, dim3(N, (C + 1023) / 1024), dim3(256), 0, st, pacc,
                        pstat, zsave, abar, att, P, pl.S, C, online);
     APA_LAUNCH_CHECK("m1_finalize_fwd_kernel");
@@ -854,12 +866,12 @@ int m1_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
         reinterpret_cast<uintptr_t>(xf->G)) & 15) == 0) {
     // training: the same conditions under which m1_backward takes the head kernel, which finishes loss[0]
     rc = m1_logits2_xent(zsave, Wt, abar, bt, xf->labels, logits, xf->loss, xf->G, xf->gscale, xf->probs,
-                         xf->pred, gemm_ws, N, C, K, st);
+                         xf->pred, gemm_ws, N, C, K, st, fp);
     xf->done = rc == APA_OK;
     return rc;
   }
   if (use_l2 && m1_logits2_supported(C, K) && (reinterpret_cast<uintptr_t>(zsave) & 15) == 0)
-    rc = m1_logits2(zsave, Wt, abar, bt, logits, gemm_ws, N, C, K, st);
+    rc = m1_logits2(zsave, Wt, abar, bt, logits, gemm_ws, N, C, K, st, fp);
   else if (m1_small_supported(C, K) && (reinterpret_cast<uintptr_t>(zsave) & 15) == 0)
     rc = m1_logits(zsave, Wt, abar, bt, logits, gemm_ws, N, C, K, st);
   else
