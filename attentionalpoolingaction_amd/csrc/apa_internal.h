@@ -53,8 +53,8 @@ inline int dbg_skip() { return g_dbg_skip; }
 constexpr int dbg_skip() { return 0; }
 #endif
 
-// Launch `kernel`; with a start / stop event the launch goes through hipExtLaunchKernel, which stamps the
-// events with the dispatch's own begin / end timestamps (the pair rocprofv3 --kernel-trace reports).
+// Launch `kernel`; with a start / stop event the launch goes through hipExtLaunchKernel, which brackets
+// exactly this dispatch with the two events.
 template <typename... KArgs, typename... Args>
 inline void launch_ev(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shm, hipStream_t st,
                       hipEvent_t e0, hipEvent_t e1, Args... args) {

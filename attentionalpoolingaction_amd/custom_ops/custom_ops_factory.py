@@ -805,9 +805,8 @@ def momentum_sgd_step(weights, weight_decay, grad_flat, acc_flat, lr, momentum=0
 class KernelTimer:
     """Per-step event pairs for the two streaming kernels of the M == 1 head (m1s_pool_fwd_kernel,
     m1s_bwd_main_kernel).  `hooks(i)` is the apa_hooks struct to pass to step i: the library launches
-    those kernels through hipExtLaunchKernel with the pair attached, so the events carry the
-    dispatch's own begin / end timestamps (what rocprofv3 --kernel-trace reports) and
-    elapsed(start, stop) is the kernel duration itself -- nothing to calibrate away."""
+    those kernels through hipExtLaunchKernel with the pair attached, so each pair brackets exactly one
+    dispatch on its own stream (reads ~1.2 us above rocprofv3's begin -> end of the same kernel)."""
 
     def __init__(self, n_steps: int, base: Optional[ApaHooks] = None):
         lib = load_library()

@@ -12,7 +12,7 @@ from collections import defaultdict
 
 def find(d, pat):
     fs = glob.glob(os.path.join(d, '**', pat), recursive=True)
-    return fs[0] if fs else None
+    return max(fs, key=os.path.getmtime) if fs else None      # gpurun merges: keep the newest run's file
 
 
 def main():
@@ -61,8 +61,11 @@ def main():
     per_step = [r for r in rows if int(r['Calls']) >= 200 and 'apa::' in r['Name']]
     with open(os.path.join(prof, tag + '_summary.md'), 'w') as f:
         f.write('# {} rocprofv3 summary (MI355X, gfx950)\n\n'.format(tag))
-        f.write('Command (inside gpurun): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py '
-                '--steps 200 --warmup 20 --no-cpu-baseline --no-extra {}`\n\n(workload: {})\n\n'.format(bench_args, cfg))
+        cmd = 'python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extra ' + bench_args
+        if os.path.exists(os.path.join(out_dir, 'cmd.txt')):
+            cmd = open(os.path.join(out_dir, 'cmd.txt')).read().strip()
+        f.write('Command (inside gpurun): `rocprofv3 --kernel-trace --stats --output-format csv -- {}`\n\n'
+                '(workload: {})\n\n'.format(cmd, cfg))
         f.write('bench line under the profiler: {} img/s, {:.2f} us/step\n\n'.format(bench['value'], bench['ms_per_step'] * 1e3))
         f.write('| kernel | calls | avg us | % |\n|---|---|---|---|\n')
         for r in per_step:
