@@ -152,8 +152,8 @@ static int attn_pool_fwd_impl(const Hooks& hk, const apa_concat_feat* catp, M1Xe
       return APA_ERR_INVALID_ARG;
     }
     if (!m1_supported(C, Ca, dtype, Xatt == X)) {
-      set_error("apa_attn_pool_fwd: M==1 kernels need C in {256,512,1024,2048,4096} (f32) or "
-                "{512,1024,2048} (bf16); got C=%d Ca=%d dtype=%d", C, Ca, dtype);
+      set_error("apa_attn_pool_fwd: M==1 needs C and Ca to be whole 16-byte vectors (multiples of 4 fp32 / "
+                "8 bf16 channels, C <= 9584); got C=%d Ca=%d dtype=%d", C, Ca, dtype);
       return APA_ERR_UNSUPPORTED;
     }
     const size_t need = m1_plan(N, P, C, Ca, K).total;

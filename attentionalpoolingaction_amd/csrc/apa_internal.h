@@ -194,6 +194,17 @@ int m1s_launch_bwd_main(int dtype, int C, bool fused, bool train, int nblk, hipS
                         const float* sn_pre, void* dX, float* dZout, float* pdwa, float* pdba,
                         int P, int S, int K, int act, const M1Rng& r, const float* dA_extra);
 
+// apa_m1_generic.hip: the same two passes for any C (run-time channel loop, LDS accumulators)
+bool m1g_supported(int C, int dtype);
+int m1g_launch_pool_fwd(int dtype, int C, bool fused, bool train, int nblk, hipStream_t st, const void* X,
+                        const float* Wa, const float* ba, float* att, float* pacc, float* pstat, int P, int S,
+                        int act, const M1Rng& r);
+int m1g_launch_bwd_main(int dtype, int C, bool fused, bool train, int nblk, hipStream_t st, const void* X,
+                        const float* Wa, const float* att, const float* dz, const float* zsave,
+                        const float* abar, const float* G, const float* bt, const float* sn_pre, void* dX,
+                        float* dZout, float* pdwa, float* pdba, int P, int S, int K, int act, const M1Rng& r,
+                        const float* dA_extra);
+
 // apa_m1_small.hip: LDS-tiled f32-MFMA kernels for the small products of the M == 1 path
 bool m1_small_supported(int C, int K);
 size_t m1_logits_ws_bytes(int N, int C, int K);

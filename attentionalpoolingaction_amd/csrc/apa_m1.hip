@@ -654,16 +654,22 @@ static int env_int(const char* name, int dflt) {
 }
 
 static bool use_stream_kernels(int C, int dtype);
-bool m1_supported(int C, int Ca, int dtype, bool fused) {
+// the register-resident per-pixel kernels of this file: C = 64 * EPV * {1, 2, 4, 8}
+static bool vec_kernels_supported(int C, int dtype) {
   const int epv = dtype == APA_DTYPE_BF16 ? 8 : 4;
-  // C = 4096 fp32 exists only in the channel-split kernels (apa_m1_stream.hip)
-  if (use_stream_kernels(C, dtype) && (fused || Ca % epv == 0)) return true;
   if (C % (64 * epv) != 0) return false;
   const int vec = C / (64 * epv);
   if (!(vec == 1 || vec == 2 || vec == 4 || vec == 8)) return false;
   if (dtype == APA_DTYPE_BF16 && vec == 8) return false;  // C = 4096 bf16: not instantiated
-  if (!fused && (Ca % epv != 0)) return false;
   return true;
+}
+// Any channel count that is a whole number of 16-byte vectors is served: the channel-split streaming
+// kernels (apa_m1_stream.hip) for the wide benchmark shapes, the per-pixel kernels of this file for the
+// other powers of two, the run-time-loop kernels of apa_m1_generic.hip for everything else.
+bool m1_supported(int C, int Ca, int dtype, bool fused) {
+  const int epv = dtype == APA_DTYPE_BF16 ? 8 : 4;
+  if (!fused && (Ca % epv != 0)) return false;
+  return use_stream_kernels(C, dtype) || vec_kernels_supported(C, dtype) || m1g_supported(C, dtype);
 }
 
 // Grid sizing.  The streaming kernels hold 2 blocks (8 waves) per CU at their register budget, so
@@ -831,9 +837,12 @@ int m1_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
   else if (use_stream_kernels(C, dtype))
     rc = m1s_launch_pool_fwd(dtype, C, fused, train, pl.nblk, st, X, Wa, ba, att, pacc, pstat, P,
                              pl.S, pool_act, r);
-  else
+  else if (vec_kernels_supported(C, dtype))
     rc = APA_DISPATCH_VEC(launch_pool_fwd, dtype, C, fused, train, pl.nblk, st, X, Wa, ba, att,
                           pacc, pstat, P, pl.S, pool_act, r);
+  else
+    rc = m1g_launch_pool_fwd(dtype, C, fused, train, pl.nblk, st, X, Wa, ba, att, pacc, pstat, P, pl.S,
+                             pool_act, r);
   if (rc != APA_OK) return rc;
   const int online = (fused && act == ACT_SOFTMAX) ? 1 : 0;
   // A/B arm, OFF by default: without an on-line softmax to merge, the finalize step (z = (1/P) sum of the S
@@ -957,10 +966,13 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
     rc = m1s_launch_bwd_main(dtype, C, fused, train, pl.nblk, st, X, Wa, att, dz, zsave, abar, G,
                              bt, small_ok ? sn_buf : nullptr, dX, dZatt, pdwa, pdba, P, pl.S, K,
                              act, r, dA_extra);
-  else
+  else if (vec_kernels_supported(C, dtype))
     rc = APA_DISPATCH_VEC(launch_bwd_main, dtype, C, fused, train, pl.nblk, st, X, Wa, att, dz,
                           zsave, abar, G, bt, small_ok ? sn_buf : nullptr, dX, dZatt, pdwa, pdba,
                           P, pl.S, K, act, r, dA_extra);
+  else
+    rc = m1g_launch_bwd_main(dtype, C, fused, train, pl.nblk, st, X, Wa, att, dz, zsave, abar, G, bt,
+                             small_ok ? sn_buf : nullptr, dX, dZatt, pdwa, pdba, P, pl.S, K, act, r, dA_extra);
   if (rc != APA_OK) return rc;
 
   int nred = pl.nblk;

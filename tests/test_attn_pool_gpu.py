@@ -113,6 +113,42 @@ def test_m1_batch_one_large_map_split_count_is_clamped(gpu, H, C, softmax):
     _grads_close(got, ref, ('dX', 'dWa', 'dba', 'dWt', 'dbt'))
 
 
+@pytest.mark.parametrize('C,softmax,relu,train', [(832, False, False, False), (1536, True, False, False),
+                                                  (1280, False, True, True), (2064, False, False, True),
+                                                  (96, True, False, True)])
+def test_m1_any_channel_count_generic_kernels(gpu, C, softmax, relu, train):
+    """The head is backbone-agnostic (nets_factory.py:63-67): channel counts the register-resident kernels
+    were not instantiated for -- 832 / 1536 (Inception taps), 1280, 2064 (= 2048 + 16, the concatenated
+    map of _WITH_POSE_FEAT taken literally), 96 -- run on the shape-generic kernels (apa_m1_generic.hip)
+    instead of returning APA_ERR_UNSUPPORTED; same oracle, same tolerances, dropout with the kernel's mask."""
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    inp = make_head_inputs(N=3, H=7, W=7, C=C, K=51, seed=C)
+    keep, seed, offset = 0.5, 5, 2
+    mask = cof.dropout_mask(tuple(inp['X'].shape), keep, seed, offset).cpu() if train else None
+    flags = orc.AttnFlags(single_layer_att=True, softmax_att=softmax, relu_att=relu)
+    ref = _oracle(inp, flags, train=train, keep=keep, mask=mask)
+    got = _run_hip(inp, gpu, softmax=softmax, relu=relu, train=train, keep=keep, seed=seed, offset=offset)
+    _close(got['logits'], ref['logits'], TIGHT, 'logits')
+    _close(got['att'].reshape(ref['att'].shape), ref['att'], TIGHT, 'attention map')
+    assert torch.equal(got['pred'], ref['logits'].argmax(dim=1))
+    _grads_close(got, ref, ('dX', 'dWa', 'dba', 'dWt', 'dbt'))
+
+
+def test_m1_generic_kernels_separate_attention_input_bf16(gpu):
+    """generic arm, cfg 003 wiring (attention map from a 200-channel tensor), bf16 features, C = 1000"""
+    inp = make_head_inputs(N=2, H=6, W=6, C=1000, K=10, Ca=200, seed=3)
+    inp['X'] = inp['X'].bfloat16().float()
+    inp['Xatt'] = inp['Xatt'].bfloat16().float()
+    flags = orc.AttnFlags(single_layer_att=False)
+    ref = _oracle(inp, flags)
+    bf = dict(inp)
+    bf['X'], bf['Xatt'] = inp['X'].bfloat16(), inp['Xatt'].bfloat16()
+    got = _run_hip(bf, gpu)
+    _close(got['logits'], ref['logits'], 1e-4, 'logits')
+    _close(got['dWt'].reshape(ref['dWt'].shape), ref['dWt'], 1e-4, 'dWt')
+    _close(got['dX'].float().reshape(ref['dX'].shape), ref['dX'], 2.0 ** -7, 'dX (bf16 store)')
+
+
 @pytest.mark.parametrize('softmax,relu', [(False, False), (True, False), (False, True)])
 def test_m1_separate_attention_input_cfg003(gpu, softmax, relu):
     # cfg 003: bottom-up map from pose_pre_logits (768 channels), top-down from conv5
@@ -190,11 +226,13 @@ def test_m1_large_batch_linearity(gpu):
 
 def test_capi_error_paths(gpu):
     from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
-    X = torch.zeros(2, 4, 300, device=gpu)        # C = 300 is not a supported channel count
-    Wa = torch.zeros(300, 1, device=gpu); ba = torch.zeros(1, device=gpu)
-    Wt = torch.zeros(300, 5, device=gpu); bt = torch.zeros(5, device=gpu)
+    X = torch.zeros(2, 4, 302, device=gpu)        # C = 302 is not a whole number of 16-byte vectors
+    Wa = torch.zeros(302, 1, device=gpu); ba = torch.zeros(1, device=gpu)
+    Wt = torch.zeros(302, 5, device=gpu); bt = torch.zeros(5, device=gpu)
     with pytest.raises(cof.ApaError, match='APA_ERR_UNSUPPORTED'):
         cof.attn_pool_fwd(X, X, Wa, ba, Wt, bt)
+    X4 = torch.zeros(2, 4, 300, device=gpu)       # C = 300 (a multiple of 4) runs on the generic kernels
+    assert cof.attn_pool_fwd(X4, X4, Wa[:300].contiguous(), ba, Wt[:300].contiguous(), bt)[0].shape == (2, 5)
     with pytest.raises(cof.ApaError, match='GPU memory'):
         cof.attn_pool_fwd(X.cpu(), X.cpu(), Wa, ba, Wt, bt)
 
