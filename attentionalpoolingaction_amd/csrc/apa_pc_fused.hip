@@ -111,11 +111,19 @@ __global__ __launch_bounds__(256) void pc_fwd_zt_kernel(
     const bf16_t* __restrict__ X, const bf16_t* __restrict__ WcatT, const float* __restrict__ bcat,
     float* __restrict__ Z, float* __restrict__ T, uint8_t* __restrict__ maskbits, int R, int C, int K,
     float inv_keep, uint32_t thresh, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev) {
-  // X is streamed from HBM exactly once, and HBM wants long contiguous bursts: a block owns BM whole rows
-  // (BM * C * 2 contiguous bytes) and fetches them KA = 256 channels at a time -- 512 contiguous bytes per
-  // row and wave-instruction pair -- while the weight slab (L2-resident, re-read by every block) moves
-  // in 64-deep k tiles.  (Fetching A in the same 64-deep tiles, 128 B per row, measured 21 us for the
-  // 25.7 MB map: every request opened a different DRAM page.)
+  // A block owns BM whole rows of X (BM * C * 2 contiguous bytes) and fetches them KA = 256 channels at a
+  // time -- 512 contiguous bytes per row -- while the weight slab (L2-resident, re-read by every block)
+  // moves in 64-deep k tiles, D of them in flight in registers.
+  // What bounds this kernel (round 2 measurements, 25.7 MB map, N = 32): NOT the HBM access pattern and not
+  // load latency -- 64-deep A tiles 23.4 us, + four tiles of register prefetch 21.3, 512-byte A bursts
+  // 24.6, tile-major weight slab 22.6 -- but the number of BYTES EACH CU LOADS through its vector-memory
+  // path: every block re-reads the whole 512 KB weight slab (L2 hits, still ~640 KB per CU), and a CU
+  // sustains only ~25-30 GB/s of global_load_dwordx4 traffic whatever level serves it (the figure that
+  // makes 256 CUs x 24.6 GB/s the chip's 6.3 TB/s copy ceiling).  A fourth form with the A fragments
+  // loaded straight from global memory per wave (16 rows x 64-byte pieces per instruction, only the slab
+  // through LDS, 32 MFMAs per barrier) measured 35.5 us: fragment-shaped loads are worse still.  The way
+  // down is the LDS-DMA path for the slab (58-90 GB/s per CU in the GEMM kernels of apa_gemm_bf16.hip),
+  // which needs the A operand on that path too (the compiler drains the DMA queue at every VGPR load).
   extern __shared__ __attribute__((aligned(16))) short smem[];
   constexpr int A_EL = BM * LDA, B_EL = 128 * LDK;
   constexpr int NA = TRAIN ? 2 : 1;             // A images per buffer: plain [, masked]
