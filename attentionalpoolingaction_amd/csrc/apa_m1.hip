@@ -195,13 +195,17 @@ __global__ __launch_bounds__(256) void m1_pool_fwd_kernel(
 }
 
 // --------------------------------------------------------------------------------------------
-// F2: merge the S block partials of each image.  grid (N, C/1024), block 256 (one float4 each).
+// F2: merge the S block partials of each image.  grid (N, C/(4 cw)), block 256, cw channel threads
+// (one float4 each).
 //   z[n,c] = (1/P) sum_s pacc[n,s,c] * w_s     w_s = exp(m_s - M)/L (on-line softmax) or 1
 //   abar[n] = (1/P) sum_p A[n,p];  softmax: att[n,p] <- exp(Z - M)/L
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void m1_finalize_fwd_kernel(
     const float* __restrict__ pacc, const float* __restrict__ pstat, float* __restrict__ z,
-    float* __restrict__ abar, float* __restrict__ att, int P, int S, int C, int online_softmax) {
+    float* __restrict__ abar, float* __restrict__ att, int P, int S, int C, int online_softmax, int cw) {
+  // cw = threads of the block that carry channels (one float4 each): the grid is (N, ceil(C / 4cw)).  A CU
+  // sustains only ~25-30 GB/s of vector loads, so the 4 MB of partials want to be spread over all 256
+  // CUs (cw = 64 at N = 32: 256 blocks x 16 KB) rather than 64 blocks x 64 KB (cw = 256).
   __shared__ float s_w[256];   // per-split weight exp(m_s - M) / L / P   (S <= 256)
   __shared__ float s_red[8];
   const int n = blockIdx.x;
@@ -211,12 +215,15 @@ __global__ __launch_bounds__(256) void m1_finalize_fwd_kernel(
   // Latency chain: every load is issued before anything is consumed -- the first 16 partial rows
   // (all of them at the benchmark batch) and the per-split statistics travel together.
   constexpr int FB = 16;
-  const int v = blockIdx.y * 256 + threadIdx.x;
+  const bool chan = (int)threadIdx.x < cw;
+  const int v = chan ? blockIdx.y * cw + threadIdx.x : 0;
   const float* pa = pacc + (size_t)n * S * C + (v * 4 < C ? v * 4 : 0);
   float4 first[FB];
+  if (chan) {   // wave-uniform: cw is a multiple of 64
 #pragma unroll
-  for (int u = 0; u < FB; ++u)
-    first[u] = *reinterpret_cast<const float4*>(pa + (size_t)min(u, S - 1) * C);
+    for (int u = 0; u < FB; ++u)
+      first[u] = *reinterpret_cast<const float4*>(pa + (size_t)min(u, S - 1) * C);
+  }
   // one split per thread: no serial dependent-load chain
   float m_s = -INFINITY, l_s = 0.f, a_s = 0.f;
   if ((int)threadIdx.x < S) {
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(256) void m1_finalize_fwd_kernel(
     asum = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
   }
   __syncthreads();
-  if (v * 4 < C) {
+  if (chan && v * 4 < C) {
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int u = 0; u < FB; ++u) {
@@ -858,8 +865,12 @@ int m1_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
   M1Partials fpart{pacc, pstat, zsave, abar, pl.S, P};
   const M1Partials* fp = fin_in_logits ? &fpart : nullptr;
   if (!fin_in_logits && !(dbg_skip() & 2)) {
-    hipLaunchKernelGGL(m1_finalize_fwd_kernel, dim3(N, (C + 1023) / 1024), dim3(256), 0, st, pacc,
-                       pstat, zsave, abar, att, P, pl.S, C, online);
+    // enough blocks to put every CU to work (the kernel is bound by the bytes each CU loads)
+    static const int cw_env = env_int("APA_M1_FIN_CW", 0);
+    int cw = cw_env ? cw_env : 256;
+    if (!cw_env) while (cw > 64 && (long)N * ((C + 4 * cw - 1) / (4 * cw)) < 256) cw >>= 1;
+    hipLaunchKernelGGL(m1_finalize_fwd_kernel, dim3(N, (C + 4 * cw - 1) / (4 * cw)), dim3(256), 0, st, pacc,
+                       pstat, zsave, abar, att, P, pl.S, C, online, cw);
     APA_LAUNCH_CHECK("m1_finalize_fwd_kernel");
   }
   // logits = z . Wt + abar (x) bt -- the first reader of Wt / bt (apa_hooks.td_weights_ready_event)
