@@ -164,6 +164,201 @@ __global__ __launch_bounds__(512) void pose_dppre_kernel(const float* __restrict
   }
 }
 
+// Round 2: the whole "small side" of the pose-head backward in ONE pass over Ppre (J <= 16):
+//   dPpre[r,c] = (sum_q dPl[r,q] W2[c,q] + ext[r,c]) * [Ppre[r,c] > 0]          (written, bf16 / fp32)
+//   db1[c] = sum_r dPpre[r,c]    db2[q] = sum_r dPl[r,q]    dW2[c,q] = sum_r Ppre[r,c] dPl[r,q]
+// The last three leave as ONE partial row per block, [dW2 (Cp*J) | db1 (Cp) | db2 (J)], reduced in fixed
+// order by a single m1_colsum launch.  Before: pose_dppre_kernel (13.2 us) + a split-K MFMA GEMM with 16
+// useful output columns (11.8 us) + its reduce (5.3 us) + colsum (4.5 us), and Ppre was read twice.
+// Block = RPB rows, thread = 2 consecutive columns of every row (its 2 x 16 slice of W2 and its
+// 2 x 16 dW2 accumulators in registers; exact fp32 FMAs, dPl is not rounded to bf16 as the MFMA path did).
+// Every row load of a block is issued up front (one HBM latency per block); surplus rows of the last block
+// re-read row R-1 and meet dPl = 0 / ext_row = 0.
+constexpr int POSE_RPB_MIN = 16;   // smallest rows-per-block variant (sizes the partial matrix)
+// leading dimension (floats) of the rows kernel's partial matrix: [dW2 | db1 | db2]; with J == 16 the dW2
+// part is padded to 32 floats per thread of the block (permuted layout, see the kernel's epilogue)
+__host__ __device__ static inline size_t pose_rows_ld(int Cp, int J, int nthr) {
+  return (J == 16 ? (size_t)nthr * 32 : (size_t)Cp * J) + Cp + J;
+}
+template <typename T, bool R1, bool EXT, int RPB>
+__global__ __launch_bounds__(512) void pose_bwd_rows_kernel(
+    const float* __restrict__ dPl, const float* __restrict__ W2, const T* __restrict__ ext,
+    const float* __restrict__ ext_row, const float* __restrict__ ext_col, const T* __restrict__ Ppre,
+    T* __restrict__ dPpre, float* __restrict__ partial, long R, int Cp, int J) {
+  // The block's [RPB][Cp] tile of Ppre (and of ext) is parked in LDS, one slot per thread and row, written
+  // and read by the same thread: a register file extension that a REAL loop can index.  (With the rows in
+  // registers the row loop has to be unrolled, and hipcc then reorders the 32 x 64 FMAs at will -- it sank
+  // the dW2 chains below everything else and spilled every row's dPl values, 2 KB of scratch per lane.)
+  typedef typename std::conditional<sizeof(T) == 2, uint32_t, float2>::type rowvec_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  float* s_dpl = reinterpret_cast<float*>(s_raw);                       // [RPB][16]
+  float* s_er = s_dpl + RPB * 16;                                       // [RPB]
+  rowvec_t* s_pp = reinterpret_cast<rowvec_t*>(s_er + RPB);             // [RPB][nthr]
+  rowvec_t* s_ext = s_pp + (EXT ? RPB * blockDim.x : 0);                // [RPB][nthr]
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const long r0 = (long)blockIdx.x * RPB;
+  const int nrows = (int)min((long)RPB, R - r0);
+  const int c0 = tid * 2;
+  const bool active = c0 < Cp;
+  const int c0c = active ? c0 : 0;   // idle threads (Cp/2 not a multiple of 64) shadow column 0
+  {  // every row of the block is requested before anything else happens: one HBM latency per block
+    rowvec_t pv[RPB], ev[EXT ? RPB : 1];
+#pragma unroll
+    for (int u = 0; u < RPB; ++u) {
+      const size_t off = (size_t)min(r0 + u, R - 1) * Cp + c0c;   // surplus rows re-read row R-1
+      pv[u] = *reinterpret_cast<const rowvec_t*>(Ppre + off);
+      if (EXT) ev[u] = *reinterpret_cast<const rowvec_t*>(ext + off);
+    }
+#pragma unroll 1
+    for (int i = tid; i < RPB * 16; i += nthr) {
+      const int rr = i >> 4, q = i & 15;
+      s_dpl[i] = (rr < nrows && q < J) ? dPl[(r0 + rr) * J + q] : 0.f;
+    }
+    if (R1 && tid < RPB) s_er[tid] = tid < nrows ? ext_row[r0 + tid] : 0.f;
+#pragma unroll
+    for (int u = 0; u < RPB; ++u) {
+      s_pp[u * nthr + tid] = pv[u];
+      if (EXT) s_ext[u * nthr + tid] = ev[u];
+    }
+  }
+  // packed fp32 math (v_pk_fma_f32): wq[q] = (W2[c0][q], W2[c0+1][q]) pairs the thread's two columns, so
+  // the dPpre chains are sv2 += d[q] * wq[q]; the dW2 accumulators a[c][q..q+1] += pp[c] * (d[q], d[q+1]).
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  v2f wq[16];
+  if (J == 16) {   // 2 x 16 floats = one contiguous 128-byte span
+    const float4* wsrc = reinterpret_cast<const float4*>(W2 + (size_t)c0c * 16);
+    float4 t[8];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) t[v] = wsrc[v];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      wq[v * 4] = v2f{t[v].x, t[v + 4].x}; wq[v * 4 + 1] = v2f{t[v].y, t[v + 4].y};
+      wq[v * 4 + 2] = v2f{t[v].z, t[v + 4].z}; wq[v * 4 + 3] = v2f{t[v].w, t[v + 4].w};
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {   // clamped index + select: no branch between the loads
+      const float t0 = W2[(size_t)c0c * J + min(q, J - 1)];
+      const float t1 = W2[(size_t)(c0c + 1) * J + min(q, J - 1)];
+      wq[q] = q < J ? v2f{t0, t1} : v2f{0.f, 0.f};
+    }
+  }
+  v2f ecol = {0.f, 0.f};
+  if (R1) ecol = v2f{ext_col[c0c], ext_col[c0c + 1]};
+  v2f acc = {0.f, 0.f};
+  v2f a[2][8];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int h = 0; h < 8; ++h) a[c][h] = v2f{0.f, 0.f};
+  __syncthreads();
+  T* orow = dPpre + (size_t)r0 * Cp + c0;
+  // one row ahead: the next row's tile slot, ext_row entry and 16 dPl values are read from LDS before the
+  // current row's FMAs (slot RPB-1 is re-read past the end; nothing is done with it)
+  auto ld_row = [&](int rr, rowvec_t& pr, rowvec_t& xr, float& er, float4 (&d4)[4]) {
+    const int r = min(rr, RPB - 1);
+    pr = s_pp[r * nthr + tid];
+    if (EXT) xr = s_ext[r * nthr + tid];
+    if (R1) er = s_er[r];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) d4[v] = *reinterpret_cast<const float4*>(s_dpl + r * 16 + v * 4);
+  };
+  rowvec_t prn = rowvec_t(), xrn = rowvec_t();
+  float ern = 0.f;
+  float4 dn[4];
+  ld_row(0, prn, xrn, ern, dn);
+#pragma unroll 2
+  for (int rr = 0; rr < nrows; ++rr) {
+    const rowvec_t pr = prn, xr = xrn;
+    const float er = ern;
+    v2f d2[8];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { d2[2 * v] = v2f{dn[v].x, dn[v].y}; d2[2 * v + 1] = v2f{dn[v].z, dn[v].w}; }
+    ld_row(rr + 1, prn, xrn, ern, dn);
+    v2f pp, x = {0.f, 0.f};
+    if constexpr (sizeof(T) == 2) pp = v2f{bf16_lo(pr), bf16_hi(pr)};
+    else pp = v2f{pr.x, pr.y};
+    if constexpr (EXT) {
+      if constexpr (sizeof(T) == 2) x = v2f{bf16_lo(xr), bf16_hi(xr)};
+      else x = v2f{xr.x, xr.y};
+    }
+    if constexpr (R1) x = ecol * er;
+    v2f sv = x, sv_b = {0.f, 0.f};   // two chains of 8
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+      sv = __builtin_elementwise_fma(v2f{d2[h].x, d2[h].x}, wq[2 * h], sv);
+      sv_b = __builtin_elementwise_fma(v2f{d2[h].y, d2[h].y}, wq[2 * h + 1], sv_b);
+    }
+    sv += sv_b;
+    v2f o = {pp.x > 0.f ? sv.x : 0.f, pp.y > 0.f ? sv.y : 0.f};
+    acc += o;
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+      a[0][h] = __builtin_elementwise_fma(v2f{pp.x, pp.x}, d2[h], a[0][h]);
+      a[1][h] = __builtin_elementwise_fma(v2f{pp.y, pp.y}, d2[h], a[1][h]);
+    }
+    if (active) {
+      if constexpr (sizeof(T) == 2) *reinterpret_cast<uint32_t*>(orow) = pack_bf16x2(o.x, o.y);
+      else *reinterpret_cast<float2*>(orow) = make_float2(o.x, o.y);
+    }
+    orow += Cp;
+  }
+  // Partial row of the block: [dW2 | db1 | db2].  J == 16: the dW2 part is stored PERMUTED so that every
+  // wave-instruction writes 1 KiB of consecutive bytes -- float4 number v of thread t (v = 4c + q/4) goes
+  // to float offset (v * nthr + t) * 4; m1_colsum undoes the permutation when it writes dW2.  (In natural
+  // [c][q] order each lane's 128 bytes are contiguous and every store touches 64 different lines: 4.3 us.)
+  float* prow = partial + (size_t)blockIdx.x * pose_rows_ld(Cp, J, nthr);
+  const size_t dw2_cols = J == 16 ? (size_t)nthr * 32 : (size_t)Cp * J;
+  {
+    if (J == 16) {
+      float4* dst = reinterpret_cast<float4*>(prow) + tid;
+#pragma unroll
+      for (int v = 0; v < 8; ++v)
+        dst[(size_t)v * nthr] = make_float4(a[v >> 2][(v & 3) * 2].x, a[v >> 2][(v & 3) * 2].y,
+                                            a[v >> 2][(v & 3) * 2 + 1].x, a[v >> 2][(v & 3) * 2 + 1].y);
+    } else if (active) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+          if (2 * h < J) prow[(size_t)(c0 + c) * J + 2 * h] = a[c][h].x;
+          if (2 * h + 1 < J) prow[(size_t)(c0 + c) * J + 2 * h + 1] = a[c][h].y;
+        }
+    }
+    if (active) *reinterpret_cast<float2*>(prow + dw2_cols + c0) = make_float2(acc.x, acc.y);
+  }
+  if (tid < J) {
+    float sdb = 0.f;
+    for (int rr = 0; rr < nrows; ++rr) sdb += s_dpl[rr * 16 + tid];
+    prow[dw2_cols + Cp + tid] = sdb;
+  }
+}
+
+// LDS bytes of one block: dPl rows + ext_row + the [rpb][nthr] tile(s)
+static size_t pose_rows_lds(int rpb, int nthr, int dtype, bool ext) {
+  return (size_t)rpb * 17 * 4 + (size_t)rpb * nthr * (dtype == APA_DTYPE_BF16 ? 4 : 8) * (ext ? 2 : 1);
+}
+// rows per block: 32 (half the partial matrix) once that still gives every CU a block and the tile
+// stays under the 64 KB a launch gets without opting in, else 16
+static int pose_rows_per_block(long R, int nthr, int dtype, bool ext) {
+  static const int forced = [] { const char* e = getenv("APA_POSE_RPB"); return e ? atoi(e) : 0; }();
+  int rpb = (R + 31) / 32 >= 256 ? 32 : 16;
+  if (forced == 16 || forced == 32) rpb = forced;
+  if (rpb == 32 && pose_rows_lds(32, nthr, dtype, ext) > 65536) rpb = 16;
+  return rpb;
+}
+
+static bool pose_bwd_rows_ok(const float* dPl, const void* Ppre, const void* ext, const float* W2, int Cp,
+                             int J, int dtype) {
+  static const int enabled = [] { const char* e = getenv("APA_POSE_BWD_ROWS"); return e ? atoi(e) : 1; }();
+  const uintptr_t al = reinterpret_cast<uintptr_t>(Ppre) | reinterpret_cast<uintptr_t>(ext);
+  const int nthr = ((Cp / 2 + 63) / 64) * 64;
+  return enabled && dPl && J <= 16 && Cp % 4 == 0 && Cp <= 1024 && (al & 7) == 0 &&
+         (J != 16 || (reinterpret_cast<uintptr_t>(W2) & 15) == 0) &&
+         (dtype == APA_DTYPE_BF16 || dtype == APA_DTYPE_F32) &&
+         pose_rows_lds(16, nthr, dtype, ext != nullptr) <= 65536;
+}
+
 // Pl = Ppre . W2 + b2 for bf16 features: [R, Cp] x [Cp, J <= 16] -- 16 output columns, so a 128-wide GEMM
 // tile wastes 7/8 of its MFMAs and needs split-K plus a reduce launch (11.6 + 5.2 us at R = 6272).  Here
 // a wave owns 16 rows: its A fragments come straight from global memory (one 16-byte load per lane and
@@ -243,7 +438,10 @@ static PosePlan pose_plan(int N, int P, int C, int Cp, int J, int dtype) {
   pl.nchunks = (int)((pl.R + POSE_RB - 1) / POSE_RB);
   size_t off = 0;
   pl.off_dppre = off;   off += align_up((size_t)pl.R * Cp * dt_size(dtype), 256);
-  pl.off_partial = off; off += align_up((size_t)pl.nchunks * (Cp + J) * 4, 256);
+  const size_t rows_part = (size_t)((pl.R + POSE_RPB_MIN - 1) / POSE_RPB_MIN) *
+                           pose_rows_ld(Cp, J, ((Cp / 2 + 63) / 64) * 64) * 4;
+  const size_t chunk_part = (size_t)pl.nchunks * (Cp + J) * 4;
+  pl.off_partial = off; off += align_up(rows_part > chunk_part ? rows_part : chunk_part, 256);
   size_t g = gemm_ws_bytes((int)pl.R, J, 32);
   const size_t g2 = gemm_ws_bytes(Cp, J, 32), g3 = gemm_ws_bytes(C, Cp, 32);
   if (g2 > g) g = g2;
@@ -342,6 +540,36 @@ extern "C" int apa_pose_head_fwd(const void* X, const float* W1, const float* b1
   return gemm_launch(g2, st);
 }
 
+// the two dense products of the backward pass: dW1 = X^T . dPpre and dX (+)= dPpre . W1^T
+static int pose_head_bwd_big(const void* X, const float* W1, const void* dPpre, void* dX, int accumulate_dX,
+                             float* dW1, char* w, const PosePlan& pl, float* gws, int R, int C, int Cp,
+                             int dtype, hipStream_t st) {
+  const int tdt = dt_code(dtype);
+  int rc;
+  {  // dW1[c,j] = sum_r X[r,c] dPpre[r,j]
+    GemmDesc g;
+    g.A = X; g.lda = C; g.ta = tdt; g.a_kc = false;
+    g.B = dPpre; g.ldb = Cp; g.tb = tdt; g.b_kc = false;
+    g.C = dW1; g.ldc = Cp; g.tc = 0;
+    g.M = C; g.N = Cp; g.K = R;
+    g.splits = gemm_pick_splits(C, Cp, R); g.ws = gws;
+    rc = gemm_launch(g, st);
+    if (rc != APA_OK) return rc;
+  }
+  {  // dX (+)= dPpre . W1^T
+    GemmDesc g;
+    g.A = dPpre; g.lda = Cp; g.ta = tdt; g.a_kc = true;
+    int w1_tb = 0;
+    const void* W1op = pose_w1_operand(W1, w + pl.off_w1b, C, Cp, dtype, &w1_tb, st,
+                                       (accumulate_dX & APA_POSE_WS_FROM_FWD) != 0);
+    g.B = W1op; g.ldb = Cp; g.tb = w1_tb; g.b_kc = true;   // W1 [C][Cp]: n = c rows, k contiguous
+    g.C = dX; g.ldc = C; g.tc = tdt;
+    g.M = R; g.N = C; g.K = Cp; g.beta = (accumulate_dX & 1) ? 1.f : 0.f;
+    rc = gemm_launch(g, st);
+  }
+  return rc;
+}
+
 static int pose_head_bwd_impl(const void* X, const float* W1, const float* W2, const void* Ppre,
                               const float* dPl, const void* dPpre_ext, const float* ext_row,
                               const float* ext_col, void* dX, int accumulate_dX, float* dW1, float* db1,
@@ -376,6 +604,38 @@ static int pose_head_bwd_impl(const void* X, const float* W1, const float* W2, c
   if (Cp % 4 != 0) {
     set_error("apa_pose_head_bwd: Cp=%d must be a multiple of 4", Cp);
     return APA_ERR_UNSUPPORTED;
+  }
+  if (pose_bwd_rows_ok(dPl, Ppre, dPpre_ext, W2, Cp, J, dtype)) {
+    // one pass: dPpre + partial rows [dW2 | db1 | db2], one fixed-order column sum for all three
+    const int nthr2 = ((Cp / 2 + 63) / 64) * 64;
+    const int rpb = pose_rows_per_block(pl.R, nthr2, dtype, dPpre_ext != nullptr && !ext_row);
+    const int nblk = (int)((pl.R + rpb - 1) / rpb);
+    const size_t lds = pose_rows_lds(rpb, nthr2, dtype, dPpre_ext != nullptr && !ext_row);
+#define APA_ROWS2(T, R1v, EXTv, RPBv)                                                                        \
+  hipLaunchKernelGGL((pose_bwd_rows_kernel<T, R1v, EXTv, RPBv>), dim3(nblk), dim3(nthr2), lds, st, dPl, W2, \
+                     static_cast<const T*>(dPpre_ext), ext_row, ext_col, static_cast<const T*>(Ppre),       \
+                     static_cast<T*>(dPpre), partial, pl.R, Cp, J)
+#define APA_ROWS(T, R1v, EXTv)                                              \
+  do {                                                                      \
+    if (rpb == 32) APA_ROWS2(T, R1v, EXTv, 32); else APA_ROWS2(T, R1v, EXTv, 16); \
+  } while (0)
+    if (dtype == APA_DTYPE_F32) {
+      if (ext_row) APA_ROWS(float, true, false);
+      else if (dPpre_ext) APA_ROWS(float, false, true);
+      else APA_ROWS(float, false, false);
+    } else {
+      if (ext_row) APA_ROWS(bf16_t, true, false);
+      else if (dPpre_ext) APA_ROWS(bf16_t, false, true);
+      else APA_ROWS(bf16_t, false, false);
+    }
+#undef APA_ROWS2
+#undef APA_ROWS
+    APA_LAUNCH_CHECK("pose_bwd_rows_kernel");
+    const int ldp = (int)pose_rows_ld(Cp, J, nthr2), c1 = ldp - Cp - J;
+    int rc = m1_colsum(partial, nullptr, dW2, nullptr, nblk, ldp, ldp, nullptr, st, db1, c1, db2, c1 + Cp,
+                       J == 16 ? nthr2 : 0, Cp);
+    if (rc != APA_OK) return rc;
+    return pose_head_bwd_big(X, W1, dPpre, dX, accumulate_dX, dW1, w, pl, gws, R, C, Cp, dtype, st);
   }
   const int nthr = ((Cp / 4 + 63) / 64) * 64;   // one thread per 4 columns (<= 512: Cp <= 2048)
 #define APA_DPPRE(T, JM)                                                                            \
@@ -412,28 +672,7 @@ static int pose_head_bwd_impl(const void* X, const float* W1, const float* W2, c
   } else {
     APA_HIP_CHECK(hipMemsetAsync(dW2, 0, (size_t)Cp * J * sizeof(float), st));
   }
-  {  // dW1[c,j] = sum_r X[r,c] dPpre[r,j]
-    GemmDesc g;
-    g.A = X; g.lda = C; g.ta = tdt; g.a_kc = false;
-    g.B = dPpre; g.ldb = Cp; g.tb = tdt; g.b_kc = false;
-    g.C = dW1; g.ldc = Cp; g.tc = 0;
-    g.M = C; g.N = Cp; g.K = R;
-    g.splits = gemm_pick_splits(C, Cp, R); g.ws = gws;
-    rc = gemm_launch(g, st);
-    if (rc != APA_OK) return rc;
-  }
-  {  // dX (+)= dPpre . W1^T
-    GemmDesc g;
-    g.A = dPpre; g.lda = Cp; g.ta = tdt; g.a_kc = true;
-    int w1_tb = 0;
-    const void* W1op = pose_w1_operand(W1, w + pl.off_w1b, C, Cp, dtype, &w1_tb, st,
-                                       (accumulate_dX & APA_POSE_WS_FROM_FWD) != 0);
-    g.B = W1op; g.ldb = Cp; g.tb = w1_tb; g.b_kc = true;   // W1 [C][Cp]: n = c rows, k contiguous
-    g.C = dX; g.ldc = C; g.tc = tdt;
-    g.M = R; g.N = C; g.K = Cp; g.beta = (accumulate_dX & 1) ? 1.f : 0.f;
-    rc = gemm_launch(g, st);
-  }
-  return rc;
+  return pose_head_bwd_big(X, W1, dPpre, dX, accumulate_dX, dW1, w, pl, gws, R, C, Cp, dtype, st);
 }
 
 extern "C" int apa_pose_head_bwd(const void* X, const float* W1, const float* W2, const void* Ppre,

@@ -230,9 +230,11 @@ int m1_logits2_xent(const float* z, const float* Wt, const float* abar, const fl
                     const int64_t* labels, float* logits, float* loss, float* G, float gscale,
                     float* probs, int64_t* pred, float* part_ws, int N, int C, int K, hipStream_t st,
                     const M1Partials* fp = nullptr);
-// dwa2 != nullptr: columns [C1, C) of the partial matrix are summed into dwa2 instead (one launch, two outputs)
+// dwa2 != nullptr: columns [C1, C2) of the partial matrix are summed into dwa2, dwa3 != nullptr: columns
+// [C2, C) into dwa3 (one launch, up to three outputs)
 int m1_colsum(const float* pdwa, const float* pdba, float* dwa, float* dba, int nblk, int C, int ld,
-              uint64_t* rng_bump, hipStream_t st, float* dwa2 = nullptr, int C1 = 0);
+              uint64_t* rng_bump, hipStream_t st, float* dwa2 = nullptr, int C1 = 0, float* dwa3 = nullptr,
+              int C2 = 0, int perm_nthr = 0, int perm_cp = 0);
 
 // apa_gemm_bf16.hip: C = (A[:, :64] . B[:, :64]^T) * mask/keep + A[:, 64:] . B[:, 64:]^T  (all bf16, k contiguous)
 int gemm_bf16_mid_dropout(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N,

@@ -744,14 +744,18 @@ __global__ __launch_bounds__(256) void m1_bwd_head_kernel(
 // grid = ceil(C/32) blocks of 1024 threads: 32 row groups x 32 columns, 128-byte row segments.
 // The last kernel of the backward call: optionally advances the HBM dropout counter.
 // --------------------------------------------------------------------------------------------
-// Columns [0, C1) go to dwa, columns [C1, C) to dwa2 (two outputs from one partial matrix, e.g.
-// db1 | db2 of the pose head); C1 == C for a single output.
+// Columns [0, C1) go to dwa, columns [C1, C2) to dwa2, columns [C2, C) to dwa3 (up to three outputs from
+// one partial matrix, e.g. dW2 | db1 | db2 of the pose head); C1 == C2 == C for a single output.
 __global__ __launch_bounds__(1024) void m1_colsum_kernel(const float* __restrict__ pdwa,
                                                          const float* __restrict__ pdba,
                                                          float* __restrict__ dwa,
                                                          float* __restrict__ dba, int nblk, int C,
                                                          int ld, uint64_t* __restrict__ rng_bump,
-                                                         float* __restrict__ dwa2, int C1) {
+                                                         float* __restrict__ dwa2, int C1,
+                                                         float* __restrict__ dwa3, int C2, int perm_nthr,
+                                                         int perm_cp) {
+  // perm_nthr > 0: the first section holds the pose head's dW2 partials in the permuted order of
+  // pose_bwd_rows_kernel (float4 v of thread t at float4 index v * nthr + t; v = 4 (column & 1) + q / 4)
   __shared__ float red[32][33];
   const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + col;
@@ -780,8 +784,16 @@ __global__ __launch_bounds__(1024) void m1_colsum_kernel(const float* __restrict
     float s = 0.f;
 #pragma unroll
     for (int g = 0; g < 32; ++g) s += red[g][col];
-    if (c < C1) dwa[c] = s;
-    else dwa2[c - C1] = s;
+    if (c < C1) {
+      if (perm_nthr > 0) {
+        const int v = c / (4 * perm_nthr), rem = c - v * 4 * perm_nthr;
+        const int col = 2 * (rem >> 2) + (v >> 2);
+        if (col < perm_cp) dwa[col * 16 + (v & 3) * 4 + (rem & 3)] = s;
+      } else {
+        dwa[c] = s;
+      }
+    } else if (c < C2) dwa2[c - C1] = s;
+    else dwa3[c - C2] = s;
   }
   if (blockIdx.x == 0 && pdba) {
     __syncthreads();
@@ -956,10 +968,12 @@ int m1_bwd_head(const float* G, const float* Wt, const float* zsave, const float
 }
 
 int m1_colsum(const float* pdwa, const float* pdba, float* dwa, float* dba, int nblk, int C, int ld,
-              uint64_t* rng_bump, hipStream_t st, float* dwa2, int C1) {
+              uint64_t* rng_bump, hipStream_t st, float* dwa2, int C1, float* dwa3, int C2, int perm_nthr,
+              int perm_cp) {
   if (!dwa2) C1 = C;
+  if (!dwa3) C2 = C;
   hipLaunchKernelGGL(m1_colsum_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, pdwa, pdba, dwa, dba,
-                     nblk, C, ld, rng_bump, dwa2, C1);
+                     nblk, C, ld, rng_bump, dwa2, C1, dwa3, C2, perm_nthr, perm_cp);
   APA_LAUNCH_CHECK("m1_colsum_kernel");
   return APA_OK;
 }

@@ -479,6 +479,7 @@ def main():
             'dtype': args.dtype,
             'data': 'synthetic',
             'repeats': len(per),
+            'timed_ms_total': round(sum(per) * args.steps * 1e3, 3),
             'ms_per_step_min_max': [round(min(per) * 1e3, 5), round(max(per) * 1e3, 5)],
             'config': {
                 'workload': workload,

@@ -1111,7 +1111,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields(gpu):
         r = d['roofline']
         assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
         assert 0.2 < r['frac'] < 1.0 and d['value'] > 2000          # BASELINE target: >= 2000 img/s
-        assert d['repeats'] >= 5 and d['repeats'] * 20 * d['ms_per_step'] >= 45.0     # >= 50 ms measured, median
+        assert d['repeats'] >= 5 and d['timed_ms_total'] >= 50.0       # >= 50 ms measured, median of >= 5 loops
         assert 'rotated over' in d['config']['workload'] and r['timer'].startswith('hipExtLaunchKernel') and (r['rocprofv3'] is None or 0.3 < r['rocprofv3']['frac'] < 1.0)
         assert d['roofline_fwd']['kernel'] == 'm1s_pool_fwd_kernel' and 0.2 < d['roofline_fwd']['frac'] < 1.0
         if '--no-cpu-baseline' not in extra:
