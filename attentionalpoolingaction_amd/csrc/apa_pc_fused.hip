@@ -121,9 +121,10 @@ __global__ __launch_bounds__(256) void pc_fwd_zt_kernel(
   // sustains only ~25-30 GB/s of global_load_dwordx4 traffic whatever level serves it (the figure that
   // makes 256 CUs x 24.6 GB/s the chip's 6.3 TB/s copy ceiling).  A fourth form with the A fragments
   // loaded straight from global memory per wave (16 rows x 64-byte pieces per instruction, only the slab
-  // through LDS, 32 MFMAs per barrier) measured 35.5 us: fragment-shaped loads are worse still.  The way
-  // down is the LDS-DMA path for the slab (58-90 GB/s per CU in the GEMM kernels of apa_gemm_bf16.hip),
-  // which needs the A operand on that path too (the compiler drains the DMA queue at every VGPR load).
+  // through LDS, 32 MFMAs per barrier) measured 35.5 us: fragment-shaped loads are worse still.  The
+  // LDS-DMA form below (pc_fwd_zt_dma_kernel, the default) moves the same bytes in 21.9 us: ~34 GB/s per
+  // CU, the same figure the DMA-staged GEMMs reach -- the limit is per-CU ingest, whatever the path.  This
+  // register-staged kernel stays as the APA_PC_ZT_DMA=0 arm.
   extern __shared__ __attribute__((aligned(16))) short smem[];
   constexpr int A_EL = BM * LDA, B_EL = 128 * LDK;
   constexpr int NA = TRAIN ? 2 : 1;             // A images per buffer: plain [, masked]
@@ -252,6 +253,143 @@ __global__ __launch_bounds__(256) void pc_fwd_zt_kernel(
         if (half == 0) Z[(size_t)row * 64 + col] = v;
         else if (col < K) T[(size_t)row * K + col] = v;
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Forward, LDS-DMA form (round 2, the default): same tile (32 rows x 128 columns, all of C) as
+// pc_fwd_zt_kernel, but every operand byte reaches LDS by global_load_lds_dwordx4 (no VGPR round trip, no
+// ds_write pass, no masked second image).  Each block still has to pull 128 KB of X plus the whole 512 KB
+// weight slab; measured 24.0 -> 21.9 us (N = 32): ~34 GB/s per CU, which is what the DMA-staged GEMMs
+// reach as well -- per-CU ingest, not the path, is the limit, and the next step would have to cut the
+// bytes per CU (k-split with a resident slab quarter) at the price of fp32 partials for the next pass.
+// How it is built:
+//   * the DMA is issued from inline asm, so hipcc does not drain the queue before every LDS read: a ring
+//     of THREE 40 KB stages (128 channels of A and of the slab each), tile t+2 in flight while tile t is
+//     multiplied, one counted `s_waitcnt vmcnt(5)` + raw s_barrier per stage (vmcnt counts in issue order,
+//     the compiler's own stores in between only make the wait more conservative);
+//   * dropout never touches the A image: the keep decisions of a stage (32 rows x 16 bytes) are hashed one
+//     stage ahead by the whole block (one byte per thread; they depend on the element index only), parked
+//     in 512 bytes of LDS and stored to the bit map; the two T waves of a row tile zero the dropped
+//     elements of their A FRAGMENTS in registers (8 ALU per fragment), the Z waves use the fragment as is.
+// 8 waves: (half: Z | T) x (32-column group) x (16-row tile); 8 MFMAs and 12 ds_read_b128 per wave and stage.
+// Images are unpadded [row][64 k] (128-byte rows, the DMA writes 1 KiB runs) with the XOR swizzle of
+// apa_gemm_bf16.hip in the per-lane source address and in the fragment reads.
+// ---------------------------------------------------------------------------------------------
+constexpr int ZB_KT = 128;                               // channels per stage
+constexpr int ZB_A_EL = 32 * ZB_KT;                      // 4096 shorts (8 KB): two [32][64] sub-images
+constexpr int ZB_B_EL = 128 * ZB_KT;                     // 16384 shorts (32 KB): two [128][64] tiles
+constexpr int ZB_STAGE_EL = ZB_A_EL + ZB_B_EL;           // 40 KB
+constexpr int ZB_NST = 3;
+constexpr size_t ZB_LDS_BYTES = (size_t)ZB_NST * ZB_STAGE_EL * 2 + 2 * 512;
+
+__device__ __forceinline__ void glds16_asm(const void* gsrc, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ bf16x8 frag_sw64(const short* img, int rbase, int ks, int lane) {
+  const int row = rbase + (lane & 15);
+  const int chunk = (ks * 4 + (lane >> 4)) ^ ((row >> 1) & 7);
+  return *reinterpret_cast<const bf16x8*>(img + row * 64 + chunk * 8);
+}
+
+template <bool TRAIN>
+__global__ __launch_bounds__(512) void pc_fwd_zt_dma_kernel(
+    const bf16_t* __restrict__ X, const bf16_t* __restrict__ WcatT, const float* __restrict__ bcat,
+    float* __restrict__ Z, float* __restrict__ T, uint8_t* __restrict__ maskbits, int R, int C, int K,
+    float inv_keep, uint32_t thresh, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev) {
+  extern __shared__ __attribute__((aligned(16))) short smem[];
+  typedef __attribute__((address_space(3))) void* lptr;
+  uint8_t* const s_bits = reinterpret_cast<uint8_t*>(smem + ZB_NST * ZB_STAGE_EL);   // [2][32 rows][4 kb][4]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = wave >> 2, wn = (wave >> 1) & 1, mt = wave & 1;
+  const int l16 = lane & 15, kb = lane >> 4;
+  const int m0 = blockIdx.x * 32;
+  const int nkt = C / ZB_KT;
+  uint32_t k0 = 0, k1 = 0;
+  if (TRAIN) rng_key_dev(seed, offset_dev ? *offset_dev : offset, k0, k1);
+
+  // per-lane DMA sources of this wave's five 1 KiB blocks of a stage: A block `wave` (sub-image wave >> 2,
+  // rows 8 (wave & 3) ..), slab blocks 4 wave .. 4 wave + 3 (tile (4 wave + j) >> 4, rows 8 ((4 wave + j) & 15) ..)
+  const bf16_t* asrc;
+  const bf16_t* bsrc[4];
+  {
+    const int row = 8 * (wave & 3) + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    asrc = X + (size_t)min(m0 + row, R - 1) * C + (wave >> 2) * 64 + chunk * 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int blk = 4 * wave + j, n = 8 * (blk & 15) + (lane >> 3);
+      bsrc[j] = WcatT + (size_t)(blk >> 4) * (128 * 64) + n * 64 + ((lane & 7) ^ ((n >> 1) & 7)) * 8;
+    }
+  }
+  const uint32_t lds0 = (uint32_t)(size_t)(lptr)smem;
+  auto issue = [&](int t) {
+    const uint32_t st = lds0 + (uint32_t)((t % ZB_NST) * ZB_STAGE_EL * 2);
+    glds16_asm(asrc + (size_t)t * ZB_KT, st + (uint32_t)wave * 1024u);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      glds16_asm(bsrc[j] + (size_t)t * (2 * 128 * 64), st + (uint32_t)(ZB_A_EL * 2) + (uint32_t)(4 * wave + j) * 1024u);
+  };
+  // keep decisions of stage t: thread -> (row = tid >> 4, 8-channel chunk c = tid & 15 of the stage)
+  auto make_bits = [&](int t) {
+    const int row = tid >> 4, c = tid & 15;
+    const uint64_t e = (uint64_t)min(m0 + row, R - 1) * C + (uint64_t)t * ZB_KT + c * 8;
+    const uint32_t kb8 = keep_bits8(e, k0, k1, thresh);
+    // fragment (sub-image s, k step ks, lane group kb) holds chunk c = 8 s + 4 ks + kb: byte [row][kb][2 s + ks]
+    s_bits[(t & 1) * 512 + row * 16 + (c & 3) * 4 + (c >> 2)] = (uint8_t)kb8;
+    const uint32_t b1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)kb8, 0x39, 0xf, 0xf, true);   // lane + 1
+    const uint32_t b2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)kb8, 0x4E, 0xf, 0xf, true);   // lane + 2
+    const uint32_t b3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)kb8, 0x93, 0xf, 0xf, true);   // lane + 3
+    if ((c & 3) == 0 && m0 + row < R)
+      *reinterpret_cast<uint32_t*>(maskbits + (e >> 3)) = kb8 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+  };
+
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  issue(0);
+  if (nkt > 1) issue(1);
+  if (TRAIN) make_bits(0);
+  for (int t = 0; t < nkt; ++t) {
+    // tile t has landed once at most the five pieces of tile t+1 are outstanding; the barrier publishes
+    // everybody's pieces and the bits, and says that stage (t+2) % 3 (read in iteration t-1) is free
+    if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (t + 2 < nkt) issue(t + 2);
+    if (TRAIN && t + 1 < nkt) make_bits(t + 1);
+    const short* a_img = smem + (t % ZB_NST) * ZB_STAGE_EL;
+    const short* b_img = a_img + ZB_A_EL;
+    uint32_t mb = 0;
+    if (TRAIN && half) mb = *reinterpret_cast<const uint32_t*>(s_bits + (t & 1) * 512 + (mt * 16 + l16) * 16 + kb * 4);
+#pragma unroll
+    for (int sk = 0; sk < 4; ++sk) {   // sk = 2 s + ks
+      bf16x8 af = frag_sw64(a_img + (sk >> 1) * (32 * 64), mt * 16, sk & 1, lane);
+      if (TRAIN && half) {
+        const uint4 m = apply_bits8(*reinterpret_cast<const uint4*>(&af), (mb >> (8 * sk)) & 0xffu);
+        af = *reinterpret_cast<const bf16x8*>(&m);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bf16x8 bf = frag_sw64(b_img + (sk >> 1) * (128 * 64), half * 64 + wn * 32 + j * 16, sk & 1, lane);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[j], 0, 0, 0);
+      }
+    }
+  }
+  // D layout of the 16x16 MFMA: row = 4 * (lane >> 4) + reg, col = lane & 15
+  const float scale = (TRAIN && half) ? inv_keep : 1.0f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = wn * 32 + j * 16 + l16;       // within the half
+    const float bias = bcat[half * 64 + col];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + mt * 16 + 4 * kb + r;
+      if (row >= R) continue;
+      const float v = fmaf(acc[j][r], scale, bias);
+      if (half == 0) Z[(size_t)row * 64 + col] = v;
+      else if (col < K) T[(size_t)row * K + col] = v;
     }
   }
 }
@@ -417,6 +555,28 @@ int pc_fused_prep(const PcFusedWs& f, const float* Wa, const float* Wt, const fl
 
 int pc_fused_forward(const PcFusedWs& f, const void* X, float* Z, float* T, int R, int C, int K, bool train,
                      float keep_prob, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, hipStream_t st) {
+  static const int dma_env = [] { const char* e = getenv("APA_PC_ZT_DMA"); return e ? atoi(e) : 1; }();
+  if (dma_env && C % ZB_KT == 0) {
+    const float ik = train ? 1.0f / keep_prob : 1.0f;
+    const bf16_t* xx = static_cast<const bf16_t*>(X);
+    const bf16_t* ww = static_cast<const bf16_t*>(f.WcatT);
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+      APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_fwd_zt_dma_kernel<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_BYTES));
+      APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_fwd_zt_dma_kernel<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_BYTES));
+      attr_set = true;
+    }
+    if (train)
+      hipLaunchKernelGGL(pc_fwd_zt_dma_kernel<true>, dim3((R + 31) / 32), dim3(512), ZB_LDS_BYTES, st, xx, ww,
+                         f.bcat, Z, T, f.maskbits, R, C, K, ik, keep_thresh(keep_prob), seed, offset, offset_dev);
+    else
+      hipLaunchKernelGGL(pc_fwd_zt_dma_kernel<false>, dim3((R + 31) / 32), dim3(512), ZB_LDS_BYTES, st, xx, ww,
+                         f.bcat, Z, T, f.maskbits, R, C, K, ik, keep_thresh(keep_prob), seed, offset, offset_dev);
+    APA_LAUNCH_CHECK("pc_fwd_zt_dma_kernel");
+    return APA_OK;
+  }
   static const int bm_env = [] { const char* e = getenv("APA_PC_BM"); return e ? atoi(e) : 0; }();
   // 64-row tiles re-read the 512 KB weight slab half as often; 32-row tiles cover more CUs when the
   // batch is small (R / 64 < 200 blocks)
