@@ -264,6 +264,13 @@ __global__ __launch_bounds__(256) void pc_fwd_zt_kernel(
 // weight slab; measured 24.0 -> 21.9 us (N = 32): ~34 GB/s per CU, which is what the DMA-staged GEMMs
 // reach as well -- per-CU ingest, not the path, is the limit, and the next step would have to cut the
 // bytes per CU (k-split with a resident slab quarter) at the price of fp32 partials for the next pass.
+// Measured around it (tools/ingest_bench.hip, all 256 CUs pulling): HBM streams land at 24 GB/s per CU
+// (6.2 TB/s) whatever the path, L2 hits at 75-130 GB/s per CU.  Without dropout this kernel takes 13.2 us
+// (50 GB/s per CU, 84 % of the bytes are slab re-reads from L2); the remaining 8.7 us are the dropout work
+// itself -- the hash (one per element pair, ~2.8 us), zeroing the T waves' fragments (~2.5 us) and the
+// bit bookkeeping -- which adds to every stage's barrier-to-barrier chain instead of hiding under the DMA.
+// A deeper A ring (7 stages, issued by dedicated waves so that vmcnt never mixes HBM and L2 requests)
+// changed nothing (22.9 us) and was dropped.
 // How it is built:
 //   * the DMA is issued from inline asm, so hipcc does not drain the queue before every LDS read: a ring
 //     of THREE 40 KB stages (128 channels of A and of the slab each), tile t+2 in flight while tile t is
