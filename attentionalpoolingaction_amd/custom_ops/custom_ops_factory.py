@@ -387,8 +387,10 @@ def dropout_mask(shape, keep_prob, seed, offset, device='cuda') -> torch.Tensor:
 # --------------------------------------------------------------------------------------------
 # PoseLogits head (nets_factory.py:147-160)
 # --------------------------------------------------------------------------------------------
-def pose_head_fwd(X, W1, b1, W2, b2, workspace=None):
-    """Ppre [..,Cp] (dtype of X), Pl [..,J] f32, workspace = pose_head_fwd(X [N,P,C] or [N,H,W,C], ...)."""
+def pose_head_fwd(X, W1, b1, W2, b2, workspace=None, out=None):
+    """Ppre [..,Cp] (dtype of X), Pl [..,J] f32, workspace = pose_head_fwd(X [N,P,C] or [N,H,W,C], ...).
+    `out=(Ppre, Pl)`: write into these caller-owned buffers (fixed addresses, e.g. for a HeadTrainStep
+    bound to Ppre as its attention input)."""
     lib = load_library()
     N, C = X.shape[0], X.shape[-1]
     P = X.numel() // (N * C)
@@ -397,8 +399,16 @@ def pose_head_fwd(X, W1, b1, W2, b2, workspace=None):
     need = int(lib.apa_pose_head_workspace_bytes(N, P, C, Cp, J, dt))
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty((max(need, 16),), dtype=torch.uint8, device=X.device)
-    Ppre = torch.empty(tuple(X.shape[:-1]) + (Cp,), dtype=X.dtype, device=X.device)
-    Pl = torch.empty(tuple(X.shape[:-1]) + (J,), dtype=torch.float32, device=X.device)
+    if out is not None:
+        Ppre, Pl = out
+        if Ppre.dtype != X.dtype or Ppre.numel() != N * P * Cp or Pl.dtype != torch.float32 or Pl.numel() != N * P * J:
+            raise ApaError('pose_head_fwd: out=(Ppre, Pl) must be {} [N*P*{}] and float32 [N*P*{}]'.format(
+                X.dtype, Cp, J))
+        _dev_ptr(Ppre, 'Ppre', X.dtype)
+        _dev_ptr(Pl, 'Pl', torch.float32)
+    else:
+        Ppre = torch.empty(tuple(X.shape[:-1]) + (Cp,), dtype=X.dtype, device=X.device)
+        Pl = torch.empty(tuple(X.shape[:-1]) + (J,), dtype=torch.float32, device=X.device)
     rc = lib.apa_pose_head_fwd(
         _dev_ptr(X, 'X'), _dev_ptr(W1, 'W1', torch.float32), _dev_ptr(b1, 'b1', torch.float32),
         _dev_ptr(W2, 'W2', torch.float32), _dev_ptr(b2, 'b2', torch.float32), Ppre.data_ptr(),
@@ -696,16 +706,24 @@ class HeadTrainStep:
     Outputs live in the attributes `logits [N,K]`, `att [N,P,M]`, `zsave`, `abar`, `loss [1+N]`,
     `G [N,K]`, and in the gradient buffers passed as `grads = (dX, dXatt, dWa, dba, dWt, dbt)`
     (e.g. views into a flat data-parallel bucket).  `offset`: int, or a 1-element int64 CUDA tensor
-    (device-side dropout counter, advanced by the backward pass)."""
+    (device-side dropout counter, advanced by the backward pass).  `dxatt_rank1=True` (separate attention
+    input, M == 1): grads[1] is dZ, float32 [N*P] (APA_FLAG_DXATT_RANK1) -- the form
+    pose_head_bwd(ext_rank1=(dZ, wa)) consumes."""
 
     def __init__(self, X, Xatt, Wa, ba, Wt, bt, labels, grads, *, flags=0, keep_prob=1.0, seed=0,
-                 offset=0, loss_wt=1.0, grad_scale=1.0, workspace=None, hooks=None):
+                 offset=0, loss_wt=1.0, grad_scale=1.0, workspace=None, hooks=None, dxatt_rank1=False):
         self.lib = load_library()
         N, C = X.shape[0], X.shape[-1]
         P = X.numel() // (N * C)
         Ca, M, K = Xatt.shape[-1], Wa.shape[1], Wt.shape[1]
         dev = X.device
         fused = Xatt is X
+        if dxatt_rank1:     # cfg 003: `dXatt` receives dZ, f32 [N*P]; dXatt = dZ (x) Wa is left to the consumer
+            if fused or M != 1:
+                raise ApaError('HeadTrainStep: dxatt_rank1 needs a separate attention input and M == 1')
+            if grads[1].dtype != torch.float32 or grads[1].numel() != N * P:
+                raise ApaError('HeadTrainStep: dxatt_rank1 wants grads[1] = dZ, float32 [N*P]')
+            flags |= APA_FLAG_DXATT_RANK1
         dX, dXatt, dWa, dba, dWt, dbt = grads
         self.hooks = hooks            # default apa_hooks of run(); kept alive here
         self.logits = torch.empty((N, K), dtype=torch.float32, device=dev)
@@ -727,7 +745,8 @@ class HeadTrainStep:
             _dev_ptr(labels, 'labels', torch.int64), float(loss_wt), float(grad_scale),
             self.logits.data_ptr(), self.att.data_ptr(), self.zsave.data_ptr(), _dev_ptr(self.abar, 'abar'),
             self.loss.data_ptr(), self.G.data_ptr(), _dev_ptr(dX, 'dX', X.dtype),
-            None if fused else _dev_ptr(dXatt, 'dXatt', X.dtype), _dev_ptr(dWa, 'dWa', torch.float32),
+            None if fused else _dev_ptr(dXatt, 'dXatt', torch.float32 if dxatt_rank1 else X.dtype),
+            _dev_ptr(dWa, 'dWa', torch.float32),
             _dev_ptr(dba, 'dba', torch.float32), _dev_ptr(dWt, 'dWt', torch.float32),
             _dev_ptr(dbt, 'dbt', torch.float32), workspace.data_ptr(), workspace.numel(), N, P, C, Ca, K, M,
             flags, float(keep_prob), int(seed), off, _feat_dtype(X)]

@@ -116,6 +116,60 @@ def test_cfg003_pose_regularised_attention_end_to_end(gpu):
         assert _rel(got, want) < 1e-4, name
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_cfg003_one_call_attention_step_equals_the_separate_calls(gpu, dtype):
+    """cfg 003 as tools/bench_dense.py drives it: pose_head_fwd into caller-owned buffers, HeadTrainStep
+    bound to Ppre as its attention input with the attention-branch gradient in rank-1 form, then
+    pose_head_bwd(ext_rank1).  Every result must be bit-identical to the per-op sequence (same kernels
+    apart from the fused logits-reduce + cross-entropy launch, whose reduction trees are the same)."""
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    N, H, C, Cp, J, K = 4, 7, 2048, 768, 16, 393
+    P = H * H
+    X, W1, b1, W2, b2, g = _pose_problem(N, H, C, Cp, J, seed=71, dtype=dtype)
+    Wa = torch.randn(Cp, 1, generator=g) / Cp ** 0.5
+    ba = torch.randn(1, generator=g) * 0.1
+    Wt = torch.randn(C, K, generator=g) / C ** 0.5
+    bt = torch.randn(K, generator=g) * 0.1
+    labels = torch.randint(0, K, (N,), generator=g)
+    pose_lbl = torch.rand(N, H, H, J, generator=g)
+    valid = torch.rand(N, J, generator=g) > 0.3
+    d = lambda t: t.to(gpu).contiguous()
+    Xd, W1d, b1d, W2d, b2d, Wad, bad, Wtd, btd, lab = map(d, (X.view(N, P, C), W1, b1, W2, b2, Wa, ba, Wt, bt, labels))
+    flags = cof.attn_flags(False, False, True)
+    kw = dict(flags=flags, keep_prob=0.5, seed=9, offset=4)
+
+    # per-op sequence
+    Ppre, Pl, pws = cof.pose_head_fwd(Xd, W1d, b1d, W2d, b2d)
+    logits, att, zs, ab, _, ws = cof.attn_pool_fwd(Xd, Ppre, Wad, bad, Wtd, btd, **kw)
+    lossx, G, _, _ = cof.softmax_xent_fwd_bwd(logits, lab)
+    _, dPl = cof.pose_l2_loss_fwd_bwd(Pl, d(pose_lbl), d(valid))
+    dX, dZ, dWa, dba, dWt, dbt = cof.attn_pool_bwd(Xd, Ppre, Wad, bad, Wtd, btd, att, zs, ab, G, workspace=ws,
+                                                   dxatt_rank1=True, **kw)
+    want = cof.pose_head_bwd(Xd, W1d, W2d, Ppre, dPl, None, dX=dX, accumulate_dX=True, workspace=pws,
+                             ext_rank1=(dZ, Wad.view(-1)))
+
+    # the bench's form
+    Ppre2 = torch.empty((N, P, Cp), dtype=dtype, device=gpu)
+    Pl2 = torch.empty((N, P, J), dtype=torch.float32, device=gpu)
+    grads = (torch.empty_like(Xd), torch.empty((N * P,), dtype=torch.float32, device=gpu), torch.empty_like(Wad),
+             torch.empty_like(bad), torch.empty_like(Wtd), torch.empty_like(btd))
+    head = cof.HeadTrainStep(Xd, Ppre2, Wad, bad, Wtd, btd, lab, grads, dxatt_rank1=True, **kw)
+    _, _, pws2 = cof.pose_head_fwd(Xd, W1d, b1d, W2d, b2d, out=(Ppre2, Pl2))
+    _, dPl2 = cof.pose_l2_loss_fwd_bwd(Pl2, d(pose_lbl), d(valid))
+    head.run()
+    got = cof.pose_head_bwd(Xd, W1d, W2d, Ppre2, dPl2, None, dX=grads[0], accumulate_dX=True, workspace=pws2,
+                            ws_from_fwd=True, ext_rank1=(grads[1], Wad.view(-1)))
+    assert torch.equal(Ppre2, Ppre) and torch.equal(Pl2, Pl)
+    assert torch.equal(head.logits, logits) and torch.equal(head.loss, lossx) and torch.equal(head.G, G)
+    for name, a, b in (('dZ', grads[1], dZ), ('dWa', grads[2], dWa), ('dba', grads[3], dba), ('dWt', grads[4], dWt),
+                       ('dbt', grads[5], dbt)):
+        assert torch.equal(a, b), name
+    for name, a, b in zip(('dX', 'dW1', 'db1', 'dW2', 'db2'), got, want):
+        assert torch.equal(a, b), name
+    with pytest.raises(cof.ApaError):
+        cof.HeadTrainStep(Xd, Xd, Wtd[:, :1].contiguous(), bad, Wtd, btd, lab, grads, dxatt_rank1=True)
+
+
 def _pc_problem(N, H, C, K, seed, Ca=None, dtype=torch.float32):
     g = torch.Generator().manual_seed(seed)
     Ca = C if Ca is None else Ca

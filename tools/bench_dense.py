@@ -48,25 +48,37 @@ def build_cfg003(cof, dev, N=32, H=14, K=393, dtype='bf16', rank1=True):
     valid = (torch.rand(N, J, generator=g) > 0.3).to(dev)
     flags = cof.attn_flags(False, False, True)
     ctr = torch.zeros(1, dtype=torch.int64, device=dev)
-    state = {'pws': None, 'aws': None}
+    state = {'pws': None}
     wa_flat = Wa.view(-1)
+    # caller-owned activations and gradients: the attention part of the step (pooling forward, softmax
+    # cross-entropy, pooling backward) is ONE host call bound to them (cof.HeadTrainStep, the call the
+    # headline configuration uses); its attention input is the pose head's Ppre, its attention-branch
+    # gradient crosses back to the pose head in rank-1 form (dZ, wa)
+    Ppre = torch.empty((N, P, Cp), dtype=td, device=dev)
+    Pl = torch.empty((N, P, J), dtype=torch.float32, device=dev)
+    dX = torch.empty_like(X)
+    dZ = torch.empty((N * P,), dtype=torch.float32, device=dev)
+    grads = (dX, dZ, torch.empty_like(Wa), torch.empty_like(ba), torch.empty_like(Wt), torch.empty_like(bt))
+    if rank1:
+        head = cof.HeadTrainStep(X, Ppre, Wa, ba, Wt, bt, labels, grads, flags=flags, keep_prob=0.2, seed=42,
+                                 offset=ctr, dxatt_rank1=True)
 
     def step():
-        Ppre, Pl, state['pws'] = cof.pose_head_fwd(X, W1, b1, W2, b2, workspace=state['pws'])
-        logits, att, zs, ab, _, state['aws'] = cof.attn_pool_fwd(X, Ppre, Wa, ba, Wt, bt, flags=flags,
-                                                                 keep_prob=0.2, seed=42, offset=ctr,
-                                                                 workspace=state['aws'])
-        _, G, _, _ = cof.softmax_xent_fwd_bwd(logits, labels)
+        _, _, state['pws'] = cof.pose_head_fwd(X, W1, b1, W2, b2, workspace=state['pws'], out=(Ppre, Pl))
         _, dPl = cof.pose_l2_loss_fwd_bwd(Pl, lbl, valid)
-        # the attention-branch gradient crosses to the pose head in rank-1 form (dZ, wa)
-        dX, dZ, *_ = cof.attn_pool_bwd(X, Ppre, Wa, ba, Wt, bt, att, zs, ab, G, flags=flags, keep_prob=0.2,
-                                       seed=42, offset=ctr, workspace=state['aws'], dxatt_rank1=rank1)
-        if not rank1:
-            cof.pose_head_bwd(X, W1, W2, Ppre, dPl, dZ, dX=dX, accumulate_dX=True, workspace=state['pws'],
-                              ws_from_fwd=True)
-        else:
+        if rank1:
+            head.run()
             cof.pose_head_bwd(X, W1, W2, Ppre, dPl, None, dX=dX, accumulate_dX=True, workspace=state['pws'],
                               ws_from_fwd=True, ext_rank1=(dZ, wa_flat))
+            return
+        logits, att, zs, ab, _, state['aws'] = cof.attn_pool_fwd(X, Ppre, Wa, ba, Wt, bt, flags=flags,
+                                                                 keep_prob=0.2, seed=42, offset=ctr,
+                                                                 workspace=state.get('aws'))
+        _, G, _, _ = cof.softmax_xent_fwd_bwd(logits, labels)
+        dXs, dXatt, *_ = cof.attn_pool_bwd(X, Ppre, Wa, ba, Wt, bt, att, zs, ab, G, flags=flags, keep_prob=0.2,
+                                           seed=42, offset=ctr, workspace=state['aws'])
+        cof.pose_head_bwd(X, W1, W2, Ppre, dPl, dXatt, dX=dXs, accumulate_dX=True, workspace=state['pws'],
+                          ws_from_fwd=True)
 
     info = {'workload': 'cfg003 pose-regularised attention head fwd+bwd (pose head 2048->768->16 + M=1 '
                         'pooling + pose L2 + softmax-xent); per-GPU batch {} x {}x{}x{} {}, K={}, dropout '
