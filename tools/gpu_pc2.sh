@@ -1,6 +1,5 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 cd $R
-for e in 0 16 32 64 48 112; do
-echo "exp=$e"; APA_PC_EXP=$e bash tools/prof_dense.sh pcdma --workload perclass 2>&1 | grep -E "pc_fwd_zt"
-done
+APA_PC_EXP=1 bash tools/prof_dense.sh pcdx --workload perclass 2>&1 | grep -E "pc_dx|gemm_bf16"
+APA_PC_EXP=1 APA_PC_DX=0 bash tools/prof_dense.sh pcdx --workload perclass 2>&1 | grep -E "pc_dx|gemm_bf16"
