@@ -233,6 +233,22 @@ __global__ __launch_bounds__(256) void zero_out_channels_kernel(const float* __r
     out[i] = ch[i % C] ? in[i] : 0.f;
 }
 
+// dX[n,p,c..c+3] = dz[n,c..c+3] / P: one 16-byte (fp32) or 8-byte (bf16) store per thread and element group
+template <typename T>
+__global__ __launch_bounds__(256) void spatial_mean_bwd_kernel(const float* __restrict__ dz, T* __restrict__ dX,
+                                                               size_t total4, int P, int C4, float invP) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+    const size_t np = i / C4;
+    const int c4 = (int)(i - np * C4);
+    const float4 g = *reinterpret_cast<const float4*>(dz + ((np / P) * C4 + c4) * 4);
+    const float4 v = make_float4(g.x * invP, g.y * invP, g.z * invP, g.w * invP);
+    if constexpr (sizeof(T) == 2)
+      *reinterpret_cast<uint2*>(dX + i * 4) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    else
+      *reinterpret_cast<float4*>(dX + i * 4) = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ mask,
                                                            size_t n_elems, uint32_t thresh,
                                                            uint32_t k0, uint32_t k1) {
@@ -334,6 +350,33 @@ extern "C" int apa_zero_out_channels(const float* in, const uint8_t* channels, f
   hipLaunchKernelGGL(zero_out_channels_kernel, dim3((unsigned)nb), dim3(256), 0,
                      static_cast<hipStream_t>(stream), in, channels, out, total, C);
   APA_LAUNCH_CHECK("zero_out_channels_kernel");
+  return APA_OK;
+}
+
+extern "C" int apa_spatial_mean_bwd(const float* dz, void* dX, int N, int P, int C, int dtype, void* stream) {
+  if (!dz || !dX || N <= 0 || P <= 0 || C <= 0) {
+    set_error("apa_spatial_mean_bwd: null pointer or non-positive dimension");
+    return APA_ERR_INVALID_ARG;
+  }
+  if (dtype != APA_DTYPE_F32 && dtype != APA_DTYPE_BF16) {
+    set_error("apa_spatial_mean_bwd: unknown dtype %d", dtype);
+    return APA_ERR_INVALID_ARG;
+  }
+  if (C % 4 != 0 || (reinterpret_cast<uintptr_t>(dz) & 15) || (reinterpret_cast<uintptr_t>(dX) & 15)) {
+    set_error("apa_spatial_mean_bwd: C=%d must be a multiple of 4 and both buffers 16-byte aligned", C);
+    return APA_ERR_UNSUPPORTED;
+  }
+  const size_t total4 = (size_t)N * P * (C / 4);
+  size_t nb = (total4 + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == APA_DTYPE_BF16)
+    hipLaunchKernelGGL(spatial_mean_bwd_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, st, dz,
+                       static_cast<bf16_t*>(dX), total4, P, C / 4, 1.0f / (float)P);
+  else
+    hipLaunchKernelGGL(spatial_mean_bwd_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, dz,
+                       static_cast<float*>(dX), total4, P, C / 4, 1.0f / (float)P);
+  APA_LAUNCH_CHECK("spatial_mean_bwd_kernel");
   return APA_OK;
 }
 

@@ -66,6 +66,7 @@ _SIGNATURES = {
     'apa_pose_to_heatmap_out_ht': (c_int64, [c_int64, c_int64, c_int64]),
     'apa_pose_to_heatmap': (c_int, [POINTER(c_int64), c_int64, c_int64, c_int64, c_int64, c_int,
                                     c_float, c_int, POINTER(c_float), POINTER(c_uint8)]),
+    'apa_spatial_mean_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'apa_zero_out_channels': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     'apa_pose_label_replay_resize': (c_int, [POINTER(c_uint8)] + [c_int] * 11 + [c_float, POINTER(c_float)]),
     'apa_pose_labels_device': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int,
@@ -595,6 +596,21 @@ def pose_to_heatmap_float(pose_label, im_ht, im_wd, out_wd, out_channels=16, mar
         hm.ctypes.data_as(POINTER(c_float)), valid.ctypes.data_as(POINTER(c_uint8)))
     _check(rc, 'apa_pose_to_heatmap')
     return hm, valid.astype(bool)
+
+
+def spatial_mean_bwd(dz: torch.Tensor, shape, dtype) -> torch.Tensor:
+    """dX [N,..,C] (`dtype`) = dz [N,C] / P broadcast over the spatial positions: backward of the global
+    average pool of the attention-free head (cfg 001)."""
+    lib = load_library()
+    N, C = int(shape[0]), int(shape[-1])
+    P = 1
+    for d in shape[1:-1]:
+        P *= int(d)
+    dX = torch.empty(tuple(shape), dtype=dtype, device=dz.device)
+    rc = lib.apa_spatial_mean_bwd(_dev_ptr(dz, 'dz', torch.float32), dX.data_ptr(), N, P, C, _feat_dtype(dX),
+                                  _stream_ptr())
+    _check(rc, 'apa_spatial_mean_bwd')
+    return dX
 
 
 def zero_out_channels(to_zero: torch.Tensor, channels: torch.Tensor) -> torch.Tensor:

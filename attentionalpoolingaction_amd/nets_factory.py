@@ -458,13 +458,36 @@ class AttentionalPoolingHead(nn.Module):
         return logits, end_points
 
 
+class SpatialMeanFunction(torch.autograd.Function):
+    """z [N,C] f32 = mean over the spatial positions of X [N,H,W,C] (resnet_v1.py:206-208), in HIP both ways:
+    forward = the pooling pass with a constant attention map (one streaming read of X; its `zsave` output),
+    backward = apa_spatial_mean_bwd (one streaming write)."""
+
+    @staticmethod
+    def forward(ctx, X):
+        n, C = X.shape[0], X.shape[-1]
+        dev = X.device
+        ones_in = torch.zeros(tuple(X.shape[:-1]) + (8,), device=dev, dtype=X.dtype)
+        _, _, z, _, _, _ = cof.attn_pool_fwd(X.contiguous(), ones_in, torch.zeros(8, 1, device=dev),
+                                             torch.ones(1, device=dev), torch.zeros(C, 1, device=dev),
+                                             torch.zeros(1, device=dev))
+        ctx.x_shape, ctx.x_dtype = tuple(X.shape), X.dtype
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        return cof.spatial_mean_bwd(dz.contiguous().float(), ctx.x_shape, ctx.x_dtype)
+
+
 class BaselineHead(nn.Module):
     """cfg 001 (`experiments/001_MPII_ResNet.yaml`, no attention): the slim ResNet's own head --
     global average pool, dropout, 1x1 conv `resnet_v1_101/logits` (models/slim/nets/resnet_v1.py:206-217
     with the dropout of nets_factory.py:143-146 forwarded as dropout_keep_prob).  Not the hot path: it is
     the plumbing baseline of BASELINE configs[0].  In eval mode it IS the attentional-pooling op with
-    a constant attention map (mean_p X . W + b, one streaming pass in HIP); in training the dropout
-    sits between the pooled vector and the classifier, so the [N,C]-sized tail is torch ops."""
+    a constant attention map (mean_p X . W + b, one streaming pass in HIP).  In training the dropout
+    sits between the pooled vector and the classifier: the pooled vector z comes from SpatialMeanFunction,
+    and dropout + classifier are the pooling op again on z seen as a 1 x 1 map (P = 1: its dropout on the
+    "features" is the dropout on z, same counter-based mask stream, `cof.dropout_mask((N, C), ...)`)."""
 
     TF_NAMES = {'logits_weights': 'logits/weights', 'logits_biases': 'logits/biases'}
 
@@ -492,11 +515,14 @@ class BaselineHead(nn.Module):
     def forward(self, last_conv: torch.Tensor):
         n, h, w = last_conv.shape[0], last_conv.shape[1], last_conv.shape[2]
         if self.is_training and self.keep_prob < 1.0:
-            z = last_conv.float().mean(dim=(1, 2))
-            g = torch.Generator(device=z.device).manual_seed(self.seed * 1000003 + self._step)
-            self._step += 1
-            keep = torch.rand(z.shape, generator=g, device=z.device) < self.keep_prob
-            logits = (z * keep / self.keep_prob) @ self.logits_weights + self.logits_biases
+            z = SpatialMeanFunction.apply(last_conv)                    # [N, C] f32
+            offset = self._step
+            self._step += 1            # a fresh dropout mask per step
+            dev = z.device
+            logits, _, _ = attentional_pooling(
+                z.view(n, 1, 1, -1), torch.zeros(n, 1, 1, 8, device=dev), torch.zeros(8, 1, device=dev),
+                torch.ones(1, device=dev), self.logits_weights, self.logits_biases, is_training=True,
+                keep_prob=self.keep_prob, seed=self.seed, offset=offset)
         else:
             ones_in = torch.zeros(n, h, w, 8, device=last_conv.device, dtype=last_conv.dtype)
             logits, _, _ = attentional_pooling(

@@ -296,6 +296,11 @@ int apa_frame_pool_bwd(const float* logits, const float* w, const float* tatt, c
                        float* dlogits, float* dw, float* db, float* dlda_ws, int B, int F, int K,
                        void* stream);
 
+/* Backward of the global average pool of the attention-free head (cfg 001, resnet_v1.py:206-208
+ * `tf.reduce_mean(net, [1, 2])`):  dX[n,p,c] = dz[n,c] / P.   dz f32 [N,C]; dX dtype [N,P,C].
+ * (The forward pool is apa_attn_pool_fwd with a constant attention map: its zsave output.) */
+int apa_spatial_mean_bwd(const float* dz, void* dX, int N, int P, int C, int dtype, void* stream);
+
 /* zero_out_channels.cc:18-51:  out[n,h,w,c] = channels[c] ? in[n,h,w,c] : 0   (f32, device). */
 int apa_zero_out_channels(const float* in, const uint8_t* channels, float* out, size_t n_outer,
                           int C, void* stream);

@@ -992,11 +992,32 @@ def test_cfg001_baseline_head_matches_oracle(gpu):
     assert _rel(logits.detach().cpu().numpy(), ref.numpy()) < 2e-5 and 'Logits' in ep
     logits.sum().backward()
     assert _rel(Xd.grad.cpu().numpy(), np.broadcast_to((w.sum(1) / 225.0).numpy(), (1, 15, 15, 2048))) < 5e-5
-    # training mode: dropout on the pooled vector (keep 0.2), unbiased in expectation
+    # training mode: dropout on the pooled vector (keep 0.2), in HIP both ways -- the oracle is handed the
+    # op's own mask (the counter-based stream over the N*C pooled elements, one offset per step)
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
     fnt = nets_factory.get_network_fn('resnet_v1_101', 393, 16, cfg, is_training=True, device=gpu)
     fnt.head.load_state_dict(fn.head.state_dict())
-    acc = sum(fnt(X.to(gpu))[0].detach() for _ in range(200)) / 200
+    fnt.head._step = 0
+    X2 = torch.relu(torch.randn(3, 7, 7, 2048, generator=g))
+    for step in range(2):
+        Xt = X2.to(gpu).requires_grad_(True)
+        lt, _ = fnt(Xt)
+        mask = cof.dropout_mask((3, 1, 1, 2048), fnt.head.keep_prob, fnt.head.seed, step, device=gpu).cpu()
+        assert 0.1 < float(mask.float().mean()) < 0.3
+        Xr = X2.double().requires_grad_(True)
+        ref_t = orc.baseline_avgpool_logits(Xr, w, b, True, fnt.head.keep_prob, mask.double())
+        assert _rel(lt.detach().cpu().numpy(), ref_t.detach().numpy()) < 2e-5, step
+        wsum = torch.randn(3, 393, generator=g)
+        (lt * wsum.to(gpu)).sum().backward()
+        (ref_t * wsum.double()).sum().backward()
+        assert _rel(Xt.grad.cpu().numpy(), Xr.grad.numpy()) < 5e-5, step
+    assert fnt.head.get_extra_state()['dropout_step'] == 2
+    acc = sum(fnt(X.to(gpu))[0].detach() for _ in range(200)) / 200      # unbiased in expectation
     assert float((acc.cpu() - logits.detach().cpu()).abs().max()) < 0.25 * float(logits.detach().abs().max()) + 0.05
+    # bf16 features: the backward writes the feature dtype
+    Xb = X2.to(gpu).bfloat16().requires_grad_(True)
+    fnt(Xb)[0].sum().backward()
+    assert Xb.grad.dtype == torch.bfloat16 and bool(torch.isfinite(Xb.grad.float()).all())
     apa_config.reset_cfg()
 
 
