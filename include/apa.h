@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define APA_VERSION 200 /* major*10000 + minor*100 + patch */
+#define APA_VERSION 201 /* major*10000 + minor*100 + patch */
 
 typedef enum apa_status {
   APA_OK = 0,
