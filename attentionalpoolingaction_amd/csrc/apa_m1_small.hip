@@ -236,9 +236,13 @@ __global__ __launch_bounds__(256) void m1_logits_xent_kernel(
 constexpr int B_ZST = 80;   // Zs[32][80]  (64 c columns): == 16 (mod 32)
 constexpr int B_GST = 144;  // Gs[32][144] (128 k columns): == 16 (mod 32)
 
-__host__ __device__ inline int dz_kp(int K) {  // smallest Kp >= K with Kp == 2 (mod 32)
+// smallest Kp == 2 (mod 32) that covers K rounded up to whole 4-wide MFMA k steps: the role-A loop reads
+// columns up to 4 * ceil(K / 4) - 1 of a row, and they have to be that row's zero padding (with Kp >= K
+// only, K = 1, 2 (mod 32) -- K = 2, 33, 34, 513 ... -- read the first columns of the NEXT row)
+__host__ __device__ inline int dz_kp(int K) {
+  const int need = (K + 3) & ~3;
   int kp = (K / 32) * 32 + 2;
-  while (kp < K) kp += 32;
+  while (kp < need) kp += 32;
   return kp;
 }
 
@@ -315,12 +319,15 @@ __global__ __launch_bounds__(256) void m1_bwd_small_kernel(
       __syncthreads();  // previous tile's Gs / red readers are done
       fill_rows_flat<MAXV>(Gs, G + (size_t)n0 * K, min(32, N - n0), 32, K, Kp, tid);
       __syncthreads();
-      // sn[n] = G[n,:] . bt for the streaming pass: block b serves row n0 + b of this tile
-      if (wave == 0 && (int)blockIdx.x < 32 && n0 + (int)blockIdx.x < N) {
-        float acc = 0.f;
-        for (int k = lane; k < K; k += 64) acc = fmaf(Gs[blockIdx.x * Kp + k], bt[k], acc);
-        acc = wave_sum(acc);
-        if (lane == 0) sn[n0 + blockIdx.x] = acc;
+      // sn[n] = G[n,:] . bt for the streaming pass: block b serves rows n0 + b, n0 + b + nA, ... of this
+      // tile (fewer than 32 role-A blocks when C < 512)
+      if (wave == 0) {
+        for (int rr = blockIdx.x; rr < 32 && n0 + rr < N; rr += nA) {
+          float acc = 0.f;
+          for (int k = lane; k < K; k += 64) acc = fmaf(Gs[rr * Kp + k], bt[k], acc);
+          acc = wave_sum(acc);
+          if (lane == 0) sn[n0 + rr] = acc;
+        }
       }
       f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
       const float* g0 = &Gs[r * Kp + kq];

@@ -134,6 +134,26 @@ def test_m1_any_channel_count_generic_kernels(gpu, C, softmax, relu, train):
     _grads_close(got, ref, ('dX', 'dWa', 'dba', 'dWt', 'dbt'))
 
 
+@pytest.mark.parametrize('N,H,C,K,softmax,relu', [
+    (20, 5, 256, 7, False, True),      # C < 512: fewer than 32 role-A blocks have to cover 32 rows of sn
+    (3, 7, 1280, 2, False, True),      # K = 2: Kp must still cover one whole 4-wide MFMA k step
+    (4, 3, 1280, 513, True, False),    # K = 1 (mod 32), more than 4 dbt columns per block
+    (5, 4, 256, 33, False, False), (5, 4, 256, 34, True, False), (2, 3, 512, 1, False, False)])
+def test_m1_backward_fallback_kernel_shapes_found_by_the_random_sweep(gpu, N, H, C, K, softmax, relu):
+    """Shapes on which m1_bwd_small_kernel (the backward head for C < 512, K < 4 or many dbt columns per
+    block) was wrong until tools/fuzz_attn_pool.py found them: its LDS rows were padded to Kp >= K only, so
+    for K = 1, 2 (mod 32) the last MFMA k step read the next row; and with C / 16 < 32 blocks only the first
+    C / 16 rows of every 32-row tile received sn = G . bt.  dX / dWa / dba were off by up to 300x."""
+    inp = make_head_inputs(N=N, H=H, W=H, C=C, K=K, seed=N + K)
+    flags = orc.AttnFlags(single_layer_att=True, softmax_att=softmax, relu_att=relu)
+    ref = _oracle(inp, flags)
+    got = _run_hip(inp, gpu, softmax=softmax, relu=relu)
+    _close(got['logits'], ref['logits'], TIGHT, 'logits')
+    floor = 1e-6 * float(ref['dWt'].abs().max())
+    for k in ('dX', 'dWa', 'dba', 'dWt', 'dbt'):
+        _close(got[k].reshape(ref[k].shape), ref[k], 5e-5, k, atol=floor)
+
+
 def test_m1_generic_kernels_separate_attention_input_bf16(gpu):
     """generic arm, cfg 003 wiring (attention map from a 200-channel tensor), bf16 features, C = 1000"""
     inp = make_head_inputs(N=2, H=6, W=6, C=1000, K=10, Ca=200, seed=3)
