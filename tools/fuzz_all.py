@@ -1,0 +1,246 @@
+"""Random-shape sweeps of the entry points beyond tools/fuzz_attn_pool.py (tools, not tests: run through
+gpurun when kernels change).  python tools/fuzz_all.py [cases-per-family] [seed] [families]
+families: step (one-call train / eval step == per-op sequence, bit for bit), xent, perclass, pose, bf16m1"""
+import random
+import sys
+import time
+import traceback
+
+import torch
+
+sys.path.insert(0, '.')
+from oracle import attn_pool_oracle as orc                      # noqa: E402
+from tests import test_attn_pool_gpu as T                       # noqa: E402
+from tests import test_dense_gpu as D                           # noqa: E402
+from tests._synth import make_head_inputs                       # noqa: E402
+from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof   # noqa: E402
+
+gpu = torch.device('cuda:0')
+LAST = None
+
+
+def rel(a, b):
+    a = a.detach().cpu().double().reshape(-1)
+    b = b.detach().cpu().double().reshape(-1)
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+
+
+def fam_step(rnd, i):
+    """HeadTrainStep / HeadEvalStep against the per-op sequence: identical bits."""
+    C = rnd.choice([256, 512, 832, 1024, 1280, 2048])
+    K = rnd.choice([1, 2, 3, 4, 7, 33, 51, 64, 129, 393, 512, 513, 600, 700])
+    N = rnd.choice([1, 2, 5, 16, 17, 32, 33, 64, 65, 130, 300])
+    P = rnd.choice([1, 2, 9, 49, 100, 196, 225])
+    while N * P * C > 6e7:
+        N = max(1, N // 2)
+    dtype = rnd.choice([torch.float32, torch.bfloat16])
+    Ca = rnd.choice([None, None, 8, 200, 768])
+    softmax, relu = rnd.choice([(False, False), (True, False), (False, True)])
+    train = rnd.random() < 0.7
+    global LAST
+    LAST = desc = dict(N=N, P=P, C=C, K=K, Ca=Ca, dtype=str(dtype), softmax=softmax, relu=relu, train=train)
+    g = torch.Generator().manual_seed(100 + i)
+    X = torch.relu(torch.randn(N, P, C, generator=g)).to(dtype).to(gpu)
+    Xa = X if Ca is None else torch.relu(torch.randn(N, P, Ca, generator=g)).to(dtype).to(gpu)
+    ca = C if Ca is None else Ca
+    Wa = (torch.randn(ca, 1, generator=g) / ca ** 0.5).to(gpu)
+    ba = torch.full((1,), 0.1, device=gpu)
+    Wt = (torch.randn(C, K, generator=g) / C ** 0.5).to(gpu)
+    bt = (torch.randn(K, generator=g) * 0.1).to(gpu)
+    labels = torch.randint(0, K, (N,), generator=g).to(gpu)
+    flags = cof.attn_flags(softmax, relu, train)
+    kw = dict(flags=flags, keep_prob=0.5, seed=7, offset=3)
+
+    def grads():
+        return (torch.empty_like(X), None if Ca is None else torch.empty_like(Xa), torch.empty_like(Wa),
+                torch.empty_like(ba), torch.empty_like(Wt), torch.empty_like(bt))
+    ga, gb = grads(), grads()
+    st = cof.HeadTrainStep(X, Xa, Wa, ba, Wt, bt, labels, ga, grad_scale=0.5, **kw)
+    st.run()
+    logits, att, zsave, abar, _, ws = cof.attn_pool_fwd(X, Xa, Wa, ba, Wt, bt, **kw)
+    loss, G, _, _ = cof.softmax_xent_fwd_bwd(logits, labels, grad_scale=0.5)
+    cof.attn_pool_bwd(X, Xa, Wa, ba, Wt, bt, att, zsave, abar, G, workspace=ws, out=gb, **kw)
+    torch.cuda.synchronize()
+    pairs = [(st.logits, logits, 'logits'), (st.att, att, 'att'), (st.loss, loss, 'loss'), (st.G, G, 'G'),
+             (ga[0], gb[0], 'dX'), (ga[2], gb[2], 'dWa'), (ga[3], gb[3], 'dba'), (ga[4], gb[4], 'dWt'),
+             (ga[5], gb[5], 'dbt')]
+    if Ca is not None:
+        pairs.append((ga[1], gb[1], 'dXatt'))
+    for a, b, name in pairs:
+        assert torch.equal(a, b), 'train step ' + name
+    assert bool(torch.isfinite(ga[0].float()).all()) and bool(torch.isfinite(ga[4]).all())
+    ev = cof.HeadEvalStep(X, Xa, Wa, ba, Wt, bt, labels, flags=flags)
+    ev.run()
+    l2, a2, *_ = cof.attn_pool_fwd(X, Xa, Wa, ba, Wt, bt, flags=flags & ~cof.APA_FLAG_TRAIN)
+    lo2, _, pr2, pd2 = cof.softmax_xent_fwd_bwd(l2, labels, want_grad=False, want_probs=True, want_pred=True)
+    torch.cuda.synchronize()
+    for a, b, name in ((ev.logits, l2, 'logits'), (ev.att, a2, 'att'), (ev.probs, pr2, 'probs'), (ev.pred, pd2, 'pred'),
+                       (ev.loss, lo2, 'loss')):
+        assert torch.equal(a, b), 'eval step ' + name
+    return desc
+
+
+def fam_xent(rnd, i):
+    N = rnd.choice([1, 2, 3, 31, 32, 33, 63, 64, 65, 127, 200, 513, 700])
+    K = rnd.choice([1, 2, 3, 4, 5, 7, 8, 51, 127, 128, 129, 393, 511, 512, 513, 1023, 1024, 1025, 2000])
+    global LAST
+    LAST = dict(N=N, K=K)
+    g = torch.Generator().manual_seed(N * 1000 + K + i)
+    lg = torch.randn(N, K, generator=g) * rnd.choice([0.1, 3.0, 20.0])
+    lab = torch.randint(0, K, (N,), generator=g)
+    ref_lp = torch.log_softmax(lg.double(), dim=1)
+    ref_loss = -ref_lp[torch.arange(N), lab].mean()
+    ref_G = (ref_lp.exp() - torch.nn.functional.one_hot(lab, K)) / N
+    lb, G, probs, pred = cof.softmax_xent_fwd_bwd(lg.to(gpu), lab.to(gpu), want_probs=True, want_pred=True)
+    assert abs(float(lb[0]) - float(ref_loss)) < 3e-6 * max(1.0, float(ref_loss)), 'loss'
+    assert rel(G, ref_G) < 1e-5, 'G'
+    assert rel(probs, ref_lp.exp()) < 1e-5, 'probs'
+    assert torch.equal(pred.cpu(), lg.argmax(1)), 'pred'
+    return dict(N=N, K=K)
+
+
+def fam_perclass(rnd, i):
+    C = rnd.choice([256, 512, 1024, 2048])
+    K = rnd.choice([2, 3, 7, 16, 51, 64, 65, 101, 130, 393])      # (K = 1 is the M == 1 op)
+    N = rnd.choice([1, 2, 3, 8, 20, 33])
+    H = rnd.choice([1, 2, 5, 7, 14, 15])
+    while N * H * H * C * K > 3e9:
+        N = max(1, N // 2)
+        if N == 1:
+            K = max(1, K // 2)
+    softmax, relu = rnd.choice([(False, False), (True, False), (False, True)])
+    bf16 = rnd.random() < 0.5
+    train = rnd.random() < 0.5
+    Ca = rnd.choice([None, None, None, 96])
+    global LAST
+    LAST = desc = dict(N=N, H=H, C=C, K=K, softmax=softmax, relu=relu, bf16=bf16, train=train, Ca=Ca)
+    dt = torch.bfloat16 if bf16 else torch.float32
+    X, Xatt, Wa, ba, Wt, bt, labels = D._pc_problem(N, H, C, K, seed=300 + i, Ca=Ca, dtype=dt)
+    keep, seed, offset = 0.5, 21 + i, i % 3
+    mask = cof.dropout_mask(tuple(X.shape), keep, seed, offset).cpu() if train else None
+    leaf = lambda t: t.double().clone().requires_grad_(True)    # noqa: E731
+    Xr = leaf(X)
+    Xar = None if Xatt is X else leaf(Xatt)
+    War, Wtr = (leaf(Wa.bfloat16()), leaf(Wt.bfloat16())) if bf16 else (leaf(Wa), leaf(Wt))
+    bar, btr = leaf(ba), leaf(bt)
+    flags = orc.AttnFlags(single_layer_att=Xatt is X, per_class=True, softmax_att=softmax, relu_att=relu)
+    lg, ep = orc.attentional_pooling(Xr, Xar, None, [War], [bar], [Wtr], [btr], flags, is_training=train,
+                                     keep_prob=keep, dropout_mask=mask)
+    orc.action_softmax_xent(lg, labels, K).backward()
+    logits, att, _, loss, pred, (dX, dXatt, dWa, dba, dWt, dbt) = D._pc_run(
+        gpu, X, Xatt, Wa, ba, Wt, bt, labels, softmax, relu, train=train, keep=keep, seed=seed, offset=offset)
+    tl, tg = (3e-3, 4e-2) if bf16 else (2e-5, 1e-4)
+    assert rel(logits, lg) < tl or float((logits.cpu().double() - lg.detach()).abs().max()) < (5e-3 if bf16 else 1e-5), 'logits'
+    floor = 1e-5 * float(Wtr.grad.abs().max())
+    for name, got, want in (('dX', dX, Xr.grad), ('dWa', dWa, War.grad), ('dWt', dWt, Wtr.grad),
+                            ('dbt', dbt, btr.grad)) + ((('dXatt', dXatt, Xar.grad),) if Xar is not None else ()):
+        e = float((got.cpu().double().reshape(-1) - want.reshape(-1)).abs().max())
+        assert e <= tg * float(want.abs().max()) + floor, '{} err {:.2e} scale {:.2e}'.format(name, e, float(want.abs().max()))
+    return desc
+
+
+def fam_pose(rnd, i):
+    C = rnd.choice([256, 512, 2048])
+    Cp = rnd.choice([64, 200, 256, 768, 1024, 1280])
+    J = rnd.choice([1, 7, 16, 20])
+    N = rnd.choice([1, 2, 3, 9])
+    H = rnd.choice([1, 3, 5, 7, 14])
+    bf16 = rnd.random() < 0.4
+    mode = rnd.choice(['dpl', 'ext', 'both', 'rank1'])
+    global LAST
+    LAST = desc = dict(N=N, H=H, C=C, Cp=Cp, J=J, bf16=bf16, mode=mode)
+    dt = torch.bfloat16 if bf16 else torch.float32
+    X, W1, b1, W2, b2, g = D._pose_problem(N, H, C, Cp, J, seed=500 + i, dtype=dt)
+    dPl = torch.randn(N, H, H, J, generator=g)
+    row = torch.randn(N * H * H, generator=g)
+    col = torch.randn(Cp, generator=g)
+    dExt = torch.randn(N, H, H, Cp, generator=g).to(dt)
+    leaf = lambda t: t.double().clone().requires_grad_(True)    # noqa: E731
+    Xr, b1r, W2r, b2r = leaf(X), leaf(b1), leaf(W2), leaf(b2)
+    W1r = leaf(W1.bfloat16() if bf16 else W1)
+    pre, pl = orc.pose_logits_head(Xr, W1r, b1r, W2r, b2r)
+    tot = 0
+    if mode in ('dpl', 'both', 'rank1'):
+        tot = tot + (pl * dPl.double()).sum()
+    if mode in ('ext', 'both'):
+        tot = tot + (pre * dExt.double()).sum()
+    if mode == 'rank1':
+        tot = tot + (pre * (row.double().view(N, H, H, 1) * col.double())).sum()
+    tot.backward()
+    d = lambda t: t.to(gpu).contiguous()                        # noqa: E731
+    Ppre, Pl, ws = cof.pose_head_fwd(d(X), d(W1), d(b1), d(W2), d(b2))
+    assert rel(Ppre, pre) < (2 ** -7 if bf16 else 3e-5), 'Ppre'
+    if int(((Ppre.cpu().double() > 0) != (pre.detach() > 0)).sum()) > 0:
+        return desc     # a ReLU gate sits within rounding of 0: kernel and float64 oracle legitimately differ there
+    assert rel(Pl, pl) < (2e-2 if bf16 else 3e-5) or float((Pl.cpu().double() - pl.detach()).abs().max()) < (2e-2 if bf16 else 1e-6), 'Pl'
+    a_dpl = d(dPl) if mode != 'ext' else None
+    a_ext = d(dExt) if mode in ('ext', 'both') else None
+    r1 = (d(row), d(col)) if mode == 'rank1' else None
+    dX, dW1, db1, dW2, db2 = cof.pose_head_bwd(d(X), d(W1), d(W2), Ppre, a_dpl, a_ext, workspace=ws, ext_rank1=r1)
+    tol = 4e-2 if bf16 else 1e-4
+    floor = 1e-5 * float(W1r.grad.abs().max())
+    for name, got, want in (('dX', dX, Xr.grad), ('dW1', dW1, W1r.grad), ('db1', db1, b1r.grad),
+                            ('dW2', dW2, W2r.grad), ('db2', db2, b2r.grad)):
+        if want is None:
+            assert float(got.abs().max()) == 0.0, name
+            continue
+        e = float((got.cpu().double().reshape(-1) - want.reshape(-1)).abs().max())
+        assert e <= tol * float(want.abs().max()) + floor, '{} err {:.2e} scale {:.2e}'.format(name, e, float(want.abs().max()))
+    return desc
+
+
+def fam_bf16m1(rnd, i):
+    C = rnd.choice([512, 1000, 1024, 2048])
+    K = rnd.choice([2, 10, 51, 393, 513])
+    N = rnd.choice([1, 3, 8, 33])
+    H, W = rnd.choice([1, 3, 7, 14]), rnd.choice([1, 7, 15])
+    Ca = rnd.choice([None, None, 200, 768])
+    softmax, relu = rnd.choice([(False, False), (True, False), (False, True)])
+    train = rnd.random() < 0.5
+    global LAST
+    LAST = desc = dict(N=N, H=H, W=W, C=C, K=K, Ca=Ca, softmax=softmax, relu=relu, train=train)
+    inp = make_head_inputs(N=N, H=H, W=W, C=C, K=K, Ca=Ca, seed=700 + i)
+    fused = inp['Xatt'] is inp['X']
+    inp['X'] = inp['X'].bfloat16().float()
+    inp['Xatt'] = inp['X'] if fused else inp['Xatt'].bfloat16().float()
+    keep, seed, offset = 0.5, 5 + i, 1
+    mask = cof.dropout_mask(tuple(inp['X'].shape), keep, seed, offset).cpu() if train else None
+    flags = orc.AttnFlags(single_layer_att=fused, softmax_att=softmax, relu_att=relu)
+    ref = T._oracle(inp, flags, train=train, keep=keep, mask=mask)
+    bf = dict(inp)
+    bf['X'] = inp['X'].bfloat16()
+    bf['Xatt'] = bf['X'] if fused else inp['Xatt'].bfloat16()
+    got = T._run_hip(bf, gpu, softmax=softmax, relu=relu, train=train, keep=keep, seed=seed, offset=offset)
+    T._close(got['logits'], ref['logits'], 1e-4, 'logits')
+    floor = 1e-5 * float(ref['dWt'].abs().max())
+    for k in ('dWa', 'dWt', 'dbt'):
+        T._close(got[k].reshape(ref[k].shape), ref[k], 2e-4, k, atol=floor)
+    T._close(got['dX'].float().reshape(ref['dX'].shape), ref['dX'], 2.0 ** -7, 'dX (bf16 store)', atol=floor)
+    if not fused:
+        T._close(got['dXatt'].float().reshape(ref['dXatt'].shape), ref['dXatt'], 2.0 ** -7, 'dXatt', atol=floor)
+    return desc
+
+
+FAMILIES = {'step': fam_step, 'xent': fam_xent, 'perclass': fam_perclass, 'pose': fam_pose, 'bf16m1': fam_bf16m1}
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    fams = sys.argv[3].split(',') if len(sys.argv) > 3 else list(FAMILIES)
+    for name in fams:
+        rnd = random.Random(seed * 131 + len(name))
+        bad, t0 = 0, time.time()
+        for i in range(cases):
+            try:
+                FAMILIES[name](rnd, i)
+            except Exception as e:                               # noqa: BLE001
+                bad += 1
+                print('FAIL', name, i, LAST, type(e).__name__, str(e)[:200])
+                if not isinstance(e, AssertionError):
+                    traceback.print_exc(limit=3)
+        print('{}: {} cases, {} failed, {:.0f} s'.format(name, cases, bad, time.time() - t0), flush=True)
+
+
+if __name__ == '__main__':
+    main()
