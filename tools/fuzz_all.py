@@ -221,7 +221,105 @@ def fam_bf16m1(rnd, i):
     return desc
 
 
-FAMILIES = {'step': fam_step, 'xent': fam_xent, 'perclass': fam_perclass, 'pose': fam_pose, 'bf16m1': fam_bf16m1}
+def fam_catfeat(rnd, i):
+    """module level: ..._WITH_POSE_FEAT[_2LAYER] through apa_attn_pool_{fwd,bwd}_cat for odd N / H / K / J"""
+    from attentionalpoolingaction_amd import config as apa_config, nets_factory
+    single_layer, two_layer, train = rnd.random() < 0.5, rnd.random() < 0.4, rnd.random() < 0.5
+    N, H = rnd.choice([2, 3, 5]), rnd.choice([2, 3, 7, 14, 15])
+    K, J = rnd.choice([2, 7, 51, 130, 393]), rnd.choice([1, 3, 7, 16, 20])
+    global LAST
+    LAST = desc = dict(N=N, H=H, K=K, J=J, single_layer=single_layer, two_layer=two_layer, train=train)
+    C = 2048
+    cfg = apa_config.reset_cfg()
+    apa_config.cfg_from_dict({'MODEL_NAME': 'resnet_v1_101', 'NET': {
+        'USE_POSE_PRELOGITS_BASED_ATTENTION': True,
+        'USE_POSE_PRELOGITS_BASED_ATTENTION_SINGLE_LAYER_ATT': single_layer,
+        'USE_POSE_PRELOGITS_BASED_ATTENTION_WITH_POSE_FEAT': True,
+        'USE_POSE_PRELOGITS_BASED_ATTENTION_WITH_POSE_FEAT_2LAYER': two_layer}})
+    fn = nets_factory.get_network_fn('resnet_v1_101', K, J, cfg, is_training=train, device=gpu)
+    head = fn.head
+    g = torch.Generator().manual_seed(900 + i)
+    with torch.no_grad():
+        for name, p in head.named_parameters():
+            if p.dim() >= 2 and p.shape[0] > 1:
+                p.copy_(torch.randn(p.shape, generator=g) / p.shape[0] ** 0.5)
+            elif p.dim() >= 2:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.5 + 1.0)
+            else:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+        if two_layer:
+            head.pose_feat_bn_gamma.copy_(torch.rand(J, generator=g) + 0.5)
+    X = torch.relu(torch.randn(N, H, H, C, generator=g))
+    labels = torch.randint(0, K, (N,), generator=g)
+    Xd = X.to(gpu).requires_grad_(True)
+    step0 = head._step
+    logits, ep = fn(Xd)
+    torch.nn.functional.cross_entropy(logits, labels.to(gpu)).backward()
+    mask = None
+    if train:
+        m = cof.dropout_mask((N * H * H * (C + J),), head.keep_prob, head.seed, step0).cpu()
+        mask = torch.cat([m[:N * H * H * C].view(N, H, H, C), m[N * H * H * C:].view(N, H, H, J)], dim=-1)
+    p = {k: v.detach().cpu().double().requires_grad_(True) for k, v in head.named_parameters()}
+    Xr = X.double().requires_grad_(True)
+    pre, pl = orc.pose_logits_head(Xr, p['pose_w1'], p['pose_b1'], p['pose_w2'], p['pose_b2'])
+    lr, _ = orc.attentional_pooling(
+        Xr, pre, pl, [p['att_weights']], [p['att_biases']], [p['td_weights']], [p['td_biases']],
+        orc.AttnFlags(single_layer_att=single_layer, with_pose_feat=True, with_pose_feat_2layer=two_layer),
+        is_training=train, keep_prob=head.keep_prob, dropout_mask=mask,
+        pose_feat_w=p.get('pose_feat_weights'),
+        pose_feat_bn=(p['pose_feat_bn_gamma'], p['pose_feat_bn_beta']) if two_layer else None)
+    torch.nn.functional.cross_entropy(lr, labels).backward()
+    apa_config.reset_cfg()
+    assert rel(logits, lr) < 5e-5, 'logits'
+    assert rel(ep['PoseLogits'], pl) < 5e-5, 'PoseLogits'
+    floor = 1e-5 * float(p['td_weights'].grad.abs().max())
+    for k in ['td_weights', 'td_biases', 'att_weights', 'pose_w2', 'pose_w1'] + (['pose_feat_weights'] if two_layer else []):
+        want, got = p[k].grad, getattr(head, k).grad
+        e = float((got.cpu().double().reshape(-1) - want.reshape(-1)).abs().max())
+        assert e <= 1e-3 * float(want.abs().max()) + floor, '{} err {:.2e} scale {:.2e}'.format(k, e, float(want.abs().max()))
+    e = float((Xd.grad.cpu().double() - Xr.grad).abs().max())
+    assert e <= 1e-3 * float(Xr.grad.abs().max()) + floor, 'dX err {:.2e} scale {:.2e}'.format(e, float(Xr.grad.abs().max()))
+    return desc
+
+
+def fam_losses(rnd, i):
+    """pose L2 (+ its gradient), frame pooling fwd/bwd for odd shapes"""
+    N, P, J = rnd.choice([1, 2, 5, 32, 33, 70]), rnd.choice([1, 9, 49, 196, 225]), rnd.choice([1, 7, 16, 20])
+    global LAST
+    LAST = desc = dict(N=N, P=P, J=J)
+    g = torch.Generator().manual_seed(40 + i)
+    Pl = torch.randn(N, P, J, generator=g)
+    lbl = torch.rand(N, P, J, generator=g)
+    valid = torch.rand(N, J, generator=g) > 0.3
+    Plr = Pl.double().requires_grad_(True)
+    H = int(P ** 0.5)
+    if H * H == P:
+        ref = orc.pose_l2_loss(Plr.view(N, H, H, J), lbl.double().view(N, H, H, J), valid, 1.0)
+        ref.backward()
+        loss, dPl = cof.pose_l2_loss_fwd_bwd(Pl.to(gpu), lbl.to(gpu), valid.to(gpu))
+        assert abs(float(loss[0]) - float(ref.detach())) <= 2e-5 * abs(float(ref.detach())) + 1e-12, 'pose l2 loss'
+        assert rel(dPl, Plr.grad) < 2e-5 or float(Plr.grad.abs().max()) == 0.0, 'pose l2 grad'
+    B, F, K = rnd.choice([1, 2, 5, 9]), rnd.choice([1, 2, 3, 8]), rnd.choice([1, 7, 51, 393])
+    LAST = desc = dict(desc, B=B, F=F, K=K)
+    lg = torch.randn(B * F, K, generator=g)
+    w, b = torch.randn(K, generator=g) * 0.1, torch.randn(1, generator=g)
+    lgr, wr, br = lg.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    use_att = rnd.random() < 0.7
+    pooled_ref, _ = orc.frame_pooling(lgr, F, wr.view(K, 1) if use_att else None, br if use_att else None)
+    dpo = torch.randn(B, K, generator=g)
+    (pooled_ref * dpo.double()).sum().backward()
+    wd, bd = (w.to(gpu), b.to(gpu)) if use_att else (None, None)
+    pooled, tatt = cof.frame_pool_fwd(lg.to(gpu), F, wd, bd)
+    assert rel(pooled, pooled_ref) < 2e-5, 'frame pool fwd'
+    dlg, dw, db = cof.frame_pool_bwd(lg.to(gpu), F, wd, tatt, dpo.to(gpu))
+    assert rel(dlg, lgr.grad) < 5e-5, 'frame pool dlogits'
+    if use_att:
+        assert rel(dw, wr.grad) < 5e-5 and rel(db, br.grad) < 5e-5, 'frame pool dw/db'
+    return desc
+
+
+FAMILIES = {'step': fam_step, 'xent': fam_xent, 'perclass': fam_perclass, 'pose': fam_pose, 'bf16m1': fam_bf16m1,
+            'catfeat': fam_catfeat, 'losses': fam_losses}
 
 
 def main():

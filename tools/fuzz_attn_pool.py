@@ -56,6 +56,7 @@ def main():
             if not isinstance(e, AssertionError):
                 traceback.print_exc(limit=2)
     print('{} cases, {} failed, {:.0f} s'.format(cases, bad, time.time() - t0))
+    return bad
 
 
 if __name__ == '__main__':
