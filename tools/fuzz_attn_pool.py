@@ -22,8 +22,8 @@ def main():
     t0 = time.time()
     for i in range(cases):
         C = rnd.choice([8, 16, 64, 96, 256, 512, 832, 1000, 1024, 1280, 2048, 2064, 4096])
-        K = rnd.choice([1, 2, 7, 16, 51, 64, 101, 393, 400, 513, 600])
-        N = rnd.choice([1, 2, 3, 5, 8, 17, 32, 40])
+        K = rnd.choice([1, 2, 7, 16, 33, 51, 64, 101, 393, 400, 513, 600, 833, 1000, 2049, 5000])
+        N = rnd.choice([1, 2, 3, 5, 8, 17, 32, 40, 65, 130, 600])
         H, W = rnd.choice([1, 2, 3, 7, 14, 15, 20]), rnd.choice([1, 2, 7, 14, 15])
         while N * H * W * C * K > 6e9:
             N = max(1, N // 2)
