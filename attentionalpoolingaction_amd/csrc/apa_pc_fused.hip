@@ -10,19 +10,20 @@
 // GEMMs and dX as two GEMMs with a read-modify-write in between: ten passes over map-sized tensors.
 // Here the map is read ONCE per product group and dX is written once:
 //
-//   pc_fwd_zt_kernel   Z | T  = X . [Wa | Wt]        one pass over X.  The A tile goes through registers on
-//                                                    its way to LDS and is stored TWICE: as it is (the Z
-//                                                    columns read this image) and with the dropped
-//                                                    elements zeroed (the T columns read that one); the
-//                                                    1/keep scale is applied to the fp32 accumulators.
+//   pc_fwd_zt_dma_kernel  Z | T  = X . [Wa | Wt]     one pass over X, every operand byte by LDS-DMA (3-stage
+//                                                    ring); the T waves zero the dropped elements of their A
+//                                                    FRAGMENTS in registers from keep bits hashed one stage
+//                                                    ahead; the 1/keep scale goes on the fp32 accumulators.
+//   (pc_fwd_zt_kernel: the register-staged predecessor -- plain and masked A images in LDS -- kept as the
+//    APA_PC_ZT_DMA=0 arm.)
 //   pc_bwd_dw_kernel   dWt | dWa = [Xd | X]^T . [dT | dZ]   one pass over X (k-major operand, transposing
 //                                                    LDS reads), same two-image trick, split over the rows.
 //   dX                 = (dT . Wt^T) * mask/keep + dZ . Wa^T   ONE launch of the DMA-staged GEMM
 //                                                    (apa_gemm_bf16.hip) over the concatenated operands
 //                                                    [dT | dZ] . [Wt | Wa]^T: the accumulators are masked
 //                                                    in registers between the two 64-deep k tiles.
-// The dropout mask is the library's counter-based one (flat element index r*C + c), regenerated where it
-// is needed -- never stored.
+// The dropout mask is the library's counter-based one (flat element index r*C + c); the forward pass leaves
+// its keep decisions behind as a bit map (1/16 of the bf16 map) which the two backward kernels read.
 #include "apa_device.h"
 #include "apa_internal.h"
 
