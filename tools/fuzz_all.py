@@ -270,6 +270,10 @@ def fam_catfeat(rnd, i):
         pose_feat_bn=(p['pose_feat_bn_gamma'], p['pose_feat_bn_beta']) if two_layer else None)
     torch.nn.functional.cross_entropy(lr, labels).backward()
     apa_config.reset_cfg()
+    Ppre_k, _, _ = cof.pose_head_fwd(X.to(gpu), head.pose_w1.detach(), head.pose_b1.detach(), head.pose_w2.detach(),
+                                     head.pose_b2.detach())
+    if int(((Ppre_k.cpu().double() > 0) != (pre.detach() > 0)).sum()) > 0:
+        return desc     # a ReLU gate within rounding of 0 (see fam_pose)
     assert rel(logits, lr) < 5e-5, 'logits'
     assert rel(ep['PoseLogits'], pl) < 5e-5, 'PoseLogits'
     floor = 1e-5 * float(p['td_weights'].grad.abs().max())
