@@ -245,20 +245,21 @@ class AttentionalPoolingHead(nn.Module):
         self.with_pose_feat = bool(net.USE_POSE_PRELOGITS_BASED_ATTENTION_WITH_POSE_FEAT)
         if self.rank < 1:
             raise ValueError('USE_POSE_PRELOGITS_BASED_ATTENTION_RANK must be >= 1')
-        if self.rank > 1 and (net.USE_POSE_PRELOGITS_BASED_ATTENTION_PER_CLASS or
-                              net.USE_POSE_PRELOGITS_BASED_ATTENTION_SOFTMAX_ATT or
-                              net.USE_POSE_PRELOGITS_BASED_ATTENTION_RELU_ATT or want_topdown):
-            # softmax + rank > 1 does not even build in the reference (a 4-entry transpose perm on a
-            # 5-D tensor, nets_factory.py:278); relu / per-class maps / the TopDownAttention dump break
-            # the affine collapse used below and no shipped config selects them
-            raise NotImplementedError('rank > 1 is built for the class-agnostic map without '
-                                      'softmax/relu (nets_factory.py:258-274,298-309,322-328)')
+        if self.rank > 1 and net.USE_POSE_PRELOGITS_BASED_ATTENTION_SOFTMAX_ATT:
+            # does not build in the reference either: a 4-entry transpose perm on the stacked 5-D tensor
+            # (nets_factory.py:271-279)
+            raise ValueError('USE_POSE_PRELOGITS_BASED_ATTENTION_SOFTMAX_ATT with ..._RANK > 1 is not a valid '
+                             'reference configuration (nets_factory.py:271-279)')
         self.pose_feat_2layer = bool(self.with_pose_feat and
                                      net.USE_POSE_PRELOGITS_BASED_ATTENTION_WITH_POSE_FEAT_2LAYER)
-        if self.with_pose_feat and (net.USE_POSE_PRELOGITS_BASED_ATTENTION_PER_CLASS or self.rank > 1
-                                    or want_topdown):
-            raise NotImplementedError('..._WITH_POSE_FEAT is built for the class-agnostic rank-1 map '
+        if self.with_pose_feat and (net.USE_POSE_PRELOGITS_BASED_ATTENTION_PER_CLASS or want_topdown):
+            raise NotImplementedError('..._WITH_POSE_FEAT is built for the class-agnostic map '
                                       '(without the TopDownAttention dump)')
+        # rank > 1: identity activation on ONE map collapses to two streaming passes for any R (forward());
+        # relu / per-class maps / the TopDownAttention dump / the pose features run one pass of the op per rank
+        self.rank_collapsed = bool(self.rank > 1 and not (
+            net.USE_POSE_PRELOGITS_BASED_ATTENTION_PER_CLASS or net.USE_POSE_PRELOGITS_BASED_ATTENTION_RELU_ATT
+            or want_topdown or self.with_pose_feat))
         self.num_classes = num_classes
         self.single_layer = bool(net.USE_POSE_PRELOGITS_BASED_ATTENTION_SINGLE_LAYER_ATT)
         self.softmax_att = bool(net.USE_POSE_PRELOGITS_BASED_ATTENTION_SOFTMAX_ATT)
@@ -306,11 +307,11 @@ class AttentionalPoolingHead(nn.Module):
         # ([M,M] = [1,1] weights, scopes Conv2d_PrePose_Attn1, ...); one more top-down conv per rank
         # (scopes Conv_1, ...)
         self.att_weights_r = nn.ParameterList(
-            [nn.Parameter(torch.randn(1, 1) * 0.001) for _ in range(self.rank - 1)])
+            [nn.Parameter(torch.randn(n_maps, n_maps) * 0.001) for _ in range(self.rank - 1)])
         self.att_biases_r = nn.ParameterList(
-            [nn.Parameter(torch.zeros(1)) for _ in range(self.rank - 1)])
+            [nn.Parameter(torch.zeros(n_maps)) for _ in range(self.rank - 1)])
         self.td_weights_r = nn.ParameterList(
-            [nn.Parameter(torch.randn(in_channels, num_classes) * 0.001) for _ in range(self.rank - 1)])
+            [nn.Parameter(torch.randn(td_in, num_classes) * 0.001) for _ in range(self.rank - 1)])
         self.td_biases_r = nn.ParameterList(
             [nn.Parameter(torch.zeros(num_classes)) for _ in range(self.rank - 1)])
 
@@ -396,7 +397,8 @@ class AttentionalPoolingHead(nn.Module):
         kw = dict(softmax_att=self.softmax_att, relu_att=self.relu_att, is_training=self.is_training,
                   keep_prob=self.keep_prob, seed=self.seed, offset=offset)
 
-        if self.rank == 1 and self.with_pose_feat:
+        xext = None
+        if self.with_pose_feat:
             # :289-296: concat(last_conv, pose_logits) -> dropout -> top-down conv.  The J extra channels
             # run through the same HIP op (apa_attn_pool_*_cat): same dropout stream, same attention-
             # weighted mean, their share of dA fed to the streaming backward kernel.
@@ -411,6 +413,7 @@ class AttentionalPoolingHead(nn.Module):
                         self.pose_feat_bn_moving_variance.mul_(0.997).add_(var.detach(), alpha=0.003)
                 y = (y - mean) * torch.rsqrt(var + 1e-5) * self.pose_feat_bn_gamma + self.pose_feat_bn_beta
                 xext = torch.relu(y)
+        if self.rank == 1 and self.with_pose_feat:
             flags = cof.attn_flags(self.softmax_att, self.relu_att, self.is_training)
             logits, att = AttentionalPoolingCatFunction.apply(
                 last_conv, xatt, xext, self.att_weights, self.att_biases, self.td_weights, self.td_biases,
@@ -423,6 +426,37 @@ class AttentionalPoolingHead(nn.Module):
             end_points['PosePrelogitsBasedAttention'] = att.view(n, h, w, -1)    # :287
             if topdown is not None:
                 end_points['TopDownAttention'] = topdown.view(n, h, w, -1)       # :309
+        elif not self.rank_collapsed:
+            # rank R > 1 in general (:258-274, :298-309, :322-328): conv r consumes the output of conv r-1,
+            # so map r is an affine function of the attention input with the effective weights
+            #   Wa_r = Wa_0 W_1 .. W_r,   ba_r = ba_{r-1} W_r + b_r          ([Cin,M] / [M], M = 1 or K)
+            # (tiny products of PARAMETERS, differentiable torch ops); the activation acts on every map
+            # separately and the ranks are summed after the spatial mean -- one pass of the HIP op per rank,
+            # all with the same dropout mask (the reference drops last_conv once, before the rank loop).
+            wa_r, ba_r = self.att_weights, self.att_biases
+            wts = [self.td_weights] + list(self.td_weights_r)
+            bts = [self.td_biases] + list(self.td_biases_r)
+            logits, atts, tds = None, [], []
+            for r in range(self.rank):
+                if r > 0:
+                    wa_r = wa_r @ self.att_weights_r[r - 1]
+                    ba_r = ba_r @ self.att_weights_r[r - 1] + self.att_biases_r[r - 1]
+                if self.with_pose_feat:
+                    flags = cof.attn_flags(self.softmax_att, self.relu_att, self.is_training)
+                    lg_r, att_r = AttentionalPoolingCatFunction.apply(
+                        last_conv, xatt, xext, wa_r, ba_r, wts[r], bts[r], flags,
+                        self.keep_prob if self.is_training else 1.0, self.seed, offset)
+                    td_r = None
+                else:
+                    lg_r, att_r, td_r = attentional_pooling(last_conv, xatt, wa_r, ba_r, wts[r], bts[r],
+                                                            want_topdown=self.want_topdown, **kw)
+                logits = lg_r if logits is None else logits + lg_r
+                atts.append(att_r.view(n, h, w, -1))
+                if td_r is not None:
+                    tds.append(td_r.view(n, h, w, -1))
+            end_points['PosePrelogitsBasedAttention'] = torch.stack(atts, dim=-1)   # [N,H,W,M,R] (:271-274)
+            if tds:
+                end_points['TopDownAttention'] = torch.stack(tds, dim=-1)           # [N,H,W,K,R] (:305-309)
         else:
             # rank R > 1, identity activation, one bottom-up map.  Z_r = Z_{r-1} w_r + b_r with scalar
             # (w_r, b_r), so Z_r = alpha_r Z_0 + beta_r and

@@ -486,6 +486,86 @@ def test_head_module_rank3_matches_oracle(gpu, single_layer):
     apa_config.reset_cfg()
 
 
+@pytest.mark.parametrize('single_layer,relu,per_class,topdown,pose_feat,train', [
+    (True, True, False, False, False, False),     # relu on every stacked map
+    (False, False, True, False, False, True),     # per-class maps from pose_pre_logits, [K,K] chained convs
+    (True, True, True, False, False, False),
+    (True, False, False, True, False, False),     # TopDownAttention dump [N,H,W,K,R]
+    (False, False, False, False, True, True),     # _WITH_POSE_FEAT: every rank's top-down conv sees C + J
+])
+def test_head_module_rank_gt1_general_forms(gpu, single_layer, relu, per_class, topdown, pose_feat, train):
+    """..._RANK > 1 beyond the collapsed identity form: the reference's loop (nets_factory.py:258-274, 298-309,
+    322-328) also admits relu, per-class maps, the end-point dump and the pose features; here one pass of the
+    HIP op per rank with the chained convs folded into effective attention weights.  (softmax + rank > 1 does
+    not build in the reference.)"""
+    from attentionalpoolingaction_amd import config as apa_config
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    R = 2 if pose_feat else 3
+    kw = {'want_topdown': True} if topdown else {}
+    fn, _ = _make_head(gpu, {'USE_POSE_PRELOGITS_BASED_ATTENTION_SINGLE_LAYER_ATT': single_layer,
+                             'USE_POSE_PRELOGITS_BASED_ATTENTION_RANK': R,
+                             'USE_POSE_PRELOGITS_BASED_ATTENTION_RELU_ATT': relu,
+                             'USE_POSE_PRELOGITS_BASED_ATTENTION_PER_CLASS': per_class,
+                             'USE_POSE_PRELOGITS_BASED_ATTENTION_WITH_POSE_FEAT': pose_feat},
+                       is_training=train, **kw)
+    head = fn.head
+    assert not head.rank_collapsed
+    with torch.no_grad():      # chained [M,M] convs near the identity, so that every rank matters
+        for r in range(R - 1):
+            m = head.att_weights_r[r].shape[0]
+            head.att_weights_r[r].copy_(torch.eye(m) * 0.8 + torch.randn(m, m, generator=torch.Generator().manual_seed(r)) * 0.05)
+    N, H, C, K, J = 2, 7, 2048, 51, 16
+    g = torch.Generator().manual_seed(23)
+    X = torch.relu(torch.randn(N, H, H, C, generator=g))
+    labels = torch.randint(0, K, (N,), generator=g)
+    Xd = X.to(gpu).requires_grad_(True)
+    step0 = head._step
+    logits, ep = fn(Xd)
+    torch.nn.functional.cross_entropy(logits, labels.to(gpu)).backward()
+    mask = None
+    if train:
+        ce = C + (J if pose_feat else 0)
+        m = cof.dropout_mask((N * H * H * ce,), head.keep_prob, head.seed, step0).cpu()
+        mask = m[:N * H * H * C].view(N, H, H, C)
+        if pose_feat:
+            mask = torch.cat([mask, m[N * H * H * C:].view(N, H, H, J)], dim=-1)
+    p = {k: v.detach().cpu().double().requires_grad_(True) for k, v in head.named_parameters()}
+    Xr = X.double().requires_grad_(True)
+    pre = pl = None
+    if not single_layer or pose_feat:
+        pre, pl = orc.pose_logits_head(Xr, p['pose_w1'], p['pose_b1'], p['pose_w2'], p['pose_b2'])
+    aw = [p['att_weights']] + [p['att_weights_r.%d' % r] for r in range(R - 1)]
+    ab = [p['att_biases']] + [p['att_biases_r.%d' % r] for r in range(R - 1)]
+    tw = [p['td_weights']] + [p['td_weights_r.%d' % r] for r in range(R - 1)]
+    tb = [p['td_biases']] + [p['td_biases_r.%d' % r] for r in range(R - 1)]
+    lr, epr = orc.attentional_pooling(
+        Xr, pre, pl, aw, ab, tw, tb,
+        orc.AttnFlags(single_layer_att=single_layer, rank=R, relu_att=relu, per_class=per_class,
+                      with_pose_feat=pose_feat), is_training=train, keep_prob=head.keep_prob, dropout_mask=mask)
+    torch.nn.functional.cross_entropy(lr, labels).backward()
+    assert _rel(logits.detach().cpu().numpy(), lr.detach().numpy()) < 5e-5
+    att_ref = epr['PosePrelogitsBasedAttention']
+    assert ep['PosePrelogitsBasedAttention'].shape == att_ref.shape == (N, H, H, K if per_class else 1, R)
+    assert _rel(ep['PosePrelogitsBasedAttention'].detach().cpu().numpy(), att_ref.detach().numpy()) < 5e-5
+    if topdown:
+        assert ep['TopDownAttention'].shape == (N, H, H, K, R)
+        assert _rel(ep['TopDownAttention'].detach().cpu().float().numpy(), epr['TopDownAttention'].detach().numpy()) < 5e-5
+    assert _rel(Xd.grad.cpu().numpy(), Xr.grad.numpy()) < 2e-4
+    for k, v in head.named_parameters():
+        if p[k].grad is None:
+            assert v.grad is None or float(v.grad.abs().max()) == 0.0, k
+            continue
+        assert _rel(v.grad.cpu().numpy(), p[k].grad.numpy()) < 2e-4, k
+    if pose_feat:
+        assert head.td_weights_r[0].shape == (C + J, K)
+    apa_config.reset_cfg()
+    # softmax over the stacked maps does not build in the reference either
+    with pytest.raises(ValueError):
+        _make_head(gpu, {'USE_POSE_PRELOGITS_BASED_ATTENTION_RANK': 2,
+                         'USE_POSE_PRELOGITS_BASED_ATTENTION_SOFTMAX_ATT': True})
+    apa_config.reset_cfg()
+
+
 @pytest.mark.parametrize('single_layer,two_layer,train', [(False, False, False), (False, False, True),
                                                           (True, False, True), (False, True, True),
                                                           (True, True, False)])
