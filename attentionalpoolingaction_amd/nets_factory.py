@@ -252,9 +252,6 @@ class AttentionalPoolingHead(nn.Module):
                              'reference configuration (nets_factory.py:271-279)')
         self.pose_feat_2layer = bool(self.with_pose_feat and
                                      net.USE_POSE_PRELOGITS_BASED_ATTENTION_WITH_POSE_FEAT_2LAYER)
-        if self.with_pose_feat and (net.USE_POSE_PRELOGITS_BASED_ATTENTION_PER_CLASS or want_topdown):
-            raise NotImplementedError('..._WITH_POSE_FEAT is built for the class-agnostic map '
-                                      '(without the TopDownAttention dump)')
         # rank > 1: identity activation on ONE map collapses to two streaming passes for any R (forward());
         # relu / per-class maps / the TopDownAttention dump / the pose features run one pass of the op per rank
         self.rank_collapsed = bool(self.rank > 1 and not (
@@ -413,7 +410,17 @@ class AttentionalPoolingHead(nn.Module):
                         self.pose_feat_bn_moving_variance.mul_(0.997).add_(var.detach(), alpha=0.003)
                 y = (y - mean) * torch.rsqrt(var + 1e-5) * self.pose_feat_bn_gamma + self.pose_feat_bn_beta
                 xext = torch.relu(y)
-        if self.rank == 1 and self.with_pose_feat:
+        x_td, xatt_td, cat_op = last_conv, xatt, self.with_pose_feat
+        if self.with_pose_feat and (self.per_class or self.want_topdown):
+            # per-class maps + pose features, or the TopDownAttention dump of the pose-feature head (no shipped
+            # config): the M == K kernels have no split-channel form and the split-channel M == 1 entry
+            # points never form the top-down tensor, so the concatenation is made as the reference makes it
+            # (tf.concat, :295 -- a copy, not arithmetic) and the plain op runs on it with the map itself as its
+            # separate attention input; the dropout mask is then the flat stream over the [N,H,W,C+J] tensor
+            x_td = torch.cat([last_conv, xext.to(last_conv.dtype)], dim=-1)
+            xatt_td = last_conv if self.single_layer else pose_pre
+            cat_op = False
+        if self.rank == 1 and cat_op:
             flags = cof.attn_flags(self.softmax_att, self.relu_att, self.is_training)
             logits, att = AttentionalPoolingCatFunction.apply(
                 last_conv, xatt, xext, self.att_weights, self.att_biases, self.td_weights, self.td_biases,
@@ -421,7 +428,7 @@ class AttentionalPoolingHead(nn.Module):
             end_points['PosePrelogitsBasedAttention'] = att.view(n, h, w, -1)    # :287
         elif self.rank == 1:
             logits, att, topdown = attentional_pooling(
-                last_conv, xatt, self.att_weights, self.att_biases, self.td_weights, self.td_biases,
+                x_td, xatt_td, self.att_weights, self.att_biases, self.td_weights, self.td_biases,
                 want_topdown=self.want_topdown, relu_input=preactivation, **kw)
             end_points['PosePrelogitsBasedAttention'] = att.view(n, h, w, -1)    # :287
             if topdown is not None:
@@ -441,14 +448,14 @@ class AttentionalPoolingHead(nn.Module):
                 if r > 0:
                     wa_r = wa_r @ self.att_weights_r[r - 1]
                     ba_r = ba_r @ self.att_weights_r[r - 1] + self.att_biases_r[r - 1]
-                if self.with_pose_feat:
+                if cat_op:
                     flags = cof.attn_flags(self.softmax_att, self.relu_att, self.is_training)
                     lg_r, att_r = AttentionalPoolingCatFunction.apply(
                         last_conv, xatt, xext, wa_r, ba_r, wts[r], bts[r], flags,
                         self.keep_prob if self.is_training else 1.0, self.seed, offset)
                     td_r = None
                 else:
-                    lg_r, att_r, td_r = attentional_pooling(last_conv, xatt, wa_r, ba_r, wts[r], bts[r],
+                    lg_r, att_r, td_r = attentional_pooling(x_td, xatt_td, wa_r, ba_r, wts[r], bts[r],
                                                             want_topdown=self.want_topdown, **kw)
                 logits = lg_r if logits is None else logits + lg_r
                 atts.append(att_r.view(n, h, w, -1))

@@ -492,6 +492,8 @@ def test_head_module_rank3_matches_oracle(gpu, single_layer):
     (True, True, True, False, False, False),
     (True, False, False, True, False, False),     # TopDownAttention dump [N,H,W,K,R]
     (False, False, False, False, True, True),     # _WITH_POSE_FEAT: every rank's top-down conv sees C + J
+    (True, True, True, True, True, True),         # per-class maps + pose features (+ dump): literal concatenation
+    (False, False, False, True, True, False),     # class-agnostic map + pose features + dump: same route
 ])
 def test_head_module_rank_gt1_general_forms(gpu, single_layer, relu, per_class, topdown, pose_feat, train):
     """..._RANK > 1 beyond the collapsed identity form: the reference's loop (nets_factory.py:258-274, 298-309,
@@ -527,7 +529,9 @@ def test_head_module_rank_gt1_general_forms(gpu, single_layer, relu, per_class, 
         ce = C + (J if pose_feat else 0)
         m = cof.dropout_mask((N * H * H * ce,), head.keep_prob, head.seed, step0).cpu()
         mask = m[:N * H * H * C].view(N, H, H, C)
-        if pose_feat:
+        if pose_feat and (per_class or topdown):   # the op sees the concatenated tensor: one flat stream
+            mask = m.view(N, H, H, C + J)
+        elif pose_feat:
             mask = torch.cat([mask, m[N * H * H * C:].view(N, H, H, J)], dim=-1)
     p = {k: v.detach().cpu().double().requires_grad_(True) for k, v in head.named_parameters()}
     Xr = X.double().requires_grad_(True)
