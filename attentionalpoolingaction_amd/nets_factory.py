@@ -357,14 +357,20 @@ class AttentionalPoolingHead(nn.Module):
         return (self.rank == 1 and self.single_layer and not self.per_class and not self.with_pose_logits
                 and not self.with_pose_feat and not self.want_topdown and c_ok)
 
-    def forward(self, last_conv: torch.Tensor, preactivation: bool = False
+    def forward(self, last_conv: torch.Tensor, preactivation: bool = False,
+                last_conv_pose: Optional[torch.Tensor] = None
                 ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        """`last_conv_pose`: the pose head's own feature tap when cfg.NET.LAST_CONV_MAP_FOR_POSE names a
+        different end point than last_conv_map (nets_factory.py:148-150; inception_v2_tsn: 5a vs 5b).
+        None / the same tensor: the shared tap of the ResNet configs."""
         if preactivation and not self.can_fuse_input_relu(last_conv.dtype):
             last_conv, preactivation = torch.relu(last_conv), False
+        if last_conv_pose is None:
+            last_conv_pose = last_conv
         end_points: Dict[str, torch.Tensor] = {}
         pose_pre = None
         if (not self.single_layer and self.rank == 1 and not self.per_class and not self.with_pose_feat
-                and self.fuse_pose_attention):
+                and self.fuse_pose_attention and last_conv_pose is last_conv):
             # cfg 003: pose head + attention on its pre-logits as one autograd node (rank-1 hand-over)
             offset = self._step
             if self.is_training:
@@ -382,7 +388,7 @@ class AttentionalPoolingHead(nn.Module):
             end_points['Logits'] = logits
             return logits, end_points
         if self.with_pose_logits or not self.single_layer:          # :147-160
-            pose_pre, pose_logits = PoseHeadFunction.apply(last_conv, self.pose_w1, self.pose_b1,
+            pose_pre, pose_logits = PoseHeadFunction.apply(last_conv_pose, self.pose_w1, self.pose_b1,
                                                            self.pose_w2, self.pose_b2)
             end_points['PoseLogits'] = pose_logits
         xatt = None if self.single_layer else pose_pre               # :247-250
@@ -685,7 +691,16 @@ def get_network_fn(name: str, num_classes: int, num_pose_keypoints: int, cfg,
             frames_per_video = images.shape[1]
             images = images.reshape(-1, *images.shape[2:])
         last_conv = backbone(images) if backbone is not None else images
-        if fuse_final_relu and isinstance(head, AttentionalPoolingHead):
+        if isinstance(last_conv, dict):
+            # a backbone that returns its end points (slim style): the two taps by name (:136-140, :148-150)
+            eps = last_conv
+            last_conv = eps[last_conv_map[name][0]]
+            pose_tap = eps.get(getattr(cfg.NET.LAST_CONV_MAP_FOR_POSE, name, None), last_conv)
+            if isinstance(head, AttentionalPoolingHead) and pose_tap is not last_conv:
+                logits, end_points = head(last_conv, last_conv_pose=pose_tap)
+            else:
+                logits, end_points = head(last_conv)
+        elif fuse_final_relu and isinstance(head, AttentionalPoolingHead):
             logits, end_points = head(last_conv, preactivation=True)
         elif fuse_final_relu:
             logits, end_points = head(torch.relu(last_conv))

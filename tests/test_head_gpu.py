@@ -636,6 +636,44 @@ def test_head_module_with_pose_feat_matches_oracle(gpu, single_layer, two_layer,
     apa_config.reset_cfg()
 
 
+def test_separate_pose_tap_of_the_tsn_inception_config(gpu):
+    """cfg.NET.LAST_CONV_MAP_FOR_POSE (nets_factory.py:148-150, config.py:218-222): for inception_v2_tsn the
+    pose head reads `inception_5a` while the pooled features are `inception_5b`.  A backbone that returns its
+    end points by name gets both taps routed; gradients reach each tap separately."""
+    from attentionalpoolingaction_amd import config as apa_config, nets_factory
+    cfg = apa_config.reset_cfg()
+    apa_config.cfg_from_dict({'MODEL_NAME': 'inception_v2_tsn', 'NET': {'USE_POSE_PRELOGITS_BASED_ATTENTION': True}})
+    N, H, C, K, J = 3, 7, 1024, 51, 16
+    g = torch.Generator().manual_seed(41)
+    A = torch.relu(torch.randn(N, H, H, C, generator=g))      # inception_5a: pose tap
+    B = torch.relu(torch.randn(N, H, H, C, generator=g))      # inception_5b: pooled features
+    Ad, Bd = A.to(gpu).requires_grad_(True), B.to(gpu).requires_grad_(True)
+    fn = nets_factory.get_network_fn(
+        'inception_v2_tsn', K, J, cfg, is_training=False, device=gpu, with_pose_logits=True,
+        backbone=lambda images: {'InceptionV2_TSN/inception_5a': Ad, 'InceptionV2_TSN/inception_5b': Bd})
+    head = fn.head
+    with torch.no_grad():
+        for name, p in head.named_parameters():
+            p.copy_(torch.randn(p.shape, generator=g) / max(p.shape[0], 1) ** 0.5 if p.dim() >= 2
+                    else torch.randn(p.shape, generator=g) * 0.1)
+    labels = torch.randint(0, K, (N,), generator=g)
+    wpl = torch.randn(N, H, H, J, generator=g)
+    logits, ep = fn(torch.zeros(N, 8, 8, 3, device=gpu))
+    (torch.nn.functional.cross_entropy(logits, labels.to(gpu)) + (ep['PoseLogits'] * wpl.to(gpu)).sum()).backward()
+    p = {k: v.detach().cpu().double().requires_grad_(True) for k, v in head.named_parameters()}
+    Ar, Br = A.double().requires_grad_(True), B.double().requires_grad_(True)
+    pre, pl = orc.pose_logits_head(Ar, p['pose_w1'], p['pose_b1'], p['pose_w2'], p['pose_b2'])
+    lr, _ = orc.attentional_pooling(Br, pre, pl, [p['att_weights']], [p['att_biases']], [p['td_weights']],
+                                    [p['td_biases']], orc.AttnFlags(single_layer_att=False))
+    (torch.nn.functional.cross_entropy(lr, labels) + (pl * wpl.double()).sum()).backward()
+    assert _rel(logits.detach().cpu().numpy(), lr.detach().numpy()) < 5e-5
+    assert _rel(ep['PoseLogits'].detach().cpu().numpy(), pl.detach().numpy()) < 5e-5
+    assert _rel(Ad.grad.cpu().numpy(), Ar.grad.numpy()) < 2e-4 and _rel(Bd.grad.cpu().numpy(), Br.grad.numpy()) < 2e-4
+    for k in ('pose_w1', 'pose_w2', 'att_weights', 'td_weights'):
+        assert _rel(getattr(head, k).grad.cpu().numpy(), p[k].grad.numpy()) < 2e-4, k
+    apa_config.reset_cfg()
+
+
 @pytest.mark.parametrize('bdtype', [None, torch.bfloat16])
 def test_network_fn_with_resnet_backbone_end_to_end(gpu, bdtype):
     """images -> slim ResNet-v1-101 (torch-ROCm, channels-last) -> HIP head.
