@@ -338,11 +338,13 @@ __global__ __launch_bounds__(512) void pose_bwd_rows_kernel(
 static size_t pose_rows_lds(int rpb, int nthr, int dtype, bool ext) {
   return (size_t)rpb * 17 * 4 + (size_t)rpb * nthr * (dtype == APA_DTYPE_BF16 ? 4 : 8) * (ext ? 2 : 1);
 }
-// rows per block: 32 (half the partial matrix) once that still gives every CU a block and the tile
+// rows per block: 32 (half the partial matrix: its write and the column sum that follows are what the
+// choice moves -- cfg 003 at N = 32, 196 blocks of 32 rows against 392 of 16: kernel 16.9 vs 17.5 us, column sum
+// 4.6 vs 6.9 us, step -3 us in four interleaved pairs) once that still gives half the CUs a block and the tile
 // stays under the 64 KB a launch gets without opting in, else 16
 static int pose_rows_per_block(long R, int nthr, int dtype, bool ext) {
   static const int forced = [] { const char* e = getenv("APA_POSE_RPB"); return e ? atoi(e) : 0; }();
-  int rpb = (R + 31) / 32 >= 256 ? 32 : 16;
+  int rpb = (R + 31) / 32 >= 128 ? 32 : 16;
   if (forced == 16 || forced == 32) rpb = forced;
   if (rpb == 32 && pose_rows_lds(32, nthr, dtype, ext) > 65536) rpb = 16;
   return rpb;

@@ -1,8 +1,7 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 cd $R
-timeout 600 python -m pytest tests/test_dense_gpu.py -q -x -k "cfg003" 2>&1 | grep -E "passed|failed|Error|error|assert" | tail -8 | cut -c1-300
-for i in 1 2 3; do
-  python tools/bench_dense.py --workload cfg003 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'
+for i in 1 2 3 4; do
+  APA_POSE_RPB=32 python tools/bench_dense.py --workload cfg003 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | sed 's/^/rpb32 /'
+  APA_POSE_RPB=16 python tools/bench_dense.py --workload cfg003 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | sed 's/^/rpb16 /'
 done
-python tools/exp_host_dense.py 2>&1 | grep -E "host enq"
