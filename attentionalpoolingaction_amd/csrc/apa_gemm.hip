@@ -337,6 +337,8 @@ size_t gemm_ws_bytes(int M, int N, int splits) {
 int gemm_pick_splits(int M, int N, int K) {
   const int tiles = ((M + GM - 1) / GM) * ((N + GN - 1) / GN);
   if (tiles >= 128 || K <= 4 * GK) return 1;
+  static const int s_env = [] { const char* e = getenv("APA_GEMM_SPLITS"); return e ? atoi(e) : 0; }();
+  if (s_env > 0) return s_env;
   int s = (256 + tiles - 1) / tiles;
   const int maxs = K / (4 * GK) > 0 ? K / (4 * GK) : 1;
   if (s > maxs) s = maxs;
