@@ -1,5 +1,6 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 cd $R
-APA_PC_EXP=4 bash tools/prof_dense.sh pcdw --workload perclass 2>&1 | grep -E "pc_bwd_dw|pc_dw_reduce"
-for s in 8 32; do echo "splits=$s"; APA_PC_DW_SPLITS=$s bash tools/prof_dense.sh pcdw --workload perclass 2>&1 | grep -E "pc_bwd_dw|pc_dw_reduce"; done
+timeout 600 python -m pytest tests/test_dense_gpu.py tests/test_bf16_parity_gpu.py tests/test_random_shapes_gpu.py -q -x -k "per_class or perclass" 2>&1 | grep -E "passed|failed|Error|error" | tail -4 | cut -c1-300
+for i in 1 2 3; do python tools/bench_dense.py --workload perclass 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'; done
+bash tools/prof_dense.sh pcprep --workload perclass 2>&1 | grep -E "pc_prep"
