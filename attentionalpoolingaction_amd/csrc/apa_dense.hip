@@ -760,6 +760,16 @@ struct PcPadList {
 };
 
 constexpr int PC_PG = 16;   // pixel groups per block of the per-class activation passes
+constexpr int PC_MAX_PSPLIT = 8;   // pixel splits (grid.z) of the backward activation pass
+// pixel splits of pc_bwd_act_kernel: enough blocks to put one on most CUs; the spatial softmax needs the whole image
+static int pc_bwd_act_psplit(int N, int kgroups, int P, int act) {
+  static const int ps_env = [] { const char* e = getenv("APA_PC_ACT_PSPLIT"); return e ? atoi(e) : 0; }();
+  if (act == 2) return 1;
+  int ps = ps_env > 0 ? ps_env : (256 + N * kgroups - 1) / (N * kgroups);   // HMDB-51 shape, N = 32: 7.9 -> 4.9 us
+  if (ps > PC_MAX_PSPLIT) ps = PC_MAX_PSPLIT;
+  while (ps > 1 && (P + ps - 1) / ps < PC_PG) --ps;      // at least one pixel per pixel group
+  return ps < 1 ? 1 : ps;
+}
 __device__ __forceinline__ float pc_colsum(const float (&red)[PC_PG][64], int kk) {
   float s = 0.f;
 #pragma unroll
@@ -861,8 +871,12 @@ __global__ __launch_bounds__(1024) void pc_bwd_act_kernel(const float* __restric
   const size_t rbase = (size_t)n * P;
   const float invP = 1.0f / (float)P;
   const float g = ok ? G[(size_t)n * K + k] * invP : 0.f;
+  // grid.z > 1 (identity / relu only: no sum over the image's pixels is needed): block z owns a contiguous
+  // share of the pixels and its own partial row -- N x 1 blocks of 16 waves were 32 CUs' worth of latency chains
+  const int pchunk = (P + gridDim.z - 1) / gridDim.z;
+  const int p_lo = blockIdx.z * pchunk, p_hi = min(P, p_lo + pchunk);
   float corr = 0.f;
-  if (act == 2) {  // sum_p A * dA
+  if (act == 2) {  // sum_p A * dA (host: grid.z == 1)
     float s = 0.f;
     if (ok)
       for (int p = pg; p < P; p += PC_PG) s = fmaf(att[(rbase + p) * K + k], g * Tm[(rbase + p) * K + k], s);
@@ -872,7 +886,7 @@ __global__ __launch_bounds__(1024) void pc_bwd_act_kernel(const float* __restric
     __syncthreads();
   }
   float sdt = 0.f, sdz = 0.f;
-  for (int p = pg; p < P; p += PC_PG) {   // (batching the loads four pixels deep, as in the forward
+  for (int p = p_lo + pg; p < p_hi; p += PC_PG) {   // (batching the loads four pixels deep, as in the forward
     if (ok) {                               //  pass, measured slower here: 8.9 -> 10.7 us)
       const float a = att[(rbase + p) * K + k];
       const float dA = g * Tm[(rbase + p) * K + k];
@@ -893,8 +907,9 @@ __global__ __launch_bounds__(1024) void pc_bwd_act_kernel(const float* __restric
   red2[pg][kk] = sdz;
   __syncthreads();
   if (pg == 0 && ok) {
-    pdbt[(size_t)n * 2 * K + k] = pc_colsum(red, kk);       // one [N][2K] partial matrix: dbt | dba
-    pdba[(size_t)n * 2 * K + k] = pc_colsum(red2, kk);
+    const size_t prow = (size_t)n * gridDim.z + blockIdx.z;
+    pdbt[prow * 2 * K + k] = pc_colsum(red, kk);            // one [N * grid.z][2K] partial matrix: dbt | dba
+    pdba[prow * 2 * K + k] = pc_colsum(red2, kk);
   }
 }
 
@@ -915,7 +930,7 @@ static PcPlan pc_plan(int N, int P, int C, int Ca, int K, int dtype) {
   pl.off_z = off;    off += align_up((size_t)pl.R * pl.Kp * 4, 256);
   pl.off_dt = off;   off += align_up((size_t)pl.R * pl.Kp * dt_size(dtype), 256);
   pl.off_dz = off;   off += align_up((size_t)pl.R * pl.Kp * dt_size(dtype), 256);
-  pl.off_pdbt = off; off += align_up((size_t)N * 2 * K * 4, 256);   // [N][2K]: dbt | dba partials
+  pl.off_pdbt = off; off += align_up((size_t)N * PC_MAX_PSPLIT * 2 * K * 4, 256);   // [N * splits][2K]: dbt | dba partials
   pl.off_pdba = pl.off_pdbt + (size_t)K * 4;
   const int cm = C > Ca ? C : Ca;
   {
@@ -1099,11 +1114,12 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
       }
     }
     bf16_t* dTc = static_cast<bf16_t*>(f.dTdZ);              // [R][dT (64) | dZ (64)]
-    dim3 grid(N, (Kp + 63) / 64);
+    const int ps = pc_bwd_act_psplit(N, (Kp + 63) / 64, P, act_code(flags));
+    dim3 grid(N, (Kp + 63) / 64, ps);
     hipLaunchKernelGGL(pc_bwd_act_kernel<bf16_t>, grid, dim3(64 * PC_PG), 0, st, G, att, Tsave, dTc, dTc + 64,
                        pdbt, pdba, P, K, Kp, act_code(flags), 128);
     APA_LAUNCH_CHECK("pc_bwd_act_kernel");
-    rc = m1_colsum(pdbt, nullptr, dbt, nullptr, N, 2 * K, 2 * K, nullptr, st, dba, K);
+    rc = m1_colsum(pdbt, nullptr, dbt, nullptr, N * ps, 2 * K, 2 * K, nullptr, st, dba, K);
     if (rc != APA_OK) return rc;
     rc = pc_fused_dw(f, X, dWt, dWa, R, C, K, train, keep_prob, st);
     if (rc != APA_OK) return rc;
@@ -1125,7 +1141,8 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
     pads.launch(K, Kp, st);
     APA_LAUNCH_CHECK("pc_pad_kernel");
   }
-  dim3 grid(N, (Kp + 63) / 64);
+  const int ps = pc_bwd_act_psplit(N, (Kp + 63) / 64, P, act_code(flags));
+  dim3 grid(N, (Kp + 63) / 64, ps);
   if (dtype == APA_DTYPE_F32)
     hipLaunchKernelGGL(pc_bwd_act_kernel<float>, grid, dim3(64 * PC_PG), 0, st, G, att, Tsave,
                        static_cast<float*>(dT), static_cast<float*>(dZ), pdbt, pdba, P, K, Kp,
@@ -1135,7 +1152,7 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
                        static_cast<bf16_t*>(dT), static_cast<bf16_t*>(dZ), pdbt, pdba, P, K, Kp,
                        act_code(flags), Kp);
   APA_LAUNCH_CHECK("pc_bwd_act_kernel");
-  int rc = m1_colsum(pdbt, nullptr, dbt, nullptr, N, 2 * K, 2 * K, nullptr, st, dba, K);
+  int rc = m1_colsum(pdbt, nullptr, dbt, nullptr, N * ps, 2 * K, 2 * K, nullptr, st, dba, K);
   if (rc != APA_OK) return rc;
   {  // dWt[c,k] = sum_r Xt[r,c] dT[r,k]
     GemmDesc g;
