@@ -201,7 +201,9 @@ __global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict_
   if (threadIdx.x == 0) out[0] = ((red[0] + red[1]) + (red[2] + red[3])) * scale;
 }
 
-// Pose L2: block n handles image n.  ws[n] = sum_j valid[n,j] * sum_p (Pl-lbl)^2.
+// Pose L2: block (n, s) handles share s of image n's P*J elements (grid.y shares: N blocks alone were 32 CUs'
+// worth of 12-deep load chains).  ws[n * grid.y + s] = sum over the share of valid[n,j] * (Pl-lbl)^2.
+constexpr int POSE_L2_MAX_SPLIT = 8;
 __global__ __launch_bounds__(256) void pose_l2_kernel(const float* __restrict__ Pl,
                                                       const float* __restrict__ lbl,
                                                       const uint8_t* __restrict__ valid,
@@ -211,8 +213,10 @@ __global__ __launch_bounds__(256) void pose_l2_kernel(const float* __restrict__ 
   __shared__ float red[4];
   const int n = blockIdx.x;
   const size_t base = (size_t)n * P * J;
+  const int chunk = (P * J + gridDim.y - 1) / gridDim.y;
+  const int lo = blockIdx.y * chunk, hi = min(P * J, lo + chunk);
   float acc = 0.f;
-  for (int idx = threadIdx.x; idx < P * J; idx += 256) {
+  for (int idx = lo + threadIdx.x; idx < hi; idx += 256) {
     const int j = idx % J;
     const float d = Pl[base + idx] - lbl[base + idx];
     const float vm = valid[(size_t)n * J + j] ? 1.0f : 0.0f;
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(256) void pose_l2_kernel(const float* __restrict__ 
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) ws[n] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (threadIdx.x == 0) ws[(size_t)n * gridDim.y + blockIdx.y] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 __global__ __launch_bounds__(256) void zero_out_channels_kernel(const float* __restrict__ in,
@@ -309,7 +313,7 @@ extern "C" int apa_softmax_xent_fwd_bwd(const float* logits, const int64_t* labe
 
 extern "C" size_t apa_pose_l2_workspace_bytes(int N, int P, int J) {
   (void)P; (void)J;
-  return N > 0 ? (size_t)N * sizeof(float) : 0;
+  return N > 0 ? (size_t)N * POSE_L2_MAX_SPLIT * sizeof(float) : 0;
 }
 
 extern "C" int apa_pose_l2_loss_fwd_bwd(const float* Pl, const float* lbl, const uint8_t* valid,
@@ -328,11 +332,14 @@ extern "C" int apa_pose_l2_loss_fwd_bwd(const float* Pl, const float* lbl, const
   // loss.py:53-62: 0.5*sum_hw(.)^2 / (N*H*W), then mean over n of the valid ones, summed over j
   const float denom = (float)N * (float)N * (float)P;
   const float gcoef = grad_scale * wt / denom;
-  hipLaunchKernelGGL(pose_l2_kernel, dim3(N), dim3(256), 0, st, Pl, lbl, valid, dPl,
+  int split = (256 + N - 1) / N;                         // ~256 blocks
+  if (split > POSE_L2_MAX_SPLIT) split = POSE_L2_MAX_SPLIT;
+  while (split > 1 && (P * J + split - 1) / split < 256) --split;   // at least one element per thread
+  hipLaunchKernelGGL(pose_l2_kernel, dim3(N, split), dim3(256), 0, st, Pl, lbl, valid, dPl,
                      static_cast<float*>(ws), P, J, gcoef);
   APA_LAUNCH_CHECK("pose_l2_kernel");
   hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, st, static_cast<const float*>(ws),
-                     loss, N, 0.5f * wt / denom);
+                     loss, N * split, 0.5f * wt / denom);
   APA_LAUNCH_CHECK("sum_scale_kernel");
   return APA_OK;
 }
