@@ -366,7 +366,8 @@ static bool pose_bwd_rows_ok(const float* dPl, const void* Ppre, const void* ext
 // a wave owns 16 rows: its A fragments come straight from global memory (one 16-byte load per lane and
 // k step, all KS of them in flight at once), the whole W2 sits in registers as bf16 B fragments (staged
 // once per block through LDS), KS MFMAs later the 16 x 16 result leaves with the bias added.  HBM-bound
-// on the 9.6 MB pre-logit map.
+// on the 9.6 MB pre-logit map.  (Fewer waves per block to cover more CUs -- 98 blocks at N = 32 -- measured slower:
+// 4 / 2 / 1 waves 7.4 / 8.0 / 11.6 us, every block stages the whole of W2.)
 template <int KS>   // k steps of 32: Cp = 32 * KS
 __global__ __launch_bounds__(256) void pose_pl_kernel(const bf16_t* __restrict__ Ppre,
                                                       const float* __restrict__ W2,
