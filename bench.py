@@ -542,6 +542,7 @@ def main():
         run_extra('cfg002_eval', bd.build_eval002, N=32, H=14, K=393, dtype='f32')
         run_extra('cfg003_bf16_train', bd.build_cfg003, N=32, H=14, K=393, dtype='bf16')
         run_extra('hmdb51_perclass_bf16_train', bd.build_perclass, N=32, H=14, K=51, dtype='bf16')
+        run_extra('hmdb51_rank1_bf16_train', bd.build_rank1, N=32, H=14, K=51, dtype='bf16')
         # the headline step far outside every cache: N = 512 (1.6 GB of features per pass, no rotation needed)
         try:
             big = HeadWorkload(cof, args, dev, rank, world, 512, 1)

@@ -1261,6 +1261,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields(gpu):
             c = d['cpu_baseline']
             assert c['kind'] == 'port' and c['unit'] == 'images/sec' and c['cores'] >= 1 and c['value'] > 0
             # the other BASELINE configs ride on the same line
-            for k in ('cfg002_eval', 'cfg003_bf16_train', 'hmdb51_perclass_bf16_train', 'cfg002_train_n512'):
+            for k in ('cfg002_eval', 'cfg003_bf16_train', 'hmdb51_perclass_bf16_train', 'hmdb51_rank1_bf16_train',
+                      'cfg002_train_n512'):
                 assert 'error' not in d['extra'][k], d['extra'][k]
                 assert d['extra'][k]['ms_per_step'] > 0 and 0.0 < d['extra'][k]['roofline']['frac'] < 1.0

@@ -112,6 +112,28 @@ def build_perclass(cof, dev, N=32, H=14, K=51, dtype='bf16'):
     return st.run, info
 
 
+def build_rank1(cof, dev, N=32, H=14, K=51, dtype='bf16'):
+    """class-agnostic bottom-up map (M = 1, the shipped HMDB / MPII attention configs) on bf16 features:
+    the headline op, one host call per step."""
+    C, P = 2048, H * H
+    td = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    g = torch.Generator().manual_seed(42)
+    X = _features(N, P, C, td, dev)
+    Wa = (torch.randn(C, 1, generator=g) / C ** 0.5).to(dev); ba = torch.zeros(1, device=dev)
+    Wt = (torch.randn(C, K, generator=g) / C ** 0.5).to(dev); bt = torch.zeros(K, device=dev)
+    labels = torch.randint(0, K, (N,), generator=g).to(dev)
+    flags = cof.attn_flags(False, False, True)
+    ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+    grads = (torch.empty_like(X), None, torch.empty_like(Wa), torch.empty_like(ba), torch.empty_like(Wt),
+             torch.empty_like(bt))
+    st = cof.HeadTrainStep(X, X, Wa, ba, Wt, bt, labels, grads, flags=flags, keep_prob=0.2, seed=42, offset=ctr)
+    info = {'workload': 'class-agnostic map (M=1) attention head fwd + softmax-xent + bwd; per-GPU batch {} x {}x{}x{} '
+                        '{}, K={}, dropout keep=0.2'.format(N, H, H, C, dtype, K),
+            'bound': 'hbm', 'dtype': dtype, 'N': N, 'flops_per_image': 0.0,
+            'bytes_per_image': 3.0 * P * C * X.element_size()}
+    return st.run, info
+
+
 def build_eval002(cof, dev, N=32, H=14, K=393, dtype='f32'):
     C, P = 2048, H * H
     td = torch.bfloat16 if dtype == 'bf16' else torch.float32
@@ -167,7 +189,7 @@ def report(info, sec, repeats):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--workload', default='cfg003', choices=['cfg003', 'perclass', 'eval002'])
+    ap.add_argument('--workload', default='cfg003', choices=['cfg003', 'perclass', 'eval002', 'rank1'])
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--hw', type=int, default=14)
     ap.add_argument('--classes', type=int, default=None)
@@ -182,6 +204,8 @@ def main():
     if args.workload == 'cfg003':
         step, info = build_cfg003(cof, dev, args.batch, args.hw, args.classes or 393, args.dtype or 'bf16',
                                   rank1=not args.no_rank1)
+    elif args.workload == 'rank1':
+        step, info = build_rank1(cof, dev, args.batch, args.hw, args.classes or 51, args.dtype or 'bf16')
     elif args.workload == 'eval002':
         step, info = build_eval002(cof, dev, args.batch, args.hw, args.classes or 393, args.dtype or 'f32')
     else:
