@@ -63,6 +63,21 @@ __global__ __launch_bounds__(1024) void k_dma(const uint4* __restrict__ a, float
   if (lds[threadIdx.x].x == 0x12345678u) o[0] = 1.f;
 }
 
+// plain copy, 16 bytes per lane, UNROLL loads in flight per lane; grid-stride over `n_v` vectors
+template <int UNROLL>
+__global__ __launch_bounds__(256) void k_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n_v) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + (UNROLL - 1) * stride < n_v; i += UNROLL * stride) {
+    uint4 v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) v[u] = src[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) dst[i + u * stride] = v[u];
+  }
+  for (; i < n_v; i += stride) dst[i] = src[i];
+}
+
 template <typename F>
 static float time_ms(F launch, hipStream_t st) {
   hipEvent_t e0, e1;
@@ -124,6 +139,34 @@ int main() {
                    blocks, tbs * 1e3 / ncu, tbs);
           }
         }
+      }
+    }
+  }
+  // a plain copy of the size of the benchmark's backward pass (51.4 MB read + 51.4 MB written; and 16x that),
+  // source / destination rotated over the 2 GiB buffer so that no launch finds its data in the 256 MiB cache
+  printf("\ncopy (read + write), rotating 51.4 MB / 822 MB slices:\n%-10s %6s %8s %10s %8s\n", "MB each", "blocks", "unroll", "us", "TB/s");
+  for (size_t mb : {(size_t)51380224, (size_t)822083584}) {
+    const size_t n_v = mb / 16;
+    const int nslices = (int)(bytes / 2 / mb);
+    for (int blocks : {512, 1024, 2048}) {
+      for (int unroll : {2, 4}) {
+        int k = 0;
+        float acc = 0.f; int cnt = 0;
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int r = 0; r < 12; ++r) {
+          const uint4* src = a + (size_t)(k % nslices) * n_v;
+          uint4* dst = a + bytes / 32 + (size_t)(k % nslices) * n_v;
+          ++k;
+          hipEventRecord(e0, st);
+          if (unroll == 2) hipLaunchKernelGGL(k_copy<2>, dim3(blocks), dim3(256), 0, st, src, dst, n_v);
+          else hipLaunchKernelGGL(k_copy<4>, dim3(blocks), dim3(256), 0, st, src, dst, n_v);
+          hipEventRecord(e1, st);
+          hipStreamSynchronize(st);
+          float ms; hipEventElapsedTime(&ms, e0, e1);
+          if (r >= 2) { acc += ms; ++cnt; }
+        }
+        const float us = acc / cnt * 1e3f;
+        printf("%-10.1f %6d %8d %10.2f %8.2f\n", mb / 1e6, blocks, unroll, us, 2.0 * mb / (us * 1e-6) / 1e12);
       }
     }
   }
