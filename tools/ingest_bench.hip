@@ -170,5 +170,33 @@ int main() {
       }
     }
   }
+  // a read-only pass of the size of the benchmark's forward pass (51.4 MB), rotating slices
+  printf("\nread only, rotating 51.4 MB slices:\n%6s %7s %6s %10s %8s\n", "blocks", "threads", "unroll", "us", "TB/s");
+  {
+    const size_t mb = 51380224;
+    const int nslices = (int)(bytes / mb);
+    for (int blocks : {256, 512, 1024}) {
+      for (int unroll : {4, 8}) {
+        const int thr = 256;
+        const size_t per_block_v = mb / 16 / blocks;
+        const int iters = (int)(per_block_v / ((size_t)thr * unroll));
+        float acc = 0.f; int cnt = 0;
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int r = 0; r < 12; ++r) {
+          const uint4* src = a + (size_t)(r % nslices) * (mb / 16);
+          hipEventRecord(e0, st);
+          if (unroll == 4) hipLaunchKernelGGL(k_vec<4>, dim3(blocks), dim3(thr), 0, st, src, o, per_block_v, per_block_v, iters);
+          else hipLaunchKernelGGL(k_vec<8>, dim3(blocks), dim3(thr), 0, st, src, o, per_block_v, per_block_v, iters);
+          hipEventRecord(e1, st);
+          hipStreamSynchronize(st);
+          float ms; hipEventElapsedTime(&ms, e0, e1);
+          if (r >= 2) { acc += ms; ++cnt; }
+        }
+        const float us = acc / cnt * 1e3f;
+        const double moved = (double)blocks * iters * thr * unroll * 16;
+        printf("%6d %7d %6d %10.2f %8.2f\n", blocks, thr, unroll, us, moved / (us * 1e-6) / 1e12);
+      }
+    }
+  }
   return 0;
 }
