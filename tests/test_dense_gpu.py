@@ -170,6 +170,38 @@ def test_cfg003_one_call_attention_step_equals_the_separate_calls(gpu, dtype):
         cof.HeadTrainStep(Xd, Xd, Wtd[:, :1].contiguous(), bad, Wtd, btd, lab, grads, dxatt_rank1=True)
 
 
+@pytest.mark.parametrize('K,dtype', [(130, torch.bfloat16), (51, torch.bfloat16), (70, torch.float32)])
+def test_per_class_one_call_train_step_equals_the_separate_calls(gpu, K, dtype):
+    """Per-class maps through apa_attn_head_train_step: the backward half reuses what the forward half left in
+    the workspace (APA_FLAG_WS_FROM_FWD: padded bf16 weights and the materialised dropout(X) of the generic
+    path for K > 64, the prepared slab and the keep bits of the fused path for K <= 64) -- every output must
+    equal the per-op sequence bit for bit."""
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    N, P, C = 3, 49, 512
+    g = torch.Generator().manual_seed(K)
+    X = torch.relu(torch.randn(N, P, C, generator=g)).to(dtype).to(gpu)
+    Wa = (torch.randn(C, K, generator=g) / C ** 0.5).to(gpu); ba = (torch.randn(K, generator=g) * 0.1).to(gpu)
+    Wt = (torch.randn(C, K, generator=g) / C ** 0.5).to(gpu); bt = (torch.randn(K, generator=g) * 0.1).to(gpu)
+    labels = torch.randint(0, K, (N,), generator=g).to(gpu)
+    kw = dict(flags=cof.attn_flags(False, True, True), keep_prob=0.5, seed=3, offset=2)
+
+    def grads():
+        return (torch.empty_like(X), None, torch.empty_like(Wa), torch.empty_like(ba), torch.empty_like(Wt),
+                torch.empty_like(bt))
+    ga, gb = grads(), grads()
+    st = cof.HeadTrainStep(X, X, Wa, ba, Wt, bt, labels, ga, **kw)
+    st.run()
+    logits, att, Ts, _, _, ws = cof.attn_pool_fwd(X, X, Wa, ba, Wt, bt, **kw)
+    loss, G, _, _ = cof.softmax_xent_fwd_bwd(logits, labels)
+    cof.attn_pool_bwd(X, X, Wa, ba, Wt, bt, att, Ts, None, G, workspace=ws, out=gb, **kw)
+    torch.cuda.synchronize()
+    for a, b, name in ((st.logits, logits, 'logits'), (st.att, att, 'att'), (st.loss, loss, 'loss'), (st.G, G, 'G'),
+                       (ga[0], gb[0], 'dX'), (ga[2], gb[2], 'dWa'), (ga[3], gb[3], 'dba'), (ga[4], gb[4], 'dWt'),
+                       (ga[5], gb[5], 'dbt')):
+        assert torch.equal(a, b), name
+    assert bool(torch.isfinite(ga[0].float()).all()) and float(ga[4].abs().max()) > 0
+
+
 def _pc_problem(N, H, C, K, seed, Ca=None, dtype=torch.float32):
     g = torch.Generator().manual_seed(seed)
     Ca = C if Ca is None else Ca
