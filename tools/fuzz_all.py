@@ -129,6 +129,8 @@ def fam_perclass(rnd, i):
     orc.action_softmax_xent(lg, labels, K).backward()
     logits, att, _, loss, pred, (dX, dXatt, dWa, dba, dWt, dbt) = D._pc_run(
         gpu, X, Xatt, Wa, ba, Wt, bt, labels, softmax, relu, train=train, keep=keep, seed=seed, offset=offset)
+    if relu and int(((att.cpu().double().reshape(-1) > 0) != (ep['PosePrelogitsBasedAttention'].detach().reshape(-1) > 0)).sum()):
+        return desc     # a relu gate of the attention map within rounding of 0 (cf. fam_pose)
     tl, tg = (3e-3, 4e-2) if bf16 else (2e-5, 1e-4)
     assert rel(logits, lg) < tl or float((logits.cpu().double() - lg.detach()).abs().max()) < (5e-3 if bf16 else 1e-5), 'logits'
     floor = 1e-5 * float(Wtr.grad.abs().max())
