@@ -47,6 +47,17 @@ def _defaults() -> AttrDict:
     c.MAX_INPUT_IMAGE_SIZE = 512
     c.INPUT_FILE_STYLE_LABEL = ''
 
+    # --- INPUT (config.py:18-42): input formats of the data pipeline -- accepted so that any reference YAML
+    # loads, not consumed by the head (out of scope)
+    i = c.INPUT = AttrDict()
+    i.INPUT_IMAGE_FORMAT = 'normal'
+    i.INPUT_IMAGE_FORMAT_POSE_RENDER_TYPE = 'rgb'
+    i.POSE_GLIMPSE_CONTEXT_RATIO = 0.0
+    i.POSE_GLIMPSE_RESIZE = False
+    i.POSE_GLIMPSE_PARTS_KEEP = []
+    i.SPLIT_ID = 1
+    i.VIDEO = AttrDict(MODALITY='rgb')
+
     # --- TRAIN (config.py:44-133)
     t = c.TRAIN = AttrDict()
     t.BATCH_SIZE = 10
@@ -76,6 +87,19 @@ def _defaults() -> AttrDict:
     t.LOSS_FN_ACTION_WT = 1.0
     t.VIDEO_FRAMES_PER_VIDEO = 1
     t.ITER_SIZE = 1
+    # the rest of the reference's TRAIN table: optimiser variants, checkpoint / summary plumbing of the TF
+    # training loop -- accepted, not consumed here
+    t.ADAM_BETA1 = 0.9
+    t.ADAM_BETA2 = 0.999
+    t.OPT_EPSILON = 1.0
+    t.MOVING_AVERAGE_VARIABLES = None
+    t.TRAINABLE_SCOPES = ''
+    t.IGNORE_MISSING_VARS = True
+    t.VAR_NAME_MAPPER = ''
+    t.SAVE_SUMMARIES_SECS = 300
+    t.SAVE_INTERVAL_SECS = 1800
+    t.READ_SEGMENT_STYLE = False
+    t.OTHER_IMG_SUMMARIES_TO_ADD = ['PosePrelogitsBasedAttention']
 
     # --- TEST (config.py:139-157)
     e = c.TEST = AttrDict()
@@ -84,12 +108,18 @@ def _defaults() -> AttrDict:
     e.CHECKPOINT_PATH = ''
     e.VIDEO_FRAMES_PER_VIDEO = 1
     e.EVAL_METRIC = ''
+    e.MAX_NUM_BATCHES = None
+    e.MOVING_AVERAGE_DECAY = None
 
     # --- NET (config.py:160-231): the flags that select / shape the head
     n = c.NET = AttrDict()
     n.USE_POSE_ATTENTION_LOGITS = False
+    n.USE_POSE_ATTENTION_LOGITS_DIMS = [-1]
+    n.USE_POSE_ATTENTION_LOGITS_AVGED_HMAP = False
     n.USE_POSE_LOGITS_DIRECTLY = False
+    n.USE_POSE_LOGITS_DIRECTLY_PLUS_LOGITS = False
     n.USE_POSE_LOGITS_DIRECTLY_v2 = False
+    n.USE_POSE_LOGITS_DIRECTLY_v2_EXTRA_LAYER = False
     n.USE_COMPACT_BILINEAR_POOLING = False
     n.USE_POSE_PRELOGITS_BASED_ATTENTION = False
     n.USE_POSE_PRELOGITS_BASED_ATTENTION_SOFTMAX_ATT = False

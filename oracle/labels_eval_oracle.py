@@ -4,6 +4,9 @@
     are OpenCV routines that are absent from this image -- their behaviour is restated from the
     published algorithm, SURVEY.md Appendix B, and pinned only by the one input the reference
     supplies: src/custom_ops/test/pose_to_heatmap_op_test.py:10-23, expected valid = [T]*5+[F]*11.)
+    The mAP functions at the end of this file ARE pinned: tests/golden/map_reference.npz holds outputs of the
+    reference's own src/eval/cap_eval_utils.py / src/eval/utils.py executed in the build container
+    (tests/golden/make_map_reference.py), reproduced to 1e-13 with identical tie order.
 
 numpy + pure-Python loops (small sizes only).  Citations are relative to /root/reference/.
 """

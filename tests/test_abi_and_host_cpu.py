@@ -198,6 +198,61 @@ def test_compute_map_matches_oracle_and_golden():
         assert eval_utils.accuracy(scores, labels) == pytest.approx(float(np.mean(scores.argmax(1) == labels)))
 
 
+def _flat(d, pre=''):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, dict):
+            out.update(_flat(v, pre + k + '.'))
+        else:
+            out[pre + k] = v
+    return out
+
+
+def test_config_table_matches_the_reference_s_own_config_module():
+    """tests/golden/config_reference.json was produced by EXECUTING the reference's src/config.py (defaults, and
+    cfg_from_file on each of the seven shipped experiments/*.yaml; tests/golden/make_config_reference.py).
+    Every key of the reference exists here with the same default, and -- where the reference tree is mounted --
+    loading each YAML through this package's loader gives the same merged table."""
+    import json
+    from attentionalpoolingaction_amd import config as apa_config
+    ref = json.load(open(os.path.join(GOLD, 'config_reference.json')))
+    mine = _flat(apa_config.reset_cfg())
+    assert set(ref['defaults']) == set(mine)
+    for k, v in ref['defaults'].items():
+        assert mine[k] == v or (isinstance(v, float) and mine[k] == pytest.approx(v, abs=1e-15)), k
+    assert len(ref['experiments']) == 7
+    for name, table in ref['experiments'].items():
+        path = os.path.join('/root/reference/experiments', name)
+        if not os.path.exists(path):
+            continue
+        apa_config.reset_cfg()
+        got = _flat(apa_config.cfg_from_file(path))
+        assert set(got) == set(table), name
+        for k, v in table.items():
+            assert got[k] == v or (isinstance(v, float) and got[k] == pytest.approx(v, abs=1e-15)), (name, k)
+    apa_config.reset_cfg()
+
+
+def test_compute_map_matches_the_reference_s_own_code():
+    """tests/golden/map_reference.npz was produced by EXECUTING the reference's src/eval/cap_eval_utils.py and
+    src/eval/utils.py (tests/golden/make_map_reference.py): SURVEY 8(a) row a14 is pinned to the reference
+    itself, not to the restatement -- the package's vectorised rewrite and the oracle must both reproduce
+    mAP, the per-class APs (classes without positives skipped) and the P / R / score curves, ties included."""
+    d = np.load(os.path.join(GOLD, 'map_reference.npz'))
+    for ci in range(int(d['n_cases'])):
+        logits, labels = d['c%d_logits' % ci], d['c%d_labels' % ci]
+        for impl in (eval_utils, leo):
+            m, aps = impl.compute_map(logits, labels)
+            assert m == pytest.approx(float(d['c%d_map' % ci]), abs=1e-13), (ci, impl.__name__)
+            np.testing.assert_allclose(np.asarray(aps, dtype=np.float64).reshape(-1), d['c%d_aps' % ci], rtol=0, atol=1e-13)
+            cid = int(d['c%d_cid' % ci])
+            P, R, score, ap = impl.calc_pr_ovr_noref((labels == cid).astype('float32'), logits[:, cid])
+            np.testing.assert_allclose(P, d['c%d_P' % ci], rtol=0, atol=1e-13)
+            np.testing.assert_allclose(R, d['c%d_R' % ci], rtol=0, atol=1e-13)
+            np.testing.assert_array_equal(np.asarray(score, dtype=np.float64), d['c%d_score' % ci])   # tie order
+            assert float(np.asarray(ap).reshape(-1)[0]) == pytest.approx(float(d['c%d_ap' % ci]), abs=1e-13)
+
+
 def test_voc_ap_known_values():
     # perfect ranking -> 1; one positive ranked last among 4 -> 1/4
     assert eval_utils.calc_pr_ovr_noref(np.array([1, 1, 0, 0.]), np.array([.9, .8, .2, .1]))[3] == pytest.approx(1.0)
