@@ -14,7 +14,7 @@ code runs on "gloo" with CPU tensors (tests/test_deploy_gloo.py, world_size 2).
 """
 from __future__ import annotations
 
-from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+from typing import Dict, Iterable, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist

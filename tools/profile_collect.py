@@ -6,7 +6,6 @@ import csv
 import glob
 import json
 import os
-import shutil
 import subprocess
 import sys
 
