@@ -171,9 +171,9 @@ int main() {
     }
   }
   // a read-only pass of the size of the benchmark's forward pass (51.4 MB), rotating slices
-  printf("\nread only, rotating 51.4 MB slices:\n%6s %7s %6s %10s %8s\n", "blocks", "threads", "unroll", "us", "TB/s");
+  for (size_t mb : {(size_t)51380224, (size_t)25690112}) {   // fp32 / bf16 map of the benchmark batch
+  printf("\nread only, rotating %.1f MB slices:\n%6s %7s %6s %10s %8s\n", mb / 1e6, "blocks", "threads", "unroll", "us", "TB/s");
   {
-    const size_t mb = 51380224;
     const int nslices = (int)(bytes / mb);
     for (int blocks : {256, 512, 1024}) {
       for (int unroll : {4, 8}) {
@@ -197,6 +197,7 @@ int main() {
         printf("%6d %7d %6d %10.2f %8.2f\n", blocks, thr, unroll, us, moved / (us * 1e-6) / 1e12);
       }
     }
+  }
   }
   return 0;
 }
