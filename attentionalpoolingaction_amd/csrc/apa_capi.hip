@@ -22,7 +22,7 @@ int hip_fail(hipError_t e, const char* what) {
 }
 
 #ifdef APA_ABLATION
-int g_dbg_skip = [] { const char* e = getenv("APA_DBG_SKIP"); return e ? atoi(e) : 0; }();
+int g_dbg_skip = knob("APA_DBG_SKIP", 0);
 #endif
 
 }  // namespace apa
@@ -100,6 +100,20 @@ extern "C" size_t apa_attn_pool_workspace_bytes(int N, int P, int C, int Ca, int
   return 0;
 }
 
+// APA_FLAG_RNG_EXTERNAL: `seed` carries the address of the caller's keep bits
+static int check_rng_flags(const char* fn, unsigned flags, uint64_t seed) {
+  if (!(flags & APA_FLAG_RNG_EXTERNAL) || !(flags & APA_FLAG_TRAIN)) return APA_OK;
+  if (flags & (APA_FLAG_RNG_DEVICE | APA_FLAG_RELU_INPUT)) {
+    set_error("%s: APA_FLAG_RNG_EXTERNAL excludes APA_FLAG_RNG_DEVICE and APA_FLAG_RELU_INPUT", fn);
+    return (flags & APA_FLAG_RNG_DEVICE) ? APA_ERR_INVALID_ARG : APA_ERR_UNSUPPORTED;
+  }
+  if (seed == 0) {
+    set_error("%s: APA_FLAG_RNG_EXTERNAL with a null keep-bit image (seed == 0)", fn);
+    return APA_ERR_INVALID_ARG;
+  }
+  return APA_OK;
+}
+
 static int check_cat(const char* fn, const apa_concat_feat* c, int M, unsigned flags, bool topdown,
                      bool backward, CatFeat* out) {
   if (!c->Xext || !c->zext || (backward && !c->dXext)) {
@@ -135,6 +149,8 @@ static int attn_pool_fwd_impl(const Hooks& hk, const apa_concat_feat* catp, M1Xe
     set_error("apa_attn_pool_fwd: Xatt aliases X but Ca=%d != C=%d", Ca, C);
     return APA_ERR_INVALID_ARG;
   }
+  rc = check_rng_flags("apa_attn_pool_fwd", flags, seed);
+  if (rc != APA_OK) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   CatFeat cat;
   if (catp) {
@@ -174,11 +190,8 @@ static int attn_pool_fwd_impl(const Hooks& hk, const apa_concat_feat* catp, M1Xe
     if ((flags & APA_FLAG_TRAIN) && keep_prob < 1.0f) {
       g.drop_a = 1;
       g.inv_keep = 1.0f / keep_prob;
-      g.thresh = keep_thresh(keep_prob);
-      g.seed = seed;
-      g.offset = (flags & APA_FLAG_RNG_DEVICE) ? 0 : offset;
-      g.offset_dev = (flags & APA_FLAG_RNG_DEVICE)
-                         ? reinterpret_cast<const uint64_t*>(static_cast<uintptr_t>(offset)) : nullptr;
+      const RngKeyArgs k = rng_resolve(flags, keep_prob, seed, offset);
+      g.thresh = k.thresh; g.seed = k.seed; g.offset = k.offset; g.offset_dev = k.offset_dev;
     }
     return gemm_launch(g, st);
   }
@@ -238,6 +251,8 @@ static int attn_pool_bwd_impl(const Hooks& hk, const apa_concat_feat* catp, cons
     set_error("apa_attn_pool_bwd: keep_prob=%g outside (0,1]", (double)keep_prob);
     return APA_ERR_INVALID_ARG;
   }
+  rc = check_rng_flags("apa_attn_pool_bwd", flags, seed);
+  if (rc != APA_OK) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   CatFeat cat;
   if (catp) {
@@ -294,8 +309,8 @@ extern "C" int apa_attn_pool_bwd(const void* X, const void* Xatt, const float* W
                                  int M, unsigned flags, float keep_prob, uint64_t seed,
                                  uint64_t offset, int dtype, void* stream) {
   return attn_pool_bwd_impl(Hooks(), nullptr, nullptr, X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, dX, dXatt, dWa, dba,
-                            dWt, dbt, ws, ws_bytes, N, P, C, Ca, K, M, flags, keep_prob, seed, offset,
-                            dtype, stream);
+                            dWt, dbt, ws, ws_bytes, N, P, C, Ca, K, M, flags & ~APA_FLAG_WS_FROM_FWD, keep_prob,
+                            seed, offset, dtype, stream);
 }
 
 extern "C" int apa_attn_pool_bwd_ex(const apa_hooks* hooks, const void* X, const void* Xatt,
@@ -306,8 +321,8 @@ extern "C" int apa_attn_pool_bwd_ex(const apa_hooks* hooks, const void* X, const
                                     int C, int Ca, int K, int M, unsigned flags, float keep_prob,
                                     uint64_t seed, uint64_t offset, int dtype, void* stream) {
   return attn_pool_bwd_impl(Hooks(hooks), nullptr, nullptr, X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, dX, dXatt,
-                            dWa, dba, dWt, dbt, ws, ws_bytes, N, P, C, Ca, K, M, flags, keep_prob, seed,
-                            offset, dtype, stream);
+                            dWa, dba, dWt, dbt, ws, ws_bytes, N, P, C, Ca, K, M, flags & ~APA_FLAG_WS_FROM_FWD,
+                            keep_prob, seed, offset, dtype, stream);
 }
 
 extern "C" int apa_attn_pool_fwd_cat(const apa_concat_feat* cat, const apa_hooks* hooks, const void* X,
@@ -329,8 +344,8 @@ extern "C" int apa_attn_pool_bwd_cat(const apa_concat_feat* cat, const apa_hooks
                                      int P, int C, int Ca, int K, int M, unsigned flags, float keep_prob,
                                      uint64_t seed, uint64_t offset, int dtype, void* stream) {
   return attn_pool_bwd_impl(Hooks(hooks), cat, nullptr, X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, dX,
-                            dXatt, dWa, dba, dWt, dbt, ws, ws_bytes, N, P, C, Ca, K, M, flags, keep_prob,
-                            seed, offset, dtype, stream);
+                            dXatt, dWa, dba, dWt, dbt, ws, ws_bytes, N, P, C, Ca, K, M,
+                            flags & ~APA_FLAG_WS_FROM_FWD, keep_prob, seed, offset, dtype, stream);
 }
 
 extern "C" int apa_attn_head_train_step_ex(const apa_hooks* hooks, const void* X, const void* Xatt,

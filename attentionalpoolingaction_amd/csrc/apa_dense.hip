@@ -343,7 +343,7 @@ static size_t pose_rows_lds(int rpb, int nthr, int dtype, bool ext) {
 // 4.6 vs 6.9 us, step -3 us in four interleaved pairs) once that still gives half the CUs a block and the tile
 // stays under the 64 KB a launch gets without opting in, else 16
 static int pose_rows_per_block(long R, int nthr, int dtype, bool ext) {
-  static const int forced = [] { const char* e = getenv("APA_POSE_RPB"); return e ? atoi(e) : 0; }();
+  static const int forced = knob("APA_POSE_RPB", 0);
   int rpb = (R + 31) / 32 >= 128 ? 32 : 16;
   if (forced == 16 || forced == 32) rpb = forced;
   if (rpb == 32 && pose_rows_lds(32, nthr, dtype, ext) > 65536) rpb = 16;
@@ -352,7 +352,7 @@ static int pose_rows_per_block(long R, int nthr, int dtype, bool ext) {
 
 static bool pose_bwd_rows_ok(const float* dPl, const void* Ppre, const void* ext, const float* W2, int Cp,
                              int J, int dtype) {
-  static const int enabled = [] { const char* e = getenv("APA_POSE_BWD_ROWS"); return e ? atoi(e) : 1; }();
+  static const int enabled = knob("APA_POSE_BWD_ROWS", 1);
   const uintptr_t al = reinterpret_cast<uintptr_t>(Ppre) | reinterpret_cast<uintptr_t>(ext);
   const int nthr = ((Cp / 2 + 63) / 64) * 64;
   return enabled && dPl && J <= 16 && Cp % 4 == 0 && Cp <= 1024 && (al & 7) == 0 &&
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void pose_pl_kernel(const bf16_t* __restrict__
 }
 
 static bool pose_pl_fast(int Cp, int J, int dtype, const void* Ppre) {
-  static const int enabled = [] { const char* e = getenv("APA_POSE_PL_FAST"); return e ? atoi(e) : 1; }();
+  static const int enabled = knob("APA_POSE_PL_FAST", 1);
   return enabled && dtype == APA_DTYPE_BF16 && J <= 16 && (Cp == 256 || Cp == 512 || Cp == 768 || Cp == 1024) &&
          (reinterpret_cast<uintptr_t>(Ppre) & 15) == 0;
 }
@@ -547,7 +547,7 @@ extern "C" int apa_pose_head_fwd(const void* X, const float* W1, const float* b1
 // split that fills those 768 slots (C = 2048, Cp = 768: 192 tiles x 4) beats the generic "256 tiles of 128 x 128"
 // rule (x 3): product 33.2 -> 29.0 us, reduce 6.0 -> 6.5 us, cfg 003 step -3 us (three interleaved pairs)
 static int pose_dw1_splits(int C, int Cp, int R, int dtype) {
-  static const int s_env = [] { const char* e = getenv("APA_GEMM_SPLITS"); return e ? atoi(e) : 0; }();
+  static const int s_env = knob("APA_GEMM_SPLITS", 0);
   int s = gemm_pick_splits(C, Cp, R);
   if (dtype == APA_DTYPE_BF16 && s > 1 && s_env <= 0) {
     const long t64 = (long)((C + 127) / 128) * ((Cp + 63) / 64);
@@ -764,7 +764,7 @@ constexpr int PC_PG = 16;   // pixel groups per block of the per-class activatio
 constexpr int PC_MAX_PSPLIT = 8;   // pixel splits (grid.z) of the backward activation pass
 // pixel splits of pc_bwd_act_kernel: enough blocks to put one on most CUs; the spatial softmax needs the whole image
 static int pc_bwd_act_psplit(int N, int kgroups, int P, int act) {
-  static const int ps_env = [] { const char* e = getenv("APA_PC_ACT_PSPLIT"); return e ? atoi(e) : 0; }();
+  static const int ps_env = knob("APA_PC_ACT_PSPLIT", 0);
   if (act == 2) return 1;
   int ps = ps_env > 0 ? ps_env : (256 + N * kgroups - 1) / (N * kgroups);   // HMDB-51 shape, N = 32: 7.9 -> 4.9 us
   if (ps > PC_MAX_PSPLIT) ps = PC_MAX_PSPLIT;
@@ -955,14 +955,14 @@ __global__ __launch_bounds__(256) void pc_dropout_kernel(const bf16_t* __restric
                                                          uint64_t seed, uint64_t offset,
                                                          const uint64_t* __restrict__ offset_dev) {
   uint32_t k0, k1;
-  rng_key_dev(seed, offset_dev ? *offset_dev : offset, k0, k1);
+  rng_key_dev_x(seed, offset_dev ? *offset_dev : offset, thresh, k0, k1);
   for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n8; v += (size_t)gridDim.x * 256) {
     float x[8];
     Vec<bf16_t>::unpack(ld16(X + v * 8), x);
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {
       float m0, m1;
-      rng_keep2(v * 8 + e, k0, k1, thresh, m0, m1);
+      rng_keep2_x(v * 8 + e, k0, k1, thresh, m0, m1);
       x[e] *= m0 * inv_keep;
       x[e + 1] *= m1 * inv_keep;
     }
@@ -975,11 +975,9 @@ static const void* pc_dropped_features(const void* X, void* Xd, long R, int C, f
   const size_t n8 = (size_t)R * C / 8;
   size_t nb = (n8 + 255) / 256;
   if (nb > 4096) nb = 4096;
-  const bool devctr = flags & APA_FLAG_RNG_DEVICE;
+  const RngKeyArgs k = rng_resolve(flags, keep_prob, seed, offset);
   hipLaunchKernelGGL(pc_dropout_kernel, dim3((unsigned)nb), dim3(256), 0, st, static_cast<const bf16_t*>(X),
-                     static_cast<bf16_t*>(Xd), n8, 1.0f / keep_prob, keep_thresh(keep_prob), seed,
-                     devctr ? 0 : offset,
-                     devctr ? reinterpret_cast<const uint64_t*>(static_cast<uintptr_t>(offset)) : nullptr);
+                     static_cast<bf16_t*>(Xd), n8, 1.0f / keep_prob, k.thresh, k.seed, k.offset, k.offset_dev);
   return Xd;
 }
 
@@ -997,11 +995,8 @@ static void set_dropout(GemmDesc& g, bool on_a, bool on_c, float keep_prob, uint
                         uint64_t offset, unsigned flags) {
   g.drop_a = on_a; g.drop_c = on_c;
   g.inv_keep = 1.0f / keep_prob;
-  g.thresh = keep_thresh(keep_prob);
-  g.seed = seed;
-  g.offset = (flags & APA_FLAG_RNG_DEVICE) ? 0 : offset;
-  g.offset_dev = (flags & APA_FLAG_RNG_DEVICE)
-                     ? reinterpret_cast<const uint64_t*>(static_cast<uintptr_t>(offset)) : nullptr;
+  const RngKeyArgs k = rng_resolve(flags, keep_prob, seed, offset);
+  g.thresh = k.thresh; g.seed = k.seed; g.offset = k.offset; g.offset_dev = k.offset_dev;
 }
 
 int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba, const float* Wt,
@@ -1018,7 +1013,7 @@ int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
   const int tdt = dt_code(dtype);
   const bool wb16 = dtype == APA_DTYPE_BF16;   // padded weights stored as bf16
   const bool fast = dtype == APA_DTYPE_BF16 && C % 8 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
-  if (pc_fused_supported(N, P, C, Ca, K, dtype, X, Xatt)) {
+  if (pc_fused_supported(N, P, C, Ca, K, dtype, X, Xatt) && !rng_external(flags)) {
     // K <= 64 (HMDB-51): Z | T in ONE pass over X, dropout applied on the way into LDS (apa_pc_fused.hip)
     const PcFusedWs f = pc_fused_carve(w + pl.off_fused, N, P, C);
     int rc = pc_fused_prep(f, Wa, Wt, ba, bt, C, K, st);
@@ -1100,7 +1095,7 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
   const bool fused = (Xatt == X);
   const int tdt = dt_code(dtype);
   const bool wb16 = dtype == APA_DTYPE_BF16;
-  if (pc_fused_supported(N, P, C, Ca, K, dtype, X, Xatt)) {
+  if (pc_fused_supported(N, P, C, Ca, K, dtype, X, Xatt) && !rng_external(flags)) {
     const PcFusedWs f = pc_fused_carve(w + pl.off_fused, N, P, C);
     int rc = APA_OK;
     const bool devctr = flags & APA_FLAG_RNG_DEVICE;
@@ -1125,7 +1120,7 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
     rc = pc_fused_dw(f, X, dWt, dWa, R, C, K, train, keep_prob, st);
     if (rc != APA_OK) return rc;
     // dX = (dT . Wt^T) * mask/keep + dZ . Wa^T: one launch over the concatenated k = 128
-    static const int exp_mask = [] { const char* e = getenv("APA_PC_EXP"); return e ? atoi(e) : 0; }();
+    static const int exp_mask = knob("APA_PC_EXP", 0);
     if (train && !(exp_mask & 1))
       return gemm_bf16_mid_dropout(f.dTdZ, 128, f.Wcat2, 128, dX, C, R, C, 128, 1.0f / keep_prob, f.maskbits, st);
     GemmDesc g;

@@ -183,6 +183,35 @@ __device__ __forceinline__ void rng_keep2(uint64_t e, uint32_t k0, uint32_t k1, 
   m1 = (h >> 16) < thresh ? 1.0f : 0.0f;
 }
 
+// APA_FLAG_RNG_EXTERNAL (apa.h): the keep decisions come from a caller-supplied bit image instead of the
+// hash -- bit (e & 7) of byte e >> 3 for flat element e.  The host passes thresh == RNG_THRESH_EXTERNAL and
+// the ADDRESS of the image in `seed`; the `_x` helpers below understand both modes (one uniform branch per
+// call).  They serve the kernels an external mask is routed to (generic M == 1 kernels, the pose-feature
+// kernels, the per-class GEMM path); the streaming / register-resident / fused hot kernels keep the
+// branch-free helpers above and are never launched with an external mask.
+constexpr uint32_t RNG_THRESH_EXTERNAL = 0xFFFFFFFFu;
+__device__ __forceinline__ void rng_key_dev_x(uint64_t seed, uint64_t offset, uint32_t thresh, uint32_t& k0,
+                                              uint32_t& k1) {
+  if (thresh == RNG_THRESH_EXTERNAL) {
+    k0 = (uint32_t)seed;
+    k1 = (uint32_t)(seed >> 32);
+  } else {
+    rng_key_dev(seed, offset, k0, k1);
+  }
+}
+// elements e and e+1, e even: both bits live in the same byte
+__device__ __forceinline__ void rng_keep2_x(uint64_t e, uint32_t k0, uint32_t k1, uint32_t thresh, float& m0,
+                                            float& m1) {
+  if (thresh == RNG_THRESH_EXTERNAL) {
+    const uint8_t* bits = reinterpret_cast<const uint8_t*>(((uint64_t)k1 << 32) | k0);
+    const uint32_t b = bits[e >> 3] >> (e & 7);
+    m0 = (b & 1u) ? 1.0f : 0.0f;
+    m1 = (b & 2u) ? 1.0f : 0.0f;
+  } else {
+    rng_keep2(e, k0, k1, thresh, m0, m1);
+  }
+}
+
 // XCD-aware bijective block remap: consecutive logical blocks land on the same XCD (observed
 // dispatch: hardware block b runs on XCD b % 8), so the S blocks of one image share its dz / z
 // rows in one L2.  Placement only affects speed, never results.

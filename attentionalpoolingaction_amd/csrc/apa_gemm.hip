@@ -62,7 +62,7 @@ struct GemmParams {
 
 __device__ __forceinline__ float keep1(uint64_t e, uint32_t k0, uint32_t k1, uint32_t thresh) {
   float m0, m1;
-  rng_keep2(e & ~1ull, k0, k1, thresh, m0, m1);
+  rng_keep2_x(e & ~1ull, k0, k1, thresh, m0, m1);
   return (e & 1) ? m1 : m0;
 }
 
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void gemm128_kernel(GemmParams p) {
   const int kend = min(p.K, kbeg + p.k_per_split);
 
   uint32_t h0 = 0, h1 = 0;
-  if (p.drop_a || p.drop_c) rng_key_dev(p.seed, p.offset_dev ? *p.offset_dev : p.offset, h0, h1);
+  if (p.drop_a || p.drop_c) rng_key_dev_x(p.seed, p.offset_dev ? *p.offset_dev : p.offset, p.thresh, h0, h1);
 
   const TA* A = static_cast<const TA*>(p.A);
   const TB* B = static_cast<const TB*>(p.B);
@@ -337,7 +337,7 @@ size_t gemm_ws_bytes(int M, int N, int splits) {
 int gemm_pick_splits(int M, int N, int K) {
   const int tiles = ((M + GM - 1) / GM) * ((N + GN - 1) / GN);
   if (tiles >= 128 || K <= 4 * GK) return 1;
-  static const int s_env = [] { const char* e = getenv("APA_GEMM_SPLITS"); return e ? atoi(e) : 0; }();
+  static const int s_env = knob("APA_GEMM_SPLITS", 0);
   if (s_env > 0) return s_env;
   int s = (256 + tiles - 1) / tiles;
   const int maxs = K / (4 * GK) > 0 ? K / (4 * GK) : 1;

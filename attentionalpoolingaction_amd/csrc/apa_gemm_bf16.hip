@@ -146,7 +146,7 @@ __device__ __forceinline__ void store8(const FastParams& p, TC* C, int grow, int
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {
       float k0, k1;
-      rng_keep2((uint64_t)grow * p.Nout + gcol + e, h0, h1, p.thresh, k0, k1);
+      rng_keep2_x((uint64_t)grow * p.Nout + gcol + e, h0, h1, p.thresh, k0, k1);
       o[e] *= k0 * p.inv_keep;
       o[e + 1] *= k1 * p.inv_keep;
     }
@@ -185,7 +185,7 @@ __device__ __forceinline__ void store1(const FastParams& p, TC* C, int row, int 
   if (p.drop_c) {
     const uint64_t e = (uint64_t)row * p.Nout + col;
     float k0, k1;
-    rng_keep2(e & ~1ull, h0, h1, p.thresh, k0, k1);
+    rng_keep2_x(e & ~1ull, h0, h1, p.thresh, k0, k1);
     v *= ((e & 1) ? k1 : k0) * p.inv_keep;
   }
   if (p.beta != 0.f) v += c_get<TC>(C, (long)row * p.ldc + col);
@@ -198,7 +198,7 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][4], const FastParams& p
   const int wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
   uint32_t h0 = 0, h1 = 0;   // output dropout (dX = (dT.Wt^T) * mask/keep of the per-class path)
-  if (p.drop_c) rng_key_dev(p.seed, p.offset_dev ? *p.offset_dev : p.offset, h0, h1);
+  if (p.drop_c) rng_key_dev_x(p.seed, p.offset_dev ? *p.offset_dev : p.offset, p.thresh, h0, h1);
   // ---- epilogue.  D layout of the 16x16 MFMA: row = 4 * (lane >> 4) + reg, col = lane & 15.
   // Fast form (N % 8 == 0, 16-byte addressable C rows): the tile goes through LDS as fp32
   // [128][132] (conflict-free 4-byte writes) and leaves as full 16-byte row segments -- bias, relu,
@@ -246,7 +246,7 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][4], const FastParams& p
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
           float k0, k1;
-          rng_keep2((uint64_t)grow * p.Nout + gcol + e, h0, h1, p.thresh, k0, k1);
+          rng_keep2_x((uint64_t)grow * p.Nout + gcol + e, h0, h1, p.thresh, k0, k1);
           o[e] *= k0 * p.inv_keep;
           o[e + 1] *= k1 * p.inv_keep;
         }
@@ -293,7 +293,7 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][4], const FastParams& p
           if (p.drop_c) {
             const uint64_t e = (uint64_t)row * p.Nout + col;
             float k0, k1;
-            rng_keep2(e & ~1ull, h0, h1, p.thresh, k0, k1);
+            rng_keep2_x(e & ~1ull, h0, h1, p.thresh, k0, k1);
             v *= ((e & 1) ? k1 : k0) * p.inv_keep;
           }
           if (p.beta != 0.f) v += c_get<TC>(C, (long)row * p.ldc + col);
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_glds64_kernel(FastParams p) 
   TC* C = static_cast<TC*>(p.C);
   const int l16 = lane & 15, kb = lane >> 4;
   uint32_t h0 = 0, h1 = 0;
-  if (p.drop_c) rng_key_dev(p.seed, p.offset_dev ? *p.offset_dev : p.offset, h0, h1);
+  if (p.drop_c) rng_key_dev_x(p.seed, p.offset_dev ? *p.offset_dev : p.offset, p.thresh, h0, h1);
   if (p.vec_epi) {
     float* stage = reinterpret_cast<float*>(smem);   // 128 * 68 * 4 = 34 816 B <= 49 152 B
     constexpr int LDS_C = BN + 4;
@@ -768,7 +768,7 @@ int gemm_bf16_mid_dropout(const void* A, long lda, const void* B, long ldb, void
 // Eligibility: bf16 A, bf16 or fp32 B, no fused dropout, 16-byte addressable rows, K a multiple of 8,
 // at least one full vector of rows for k-major operands.
 bool gemm_bf16_eligible(const GemmDesc& d) {
-  static const int fast = [] { const char* e = getenv("APA_GEMM_FAST"); return e ? atoi(e) : 1; }();
+  static const int fast = knob("APA_GEMM_FAST", 1);
   if (!fast) return false;
   if (d.ta != 1 || d.drop_a) return false;
   if (d.drop_c && (d.n_valid > 0 && d.n_valid != d.N)) return false;   // mask index uses the row length
@@ -797,12 +797,12 @@ int gemm_bf16_launch(const GemmDesc& d, int splits, int k_per_split, hipStream_t
   p.vec_epi = p.Nout % 8 == 0 && (!d.drop_c || p.Nout % 2 == 0) && (reinterpret_cast<uintptr_t>(d.C) & 15) == 0 && (d.ldc * ec) % 16 == 0 &&
               (!d.bias || (reinterpret_cast<uintptr_t>(d.bias) & 15) == 0) &&
               (!p.partial || (reinterpret_cast<uintptr_t>(p.partial) & 15) == 0);
-  static const int use_glds = [] { const char* e = getenv("APA_GEMM_GLDS"); return e ? atoi(e) : 1; }();
+  static const int use_glds = knob("APA_GEMM_GLDS", 1);
   if (use_glds && d.tb == 1 && k_per_split % TK == 0 && d.K % TK == 0) {   // all-bf16, whole K tiles: DMA staging
     // tile shape: with fewer than ~2.5 tiles of 128 x 128 per CU the ragged last round dominates and
     // the 128 x 64 variant (twice the tiles, three blocks per CU) wins -- measured on the pose head:
     // 294 tiles 38.2 -> 32.6 us, 96 x 3 splits 40.0 -> 35.2 us, but 784 tiles 34.4 -> 37.4 us
-    static const int bn_env = [] { const char* e = getenv("APA_GEMM_BN"); return e ? atoi(e) : 0; }();
+    static const int bn_env = knob("APA_GEMM_BN", 0);
     const long tiles128 = (long)((d.M + TM - 1) / TM) * ((d.N + TN - 1) / TN) * splits;
     const int bn = bn_env ? bn_env : (tiles128 < 640 ? 64 : 128);
     if (bn == 64) {

@@ -40,6 +40,19 @@ struct Hooks {
   }
 };
 
+// The shipped library has ONE code path and never reads the environment.  The A/B knobs of the development
+// builds (`make ABLATE=1`, -DAPA_ABLATION: tools/fuzz_arms.sh, profiling experiments) go through knob(): in the
+// product build it is a constant expression equal to the default, the name strings are not even linked in
+// (`strings libapa_hip.so | grep '^APA_'` prints nothing).
+#ifdef APA_ABLATION
+inline int knob(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return (s && *s) ? atoi(s) : dflt;
+}
+#else
+constexpr int knob(const char*, int dflt) { return dflt; }
+#endif
+
 // Ablation hook for profiling experiments only (make ABLATE=1): a bit mask of kernels NOT to launch
 // (results are then wrong by construction).  Compiled out of the product build.
 #ifdef APA_ABLATION
@@ -80,6 +93,28 @@ inline uint32_t keep_thresh(float keep_prob) {
   if (t < 0) t = 0;
   if (t > 65536.0) t = 65536.0;
   return (uint32_t)t;
+}
+// The dropout key as the kernels take it, for the three sources of the mask (apa.h):
+//   default               (thresh, seed, offset, nullptr)   counter hash keyed by splitmix64(seed, offset)
+//   APA_FLAG_RNG_DEVICE   (thresh, seed, 0, offset_dev)     `offset` is the address of the step counter
+//   APA_FLAG_RNG_EXTERNAL (RNG_THRESH_EXTERNAL, bits, 0, nullptr)   `seed` is the address of the caller's
+//                         packed keep bits; understood by the rng_*_x device helpers only (apa_device.h)
+constexpr uint32_t RNG_THRESH_EXTERNAL_HOST = 0xFFFFFFFFu;
+struct RngKeyArgs {
+  uint32_t thresh; uint64_t seed, offset; const uint64_t* offset_dev;
+};
+inline bool rng_external(unsigned flags) { return (flags & 128u /* APA_FLAG_RNG_EXTERNAL */) != 0; }
+inline RngKeyArgs rng_resolve(unsigned flags, float keep_prob, uint64_t seed, uint64_t offset) {
+  RngKeyArgs k;
+  if (rng_external(flags)) {
+    k.thresh = RNG_THRESH_EXTERNAL_HOST; k.seed = seed; k.offset = 0; k.offset_dev = nullptr;
+  } else if (flags & 8u /* APA_FLAG_RNG_DEVICE */) {
+    k.thresh = keep_thresh(keep_prob); k.seed = seed; k.offset = 0;
+    k.offset_dev = reinterpret_cast<const uint64_t*>(static_cast<uintptr_t>(offset));
+  } else {
+    k.thresh = keep_thresh(keep_prob); k.seed = seed; k.offset = offset; k.offset_dev = nullptr;
+  }
+  return k;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -183,7 +218,8 @@ bool m1_cat_supported(int J);
 int m1_cat_forward(const CatFeat& cat, const float* att, const float* Wt, float* logits, int N, int P,
                    int C, int K, bool train, const M1Rng& r, hipStream_t st);
 int m1_cat_backward(const CatFeat& cat, const float* att, const float* G, const float* Wt, float* dWt,
-                    float* e_out, int N, int P, int C, int K, bool train, const M1Rng& r, hipStream_t st);
+                    float* e_out, int N, int P, int C, int K, bool softmax, bool train, const M1Rng& r,
+                    hipStream_t st);
 bool m1s_supported(int C, int dtype);
 int m1s_launch_pool_fwd(int dtype, int C, bool fused, bool train, int nblk, hipStream_t st,
                         const void* X, const float* Wa, const float* ba, float* att, float* pacc,
@@ -213,14 +249,10 @@ int m1_logits(const float* z, const float* Wt, const float* abar, const float* b
 int m1_bwd_small(const float* G, const float* Wt, const float* zsave, const float* abar,
                  const float* bt, float* dz, float* dWt, float* dbt, float* sn, int N, int C, int K,
                  hipStream_t st);
-// the finalize step folded into the logits kernel (m1_logits2_kernel<.., FIN>): the pooling pass's partials
-struct M1Partials {
-  const float* pacc; const float* pstat; float* z_out; float* abar_out; int S, P;
-};
 bool m1_logits2_supported(int C, int K);
 size_t m1_logits2_ws_bytes(int N, int C, int K);
 int m1_logits2(const float* z, const float* Wt, const float* abar, const float* bt, float* logits,
-               float* part_ws, int N, int C, int K, hipStream_t st, const M1Partials* fp = nullptr);
+               float* part_ws, int N, int C, int K, hipStream_t st);
 bool m1_bwd_head_supported(int N, int C, int K);
 int m1_bwd_head(const float* G, const float* Wt, const float* zsave, const float* abar,
                 const float* bt, float* dz, float* dWt, float* dbt, float* sn, int N, int C, int K,
@@ -228,8 +260,7 @@ int m1_bwd_head(const float* G, const float* Wt, const float* zsave, const float
 bool m1_logits_xent_supported(int N, int C, int K, bool eval);
 int m1_logits2_xent(const float* z, const float* Wt, const float* abar, const float* bt,
                     const int64_t* labels, float* logits, float* loss, float* G, float gscale,
-                    float* probs, int64_t* pred, float* part_ws, int N, int C, int K, hipStream_t st,
-                    const M1Partials* fp = nullptr);
+                    float* probs, int64_t* pred, float* part_ws, int N, int C, int K, hipStream_t st);
 // dwa2 != nullptr: columns [C1, C2) of the partial matrix are summed into dwa2, dwa3 != nullptr: columns
 // [C2, C) into dwa3 (one launch, up to three outputs)
 int m1_colsum(const float* pdwa, const float* pdba, float* dwa, float* dba, int nblk, int C, int ld,

@@ -655,11 +655,6 @@ __global__ __launch_bounds__(256) void m1_att_gemv_bwd2_kernel(
 // ============================================================================================
 // host side
 // ============================================================================================
-static int env_int(const char* name, int dflt) {
-  const char* s = getenv(name);
-  return (s && *s) ? atoi(s) : dflt;
-}
-
 static bool use_stream_kernels(int C, int dtype);
 // the register-resident per-pixel kernels of this file: C = 64 * EPV * {1, 2, 4, 8}
 static bool vec_kernels_supported(int C, int dtype) {
@@ -685,7 +680,7 @@ bool m1_supported(int C, int Ca, int dtype, bool fused) {
 // (N >= 512) one block per image.  APA_M1_TARGET_BLOCKS overrides the target for experiments.
 M1Plan m1_plan(int N, int P, int C, int Ca, int K) {
   M1Plan pl;
-  const int target = env_int("APA_M1_TARGET_BLOCKS", 512);
+  const int target = knob("APA_M1_TARGET_BLOCKS", 512);
   int S = (target + N / 2) / N;
   if (S < 1) S = 1;
   int maxS = P >= 8 ? P / 4 : 1;
@@ -720,7 +715,7 @@ typedef M1Rng RngArgs;
 // The channel-split streaming kernels (apa_m1_stream.hip) serve wide maps; APA_M1_STREAM=0 forces
 // the per-pixel kernels of this file (A/B experiments).
 static bool use_stream_kernels(int C, int dtype) {
-  static const int enabled = env_int("APA_M1_STREAM", 1);
+  static const int enabled = knob("APA_M1_STREAM", 1);
   return enabled && m1s_supported(C, dtype);
 }
 
@@ -791,12 +786,8 @@ static int act_of(unsigned flags) {
 static RngArgs rng_args(bool train, float keep_prob, uint64_t seed, uint64_t offset, unsigned flags) {
   RngArgs r;
   r.inv_keep = train ? 1.0f / keep_prob : 1.0f;
-  r.thresh = keep_thresh(keep_prob);
-  r.seed = seed;
-  r.offset = (flags & APA_FLAG_RNG_DEVICE) ? 0 : offset;
-  r.offset_dev = (flags & APA_FLAG_RNG_DEVICE)
-                     ? reinterpret_cast<const uint64_t*>(static_cast<uintptr_t>(offset))
-                     : nullptr;
+  const RngKeyArgs k = rng_resolve(flags, keep_prob, seed, offset);
+  r.thresh = k.thresh; r.seed = k.seed; r.offset = k.offset; r.offset_dev = k.offset_dev;
   r.relu_input = (flags & APA_FLAG_RELU_INPUT) != 0;
   return r;
 }
@@ -819,7 +810,7 @@ int m1_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
   r.maskbits_out = reinterpret_cast<uint8_t*>(w + pl.off_maskbits);
 
   if (r.relu_input && !(fused && use_stream_kernels(C, dtype))) {
-    set_error("APA_FLAG_RELU_INPUT: needs Xatt == X and C in {1024,2048,4096} (f32) / 2048 (bf16)");
+    set_error("attn_pool M=1: APA_FLAG_RELU_INPUT needs Xatt == X and C in {1024,2048,4096} (f32) / 2048 (bf16)");
     return APA_ERR_UNSUPPORTED;
   }
   int pool_act = act;
@@ -840,11 +831,17 @@ int m1_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
     pool_act = ACT_ID;  // att already final
   }
   int rc = APA_OK;
+  // APA_FLAG_RNG_EXTERNAL: the caller's keep bits are read by the run-time-loop kernels only
+  const bool ext = train && rng_external(flags);
+  if (ext && !m1g_supported(C, dtype)) {
+    set_error("attn_pool M=1: APA_FLAG_RNG_EXTERNAL: C=%d is not served by the generic M == 1 kernels", C);
+    return APA_ERR_UNSUPPORTED;
+  }
   if (dbg_skip() & 1) {}
-  else if (use_stream_kernels(C, dtype))
+  else if (!ext && use_stream_kernels(C, dtype))
     rc = m1s_launch_pool_fwd(dtype, C, fused, train, pl.nblk, st, X, Wa, ba, att, pacc, pstat, P,
                              pl.S, pool_act, r);
-  else if (vec_kernels_supported(C, dtype))
+  else if (!ext && vec_kernels_supported(C, dtype))
     rc = APA_DISPATCH_VEC(launch_pool_fwd, dtype, C, fused, train, pl.nblk, st, X, Wa, ba, att,
                           pacc, pstat, P, pl.S, pool_act, r);
   else
@@ -852,21 +849,9 @@ int m1_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
                              pool_act, r);
   if (rc != APA_OK) return rc;
   const int online = (fused && act == ACT_SOFTMAX) ? 1 : 0;
-  // A/B arm, OFF by default: without an on-line softmax to merge, the finalize step (z = (1/P) sum of the S
-  // partial rows, abar) can ride in the prologue of the logits kernel (m1_logits2_kernel<.., FIN>).  Measured
-  // on MI355X (round 2, bench.py, N = 32): one launch fewer but SLOWER -- training step 51.7 -> 54.1 us,
-  // evaluation step 23.2 -> 25.5 us: 128 logits blocks each gather a 128 KB slab of partials (16 MB of L2
-  // traffic, 32 dependent-free but wide loads per thread ahead of the MFMAs) where the stand-alone kernel
-  // moves 4 MB once, and a dependent kernel boundary on this chip costs only ~1.7 us.
-  static const int fuse_fin = env_int("APA_M1_FUSE_FINALIZE", 0);
-  static const int use_l2f = env_int("APA_M1_LOGITS2", 1);
-  const bool fin_in_logits = fuse_fin && use_l2f && !online && m1_logits2_supported(C, K) &&
-                             (reinterpret_cast<uintptr_t>(zsave) & 15) == 0 && pl.S <= 256;
-  M1Partials fpart{pacc, pstat, zsave, abar, pl.S, P};
-  const M1Partials* fp = fin_in_logits ? &fpart : nullptr;
-  if (!fin_in_logits && !(dbg_skip() & 2)) {
+  if (!(dbg_skip() & 2)) {
     // enough blocks to put every CU to work (the kernel is bound by the bytes each CU loads)
-    static const int cw_env = env_int("APA_M1_FIN_CW", 0);
+    static const int cw_env = knob("APA_M1_FIN_CW", 0);
     int cw = cw_env ? cw_env : 256;
     if (!cw_env) while (cw > 64 && (long)N * ((C + 4 * cw - 1) / (4 * cw)) < 256) cw >>= 1;
     hipLaunchKernelGGL(m1_finalize_fwd_kernel, dim3(N, (C + 4 * cw - 1) / (4 * cw)), dim3(256), 0, st, pacc,
@@ -875,9 +860,9 @@ int m1_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
   }
   // logits = z . Wt + abar (x) bt -- the first reader of Wt / bt (apa_hooks.td_weights_ready_event)
   if (hk.td_ready) APA_HIP_CHECK(hipStreamWaitEvent(st, hk.td_ready, 0));
-  static const int use_l2 = env_int("APA_M1_LOGITS2", 1);
-  static const int use_lx = env_int("APA_M1_LOGITS_XENT", 1);
-  static const int use_bh = env_int("APA_M1_BWD_HEAD", 1);
+  static const int use_l2 = knob("APA_M1_LOGITS2", 1);
+  static const int use_lx = knob("APA_M1_LOGITS_XENT", 1);
+  static const int use_bh = knob("APA_M1_BWD_HEAD", 1);
   const bool xeval = xf && xf->probs;
   if (cat) xf = nullptr;   // the extra channels add to the logits after the reduction: no fused loss
   if (xf && use_l2 && use_lx && (xeval || use_bh) && m1_logits_xent_supported(N, C, K, xeval) &&
@@ -886,12 +871,12 @@ int m1_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
         reinterpret_cast<uintptr_t>(xf->G)) & 15) == 0) {
     // training: the same conditions under which m1_backward takes the head kernel, which finishes loss[0]
     rc = m1_logits2_xent(zsave, Wt, abar, bt, xf->labels, logits, xf->loss, xf->G, xf->gscale, xf->probs,
-                         xf->pred, gemm_ws, N, C, K, st, fp);
+                         xf->pred, gemm_ws, N, C, K, st);
     xf->done = rc == APA_OK;
     return rc;
   }
   if (use_l2 && m1_logits2_supported(C, K) && (reinterpret_cast<uintptr_t>(zsave) & 15) == 0)
-    rc = m1_logits2(zsave, Wt, abar, bt, logits, gemm_ws, N, C, K, st, fp);
+    rc = m1_logits2(zsave, Wt, abar, bt, logits, gemm_ws, N, C, K, st);
   else if (m1_small_supported(C, K) && (reinterpret_cast<uintptr_t>(zsave) & 15) == 0)
     rc = m1_logits(zsave, Wt, abar, bt, logits, gemm_ws, N, C, K, st);
   else
@@ -923,11 +908,11 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
   float* sn_buf = pdba + pl.nblk;   // [N] floats: the pdba region is sized nblk + N
   RngArgs r = rng_args(train, keep_prob, seed, offset, flags);
   r.ev0 = hk.bwd0; r.ev1 = hk.bwd1;
-  static const int use_bits = env_int("APA_M1_KEEP_BITS", 1);
+  static const int use_bits = knob("APA_M1_KEEP_BITS", 1);
   if ((flags & APA_FLAG_WS_FROM_FWD) && use_bits)   // same workspace, untouched since the forward call
     r.maskbits_in = reinterpret_cast<const uint8_t*>(w + pl.off_maskbits);
   if (r.relu_input && !(fused && use_stream_kernels(C, dtype))) {
-    set_error("APA_FLAG_RELU_INPUT: needs Xatt == X and C in {1024,2048,4096} (f32) / 2048 (bf16)");
+    set_error("attn_pool M=1: APA_FLAG_RELU_INPUT needs Xatt == X and C in {1024,2048,4096} (f32) / 2048 (bf16)");
     return APA_ERR_UNSUPPORTED;
   }
 
@@ -939,7 +924,7 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
   if (dbg_skip() & 32) { rc = APA_OK; }
   else if (small_ok) {
     // dz = G . Wt^T, dWt = z^T . G, dbt = abar^T G in one launch
-    static const int use_head = env_int("APA_M1_BWD_HEAD", 1);
+    static const int use_head = knob("APA_M1_BWD_HEAD", 1);
     if (use_head && m1_bwd_head_supported(N, C, K))
       rc = m1_bwd_head(G, Wt, zsave, abar, bt, dz, dWt, dbt, sn_buf, N, C, K, st,
                        xf && xf->done ? xf->loss : nullptr, xf ? xf->lscale : 0.f);
@@ -965,19 +950,24 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
   const float* dA_extra = nullptr;
   if (cat) {   // dWt rows C..C+J-1, dXext, and the extra channels' per-pixel share of dA
     float* e = reinterpret_cast<float*>(w + pl.off_cat_e);
-    rc = m1_cat_backward(*cat, att, G, Wt, dWt, e, N, P, C, K, train, r, st);
+    rc = m1_cat_backward(*cat, att, G, Wt, dWt, e, N, P, C, K, act == ACT_SOFTMAX, train, r, st);
     if (rc != APA_OK) return rc;
     dA_extra = e;
   }
   // dWt / dbt are final here (fast path): let a data-parallel caller start their all-reduce now
   if (small_ok && hk.grad_ready) APA_HIP_CHECK(hipEventRecord(hk.grad_ready, st));
 
+  const bool ext = train && rng_external(flags);
+  if (ext && !m1g_supported(C, dtype)) {
+    set_error("attn_pool M=1: APA_FLAG_RNG_EXTERNAL: C=%d is not served by the generic M == 1 kernels", C);
+    return APA_ERR_UNSUPPORTED;
+  }
   if (dbg_skip() & 64) {}
-  else if (use_stream_kernels(C, dtype))
+  else if (!ext && use_stream_kernels(C, dtype))
     rc = m1s_launch_bwd_main(dtype, C, fused, train, pl.nblk, st, X, Wa, att, dz, zsave, abar, G,
                              bt, small_ok ? sn_buf : nullptr, dX, dZatt, pdwa, pdba, P, pl.S, K,
                              act, r, dA_extra);
-  else if (vec_kernels_supported(C, dtype))
+  else if (!ext && vec_kernels_supported(C, dtype))
     rc = APA_DISPATCH_VEC(launch_bwd_main, dtype, C, fused, train, pl.nblk, st, X, Wa, att, dz,
                           zsave, abar, G, bt, small_ok ? sn_buf : nullptr, dX, dZatt, pdwa, pdba,
                           P, pl.S, K, act, r, dA_extra);
@@ -996,7 +986,7 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
     if (nb > pl.nblk) nb = pl.nblk;  // partial buffer is sized for nblk rows
     const size_t shm = ((size_t)4 * Ca + 8) * sizeof(float);
     const int epv = dtype == APA_DTYPE_F32 ? 4 : 8;
-    static const int use_v2 = env_int("APA_M1_GEMV_BWD2", 1);
+    static const int use_v2 = knob("APA_M1_GEMV_BWD2", 1);
     if (use_v2 && Ca % epv == 0 && Ca / epv <= 256) {   // register-resident form
       const int nthr = ((Ca / epv + 63) / 64) * 64;
 #define APA_GB2(T, ST)                                                                        \
@@ -1007,7 +997,7 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
       else { if (rank1) APA_GB2(bf16_t, false); else APA_GB2(bf16_t, true); }
 #undef APA_GB2
     } else if (rank1) {
-      set_error("APA_FLAG_DXATT_RANK1: Ca=%d not served by the register-resident GEMV", Ca);
+      set_error("attn_pool M=1: APA_FLAG_DXATT_RANK1: Ca=%d not served by the register-resident GEMV", Ca);
       return APA_ERR_UNSUPPORTED;
     } else if (dtype == APA_DTYPE_F32)
       hipLaunchKernelGGL(m1_att_gemv_bwd_kernel<float>, dim3(nb), dim3(256), shm, st,

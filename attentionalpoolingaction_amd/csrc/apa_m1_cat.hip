@@ -24,10 +24,9 @@ constexpr int CAT_MAX_J = 64;
 
 // keep decision (1.0f / 0.0f) of flat element e (any parity): half (e & 1) of the pair hash
 __device__ __forceinline__ float rng_keep_at(uint64_t e, uint32_t k0, uint32_t k1, uint32_t thresh) {
-  const uint64_t q = e >> 1;
-  const uint32_t h = rng_hash((uint32_t)q, k0, k1 ^ __umul24((uint32_t)(q >> 32), 0x9E3779u));
-  const uint32_t b = (e & 1u) ? (h >> 16) : (h & 0xffffu);
-  return b < thresh ? 1.0f : 0.0f;
+  float m0, m1;
+  rng_keep2_x(e & ~1ull, k0, k1, thresh, m0, m1);   // hash or APA_FLAG_RNG_EXTERNAL bit image
+  return (e & 1u) ? m1 : m0;
 }
 
 // zext[n,j] = (1/P) sum_p A[n,p] * Xext'[n,p,j].  One block per image; thread t owns channel
@@ -39,7 +38,7 @@ __global__ __launch_bounds__(256) void m1_cat_pool_kernel(
     const uint64_t* __restrict__ offset_dev) {
   __shared__ float red[256];
   uint32_t k0 = 0, k1 = 0;
-  if (train) rng_key_dev(seed, offset_dev ? *offset_dev : offset, k0, k1);
+  if (train) rng_key_dev_x(seed, offset_dev ? *offset_dev : offset, thresh, k0, k1);
   const int n = blockIdx.x, tid = threadIdx.x;
   const int groups = 256 / J;           // J <= 64 -> at least 4 pixel lanes
   const int j = tid % J, pg = tid / J;
@@ -79,7 +78,7 @@ __global__ __launch_bounds__(256) void m1_cat_bwd_kernel(
     const float* __restrict__ Xext, const float* __restrict__ att, const float* __restrict__ zext,
     const float* __restrict__ G, const float* __restrict__ Wext, float* __restrict__ dXext,
     float* __restrict__ dWext, float* __restrict__ e_out, int N, int P, int J, int K, uint64_t ebase,
-    int train, float inv_keep, uint32_t thresh, uint64_t seed, uint64_t offset,
+    int softmax, int train, float inv_keep, uint32_t thresh, uint64_t seed, uint64_t offset,
     const uint64_t* __restrict__ offset_dev) {
   __shared__ float dze[CAT_MAX_J];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -93,7 +92,7 @@ __global__ __launch_bounds__(256) void m1_cat_bwd_kernel(
     return;
   }
   uint32_t k0 = 0, k1 = 0;
-  if (train) rng_key_dev(seed, offset_dev ? *offset_dev : offset, k0, k1);
+  if (train) rng_key_dev_x(seed, offset_dev ? *offset_dev : offset, thresh, k0, k1);
   const int n = blockIdx.x;
   for (int j = wave; j < J; j += 4) {      // dzext[n,j] = G[n,:] . Wt[C+j,:]
     float acc = 0.f;
@@ -103,6 +102,16 @@ __global__ __launch_bounds__(256) void m1_cat_bwd_kernel(
   }
   __syncthreads();
   const float invP = 1.0f / (float)P;
+  // Spatial softmax: dZ_p = A_p (dA_p - sum_q A_q dA_q), and the extra channels' part of that sum is
+  //   sum_q A_q e_q / P = sum_j zext[n,j] dzext[n,j] =: c_n,
+  // which the streaming kernels' correction term (z.dz + sn*abar) does not contain.  Folding -P*c_n into e
+  // turns their dA_p into dA_p - c_n, i.e. adds c_n to the correction, for every pixel of the image.
+  float shift = 0.f;
+  if (softmax) {
+    float c = 0.f;
+    for (int j = 0; j < J; ++j) c = fmaf(zext[(size_t)n * J + j], dze[j], c);   // same order in every thread
+    shift = c * (float)P;
+  }
   for (int p = tid; p < P; p += 256) {
     const float ap = att[(size_t)n * P + p] * invP;
     float e = 0.f;
@@ -112,7 +121,7 @@ __global__ __launch_bounds__(256) void m1_cat_bwd_kernel(
       e = fmaf(Xext[idx] * m, dze[j], e);
       dXext[idx] = ap * dze[j] * m;
     }
-    e_out[(size_t)n * P + p] = e;
+    e_out[(size_t)n * P + p] = e - shift;
   }
 }
 }  // namespace
@@ -132,11 +141,12 @@ int m1_cat_forward(const CatFeat& cat, const float* att, const float* Wt, float*
 }
 
 int m1_cat_backward(const CatFeat& cat, const float* att, const float* G, const float* Wt, float* dWt,
-                    float* e_out, int N, int P, int C, int K, bool train, const M1Rng& r, hipStream_t st) {
+                    float* e_out, int N, int P, int C, int K, bool softmax, bool train, const M1Rng& r,
+                    hipStream_t st) {
   const uint64_t ebase = (uint64_t)N * P * C;
   hipLaunchKernelGGL(m1_cat_bwd_kernel, dim3(N + 1), dim3(256), 0, st, cat.Xext, att, cat.zext, G,
                      Wt + (size_t)C * K, cat.dXext, dWt + (size_t)C * K, e_out, N, P, cat.J, K, ebase,
-                     train ? 1 : 0, r.inv_keep, r.thresh, r.seed, r.offset, r.offset_dev);
+                     softmax ? 1 : 0, train ? 1 : 0, r.inv_keep, r.thresh, r.seed, r.offset, r.offset_dev);
   APA_LAUNCH_CHECK("m1_cat_bwd_kernel");
   return APA_OK;
 }

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void m1g_pool_fwd_kernel(
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][C] accumulators, then 16 stats
   float* sm_stat = sm + 4 * (size_t)C;
   uint32_t k0 = 0, k1 = 0;
-  if (TRAIN) rng_key_dev(seed, offset_dev ? *offset_dev : offset, k0, k1);
+  if (TRAIN) rng_key_dev_x(seed, offset_dev ? *offset_dev : offset, thresh, k0, k1);
   const int blk = blockIdx.x, n = blk / S, s = blk % S;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int p_begin = (int)(((long)s * P) / S), p_end = (int)(((long)(s + 1) * P) / S);
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void m1g_pool_fwd_kernel(
 #pragma unroll
       for (int e = 0; e < EPV; e += 2) {
         float m0 = 1.f, m1 = 1.f;
-        if (TRAIN) rng_keep2(ebase + (uint64_t)v * EPV + e, k0, k1, thresh, m0, m1);
+        if (TRAIN) rng_keep2_x(ebase + (uint64_t)v * EPV + e, k0, k1, thresh, m0, m1);
         const int c = v * EPV + e;
         my[c] = fmaf(my[c], scale, ak * m0 * x[e]);
         my[c + 1] = fmaf(my[c + 1], scale, ak * m1 * x[e + 1]);
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void m1g_bwd_main_kernel(
   extern __shared__ __attribute__((aligned(16))) float sm[];   // FUSED: [4][C] dwa accumulators; then 8 floats
   float* sm_aux = sm + (FUSED ? 4 * (size_t)C : 0);
   uint32_t k0 = 0, k1 = 0;
-  if (TRAIN) rng_key_dev(seed, offset_dev ? *offset_dev : offset, k0, k1);
+  if (TRAIN) rng_key_dev_x(seed, offset_dev ? *offset_dev : offset, thresh, k0, k1);
   const int blk = blockIdx.x, n = blk / S, s = blk % S;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int p_begin = (int)(((long)s * P) / S), p_end = (int)(((long)(s + 1) * P) / S);
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void m1g_bwd_main_kernel(
 #pragma unroll
       for (int e = 0; e < EPV; e += 2) {
         float m0 = 1.f, m1 = 1.f;
-        if (TRAIN) rng_keep2(ebase + (uint64_t)v * EPV + e, k0, k1, thresh, m0, m1);
+        if (TRAIN) rng_keep2_x(ebase + (uint64_t)v * EPV + e, k0, k1, thresh, m0, m1);
         d = fmaf(x[e] * m0, dzr[v * EPV + e], d);
         d = fmaf(x[e + 1] * m1, dzr[v * EPV + e + 1], d);
       }
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void m1g_bwd_main_kernel(
 #pragma unroll
       for (int e = 0; e < EPV; e += 2) {
         float m0 = 1.f, m1 = 1.f;
-        if (TRAIN) rng_keep2(ebase + (uint64_t)v * EPV + e, k0, k1, thresh, m0, m1);
+        if (TRAIN) rng_keep2_x(ebase + (uint64_t)v * EPV + e, k0, k1, thresh, m0, m1);
         const int c = v * EPV + e;
         o[e] = ap * m0 * dzr[c];
         o[e + 1] = ap * m1 * dzr[c + 1];

@@ -435,28 +435,14 @@ __global__ __launch_bounds__(256) void m1_bwd_small_kernel(
 // the pooling pass -- was measured slower than the separate, fully coalesced finalize kernel:
 // 32 strided 16-byte loads per lane, 8.4 us vs 3 + 4 us.)
 // --------------------------------------------------------------------------------------------
-// FIN (the id / relu attention of the streaming passes, i.e. no on-line softmax to merge): the finalize
-// step rides in this kernel's prologue -- "combine in the next kernel's prologue" -- instead of being a
-// launch of its own.  The block forms its [32 n][64 c] tile of z from the S per-block partial rows of
-// the pooling pass with COALESCED loads (256-byte row segments, every load of the block issued before the
-// first is consumed; the earlier attempt that fed the MFMA A registers straight from the partials with
-// 32 strided loads per lane measured slower than two launches), in the summation order of
-// m1_finalize_fwd_kernel, parks it in LDS for the A fragments, and the gx == 0 blocks publish it as
-// zsave (+ abar from the cx == 0 one).  One launch and one 4 MB round trip less per step.
-struct M1Fin {
-  const float* pacc;    // [N*S][C] partial sums of the pooling pass
-  const float* pstat;   // [N*S][4]: {m, l, asum, -}
-  float* z_out;         // [N][C]
-  float* abar_out;      // [N]
-  int S, P;
-};
-
-template <int KG, bool FIN>
+// (A variant that also did the finalize step in its prologue -- one launch fewer -- measured slower, round 2:
+// training step 51.7 -> 54.1 us; it was removed in round 3.)
+template <int KG>
 __global__ __launch_bounds__(256) void m1_logits2_kernel(const float* __restrict__ z,
                                                          const float* __restrict__ Wt,
                                                          float* __restrict__ part, int N, int C,
-                                                         int K, M1Fin fin) {
-  extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][2*KG tiles][256] (+ FIN: z tile)
+                                                         int K) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][2*KG tiles][256]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 15, kq = lane >> 4;
   const int cx = blockIdx.x, gx = blockIdx.y, n0 = blockIdx.z * 32;
@@ -464,7 +450,7 @@ __global__ __launch_bounds__(256) void m1_logits2_kernel(const float* __restrict
   const int ktiles = (K + 15) >> 4;
   const int na = min(n0 + r, N - 1), nb = min(n0 + 16 + r, N - 1);   // rows >= N: discarded at the store
 
-  // ---- one batch of loads: B fragments (Wt), A fragments (z, or the S partial rows) ----
+  // ---- one batch of loads: B fragments (Wt), A fragments (z) ----
   float bw[KG][4];
 #pragma unroll
   for (int j = 0; j < KG; ++j) {
@@ -472,61 +458,8 @@ __global__ __launch_bounds__(256) void m1_logits2_kernel(const float* __restrict
 #pragma unroll                                                            // recomputed, discarded
     for (int e = 0; e < 4; ++e) bw[j][e] = Wt[(size_t)(cw + 4 * kq + e) * K + col];
   }
-  float4 a0, a1;
-  if (FIN) {
-    constexpr int ZLD = 68;
-    float* zt = red + 4 * 2 * KG * 256;          // [32][68]
-    const float invP = 1.0f / (float)fin.P;
-    const int S = fin.S;
-    // thread -> two (row, float4) slots of the tile: slot = tid + 256 u, row = slot >> 4, c4 = slot & 15
-    float4 acc[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s0 = 0; s0 < S; s0 += 16) {
-      float4 v[2][16];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int slot = tid + 256 * u;
-        const int n = min(n0 + (slot >> 4), N - 1);
-        const float* src = fin.pacc + ((size_t)n * S) * C + cx * 64 + (slot & 15) * 4;
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-          v[u][q] = *reinterpret_cast<const float4*>(src + (size_t)min(s0 + q, S - 1) * C);
-      }
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const float w = s0 + q < S ? invP : 0.f;
-          acc[u].x = fmaf(v[u][q].x, w, acc[u].x); acc[u].y = fmaf(v[u][q].y, w, acc[u].y);
-          acc[u].z = fmaf(v[u][q].z, w, acc[u].z); acc[u].w = fmaf(v[u][q].w, w, acc[u].w);
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int slot = tid + 256 * u, row = slot >> 4, c4 = (slot & 15) * 4;
-      *reinterpret_cast<float4*>(zt + row * ZLD + c4) = acc[u];
-      if (gx == 0 && n0 + row < N)
-        *reinterpret_cast<float4*>(fin.z_out + (size_t)(n0 + row) * C + cx * 64 + c4) = acc[u];
-    }
-    if (cx == 0 && gx == 0) {   // abar[n] = (1/P) sum_s asum[n,s], the reduction tree of the finalize kernel
-      for (int row = wave; row < 32 && n0 + row < N; row += 4) {
-        float sg[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int sidx = 64 * g + lane;
-          sg[g] = wave_sum(sidx < S ? fin.pstat[((size_t)(n0 + row) * S + sidx) * 4 + 2] : 0.f);
-        }
-        if (lane == 0) fin.abar_out[n0 + row] = ((sg[0] + sg[1]) + (sg[2] + sg[3])) * invP;
-      }
-    }
-    __syncthreads();
-    a0 = *reinterpret_cast<const float4*>(zt + r * ZLD + wave * 16 + 4 * kq);
-    a1 = *reinterpret_cast<const float4*>(zt + (16 + r) * ZLD + wave * 16 + 4 * kq);
-  } else {
-    a0 = *reinterpret_cast<const float4*>(z + (size_t)na * C + cw + 4 * kq);
-    a1 = *reinterpret_cast<const float4*>(z + (size_t)nb * C + cw + 4 * kq);
-  }
+  const float4 a0 = *reinterpret_cast<const float4*>(z + (size_t)na * C + cw + 4 * kq);
+  const float4 a1 = *reinterpret_cast<const float4*>(z + (size_t)nb * C + cw + 4 * kq);
 
   f32x4 acc0[KG], acc1[KG];
 #pragma unroll
@@ -847,35 +780,20 @@ int m1_logits(const float* z, const float* Wt, const float* abar, const float* b
 bool m1_logits2_supported(int C, int K) { return C % 64 == 0 && K >= 1; }
 size_t m1_logits2_ws_bytes(int N, int C, int K) { return (size_t)(C / 64) * N * K * sizeof(float); }
 
-static int launch_logits2(const float* z, const float* Wt, float* part_ws, int N, int C, int K,
-                          const M1Partials* fp, hipStream_t st) {
+static int launch_logits2(const float* z, const float* Wt, float* part_ws, int N, int C, int K, hipStream_t st) {
   constexpr int KG = 7;
   const int ktiles = (K + 15) / 16;
   dim3 grid(C / 64, (ktiles + KG - 1) / KG, (N + 31) / 32);
-  size_t shm = (size_t)4 * 2 * KG * 256 * sizeof(float);   // 56 KB
-  M1Fin fin{};
-  if (fp) {
-    fin.pacc = fp->pacc; fin.pstat = fp->pstat; fin.z_out = fp->z_out; fin.abar_out = fp->abar_out;
-    fin.S = fp->S; fin.P = fp->P;
-    shm += (size_t)32 * 68 * sizeof(float);
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
-      APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(m1_logits2_kernel<KG, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-      attr_set = true;
-    }
-    hipLaunchKernelGGL((m1_logits2_kernel<KG, true>), grid, dim3(256), shm, st, z, Wt, part_ws, N, C, K, fin);
-  } else {
-    hipLaunchKernelGGL((m1_logits2_kernel<KG, false>), grid, dim3(256), shm, st, z, Wt, part_ws, N, C, K, fin);
-  }
+  const size_t shm = (size_t)4 * 2 * KG * 256 * sizeof(float);   // 56 KB
+  hipLaunchKernelGGL((m1_logits2_kernel<KG>), grid, dim3(256), shm, st, z, Wt, part_ws, N, C, K);
   APA_LAUNCH_CHECK("m1_logits2_kernel");
   return APA_OK;
 }
 
 int m1_logits2(const float* z, const float* Wt, const float* abar, const float* bt, float* logits,
-               float* part_ws, int N, int C, int K, hipStream_t st, const M1Partials* fp) {
+               float* part_ws, int N, int C, int K, hipStream_t st) {
   if (!(dbg_skip() & 4)) {
-    const int rc = launch_logits2(z, Wt, part_ws, N, C, K, fp, st);
+    const int rc = launch_logits2(z, Wt, part_ws, N, C, K, st);
     if (rc != APA_OK) return rc;
   }
   if (!(dbg_skip() & 8))
@@ -894,10 +812,9 @@ bool m1_logits_xent_supported(int N, int C, int K, bool eval) {
 
 int m1_logits2_xent(const float* z, const float* Wt, const float* abar, const float* bt,
                     const int64_t* labels, float* logits, float* loss, float* G, float gscale,
-                    float* probs, int64_t* pred, float* part_ws, int N, int C, int K, hipStream_t st,
-                    const M1Partials* fp) {
+                    float* probs, int64_t* pred, float* part_ws, int N, int C, int K, hipStream_t st) {
   {
-    const int rc = launch_logits2(z, Wt, part_ws, N, C, K, fp, st);
+    const int rc = launch_logits2(z, Wt, part_ws, N, C, K, st);
     if (rc != APA_OK) return rc;
   }
 #define APA_LX(NV4)                                                                                  \

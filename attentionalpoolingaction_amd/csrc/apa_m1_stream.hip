@@ -577,7 +577,7 @@ bool m1s_supported(int C, int dtype) {
 }
 
 static int env_pix() {
-  static const int v = [] { const char* e = getenv("APA_M1S_PIX"); return (e && *e) ? atoi(e) : 2; }();
+  static const int v = knob("APA_M1S_PIX", 2);
   return v;
 }
 
@@ -589,7 +589,7 @@ static int launch_fwd_t(bool fused, bool train, int nblk, hipStream_t st, const 
   uint8_t* mbits = r.maskbits_out;
   if (r.relu_input) {   // instantiated for the default chunk width and the fused map only
     if (!fused || PIX != 2) {
-      set_error("APA_FLAG_RELU_INPUT needs Xatt == X (and the default APA_M1S_PIX)");
+      set_error("attn_pool M=1 stream kernels: APA_FLAG_RELU_INPUT needs Xatt == X");
       return APA_ERR_UNSUPPORTED;
     }
     if constexpr (PIX == 2) {
@@ -627,7 +627,7 @@ static int launch_bwd_t(bool fused, bool train, int nblk, hipStream_t st, const 
   const uint8_t* mbits = r.maskbits_in;    // non-null: the forward call's keep-bits (APA_FLAG_WS_FROM_FWD)
   if (r.relu_input) {
     if (!fused || PIX != 2) {
-      set_error("APA_FLAG_RELU_INPUT needs Xatt == X (and the default APA_M1S_PIX)");
+      set_error("attn_pool M=1 stream kernels: APA_FLAG_RELU_INPUT needs Xatt == X");
       return APA_ERR_UNSUPPORTED;
     }
     if constexpr (PIX == 2) {

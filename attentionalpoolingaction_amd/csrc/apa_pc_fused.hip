@@ -14,8 +14,6 @@
 //                                                    ring); the T waves zero the dropped elements of their A
 //                                                    FRAGMENTS in registers from keep bits hashed one stage
 //                                                    ahead; the 1/keep scale goes on the fp32 accumulators.
-//   (pc_fwd_zt_kernel: the register-staged predecessor -- plain and masked A images in LDS -- kept as the
-//    APA_PC_ZT_DMA=0 arm.)
 //   pc_bwd_dw_kernel   dWt | dWa = [Xd | X]^T . [dT | dZ]   one pass over X (k-major operand, transposing
 //                                                    LDS reads), same two-image trick, split over the rows.
 //   dX                 = (dT . Wt^T) * mask/keep + dZ . Wa^T   ONE launch of the DMA-staged GEMM
@@ -34,7 +32,6 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int FK = 64;          // k tile
-constexpr int LDK = FK + 8;     // [row][k] image: 144-byte rows, conflict-free ds_read_b128
 constexpr int LDM = 128 + 8;    // [k][row] image: 272-byte rows (transposing reads)
 
 // keep decisions of 8 consecutive elements (flat element index e, a multiple of 8) as bits 0..7
@@ -126,163 +123,8 @@ __global__ __launch_bounds__(256) void pc_prep_kernel(const float* __restrict__ 
 // Block = BM rows x 128 columns, 4 waves: wave w -> column half (w >> 1: 0 = Z, 1 = T) x 32 columns
 // (w & 1), all BM rows.  Two LDS stages; the next tile's global loads fly under this tile's MFMAs.
 // ---------------------------------------------------------------------------------------------
-constexpr int KA = 256;          // k extent of one A load (512 contiguous bytes per row)
-constexpr int LDA = KA + 8;      // A image row stride: 528 B = 132 dwords -> 16 rows cover the 64 banks once
-
-template <int BM, bool TRAIN>
-__global__ __launch_bounds__(256) void pc_fwd_zt_kernel(
-    const bf16_t* __restrict__ X, const bf16_t* __restrict__ WcatT, const float* __restrict__ bcat,
-    float* __restrict__ Z, float* __restrict__ T, uint8_t* __restrict__ maskbits, int R, int C, int K,
-    float inv_keep, uint32_t thresh, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev) {
-  // A block owns BM whole rows of X (BM * C * 2 contiguous bytes) and fetches them KA = 256 channels at a
-  // time -- 512 contiguous bytes per row -- while the weight slab (L2-resident, re-read by every block)
-  // moves in 64-deep k tiles, D of them in flight in registers.
-  // What bounds this kernel (round 2 measurements, 25.7 MB map, N = 32): NOT the HBM access pattern and not
-  // load latency -- 64-deep A tiles 23.4 us, + four tiles of register prefetch 21.3, 512-byte A bursts
-  // 24.6, tile-major weight slab 22.6 -- but the number of BYTES EACH CU LOADS through its vector-memory
-  // path: every block re-reads the whole 512 KB weight slab (L2 hits, still ~640 KB per CU), and a CU
-  // sustains only ~25-30 GB/s of global_load_dwordx4 traffic whatever level serves it (the figure that
-  // makes 256 CUs x 24.6 GB/s the chip's 6.3 TB/s copy ceiling).  A fourth form with the A fragments
-  // loaded straight from global memory per wave (16 rows x 64-byte pieces per instruction, only the slab
-  // through LDS, 32 MFMAs per barrier) measured 35.5 us: fragment-shaped loads are worse still.  The
-  // LDS-DMA form below (pc_fwd_zt_dma_kernel, the default) moves the same bytes in 21.9 us: ~34 GB/s per
-  // CU, the same figure the DMA-staged GEMMs reach -- the limit is per-CU ingest, whatever the path.  This
-  // register-staged kernel stays as the APA_PC_ZT_DMA=0 arm.
-  extern __shared__ __attribute__((aligned(16))) short smem[];
-  constexpr int A_EL = BM * LDA, B_EL = 128 * LDK;
-  constexpr int NA = TRAIN ? 2 : 1;             // A images per buffer: plain [, masked]
-  constexpr int AV = BM * (KA / 8) / 256;       // 16-byte vectors of an A load per thread
-  constexpr int MT = BM / 16;                   // MFMA row tiles per wave
-  constexpr int D = 4;                          // B tiles in flight (register sets); also KA / FK
-  static_assert(KA / FK == D, "one A load spans D sub-steps");
-  short* const a_base = smem;                   // [2][NA][BM][LDA]
-  short* const b_base = smem + 2 * NA * A_EL;   // [2][128][LDK]
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int half = wave >> 1, wn = wave & 1;
-  const int l16 = lane & 15, kb = lane >> 4;
-  const int m0 = blockIdx.x * BM;
-  const int nk = C / FK, nsuper = C / KA;
-  uint32_t k0 = 0, k1 = 0;
-  if (TRAIN) rng_key_dev(seed, offset_dev ? *offset_dev : offset, k0, k1);
-
-  uint4 av[AV], bv[D][4];
-  auto load_a = [&](int sidx) {
-    const int sc = min(sidx, nsuper - 1);       // past the end: re-load the last one (never stored)
-#pragma unroll
-    for (int i = 0; i < AV; ++i) {
-      const int vi = tid + i * 256;
-      const int grow = min(m0 + (vi >> 5), R - 1);
-      av[i] = ld16(X + (size_t)grow * C + sc * KA + (vi & 31) * 8);
-    }
-  };
-  auto store_a = [&](int buf, int sidx) {
-    short* a0 = a_base + buf * NA * A_EL;
-#pragma unroll
-    for (int i = 0; i < AV; ++i) {
-      const int vi = tid + i * 256;
-      const int row = vi >> 5, kc = (vi & 31) * 8;
-      *reinterpret_cast<uint4*>(a0 + row * LDA + kc) = av[i];
-      if (TRAIN) {
-        const uint64_t e = (uint64_t)min(m0 + row, R - 1) * C + sidx * KA + kc;
-        const uint32_t kb8 = keep_bits8(e, k0, k1, thresh);
-        *reinterpret_cast<uint4*>(a0 + A_EL + row * LDA + kc) = apply_bits8(av[i], kb8);
-        // the bytes of 4 neighbouring lanes (32 consecutive channels of one row) leave as ONE dword
-        // (byte stores from every lane cost 4 us on the 1.6 MB bit map)
-        const uint32_t b1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)kb8, 0x39, 0xf, 0xf, true);   // lane + 1
-        const uint32_t b2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)kb8, 0x4E, 0xf, 0xf, true);   // lane + 2
-        const uint32_t b3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)kb8, 0x93, 0xf, 0xf, true);   // lane + 3
-        if ((lane & 3) == 0 && m0 + row < R)
-          *reinterpret_cast<uint32_t*>(maskbits + (e >> 3)) = kb8 | (b1 << 8) | (b2 << 16) | (b3 << 24);
-      }
-    }
-  };
-  auto load_b = [&](uint4 (&b)[4], int t) {
-    const int tc = min(t, nk - 1);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int vi = tid + i * 256;
-      b[i] = ld16(WcatT + (size_t)tc * (128 * FK) + vi * 8);   // tile-major: 1 KiB per wave-instruction
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto store_b = [&](const uint4 (&b)[4], int buf) {
-    short* bi = b_base + buf * B_EL;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int vi = tid + i * 256;
-      *reinterpret_cast<uint4*>(bi + (vi >> 3) * LDK + (vi & 7) * 8) = b[i];
-    }
-  };
-
-  f32x4 acc[MT][2];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto compute = [&](int abuf, int sub, int bbuf) {
-    const short* a_img = a_base + (abuf * NA + ((TRAIN && half) ? 1 : 0)) * A_EL + sub * FK;
-    const short* b_img = b_base + bbuf * B_EL;
-#pragma unroll
-    for (int ks = 0; ks < FK / 32; ++ks) {
-      bf16x8 af[MT], bf[2];
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-        af[i] = *reinterpret_cast<const bf16x8*>(a_img + (i * 16 + l16) * LDA + ks * 32 + kb * 8);
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        bf[j] = *reinterpret_cast<const bf16x8*>(b_img + (half * 64 + wn * 32 + j * 16 + l16) * LDK + ks * 32 + kb * 8);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-    }
-  };
-
-  load_a(0);
-#pragma unroll
-  for (int d = 0; d < D; ++d) load_b(bv[d], d);
-  store_a(0, 0);
-  load_a(1);
-  store_b(bv[0], 0);
-  __syncthreads();
-  for (int sidx = 0; sidx < nsuper; ++sidx) {
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      const int t = sidx * D + d;
-      load_b(bv[d], t + D);                   // set d went to LDS in the previous sub-step: free again
-      compute(sidx & 1, d, t & 1);
-      if (t + 1 < nk) store_b(bv[(d + 1) % D], (t + 1) & 1);
-      if (d == D - 1 && sidx + 1 < nsuper) {  // the next A load has had D sub-steps to arrive
-        store_a((sidx + 1) & 1, sidx + 1);
-        load_a(sidx + 2);
-      }
-      __syncthreads();
-    }
-  }
-  // D layout of the 16x16 MFMA: row = 4 * (lane >> 4) + reg, col = lane & 15
-  const float scale = (TRAIN && half) ? inv_keep : 1.0f;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = wn * 32 + j * 16 + l16;       // within the half
-    const float bias = bcat[half * 64 + col];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + i * 16 + 4 * kb + r;
-        if (row >= R) continue;
-        const float v = fmaf(acc[i][j][r], scale, bias);
-        if (half == 0) Z[(size_t)row * 64 + col] = v;
-        else if (col < K) T[(size_t)row * K + col] = v;
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
-// Forward, LDS-DMA form (round 2, the default): same tile (32 rows x 128 columns, all of C) as
-// pc_fwd_zt_kernel, but every operand byte reaches LDS by global_load_lds_dwordx4 (no VGPR round trip, no
+// Forward, LDS-DMA form: a 32-row x 128-column tile over all of C; every operand byte reaches LDS by global_load_lds_dwordx4 (no VGPR round trip, no
 // ds_write pass, no masked second image).  Each block still has to pull 128 KB of X plus the whole 512 KB
 // weight slab; measured 24.0 -> 21.9 us (N = 32): ~34 GB/s per CU, which is what the DMA-staged GEMMs
 // reach as well -- per-CU ingest, not the path, is the limit, and the next step would have to cut the
@@ -544,7 +386,7 @@ __global__ __launch_bounds__(256) void pc_dw_reduce_kernel(const float* __restri
 }  // namespace
 
 bool pc_fused_supported(int N, int P, int C, int Ca, int K, int dtype, const void* X, const void* Xatt) {
-  static const int enabled = [] { const char* e = getenv("APA_PC_FUSED"); return e ? atoi(e) : 1; }();
+  static const int enabled = knob("APA_PC_FUSED", 1);
   (void)N; (void)P;
   return enabled && dtype == APA_DTYPE_BF16 && Xatt == X && Ca == C && K >= 1 && K <= 64 && C % 256 == 0 &&
          (reinterpret_cast<uintptr_t>(X) & 15) == 0;
@@ -585,54 +427,28 @@ int pc_fused_prep(const PcFusedWs& f, const float* Wa, const float* Wt, const fl
 
 int pc_fused_forward(const PcFusedWs& f, const void* X, float* Z, float* T, int R, int C, int K, bool train,
                      float keep_prob, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, hipStream_t st) {
-  static const int dma_env = [] { const char* e = getenv("APA_PC_ZT_DMA"); return e ? atoi(e) : 1; }();
-  if (dma_env && C % ZB_KT == 0) {
-    const float ik = train ? 1.0f / keep_prob : 1.0f;
-    const bf16_t* xx = static_cast<const bf16_t*>(X);
-    const bf16_t* ww = static_cast<const bf16_t*>(f.WcatT);
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
-      APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_fwd_zt_dma_kernel<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_BYTES));
-      APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_fwd_zt_dma_kernel<false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_BYTES));
-      attr_set = true;
-    }
-    if (train)
-      hipLaunchKernelGGL(pc_fwd_zt_dma_kernel<true>, dim3((R + 31) / 32), dim3(512), ZB_LDS_BYTES, st, xx, ww,
-                         f.bcat, Z, T, f.maskbits, R, C, K, ik, keep_thresh(keep_prob), seed, offset, offset_dev);
-    else
-      hipLaunchKernelGGL(pc_fwd_zt_dma_kernel<false>, dim3((R + 31) / 32), dim3(512), ZB_LDS_BYTES, st, xx, ww,
-                         f.bcat, Z, T, f.maskbits, R, C, K, ik, keep_thresh(keep_prob), seed, offset, offset_dev);
-    APA_LAUNCH_CHECK("pc_fwd_zt_dma_kernel");
-    return APA_OK;
+  if (C % ZB_KT != 0) {     // pc_fused_supported() admits multiples of 256 only
+    set_error("pc_fused_forward: C=%d is not a multiple of %d", C, ZB_KT);
+    return APA_ERR_UNSUPPORTED;
   }
-  static const int bm_env = [] { const char* e = getenv("APA_PC_BM"); return e ? atoi(e) : 0; }();
-  // 64-row tiles re-read the 512 KB weight slab half as often; 32-row tiles cover more CUs when the
-  // batch is small (R / 64 < 200 blocks)
-  const int bm = bm_env ? bm_env : ((R + 63) / 64 >= 200 ? 64 : 32);
-  static const int exp_mask = [] { const char* e = getenv("APA_PC_EXP"); return e ? atoi(e) : 0; }();
-  if (exp_mask & 2) train = false;    // timing experiments only (wrong results)
-  const float inv_keep = train ? 1.0f / keep_prob : 1.0f;
-  const uint32_t thresh = keep_thresh(keep_prob);
-  const bf16_t* x = static_cast<const bf16_t*>(X);
-  const bf16_t* wb = static_cast<const bf16_t*>(f.WcatT);
-#define APA_ZT(BM, TR)                                                                                   \
-  do {                                                                                                   \
-    const size_t shm = (size_t)2 * ((TR ? 2 : 1) * BM * LDA + 128 * LDK) * sizeof(short);                \
-    static thread_local bool attr_set = false;                                                           \
-    if (!attr_set) {                                                                                     \
-      APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_fwd_zt_kernel<BM, TR>),           \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));          \
-      attr_set = true;                                                                                   \
-    }                                                                                                    \
-    hipLaunchKernelGGL((pc_fwd_zt_kernel<BM, TR>), dim3((R + BM - 1) / BM), dim3(256), shm, st, x, wb,     \
-                       f.bcat, Z, T, f.maskbits, R, C, K, inv_keep, thresh, seed, offset, offset_dev);    \
-  } while (0)
-  if (bm == 64) { if (train) APA_ZT(64, true); else APA_ZT(64, false); }
-  else          { if (train) APA_ZT(32, true); else APA_ZT(32, false); }
-#undef APA_ZT
-  APA_LAUNCH_CHECK("pc_fwd_zt_kernel");
+  const float ik = train ? 1.0f / keep_prob : 1.0f;
+  const bf16_t* xx = static_cast<const bf16_t*>(X);
+  const bf16_t* ww = static_cast<const bf16_t*>(f.WcatT);
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_fwd_zt_dma_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_BYTES));
+    APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_fwd_zt_dma_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_BYTES));
+    attr_set = true;
+  }
+  if (train)
+    hipLaunchKernelGGL(pc_fwd_zt_dma_kernel<true>, dim3((R + 31) / 32), dim3(512), ZB_LDS_BYTES, st, xx, ww,
+                       f.bcat, Z, T, f.maskbits, R, C, K, ik, keep_thresh(keep_prob), seed, offset, offset_dev);
+  else
+    hipLaunchKernelGGL(pc_fwd_zt_dma_kernel<false>, dim3((R + 31) / 32), dim3(512), ZB_LDS_BYTES, st, xx, ww,
+                       f.bcat, Z, T, f.maskbits, R, C, K, ik, keep_thresh(keep_prob), seed, offset, offset_dev);
+  APA_LAUNCH_CHECK("pc_fwd_zt_dma_kernel");
   return APA_OK;
 }
 
@@ -649,7 +465,7 @@ int pc_fused_maskbits(const PcFusedWs& f, size_t n_elems, float keep_prob, uint6
 
 int pc_fused_dw(const PcFusedWs& f, const void* X, float* dWt, float* dWa, int R, int C, int K, bool train,
                 float keep_prob, hipStream_t st) {
-  static const int s_env = [] { const char* e = getenv("APA_PC_DW_SPLITS"); return e ? atoi(e) : 0; }();
+  static const int s_env = knob("APA_PC_DW_SPLITS", 0);
   const int ctiles = C / 128;
   int S = s_env ? s_env : (256 + ctiles - 1) / ctiles;            // one block per CU
   if (S > PC_DW_MAX_SPLITS) S = PC_DW_MAX_SPLITS;
@@ -657,7 +473,7 @@ int pc_fused_dw(const PcFusedWs& f, const void* X, float* dWt, float* dWa, int R
   if (S > ktiles) S = ktiles;
   const int rows_per_split = ((ktiles + S - 1) / S) * FK;
   S = (R + rows_per_split - 1) / rows_per_split;
-  static const int exp_mask = [] { const char* e = getenv("APA_PC_EXP"); return e ? atoi(e) : 0; }();
+  static const int exp_mask = knob("APA_PC_EXP", 0);
   if (exp_mask & 4) train = false;    // timing experiments only (wrong results)
   const size_t shm = (size_t)2 * (train ? 3 : 2) * FK * LDM * sizeof(short);
   const bf16_t* x = static_cast<const bf16_t*>(X);

@@ -33,6 +33,7 @@ APA_FLAG_TRAIN = 4
 APA_FLAG_RNG_DEVICE = 8
 APA_FLAG_RELU_INPUT = 16  # X in memory is the pre-activation map: relu fused into both passes
 APA_FLAG_DXATT_RANK1 = 32  # attn_pool_bwd returns dZ [N*P] instead of dXatt = dZ (x) Wa
+APA_FLAG_RNG_EXTERNAL = 128  # `seed` is the address of a caller-supplied, bit-packed dropout keep mask
 
 # every symbol include/apa.h declares: name -> (restype, argtypes)
 _SIGNATURES = {
@@ -158,14 +159,45 @@ def _feat_dtype(t: torch.Tensor) -> int:
     raise ApaError('feature maps must be float32 or bfloat16, got {}'.format(t.dtype))
 
 
-def _rng_offset(offset, flags):
-    """An int is passed by value; a 1-element int64 CUDA tensor is passed by address
-    (APA_FLAG_RNG_DEVICE) so that hipGraph replays read -- and the backward advances -- it."""
+class KeepMask(object):
+    """A dropout keep mask drawn OUTSIDE the library (the reference's tf.nn.dropout: floor(keep_prob + U),
+    nets_factory.py:143-146,296), bit-packed for APA_FLAG_RNG_EXTERNAL: pass it as `seed=` to any of the
+    attentional-pooling wrappers (forward AND backward).  Build one with pack_keep_mask()."""
+
+    def __init__(self, bits: torch.Tensor, n_elems: int):
+        self.bits, self.n_elems = bits, int(n_elems)
+
+
+def pack_keep_mask(*parts: torch.Tensor, device='cuda') -> KeepMask:
+    """{0,1} / bool tensors in the flat element order of the [N,P,C] feature map (for the *_cat ops followed
+    by the [N,P,J] extra channels): concatenated and packed LSB-first -- bit (e & 7) of byte e >> 3 is
+    element e (include/apa.h, APA_FLAG_RNG_EXTERNAL)."""
+    flat = torch.cat([p.reshape(-1).to(device=device, dtype=torch.uint8) for p in parts])
+    n = flat.numel()
+    pad = (-n) % 64                                          # whole 8-byte words
+    if pad:
+        flat = torch.cat([flat, torch.zeros(pad, dtype=torch.uint8, device=flat.device)])
+    w = (1 << torch.arange(8, device=flat.device, dtype=torch.int32))
+    bits = ((flat.view(-1, 8) != 0).to(torch.int32) * w).sum(dim=1).to(torch.uint8).contiguous()
+    return KeepMask(bits, n)
+
+
+def _rng_key(seed, offset, flags):
+    """-> (seed, offset, flags) as the C ABI takes them.  offset: an int is passed by value; a 1-element
+    int64 CUDA tensor by address (APA_FLAG_RNG_DEVICE) so that hipGraph replays read -- and the backward
+    advances -- it.  seed: an int keys the library's own counter hash; a KeepMask replays an external mask
+    (APA_FLAG_RNG_EXTERNAL: its address travels in `seed`)."""
+    if isinstance(seed, KeepMask):
+        if isinstance(offset, torch.Tensor):
+            raise ApaError('an external keep mask excludes the device-side dropout counter')
+        if not seed.bits.is_cuda:
+            raise ApaError('the packed keep mask must live on the GPU')
+        return seed.bits.data_ptr(), 0, flags | APA_FLAG_RNG_EXTERNAL
     if isinstance(offset, torch.Tensor):
         if not (offset.is_cuda and offset.dtype == torch.int64 and offset.numel() == 1):
             raise ApaError('a device-side dropout counter must be a 1-element int64 CUDA tensor')
-        return offset.data_ptr(), flags | APA_FLAG_RNG_DEVICE
-    return int(offset), flags
+        return int(seed), offset.data_ptr(), flags | APA_FLAG_RNG_DEVICE
+    return int(seed), int(offset), flags
 
 
 class ApaHooks(ctypes.Structure):
@@ -244,7 +276,7 @@ def attn_pool_fwd(X, Xatt, Wa, ba, Wt, bt, *, flags=0, keep_prob=1.0, seed=0, of
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty((max(need, 16),), dtype=torch.uint8, device=dev)
     xatt_ptr = _dev_ptr(X, 'X') if Xatt is X else _dev_ptr(Xatt, 'Xatt', X.dtype)
-    offset, flags = _rng_offset(offset, flags)
+    seed, offset, flags = _rng_key(seed, offset, flags)
     rc = lib.apa_attn_pool_fwd_ex(
         _hooks_ptr(hooks), _dev_ptr(X, 'X'), xatt_ptr, _dev_ptr(Wa, 'Wa', torch.float32),
         _dev_ptr(ba, 'ba', torch.float32), _dev_ptr(Wt, 'Wt', torch.float32),
@@ -292,7 +324,7 @@ def attn_pool_bwd(X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, *, flags=0, keep
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty((max(need, 16),), dtype=torch.uint8, device=dev)
     xatt_ptr = _dev_ptr(X, 'X') if fused else _dev_ptr(Xatt, 'Xatt', X.dtype)
-    offset, flags = _rng_offset(offset, flags)
+    seed, offset, flags = _rng_key(seed, offset, flags)
     rc = lib.apa_attn_pool_bwd_ex(
         _hooks_ptr(hooks), _dev_ptr(X, 'X'), xatt_ptr, _dev_ptr(Wa, 'Wa', torch.float32),
         _dev_ptr(ba, 'ba', torch.float32), _dev_ptr(Wt, 'Wt', torch.float32),
@@ -332,7 +364,7 @@ def attn_pool_fwd_cat(X, Xatt, Xext, Wa, ba, Wt, bt, *, flags=0, keep_prob=1.0, 
         workspace = torch.empty((max(need, 16),), dtype=torch.uint8, device=dev)
     cat = ApaConcatFeat(_dev_ptr(Xext, 'Xext', torch.float32), J, zext.data_ptr(), None)
     xatt_ptr = _dev_ptr(X, 'X') if Xatt is X else _dev_ptr(Xatt, 'Xatt', X.dtype)
-    offset, flags = _rng_offset(offset, flags)
+    seed, offset, flags = _rng_key(seed, offset, flags)
     rc = lib.apa_attn_pool_fwd_cat(
         ctypes.addressof(cat), _hooks_ptr(hooks), _dev_ptr(X, 'X'), xatt_ptr, _dev_ptr(Wa, 'Wa', torch.float32),
         _dev_ptr(ba, 'ba', torch.float32), _dev_ptr(Wt, 'Wt', torch.float32),
@@ -362,7 +394,7 @@ def attn_pool_bwd_cat(X, Xatt, Xext, zext, Wa, ba, Wt, bt, att, zsave, abar, G, 
     cat = ApaConcatFeat(_dev_ptr(Xext, 'Xext', torch.float32), J, _dev_ptr(zext, 'zext', torch.float32),
                         dXext.data_ptr())
     xatt_ptr = _dev_ptr(X, 'X') if fused else _dev_ptr(Xatt, 'Xatt', X.dtype)
-    offset, flags = _rng_offset(offset, flags)
+    seed, offset, flags = _rng_key(seed, offset, flags)
     rc = lib.apa_attn_pool_bwd_cat(
         ctypes.addressof(cat), _hooks_ptr(hooks), _dev_ptr(X, 'X'), xatt_ptr, _dev_ptr(Wa, 'Wa', torch.float32),
         _dev_ptr(ba, 'ba', torch.float32), _dev_ptr(Wt, 'Wt', torch.float32),
@@ -752,8 +784,8 @@ class HeadTrainStep:
         if workspace is None or workspace.numel() < need:
             workspace = torch.empty((max(need, 16),), dtype=torch.uint8, device=dev)
         self.workspace = workspace
-        off, flags = _rng_offset(offset, flags)
-        self._keep = (X, Xatt, Wa, ba, Wt, bt, labels, grads, offset)     # the pointers below stay valid
+        self._keep = (X, Xatt, Wa, ba, Wt, bt, labels, grads, offset, seed)
+        seed, off, flags = _rng_key(seed, offset, flags)     # the pointers below stay valid
         self._args = [
             _dev_ptr(X, 'X'), _dev_ptr(X, 'X') if fused else _dev_ptr(Xatt, 'Xatt', X.dtype),
             _dev_ptr(Wa, 'Wa', torch.float32), _dev_ptr(ba, 'ba', torch.float32),

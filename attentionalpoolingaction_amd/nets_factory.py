@@ -30,6 +30,49 @@ last_conv_map = {  # nets_factory.py:63-67 ; channel counts of the taps
 }
 
 
+class EndPoints(dict):
+    """The end-point dictionary network_fn returns.  A TF graph evaluates an end point only when it is fetched;
+    `lazy(name, thunk)` gives an entry the same behaviour here: it is computed (and cached) on first access.
+    Used for end_points['PoseLogits'], which the reference builds for every configuration (nets_factory.py:
+    147-160) and reads unconditionally (src/train.py:400) but TF prunes whenever no loss or attention input
+    consumes it (cfg 002): the pose head's 617 MFLOP/image only run if somebody actually looks."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self._lazy = {}
+
+    def lazy(self, name, thunk):
+        self._lazy[name] = thunk
+
+    def __missing__(self, name):
+        if name in self._lazy:
+            value = self._lazy.pop(name)()
+            self[name] = value
+            return value
+        raise KeyError(name)
+
+    def __contains__(self, name):
+        return dict.__contains__(self, name) or name in self._lazy
+
+    def get(self, name, default=None):
+        return self[name] if name in self else default
+
+    def keys(self):
+        return list(dict.keys(self)) + [k for k in self._lazy if not dict.__contains__(self, k)]
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return len(self.keys())
+
+
+ARG_SCOPE_OF = {  # arg_scopes_map (nets_factory.py:69-91): which slim defaults surround the head
+    'inception_v3': 'inception_v3', 'inception_v2_tsn': 'inception_v2_tsn', 'resnet_v1_101': 'resnet',
+    'vgg_16': 'vgg',
+}
+
+
 class AttentionalPoolingFunction(torch.autograd.Function):
     """logits, att[, topdown] = f(X, Xatt, Wa, ba, Wt, bt); nets_factory.py:247-328 in two HIP calls.
 
@@ -233,10 +276,25 @@ class AttentionalPoolingHead(nn.Module):
     }
     POSE_PRELOGITS = 768
 
+    # what the backbone's arg_scope makes of the un-annotated ..._WITH_POSE_FEAT_2LAYER conv (nets_factory.py:
+    # 291-294 passes neither activation_fn nor normalizer_fn): (batch-norm?, eps, gamma?, relu?) -- executed from
+    # the reference's own arg-scope functions in tests/golden/make_head_reference.py
+    ARG_SCOPES = {
+        'resnet': dict(bn=True, eps=1e-5, decay=0.997, scale=True, relu=True),          # resnet_utils.py:232-246
+        'inception_v3': dict(bn=True, eps=1e-3, decay=0.9997, scale=False, relu=True),  # inception_utils.py:48-71
+        'vgg': dict(bn=False, relu=True),                                               # vgg.py:58-62
+        'inception_v2_tsn': dict(bn=False, relu=False),                                 # inception_v2_tsn.py:320-329
+    }
+
     def __init__(self, num_classes: int, cfg, in_channels: int = 2048, num_pose_keypoints: int = 16,
                  is_training: bool = False, seed: int = 42, with_pose_logits: Optional[bool] = None,
-                 want_topdown: bool = False, fuse_pose_attention: bool = True):
+                 want_topdown: bool = False, fuse_pose_attention: bool = True,
+                 pose_in_channels: Optional[int] = None, arg_scope: str = 'resnet'):
         super().__init__()
+        if arg_scope not in self.ARG_SCOPES:
+            raise ValueError('arg_scope must be one of %s' % sorted(self.ARG_SCOPES))
+        self.arg_scope = arg_scope
+        self._replay_mask = None      # replay_dropout_mask(): an externally drawn keep mask for the next forward
         self.fuse_pose_attention = fuse_pose_attention   # cfg 003: one autograd node for pose head + pooling
         net = cfg.NET
         if not net.USE_POSE_PRELOGITS_BASED_ATTENTION:
@@ -273,7 +331,8 @@ class AttentionalPoolingHead(nn.Module):
         n_maps = num_classes if self.per_class else 1
         cp = self.POSE_PRELOGITS
         cin = in_channels if self.single_layer else cp
-        self.pose_w1 = nn.Parameter(torch.randn(in_channels, cp) * 0.001)
+        # cfg.NET.LAST_CONV_MAP_FOR_POSE may name another end point with its own channel count (:148-150)
+        self.pose_w1 = nn.Parameter(torch.randn(pose_in_channels or in_channels, cp) * 0.001)
         self.pose_b1 = nn.Parameter(torch.zeros(cp))
         # slim.variance_scaling_initializer(): truncated normal, std = sqrt(1.3 * 2 / fan_in)
         self.pose_w2 = nn.Parameter(torch.nn.init.trunc_normal_(
@@ -294,12 +353,20 @@ class AttentionalPoolingHead(nn.Module):
             # is_training=True: batch statistics in training AND in evaluation (reproduced literally).
             # Unnamed conv created before the top-down conv -> it is scope 'Conv' and the top-down
             # conv becomes 'Conv_1' (tf_variable_names()).  [N,P,J]-sized: torch ops on the device.
+            # Under the other backbones' arg-scopes (ARG_SCOPES) the same line builds a different layer:
+            # vgg: biases + relu, no normalizer; inception_v2_tsn: biases, linear; inception_v3: batch-norm
+            # without gamma (eps 1e-3) + relu.
             J = max(num_pose_keypoints, 1)
+            sc = self.ARG_SCOPES[arg_scope]
             self.pose_feat_weights = nn.Parameter(torch.randn(J, J) * 0.001)
-            self.pose_feat_bn_gamma = nn.Parameter(torch.ones(J))
-            self.pose_feat_bn_beta = nn.Parameter(torch.zeros(J))
-            self.register_buffer('pose_feat_bn_moving_mean', torch.zeros(J))
-            self.register_buffer('pose_feat_bn_moving_variance', torch.ones(J))
+            if sc['bn']:
+                if sc['scale']:
+                    self.pose_feat_bn_gamma = nn.Parameter(torch.ones(J))
+                self.pose_feat_bn_beta = nn.Parameter(torch.zeros(J))
+                self.register_buffer('pose_feat_bn_moving_mean', torch.zeros(J))
+                self.register_buffer('pose_feat_bn_moving_variance', torch.ones(J))
+            else:
+                self.pose_feat_biases = nn.Parameter(torch.zeros(J))
         # rank > 1 (:258-274, :298-309): the r-th attention conv consumes the OUTPUT of conv r-1
         # ([M,M] = [1,1] weights, scopes Conv2d_PrePose_Attn1, ...); one more top-down conv per rank
         # (scopes Conv_1, ...)
@@ -318,18 +385,44 @@ class AttentionalPoolingHead(nn.Module):
         if getattr(self, 'pose_feat_2layer', False):
             pre = 'PosePrelogitsBasedAttention/'
             names.update({'pose_feat_weights': pre + 'Conv/weights',
-                          'pose_feat_bn_gamma': pre + 'Conv/BatchNorm/gamma',
-                          'pose_feat_bn_beta': pre + 'Conv/BatchNorm/beta',
-                          'pose_feat_bn_moving_mean': pre + 'Conv/BatchNorm/moving_mean',
-                          'pose_feat_bn_moving_variance': pre + 'Conv/BatchNorm/moving_variance',
                           'td_weights': pre + 'Conv_1/weights', 'td_biases': pre + 'Conv_1/biases'})
+            sc = self.ARG_SCOPES[self.arg_scope]
+            if sc['bn']:
+                names.update({'pose_feat_bn_beta': pre + 'Conv/BatchNorm/beta',
+                              'pose_feat_bn_moving_mean': pre + 'Conv/BatchNorm/moving_mean',
+                              'pose_feat_bn_moving_variance': pre + 'Conv/BatchNorm/moving_variance'})
+                if sc['scale']:
+                    names['pose_feat_bn_gamma'] = pre + 'Conv/BatchNorm/gamma'
+            else:
+                names['pose_feat_biases'] = pre + 'Conv/biases'
+        two = 1 if getattr(self, 'pose_feat_2layer', False) else 0
         for r in range(1, self.rank):
+            # unnamed convs are numbered in creation order: the _2LAYER conv (if any) took 'Conv'
             pre = 'PosePrelogitsBasedAttention/'
             names['att_weights_r.%d' % (r - 1)] = pre + 'Conv2d_PrePose_Attn%d/weights' % r
             names['att_biases_r.%d' % (r - 1)] = pre + 'Conv2d_PrePose_Attn%d/biases' % r
-            names['td_weights_r.%d' % (r - 1)] = pre + 'Conv_%d/weights' % r
-            names['td_biases_r.%d' % (r - 1)] = pre + 'Conv_%d/biases' % r
+            names['td_weights_r.%d' % (r - 1)] = pre + 'Conv_%d/weights' % (r + two)
+            names['td_biases_r.%d' % (r - 1)] = pre + 'Conv_%d/biases' % (r + two)
         return names
+
+    def replay_dropout_mask(self, keep_mask: Optional[torch.Tensor]) -> None:
+        """Use an externally drawn dropout mask for the NEXT training-mode forward (and its backward) instead of
+        the head's own counter-hash stream: `keep_mask` is the {0,1} tensor tf.nn.dropout multiplies the top-down
+        input with (floor(keep_prob + U), nets_factory.py:296), shaped like that input -- [N,H,W,C], or
+        [N,H,W,C+J] with ..._WITH_POSE_FEAT.  One-shot; None clears it.  (APA_FLAG_RNG_EXTERNAL, include/apa.h:
+        a parity facility -- the replayed mask runs through the library's generic kernels.)"""
+        self._replay_mask = keep_mask
+
+    def _dropout_seed(self, split_at: Optional[int] = None):
+        """the `seed` argument of the pooling ops for this forward: the head's integer seed, or the packed replay
+        mask (split_at = C: the split-channel *_cat ops take X's elements first, then the extra channels)"""
+        m = self._replay_mask
+        if m is None or not self.is_training:
+            return self.seed
+        dev = self.td_weights.device
+        if split_at is None:
+            return cof.pack_keep_mask(m, device=dev)
+        return cof.pack_keep_mask(m[..., :split_at].contiguous(), m[..., split_at:].contiguous(), device=dev)
 
     def get_extra_state(self):
         # the dropout step counter keys the mask stream: checkpoint it, so a resumed run does not
@@ -340,11 +433,13 @@ class AttentionalPoolingHead(nn.Module):
         self._step = int(state.get('dropout_step', 0)) if state else 0
 
     def regularized_weights(self):
-        """conv weights carry slim.l2_regularizer from the resnet arg-scope (resnet_utils.py:241);
-        biases do not.  Pose-head weights only count when the pose head is in the graph."""
-        ws = [self.att_weights, self.td_weights] + list(self.att_weights_r) + list(self.td_weights_r)
-        if self.with_pose_logits or not self.single_layer:
-            ws += [self.pose_w1, self.pose_w2]
+        """conv weights carry slim.l2_regularizer from the backbone's arg-scope (resnet_utils.py:241);
+        biases and batch-norm parameters do not."""
+        # The PoseLogits convs are ALWAYS built (:147-160) and their weights sit in REGULARIZATION_LOSSES even
+        # when nothing consumes the pose head (cfg 002: TF prunes the ops, not the regulariser) -- the reference's
+        # total loss and the decay of those weights include them (tests/golden/ref_head_cfg002_*.npz).
+        ws = [self.pose_w1, self.pose_w2, self.att_weights, self.td_weights] + list(self.att_weights_r) + \
+            list(self.td_weights_r)
         if getattr(self, 'pose_feat_2layer', False):
             ws.append(self.pose_feat_weights)
         return ws
@@ -363,11 +458,12 @@ class AttentionalPoolingHead(nn.Module):
         """`last_conv_pose`: the pose head's own feature tap when cfg.NET.LAST_CONV_MAP_FOR_POSE names a
         different end point than last_conv_map (nets_factory.py:148-150; inception_v2_tsn: 5a vs 5b).
         None / the same tensor: the shared tap of the ResNet configs."""
-        if preactivation and not self.can_fuse_input_relu(last_conv.dtype):
+        replay = self._replay_mask is not None and self.is_training
+        if preactivation and (replay or not self.can_fuse_input_relu(last_conv.dtype)):
             last_conv, preactivation = torch.relu(last_conv), False
         if last_conv_pose is None:
             last_conv_pose = last_conv
-        end_points: Dict[str, torch.Tensor] = {}
+        end_points: Dict[str, torch.Tensor] = EndPoints()
         pose_pre = None
         if (not self.single_layer and self.rank == 1 and not self.per_class and not self.with_pose_feat
                 and self.fuse_pose_attention and last_conv_pose is last_conv):
@@ -380,7 +476,8 @@ class AttentionalPoolingHead(nn.Module):
             logits, att, pose_logits, topdown = PoseAttentionFunction.apply(
                 last_conv, self.pose_w1, self.pose_b1, self.pose_w2, self.pose_b2, self.att_weights,
                 self.att_biases, self.td_weights, self.td_biases, flags,
-                self.keep_prob if self.is_training else 1.0, self.seed, offset, self.want_topdown)
+                self.keep_prob if self.is_training else 1.0, self._dropout_seed(), offset, self.want_topdown)
+            self._replay_mask = None
             end_points['PoseLogits'] = pose_logits
             end_points['PosePrelogitsBasedAttention'] = att.view(n, h, w, -1)
             if topdown is not None:
@@ -391,6 +488,9 @@ class AttentionalPoolingHead(nn.Module):
             pose_pre, pose_logits = PoseHeadFunction.apply(last_conv_pose, self.pose_w1, self.pose_b1,
                                                            self.pose_w2, self.pose_b2)
             end_points['PoseLogits'] = pose_logits
+        else:   # built by the reference all the same (:147-160), evaluated only if fetched
+            end_points.lazy('PoseLogits', lambda: PoseHeadFunction.apply(
+                last_conv_pose, self.pose_w1, self.pose_b1, self.pose_w2, self.pose_b2)[1])
         xatt = None if self.single_layer else pose_pre               # :247-250
         offset = self._step
         if self.is_training:
@@ -398,7 +498,7 @@ class AttentionalPoolingHead(nn.Module):
         n, h, w = last_conv.shape[0], last_conv.shape[1], last_conv.shape[2]
         C = self.in_channels
         kw = dict(softmax_att=self.softmax_att, relu_att=self.relu_att, is_training=self.is_training,
-                  keep_prob=self.keep_prob, seed=self.seed, offset=offset)
+                  keep_prob=self.keep_prob, seed=self.seed, offset=offset)    # seed: see below (replay mask)
 
         xext = None
         if self.with_pose_feat:
@@ -407,15 +507,23 @@ class AttentionalPoolingHead(nn.Module):
             # weighted mean, their share of dA fed to the streaming backward kernel.
             xext = end_points['PoseLogits']
             if self.pose_feat_2layer:
+                sc = self.ARG_SCOPES[self.arg_scope]
                 y = xext.float() @ self.pose_feat_weights
-                mean = y.mean(dim=(0, 1, 2))
-                var = y.var(dim=(0, 1, 2), unbiased=False)           # tf.nn.moments
-                if self.is_training:
-                    with torch.no_grad():                             # UPDATE_OPS, decay 0.997
-                        self.pose_feat_bn_moving_mean.mul_(0.997).add_(mean.detach(), alpha=0.003)
-                        self.pose_feat_bn_moving_variance.mul_(0.997).add_(var.detach(), alpha=0.003)
-                y = (y - mean) * torch.rsqrt(var + 1e-5) * self.pose_feat_bn_gamma + self.pose_feat_bn_beta
-                xext = torch.relu(y)
+                if sc['bn']:
+                    mean = y.mean(dim=(0, 1, 2))
+                    var = y.var(dim=(0, 1, 2), unbiased=False)           # tf.nn.moments
+                    if self.is_training:
+                        with torch.no_grad():                             # UPDATE_OPS: mov -= (1 - decay) (mov - batch)
+                            d = 1.0 - sc['decay']
+                            self.pose_feat_bn_moving_mean.mul_(1.0 - d).add_(mean.detach(), alpha=d)
+                            self.pose_feat_bn_moving_variance.mul_(1.0 - d).add_(var.detach(), alpha=d)
+                    inv = torch.rsqrt(var + sc['eps'])
+                    if sc['scale']:
+                        inv = inv * self.pose_feat_bn_gamma
+                    y = (y - mean) * inv + self.pose_feat_bn_beta
+                else:
+                    y = y + self.pose_feat_biases
+                xext = torch.relu(y) if sc['relu'] else y
         x_td, xatt_td, cat_op = last_conv, xatt, self.with_pose_feat
         if self.with_pose_feat and (self.per_class or self.want_topdown):
             # per-class maps + pose features, or the TopDownAttention dump of the pose-feature head (no shipped
@@ -426,11 +534,15 @@ class AttentionalPoolingHead(nn.Module):
             x_td = torch.cat([last_conv, xext.to(last_conv.dtype)], dim=-1)
             xatt_td = last_conv if self.single_layer else pose_pre
             cat_op = False
+        # the dropout key of every pooling pass below: the head's own seed, or the one-shot replay mask
+        seed = self._dropout_seed(split_at=C if (self.with_pose_feat and cat_op) else None)
+        kw['seed'] = seed
+        self._replay_mask = None
         if self.rank == 1 and cat_op:
             flags = cof.attn_flags(self.softmax_att, self.relu_att, self.is_training)
             logits, att = AttentionalPoolingCatFunction.apply(
                 last_conv, xatt, xext, self.att_weights, self.att_biases, self.td_weights, self.td_biases,
-                flags, self.keep_prob if self.is_training else 1.0, self.seed, offset)
+                flags, self.keep_prob if self.is_training else 1.0, seed, offset)
             end_points['PosePrelogitsBasedAttention'] = att.view(n, h, w, -1)    # :287
         elif self.rank == 1:
             logits, att, topdown = attentional_pooling(
@@ -458,7 +570,7 @@ class AttentionalPoolingHead(nn.Module):
                     flags = cof.attn_flags(self.softmax_att, self.relu_att, self.is_training)
                     lg_r, att_r = AttentionalPoolingCatFunction.apply(
                         last_conv, xatt, xext, wa_r, ba_r, wts[r], bts[r], flags,
-                        self.keep_prob if self.is_training else 1.0, self.seed, offset)
+                        self.keep_prob if self.is_training else 1.0, seed, offset)
                     td_r = None
                 else:
                     lg_r, att_r, td_r = attentional_pooling(x_td, xatt_td, wa_r, ba_r, wts[r], bts[r],
@@ -638,7 +750,9 @@ def get_network_fn(name: str, num_classes: int, num_pose_keypoints: int, cfg,
     """
     if name not in last_conv_map:
         raise ValueError('Name of network unknown %s' % name)
-    channels = last_conv_map[name][1]
+    # `in_channels=` overrides the tap's nominal channel count (a caller-supplied backbone / feature map)
+    channels = head_kwargs.pop('in_channels', None) or last_conv_map[name][1]
+    head_kwargs.setdefault('arg_scope', ARG_SCOPE_OF[name])
     if clone_index is None:      # one clone per data-parallel rank (model_deploy.py:189-197)
         import torch.distributed as dist
         clone_index = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
@@ -674,6 +788,7 @@ def get_network_fn(name: str, num_classes: int, num_pose_keypoints: int, cfg,
                                       num_pose_keypoints=num_pose_keypoints, is_training=is_training,
                                       seed=head_seed, **head_kwargs).to(device)
     else:   # cfg 001: the backbone's own average-pool + logits head
+        head_kwargs.pop('arg_scope', None)
         head = BaselineHead(num_classes, cfg, in_channels=channels, is_training=is_training,
                             seed=head_seed).to(device)
     temporal = None

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define APA_VERSION 201 /* major*10000 + minor*100 + patch */
+#define APA_VERSION 300 /* major*10000 + minor*100 + patch */
 
 typedef enum apa_status {
   APA_OK = 0,
@@ -69,10 +69,21 @@ typedef enum apa_status {
                                 /* [N,P,Ca] tensor is never written (its consumer,                     */
                                 /* apa_pose_head_bwd_rank1ext, re-forms it in registers)              */
 
-#define APA_FLAG_WS_FROM_FWD 64u /* apa_attn_pool_bwd only: `ws` is the workspace of the matching forward   */
-                                /* call and has not been written since -- prepared operands the forward  */
-                                /* left there (padded bf16 weights of the per-class path) are reused      */
-                                /* instead of rebuilt.  apa_attn_head_train_step sets it by itself.       */
+#define APA_FLAG_WS_FROM_FWD 64u /* RESERVED for the library: apa_attn_head_train_step sets it on its own     */
+                                /* backward half (same workspace, nothing in between: operands the forward */
+                                /* pass prepared there are reused).  The public apa_attn_pool_bwd* entry    */
+                                /* points clear it -- a caller cannot vouch for a workspace's history.      */
+#define APA_FLAG_RNG_EXTERNAL 128u /* replay a dropout mask drawn ELSEWHERE (the reference's tf.nn.dropout:   */
+                                /* binary = floor(keep_prob + uniform), nets_factory.py:143-146,296): `seed` */
+                                /* is the ADDRESS of the keep decisions in HBM, bit-packed -- bit (e & 7) of */
+                                /* byte e >> 3 belongs to flat element e of the [N,P,C] map (the *_cat entry */
+                                /* points: elements N*P*C .. continue into the [N,P,J] extra channels), the   */
+                                /* image is ceil(n/8) bytes rounded up to a multiple of 8; `offset` is        */
+                                /* ignored; kept elements are scaled by 1/keep_prob.  Pass the same image to  */
+                                /* the backward call.  Excludes APA_FLAG_RNG_DEVICE / APA_FLAG_RELU_INPUT.    */
+                                /* A replayed mask is read by the library's run-time-loop kernels (any C that */
+                                /* is a whole number of 16-byte vectors; per-class maps take the GEMM route), */
+                                /* not by the hash-fused streaming kernels: a parity facility, not a fast path */
 
 int apa_version(void);
 /* Thread-local, never NULL; describes the last failure on the calling thread. */
@@ -98,7 +109,8 @@ const char* apa_status_string(int status);
  *                                    (the reference needs it for eval.py --ept dumps only)
  * ws / ws_bytes: scratch of at least apa_attn_pool_workspace_bytes(...) bytes.
  * seed/offset: counter-based dropout RNG key (APA_FLAG_TRAIN); the same pair must be passed to
- *              the backward call.  apa_dropout_mask() materialises the identical mask.
+ *              the backward call.  apa_dropout_mask() materialises the identical mask.  With
+ *              APA_FLAG_RNG_EXTERNAL the mask is the caller's own (see the flag).
  * M == 1 runs the factorised HBM-bound path (T is never formed); M == K the dense MFMA path.
  */
 size_t apa_attn_pool_workspace_bytes(int N, int P, int C, int Ca, int K, int M, unsigned flags);

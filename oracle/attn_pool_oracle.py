@@ -1,13 +1,23 @@
 """CPU oracle for the attentional-pooling hot path  --  TEST INFRASTRUCTURE ONLY.
 
-    *** PARITY UNPINNED ***
-    The reference's arithmetic lives in un-vendored TensorFlow 1.1.0-rc2 (tf.contrib.slim
-    conv2d / dropout / softmax / reduce_mean / losses) and the reference ships no golden
-    vectors or value-asserting tests for this path.  TensorFlow,
-    Python 2 and OpenCV are absent from this image, so the reference cannot be executed
-    here.  This file is therefore an op-by-op *restatement* of the reference graph,
-    written from the cited lines; the golden fixtures under tests/golden/ are produced by
-    THIS restatement (tests/golden/make_golden.py), not by TF1.
+    PARITY STATUS: PINNED TO THE REFERENCE'S OWN GRAPH CODE, not to TensorFlow's kernels.
+    The reference's head and losses are plain Python graph construction
+    (models/slim/nets/nets_factory.py:94-380, src/loss.py:4-105); the arithmetic of each op lives
+    in un-vendored TensorFlow 1.1.0-rc2, which -- like Python 2 and OpenCV -- is absent from this
+    image.  tests/golden/make_head_reference.py therefore EXECUTES those two reference files (plus
+    src/config.py, the shipped experiments/*.yaml and the backbones' arg_scope functions) from the
+    reference tree behind a float64 stand-in for the ~40 TF/slim symbols they call
+    (tests/golden/tf1_shim.py, written from TF's documented op semantics, independent of this file)
+    and commits the results as tests/golden/ref_head_*.npz / ref_losses.npz: 37 head configurations
+    (cfg 002 / 003 from their YAML, softmax / relu / per-class / rank 2-3 / _WITH_POSE_FEAT(+_2LAYER)
+    under four arg-scopes / video frame pooling / temporal attention / separate pose tap, training
+    mode with the recorded dropout mask) and 12 gen_losses cases.
+    tests/test_reference_fixtures_cpu.py holds THIS restatement to those fixtures at 1e-12 --
+    logits, end points, every loss and regularisation term, every gradient.
+    What remains unpinned (needs TensorFlow itself): float32 rounding of TF's conv / softmax / reduce
+    kernels, TF's RNG streams (random draws are a recorded stream here), and cv::circle for the label
+    generator (oracle/labels_eval_oracle.py).  The older fixtures tests/golden/attn_*.npz, losses.npz
+    are outputs of THIS file (tests/golden/make_golden.py): regression pins only.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 The shipped package (attentionalpoolingaction_amd/) never imports it.
@@ -113,6 +123,8 @@ def attentional_pooling(last_conv: torch.Tensor,
                         dropout_mask: Optional[torch.Tensor] = None,
                         pose_feat_w: Optional[torch.Tensor] = None,
                         pose_feat_bn: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                        pose_feat_b: Optional[torch.Tensor] = None,
+                        arg_scope: str = 'resnet',
                         ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
     """Literal restatement of the `USE_POSE_PRELOGITS_BASED_ATTENTION` branch.
 
@@ -147,11 +159,26 @@ def attentional_pooling(last_conv: torch.Tensor,
             # arg_scope([slim.batch_norm], is_training=...) (resnet_v1.py:191-194), so it runs with
             # slim's default is_training=True: batch statistics (tf.nn.moments, biased variance) in
             # training and in evaluation alike.  pose_feat_bn = (gamma, beta).
-            y = conv1x1(pl, pose_feat_w, None)
-            mean = y.mean(dim=(0, 1, 2))
-            var = y.var(dim=(0, 1, 2), unbiased=False)
-            gamma, beta = pose_feat_bn
-            pl = torch.relu((y - mean) / torch.sqrt(var + 1e-5) * gamma + beta)
+            # Under the other backbones' arg-scopes the same un-annotated conv is a different layer:
+            #   vgg_arg_scope (vgg.py:49-62): activation relu, biases, no normalizer  -> relu(y + b)
+            #   inception_v2_tsn_arg_scope (inception_v2_tsn.py:320-329): activation_fn=None,
+            #   normalizer_fn=None                                                      -> y + b
+            # (executed from the reference's own arg-scope functions in tests/golden/make_head_reference.py)
+            #   inception_arg_scope (inception_utils.py:48-71, inception_v3): batch-norm with eps 1e-3 and NO gamma
+            #   (scale defaults to False) + relu
+            if arg_scope in ('resnet', 'inception_v3'):
+                y = conv1x1(pl, pose_feat_w, None)
+                mean = y.mean(dim=(0, 1, 2))
+                var = y.var(dim=(0, 1, 2), unbiased=False)
+                gamma, beta = pose_feat_bn
+                y = (y - mean) / torch.sqrt(var + (1e-5 if arg_scope == 'resnet' else 1e-3))
+                pl = torch.relu((y * gamma if gamma is not None else y) + beta)
+            elif arg_scope == 'vgg':
+                pl = torch.relu(conv1x1(pl, pose_feat_w, pose_feat_b))
+            elif arg_scope == 'inception_v2_tsn':
+                pl = conv1x1(pl, pose_feat_w, pose_feat_b)
+            else:
+                raise ValueError('arg_scope %r' % arg_scope)
         feats = torch.cat([feats, pl], dim=-1)
     feats = dropout(feats, keep_prob, dropout_mask, is_training)            # :296
 
@@ -200,16 +227,21 @@ def frame_pooling(logits: torch.Tensor, frames_per_video: int,
 # TF1 legacy bilinear resize (align_corners=False, no half-pixel)  -- SURVEY Appendix B
 # --------------------------------------------------------------------------------------
 def tf1_resize_bilinear(img: torch.Tensor, out_h: int, out_w: int) -> torch.Tensor:
-    """tf.image.resize_images(..., BILINEAR) as of TF 1.1: src = dst * (in/out),
-    lo = floor(src), hi = min(lo+1, in-1), lerp.  img: [N,H,W,C].
+    """tf.image.resize_images(..., BILINEAR) as of TF 1.1: src = dst * (in/out) in float32,
+    lo = floor(src), hi = min(lo+1, in-1) (== min(ceil(src), in-1) whenever the lerp weight is non-zero), lerp.
+    img: [N,H,W,C].
     Call sites: src/loss.py:21, src/preprocess_pipeline.py:204-207."""
     n, h, w, c = img.shape
     if (h, w) == (out_h, out_w):
         return img
-    ys = torch.arange(out_h, dtype=torch.float64) * (h / out_h)
-    xs = torch.arange(out_w, dtype=torch.float64) * (w / out_w)
-    y0 = ys.floor().long(); y1 = torch.clamp(y0 + 1, max=h - 1); fy = (ys - y0).to(img.dtype)
-    x0 = xs.floor().long(); x1 = torch.clamp(x0 + 1, max=w - 1); fx = (xs - x0).to(img.dtype)
+    # the TF kernel (resize_bilinear_op.cc / image_resizer_state.h) computes scale and source coordinate in
+    # FLOAT32: scale = in / float(out); src = float(dst) * scale -- restated with float32 tensors
+    sy = torch.tensor(float(h), dtype=torch.float32) / torch.tensor(float(out_h), dtype=torch.float32)
+    sx = torch.tensor(float(w), dtype=torch.float32) / torch.tensor(float(out_w), dtype=torch.float32)
+    ys = torch.arange(out_h, dtype=torch.float32) * sy
+    xs = torch.arange(out_w, dtype=torch.float32) * sx
+    y0 = ys.floor().long(); y1 = torch.clamp(y0 + 1, max=h - 1); fy = (ys - ys.floor()).to(img.dtype)
+    x0 = xs.floor().long(); x1 = torch.clamp(x0 + 1, max=w - 1); fx = (xs - xs.floor()).to(img.dtype)
     top = img[:, y0][:, :, x0] * (1 - fx)[None, None, :, None] + img[:, y0][:, :, x1] * fx[None, None, :, None]
     bot = img[:, y1][:, :, x0] * (1 - fx)[None, None, :, None] + img[:, y1][:, :, x1] * fx[None, None, :, None]
     return top * (1 - fy)[None, :, None, None] + bot * fy[None, :, None, None]
@@ -344,6 +376,8 @@ def gen_losses(labels_action, logits_action, loss_type_action, num_action_classe
             losses.append(loss_p)
         else:
             losses.append(pose_l2_loss(logits_pose, labels_pose, labels_pose_valid, pose_loss_wt))
+            if end_points is not None:                                              # loss.py:54,57,68
+                end_points['PoseLossMask'] = torch.ones_like(logits_pose)
     if loss_type_action == 'softmax-xentropy':
         losses.append(action_softmax_xent(logits_action, labels_action, num_action_classes, action_loss_wt))
     elif loss_type_action == 'l2':

@@ -1,0 +1,517 @@
+#!/usr/bin/env python
+"""Golden vectors for the attentional-pooling head and the losses, produced by EXECUTING THE REFERENCE'S OWN
+graph-construction code:
+
+    /root/reference/models/slim/nets/nets_factory.py   get_network_fn / network_fn        (:94-380)
+    /root/reference/src/loss.py                         gen_losses                         (:4-105)
+    /root/reference/src/config.py + experiments/*.yaml  the flag table and the shipped configurations
+    /root/reference/models/slim/nets/{resnet_utils,vgg,inception_v2_tsn,inception_utils}.py   the arg_scopes (which slim
+                                                        defaults leak into the head's un-annotated convs)
+
+The files are READ from the reference tree and exec'd behind `tests/golden/tf1_shim.py`, a float64 stand-in
+for the ~40 TensorFlow 1.1 / slim symbols they call (the shim states, op by op, which TF behaviour it
+implements; it does not look at oracle/).  Nothing of the reference is copied into this repository.  The
+backbone is replaced by a stub `networks_map[name]` that returns the supplied conv5 feature map as its
+end point -- exactly the drop-in boundary of this repository.  torch.autograd on the
+shim's tensors plays tf.gradients / optimizer.compute_gradients (model_deploy.py:263) of
+total_loss = sum(tf.losses) + sum(regularization losses)  (model_deploy.py:200-238, one clone).
+
+What this pins: the reference's graph structure for every flag combination below (scopes and variable names,
+chained rank convs, where dropout sits, which tensor feeds which conv, the arg-scope leak into the _2LAYER
+conv, lbl/lgt swap and the N*H*W divisor of the pose loss, the sampled-loss mask, reduction choices, frame
+pooling / temporal attention, the regulariser set).  What it cannot pin (TF absent): float32 kernel rounding
+of TF's conv/softmax/reduce kernels and TF's RNG streams -- random draws are a recorded numpy stream.
+
+Run in the build container (the GPU box has no reference tree):
+
+    python tests/golden/make_head_reference.py          # writes tests/golden/ref_head_*.npz, ref_losses.npz
+"""
+import copy
+import json
+import os
+import sys
+import types
+import zlib
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import tf1_shim as tfs                                   # noqa: E402
+from make_config_reference import EasyDict               # noqa: E402
+
+REF = '/root/reference'
+NETS = os.path.join(REF, 'models', 'slim', 'nets')
+BIG = 4096             # float64 tensors with more elements are stored as float32 (listed in meta['f32_keys'])
+
+
+# ----------------------------------------------------------------------------- loading the reference code
+class _StubModule(types.ModuleType):
+    """a `nets.<x>` module the head never calls into: every attribute is a named placeholder"""
+
+    def __getattr__(self, k):
+        if k.startswith('__'):
+            raise AttributeError(k)
+        return '%s.%s (not loaded)' % (self.__name__, k)
+
+
+def _exec_ref(path, modname, extra=None):
+    src = open(path).read()
+    mod = types.ModuleType(modname)
+    mod.__file__ = path
+    if extra:
+        mod.__dict__.update(extra)
+    exec(compile(src, path, 'exec'), mod.__dict__)
+    sys.modules[modname] = mod
+    return mod
+
+
+def load_reference():
+    """-> (cfg module, nets_factory module, loss module), all exec'd from /root/reference."""
+    for k, m in tfs.build_modules().items():
+        sys.modules[k] = m
+    tf = sys.modules['tensorflow']
+    # a few more names the arg-scope files touch at import / call time
+    tf.truncated_normal_initializer = lambda mean=0.0, stddev=1.0, seed=None, dtype=None: \
+        {'kind': 'truncated_normal', 'mean': float(mean), 'stddev': float(stddev)}
+    layers = types.ModuleType('tensorflow.contrib.layers')
+    layers.xavier_initializer = tfs.xavier_initializer
+    tf.contrib.layers = layers
+    py = types.ModuleType('tensorflow.python')
+    ops = types.ModuleType('tensorflow.python.ops')
+    init_ops = types.ModuleType('tensorflow.python.ops.init_ops')
+    init_ops.constant_initializer = tfs.constant_initializer
+    ops.init_ops = init_ops
+    plat = types.ModuleType('tensorflow.python.platform')
+    tflog = types.ModuleType('tensorflow.python.platform.tf_logging')
+    tflog.info = tf.logging.info
+    plat.tf_logging = tflog
+    py.ops, py.platform = ops, plat
+    sys.modules.update({'tensorflow.python': py, 'tensorflow.python.ops': ops,
+                        'tensorflow.python.ops.init_ops': init_ops, 'tensorflow.python.platform': plat,
+                        'tensorflow.python.platform.tf_logging': tflog, 'tensorflow.contrib.layers': layers})
+
+    # src/config.py (python 2 source: easydict + yaml.load without Loader)
+    ed = types.ModuleType('easydict')
+    ed.EasyDict = EasyDict
+    sys.modules['easydict'] = ed
+    import yaml
+    if not hasattr(yaml, '_orig_load'):
+        yaml._orig_load = yaml.load
+        yaml.load = lambda f, Loader=None: yaml._orig_load(f, Loader=Loader or yaml.SafeLoader)
+    cfgmod = _exec_ref(os.path.join(REF, 'src', 'config.py'), 'refconfig')
+
+    # the arg_scopes: the real functions of the reference
+    nets = types.ModuleType('nets')
+    nets.__path__ = []
+    sys.modules['nets'] = nets
+    resnet_utils = _exec_ref(os.path.join(NETS, 'resnet_utils.py'), 'nets.resnet_utils')
+    vgg = _exec_ref(os.path.join(NETS, 'vgg.py'), 'nets.vgg')
+    tsn = _exec_ref(os.path.join(NETS, 'inception_v2_tsn.py'), 'nets.inception_v2_tsn')
+    inc_utils = _exec_ref(os.path.join(NETS, 'inception_utils.py'), 'nets.inception_utils')
+    for name in ('alexnet', 'cifarnet', 'inception', 'lenet', 'overfeat', 'resnet_v1', 'resnet_v2'):
+        m = _StubModule('nets.' + name)
+        sys.modules['nets.' + name] = m
+        setattr(nets, name, m)
+    nets.vgg = vgg
+    nets.resnet_utils = resnet_utils
+    nets.resnet_v1.resnet_arg_scope = resnet_utils.resnet_arg_scope           # resnet_v1.py:276
+    nets.inception.inception_v2_tsn_arg_scope = tsn.inception_v2_tsn_arg_scope  # inception.py re-export
+    nets.inception.inception_v3_arg_scope = inc_utils.inception_arg_scope       # inception_v3.py:560
+    cbp = types.ModuleType('compact_bilinear_pooling')                         # un-vendored, not on this path
+    cbp.compact_bilinear_pooling_layer = None
+    sys.modules['compact_bilinear_pooling'] = cbp
+    nf = _exec_ref(os.path.join(NETS, 'nets_factory.py'), 'nets.nets_factory')
+    loss = _exec_ref(os.path.join(REF, 'src', 'loss.py'), 'refloss')
+    return cfgmod, nf, loss
+
+
+# ------------------------------------------------------------------------------------------ random values
+def _rs(*keys):
+    return np.random.RandomState(zlib.crc32('|'.join(str(k) for k in keys).encode()) & 0x7fffffff)
+
+
+def f32(a):
+    """float32-representable float64 values: what is stored is exactly what was used"""
+    return np.asarray(a, dtype=np.float32).astype(np.float64)
+
+
+def make_value_fn(case, mode):
+    """mode 'trained': weights ~ N(0, 1/fan_in), biases ~ N(0, 0.1^2) (so that a 1e-3 absolute tolerance on
+    the logits means something); mode 'init': the reference's own initialisers."""
+
+    def value_fn(name, shape, desc):
+        r = _rs(case, name)
+        kind = desc.get('kind')
+        leaf = name.rsplit('/', 1)[-1]
+        if mode == 'init':
+            if kind == 'random_normal':
+                v = desc['mean'] + desc['stddev'] * r.randn(*shape)
+            elif kind == 'zeros':
+                v = np.zeros(shape)
+            elif kind == 'ones':
+                v = np.ones(shape)
+            elif kind == 'constant':
+                v = np.full(shape, desc['value'])
+            elif kind == 'variance_scaling':
+                std = np.sqrt(1.3 * desc['factor'] / desc['fan_in'])
+                v = np.clip(r.randn(*shape), -2, 2) * std
+            elif kind == 'xavier':
+                lim = np.sqrt(6.0 / (desc['fan_in'] + desc['fan_out']))
+                v = r.uniform(-lim, lim, size=shape)
+            else:
+                raise ValueError('initializer %r' % (desc,))
+            return f32(v)
+        if leaf == 'weights':
+            return f32(r.randn(*shape) / np.sqrt(desc['fan_in']))
+        if leaf == 'biases':
+            base = desc.get('value', 0.0) if kind == 'constant' else 0.0
+            return f32(base + 0.1 * r.randn(*shape))
+        if leaf == 'gamma':
+            return f32(1.0 + 0.1 * r.randn(*shape))
+        if leaf == 'beta':
+            return f32(0.1 * r.randn(*shape))
+        if leaf == 'moving_mean':
+            return f32(0.1 * r.randn(*shape))
+        if leaf == 'moving_variance':
+            return f32(1.0 + 0.1 * np.abs(r.randn(*shape)))
+        raise ValueError(name)
+    return value_fn
+
+
+def make_uniform_fn(case):
+    count = [0]
+
+    def uniform_fn(shape, what):
+        r = _rs(case, 'uniform', count[0])
+        count[0] += 1
+        return np.minimum(f32(r.random_sample(shape)), f32(1.0 - 2.0 ** -24))      # float32 draws in [0,1)
+    return uniform_fn
+
+
+# -------------------------------------------------------------------------------------------------- cases
+def reset_cfg(cfgmod, defaults):
+    for k in list(cfgmod.cfg.keys()):
+        del cfgmod.cfg[k]
+    for k, v in copy.deepcopy(defaults).items():
+        cfgmod.cfg[k] = v
+
+
+def merge(cfg, d):
+    for k, v in d.items():
+        if isinstance(v, dict):
+            merge(cfg[k], v)
+        else:
+            if k not in cfg:
+                raise KeyError('%s is not a reference config key' % k)
+            cfg[k] = v
+
+
+P = 'USE_POSE_PRELOGITS_BASED_ATTENTION'
+NOPOSE = {'LOSS_FN_POSE': ''}        # cfg.TRAIN.LOSS_FN_POSE defaults to 'l2' (config.py:116); the 002 yaml clears it
+SL = {P: True, P + '_SINGLE_LAYER_ATT': True}
+HEAD_CASES = [
+    # yaml: start from a shipped experiment file; net / train_cfg: overrides of cfg.NET / cfg.TRAIN;
+    # shape = the conv5 map [N,H,W,C] (or [B,F,H,W,C] video); K classes
+    dict(name='cfg002_eval', yaml='002_MPII_ResNet_withAttention.yaml', train=False, shape=(3, 5, 5, 128), K=393),
+    dict(name='cfg002_train', yaml='002_MPII_ResNet_withAttention.yaml', train=True, shape=(3, 5, 5, 128), K=393),
+    dict(name='cfg002_refinit', yaml='002_MPII_ResNet_withAttention.yaml', train=True, shape=(2, 4, 4, 64), K=393,
+         values='init'),
+    dict(name='cfg002_dropout_half', yaml='002_MPII_ResNet_withAttention.yaml', train=True, shape=(2, 4, 5, 64),
+         K=51, net={'DROPOUT': 0.5}),
+    dict(name='cfg003_eval', yaml='003_MPII_ResNet_withPoseAttention.yaml', train=False, shape=(2, 4, 4, 64), K=393),
+    dict(name='cfg003_train', yaml='003_MPII_ResNet_withPoseAttention.yaml', train=True, shape=(2, 4, 4, 64), K=393),
+    dict(name='cfg003_train_softmax', yaml='003_MPII_ResNet_withPoseAttention.yaml', train=True, shape=(2, 3, 4, 32),
+         K=51, net={P + '_SOFTMAX_ATT': True}),
+    dict(name='cfg003_no_pose_loss', yaml='003_MPII_ResNet_withPoseAttention.yaml', train=True, shape=(2, 3, 3, 32),
+         K=51, train_cfg=NOPOSE),
+    dict(name='cfg002_with_pose_loss', yaml='002_MPII_ResNet_withAttention.yaml', train=True, shape=(2, 3, 4, 32),
+         K=51, train_cfg={'LOSS_FN_POSE': 'l2', 'LOSS_FN_POSE_WT': 0.5}),
+    dict(name='softmax_train', train=True, shape=(2, 5, 6, 64), K=51, train_cfg=NOPOSE,
+         net=dict(SL, **{P + '_SOFTMAX_ATT': True})),
+    dict(name='relu_eval', train=False, shape=(2, 4, 4, 32), K=10, train_cfg=NOPOSE,
+         net=dict(SL, **{P + '_RELU_ATT': True})),
+    dict(name='relu_train', train=True, shape=(2, 4, 4, 32), K=10, train_cfg=NOPOSE,
+         net=dict(SL, **{P + '_RELU_ATT': True})),
+    dict(name='softmax_relu_train', train=True, shape=(2, 3, 3, 32), K=10, train_cfg=NOPOSE,
+         net=dict(SL, **{P + '_SOFTMAX_ATT': True, P + '_RELU_ATT': True})),
+    dict(name='perclass_train', train=True, shape=(2, 4, 4, 64), K=51, train_cfg=NOPOSE,
+         net=dict(SL, **{P + '_PER_CLASS': True})),
+    dict(name='perclass_softmax_eval', train=False, shape=(2, 4, 4, 64), K=51, train_cfg=NOPOSE,
+         net=dict(SL, **{P + '_PER_CLASS': True, P + '_SOFTMAX_ATT': True})),
+    dict(name='perclass_relu_train', train=True, shape=(2, 3, 4, 64), K=20, train_cfg=NOPOSE,
+         net=dict(SL, **{P + '_PER_CLASS': True, P + '_RELU_ATT': True})),
+    dict(name='perclass_posepre_train', train=True, shape=(2, 3, 3, 16), K=51, net={P: True, P + '_PER_CLASS': True}),
+    dict(name='rank2_train', train=True, shape=(2, 4, 4, 32), K=20, train_cfg=NOPOSE, net=dict(SL, **{P + '_RANK': 2})),
+    dict(name='rank3_relu_train', train=True, shape=(2, 3, 4, 32), K=20, train_cfg=NOPOSE,
+         net=dict(SL, **{P + '_RANK': 3, P + '_RELU_ATT': True})),
+    dict(name='rank2_perclass_eval', train=False, shape=(2, 3, 3, 32), K=12, train_cfg=NOPOSE,
+         net=dict(SL, **{P + '_RANK': 2, P + '_PER_CLASS': True})),
+    dict(name='rank2_posepre_train', train=True, shape=(2, 3, 3, 16), K=12, net={P: True, P + '_RANK': 2}),
+    dict(name='posefeat_train', train=True, shape=(2, 4, 4, 16), K=51, net=dict(SL, **{P + "_WITH_POSE_FEAT": True})),
+    dict(name='posefeat_softmax_train', train=True, shape=(2, 4, 4, 16), K=51,
+         net=dict(SL, **{P + '_WITH_POSE_FEAT': True, P + '_SOFTMAX_ATT': True})),
+    dict(name='posefeat_relu_eval', train=False, shape=(2, 3, 3, 16), K=20,
+         net=dict(SL, **{P + '_WITH_POSE_FEAT': True, P + '_RELU_ATT': True})),
+    dict(name='posefeat_posepre_train', train=True, shape=(2, 3, 4, 16), K=51,
+         net={P: True, P + '_WITH_POSE_FEAT': True}),
+    dict(name='posefeat_perclass_train', train=True, shape=(2, 3, 3, 16), K=20,
+         net=dict(SL, **{P + '_WITH_POSE_FEAT': True, P + '_PER_CLASS': True})),
+    dict(name='posefeat_rank2_train', train=True, shape=(2, 3, 3, 16), K=20,
+         net=dict(SL, **{P + '_WITH_POSE_FEAT': True, P + '_RANK': 2})),
+    dict(name='posefeat_2layer_train', train=True, shape=(3, 3, 4, 16), K=51,
+         net=dict(SL, **{P + '_WITH_POSE_FEAT': True, P + '_WITH_POSE_FEAT_2LAYER': True})),
+    dict(name='posefeat_2layer_eval', train=False, shape=(3, 3, 4, 16), K=51,
+         net=dict(SL, **{P + '_WITH_POSE_FEAT': True, P + '_WITH_POSE_FEAT_2LAYER': True})),
+    dict(name='video_framepool_eval', train=False, shape=(2, 3, 3, 3, 32), K=51, train_cfg=NOPOSE, net=SL),
+    dict(name='video_temporal_att_train', train=True, shape=(2, 3, 3, 3, 32), K=51, train_cfg=NOPOSE,
+         net=dict(SL, USE_TEMPORAL_ATT=True)),
+    dict(name='video_temporal_att_eval', train=False, shape=(3, 4, 2, 2, 32), K=20, train_cfg=NOPOSE,
+         net=dict(SL, USE_TEMPORAL_ATT=True)),
+    dict(name='vgg16_train', model='vgg_16', train=True, shape=(2, 4, 4, 64), K=51, relu_input=False,
+         train_cfg=NOPOSE, net=SL),
+    dict(name='vgg16_posefeat_2layer_train', model='vgg_16', train=True, shape=(2, 3, 3, 16), K=20, relu_input=False,
+         net=dict(SL, **{P + '_WITH_POSE_FEAT': True, P + '_WITH_POSE_FEAT_2LAYER': True})),
+    dict(name='tsn_separate_pose_tap_train', model='inception_v2_tsn', train=True, shape=(2, 3, 3, 64), K=51,
+         pose_tap_channels=40, net={P: True}),
+    dict(name='inceptionv3_posefeat_2layer_train', model='inception_v3', train=True, shape=(3, 3, 3, 16), K=20,
+         net=dict(SL, **{P + '_WITH_POSE_FEAT': True, P + '_WITH_POSE_FEAT_2LAYER': True})),
+    dict(name='tsn_posefeat_2layer_train', model='inception_v2_tsn', train=True, shape=(2, 3, 3, 16), K=20,
+         pose_tap_channels=24, net=dict(SL, **{P + '_WITH_POSE_FEAT': True, P + '_WITH_POSE_FEAT_2LAYER': True})),
+]
+
+
+def run_head_case(cfgmod, nf, lossmod, defaults, case):
+    name = case['name']
+    reset_cfg(cfgmod, defaults)
+    cfg = cfgmod.cfg
+    if case.get('yaml'):
+        cfgmod.cfg_from_file(os.path.join(REF, 'experiments', case['yaml']))
+    merge(cfg.NET, case.get('net', {}))
+    merge(cfg.TRAIN, case.get('train_cfg', {}))
+    model = case.get('model', 'resnet_v1_101')
+    K, J = case['K'], 16
+    wd = float(cfg.TRAIN.WEIGHT_DECAY)
+    train = case['train']
+
+    g = tfs.Graph(make_value_fn(name, case.get('values', 'trained')), make_uniform_fn(name))
+    tfs.set_graph(g)
+    r = _rs(name, 'inputs')
+    shape = case['shape']
+    X = r.randn(*shape)
+    if case.get('relu_input', True):
+        X = np.maximum(X, 0)                                  # conv5 of the ResNet is post-ReLU
+    X = f32(X)
+    images = tfs.Tensor(torch.from_numpy(X).requires_grad_(True))
+    n_img = int(np.prod(shape[:-3]))
+    sp = shape[-3:-1]
+    pose_tap = None
+    if case.get('pose_tap_channels'):
+        pose_tap = tfs.Tensor(torch.from_numpy(
+            f32(np.maximum(r.randn(n_img, sp[0], sp[1], case['pose_tap_channels']), 0))).requires_grad_(True))
+
+    seen = {}
+
+    def backbone_stub(imgs, num_classes, is_training=False, train_top_bn=False, **kw):
+        """networks_map[name]: the conv5 map handed in IS the backbone's end point (the drop-in boundary)"""
+        seen.update(num_classes=num_classes, is_training=is_training, train_top_bn=train_top_bn, kwargs=dict(kw))
+        eps = {nf.last_conv_map[model]: imgs}
+        if pose_tap is not None:
+            eps[getattr(cfg.NET.LAST_CONV_MAP_FOR_POSE, model)] = pose_tap
+        return tfs.Tensor(torch.zeros(imgs.v.shape[0], num_classes, dtype=tfs.DT)), eps
+    nf.networks_map[model] = backbone_stub
+
+    network_fn = nf.get_network_fn(model, K, J, cfg, weight_decay=wd, is_training=train)
+    logits, end_points = network_fn(images)
+
+    labels_action = r.randint(0, K, size=(logits.v.shape[0],))
+    use_pose_loss = bool(cfg.TRAIN.LOSS_FN_POSE)           # train.py hands cfg.TRAIN.LOSS_FN_POSE to gen_losses
+    lab_pose = valid = None
+    if use_pose_loss:
+        pl = end_points['PoseLogits']
+        lab_pose = f32(r.rand(*pl.v.shape))
+        valid = r.rand(pl.v.shape[0], J) > 0.3
+    lossmod.gen_losses(
+        tfs.Tensor(torch.from_numpy(labels_action)), logits, cfg.TRAIN.LOSS_FN_ACTION, K,
+        cfg.TRAIN.LOSS_FN_ACTION_WT,
+        tfs.Tensor(torch.from_numpy(lab_pose)) if use_pose_loss else None,
+        end_points['PoseLogits'] if use_pose_loss else None,
+        cfg.TRAIN.LOSS_FN_POSE if use_pose_loss else '',
+        tfs.Tensor(torch.from_numpy(valid)) if use_pose_loss else None,
+        cfg.TRAIN.LOSS_FN_POSE_WT, end_points, cfg)
+    losses = g.get_collection(tfs.GraphKeys.LOSSES)
+    regs = g.get_collection(tfs.GraphKeys.REGULARIZATION_LOSSES)
+    total = sum(l.v for l in losses) + sum(l.v for l in regs)
+    total.backward()
+
+    out, f32_keys = {}, []
+
+    def put(key, arr, exact=False):
+        arr = np.asarray(arr)
+        if arr.dtype == np.float64 and arr.size > BIG and not exact:
+            f32_keys.append(key)
+            arr = arr.astype(np.float32)
+        out[key] = arr
+
+    put('in/images', X.astype(np.float32))
+    if pose_tap is not None:
+        put('in/pose_tap', pose_tap.v.detach().numpy().astype(np.float32))
+        put('grad/pose_tap', pose_tap.v.grad.numpy())
+    put('in/labels_action', labels_action.astype(np.int64))
+    if use_pose_loss:
+        put('in/labels_pose', lab_pose.astype(np.float32))
+        put('in/labels_pose_valid', valid)
+    trainable, reg_only, seeded = [], [], []
+    for vn in g.var_order:
+        v = g.variables[vn]
+        val = v.detach().numpy()
+        grad = None
+        if v.requires_grad:
+            trainable.append(vn)
+            grad = v.grad.numpy() if v.grad is not None else np.zeros(v.shape)
+            # a variable that only the regulariser sees (the pose head of cfg 002 is pruned from the data path but
+            # its conv weights stay in REGULARIZATION_LOSSES): gradient == weight_decay * value, not stored
+            if vn.endswith('/weights') and wd > 0 and np.array_equal(grad, wd * val) and np.abs(val).max() > 0:
+                reg_only.append(vn)
+                grad = None
+        if grad is None and vn in reg_only and val.size > BIG and case.get('values', 'trained') == 'trained':
+            # ... and whose values are therefore only needed for sum(w^2): stored as the seed of the documented
+            # generator (make_value_fn: f32(RandomState(crc32(case|name)).randn(*shape) / sqrt(fan_in))) + checksums
+            seeded.append(vn)
+            put('varseed/' + vn, np.array([zlib.crc32(('%s|%s' % (name, vn)).encode()) & 0x7fffffff,
+                                           g.var_init[vn]['fan_in']] + list(val.shape), dtype=np.int64))
+            put('varsum/' + vn, np.array([val.sum(), (val ** 2).sum()]))
+        else:
+            put('var/' + vn, val.astype(np.float32))
+        if grad is not None:
+            put('grad/var/' + vn, grad)
+    draws = []
+    for i, d in enumerate(g.random_draws):
+        if d['kind'] == 'dropout':
+            keep = np.floor(d['keep_prob'] + d['uniform']).astype(np.uint8)     # tf.nn.dropout's binary_tensor
+            put('rand/%d/keep_bits' % i, np.packbits(keep.reshape(-1)))
+            draws.append({'kind': 'dropout', 'keep_prob': d['keep_prob'], 'shape': list(keep.shape)})
+        else:
+            put('rand/%d/uniform' % i, d['uniform'].astype(np.float32))
+            draws.append({'kind': 'random_uniform', 'shape': list(d['uniform'].shape)})
+    put('out/logits', logits.v.detach().numpy())
+    for k, v in end_points.items():
+        if isinstance(v, tfs.Tensor) and k != nf.last_conv_map[model] and \
+                k != getattr(cfg.NET.LAST_CONV_MAP_FOR_POSE, model, None):
+            put('out/ep/' + k, v.v.detach().numpy().astype(np.float64))
+    put('out/losses', np.array([float(l.v.detach()) for l in losses]))
+    put('out/reg_losses', np.array([float(l.v.detach()) for l in regs]))
+    put('out/total', np.float64(float(total.detach())))
+    put('grad/images', images.v.grad.numpy())
+    updates = {}
+    for kind, val in g.get_collection(tfs.GraphKeys.UPDATE_OPS):
+        updates.setdefault(kind, []).append(val.numpy())
+    for kind, vals in updates.items():
+        put('out/update/' + kind, np.stack(vals))
+    net_flags = {k: v for k, v in cfg.NET.items() if not isinstance(v, dict)}
+    meta = dict(case=name, model=model, num_classes=K, num_pose_keypoints=J, is_training=train, weight_decay=wd,
+                yaml=case.get('yaml'), net=net_flags,
+                train_cfg={k: cfg.TRAIN[k] for k in ('LOSS_FN_POSE', 'LOSS_FN_POSE_WT', 'LOSS_FN_POSE_SAMPLED',
+                                                     'LOSS_FN_ACTION', 'LOSS_FN_ACTION_WT', 'WEIGHT_DECAY')},
+                last_conv=nf.last_conv_map[model],
+                last_conv_pose=getattr(cfg.NET.LAST_CONV_MAP_FOR_POSE, model),
+                backbone_call={k: (v if not isinstance(v, dict) else v) for k, v in seen.items()},
+                var_order=g.var_order, trainable=trainable, reg_only_grad=reg_only, seeded_vars=seeded, var_init=g.var_init, draws=draws,
+                n_losses=len(losses), n_reg_losses=len(regs), f32_keys=f32_keys,
+                end_points=sorted(k for k in out if k.startswith('out/ep/')), values=case.get('values', 'trained'))
+    out['meta'] = np.array(json.dumps(meta, sort_keys=True, default=str))
+    tfs.set_graph(None)
+    return out
+
+
+LOSS_CASES = [
+    # name, action loss type, action wt, pose loss type, pose wt, sampled, label spatial size (None = same)
+    dict(name='xent_pose_l2', action='softmax-xentropy', awt=1.0, pose='l2', pwt=1.0),
+    dict(name='xent_wt_pose_wt', action='softmax-xentropy', awt=1.3, pose='l2', pwt=0.7),
+    dict(name='xent_only', action='softmax-xentropy', awt=1.0, pose='', pwt=1.0),
+    dict(name='xent_zero_wt', action='softmax-xentropy', awt=0.0, pose='', pwt=1.0),
+    dict(name='pose_only', action='', awt=1.0, pose='l2', pwt=2.0),
+    dict(name='action_l2', action='l2', awt=0.5, pose='', pwt=1.0),
+    dict(name='multi_label', action='multi-label', awt=3.0, pose='', pwt=1.0, multihot=True),
+    dict(name='multi_label_2', action='multi-label-2', awt=3.0, pose='', pwt=1.0, multihot=True),
+    dict(name='pose_resized_labels', action='softmax-xentropy', awt=1.0, pose='l2', pwt=1.0, label_hw=(9, 7)),
+    dict(name='pose_resized_labels_up', action='', awt=1.0, pose='l2', pwt=1.0, label_hw=(3, 2)),
+    dict(name='pose_sampled', action='softmax-xentropy', awt=1.0, pose='l2', pwt=1.5, sampled=True),
+    dict(name='pose_all_invalid', action='', awt=1.0, pose='l2', pwt=1.0, all_invalid=True),
+]
+
+
+def run_loss_case(cfgmod, lossmod, defaults, case, out):
+    name = case['name']
+    reset_cfg(cfgmod, defaults)
+    cfg = cfgmod.cfg
+    cfg.TRAIN.LOSS_FN_POSE_SAMPLED = bool(case.get('sampled', False))
+    g = tfs.Graph(make_value_fn(name, 'trained'), make_uniform_fn(name))
+    tfs.set_graph(g)
+    r = _rs('loss', name)
+    N, H, W, J, K = 3, 5, 4, 16, 11
+    logits = f32(r.randn(N, K) * 2)
+    if case.get('multihot'):
+        labels = (r.rand(N, K) < 0.2).astype(np.int64)
+    else:
+        labels = r.randint(0, K, size=(N,)).astype(np.int64)
+    Pl = f32(r.randn(N, H, W, J) * 0.5)
+    lh, lw = case.get('label_hw') or (H, W)
+    lbl = f32(r.rand(N, lh, lw, J))
+    if case.get('sampled'):
+        lbl = f32(lbl * (r.rand(N, lh, lw, J) < 0.3))        # heat-maps are mostly exact zeros (the "negative area")
+    valid = (r.rand(N, J) > 0.3) & (not case.get('all_invalid', False))
+    tl = tfs.Tensor(torch.from_numpy(logits).requires_grad_(True))
+    tp = tfs.Tensor(torch.from_numpy(Pl).requires_grad_(True))
+    ep = {}
+    lossmod.gen_losses(tfs.Tensor(torch.from_numpy(labels)), tl, case['action'], K, case['awt'],
+                       tfs.Tensor(torch.from_numpy(lbl)), tp, case['pose'], tfs.Tensor(torch.from_numpy(valid)),
+                       case['pwt'], ep, cfg)
+    losses = g.get_collection(tfs.GraphKeys.LOSSES)
+    total = sum(l.v for l in losses) if losses else torch.zeros((), dtype=tfs.DT)
+    if total.requires_grad:
+        total.backward()
+    pre = name + '/'
+    out[pre + 'logits'], out[pre + 'labels'] = logits.astype(np.float32), labels
+    out[pre + 'Pl'], out[pre + 'lbl'], out[pre + 'valid'] = Pl.astype(np.float32), lbl.astype(np.float32), valid
+    out[pre + 'losses'] = np.array([float(l.v.detach()) for l in losses])
+    out[pre + 'G'] = tl.v.grad.numpy() if tl.v.grad is not None else np.zeros_like(logits)
+    out[pre + 'dPl'] = tp.v.grad.numpy() if tp.v.grad is not None else np.zeros_like(Pl)
+    if 'PoseLossMask' in ep:
+        out[pre + 'PoseLossMask'] = ep['PoseLossMask'].v.numpy()
+    for i, d in enumerate(g.random_draws):
+        out[pre + 'uniform/%d' % i] = d['uniform'].astype(np.float32)
+    meta = dict(case)
+    meta.update(N=N, H=H, W=W, J=J, K=K, n_draws=len(g.random_draws), n_losses=len(losses))
+    out[pre + 'meta'] = np.array(json.dumps(meta, sort_keys=True))
+    tfs.set_graph(None)
+
+
+def main():
+    cfgmod, nf, lossmod = load_reference()
+    defaults = copy.deepcopy(cfgmod.cfg)
+    only = set(sys.argv[1:])
+    tot = 0
+    for case in HEAD_CASES:
+        if only and case['name'] not in only:
+            continue
+        out = run_head_case(cfgmod, nf, lossmod, defaults, case)
+        dst = os.path.join(HERE, 'ref_head_%s.npz' % case['name'])
+        np.savez_compressed(dst, **out)
+        tot += os.path.getsize(dst)
+        meta = json.loads(str(out['meta']))
+        print('%-32s %7.1f KB  vars: %s' % (case['name'], os.path.getsize(dst) / 1024, ', '.join(meta['var_order'])))
+    if not only or 'losses' in only:
+        out = {}
+        for case in LOSS_CASES:
+            run_loss_case(cfgmod, lossmod, defaults, case, out)
+        out['cases'] = np.array(json.dumps([c['name'] for c in LOSS_CASES]))
+        dst = os.path.join(HERE, 'ref_losses.npz')
+        np.savez_compressed(dst, **out)
+        tot += os.path.getsize(dst)
+    print('wrote reference fixtures, %.1f KB total' % (tot / 1024))
+
+
+if __name__ == '__main__':
+    main()

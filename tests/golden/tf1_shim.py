@@ -1,0 +1,776 @@
+"""A minimal float64 stand-in for the parts of TensorFlow 1.1 / tf.contrib.slim that the reference's head
+code calls  --  TEST INFRASTRUCTURE, used only by tests/golden/make_head_reference.py.
+
+Purpose: /root/reference/models/slim/nets/nets_factory.py (get_network_fn / network_fn, :94-380) and
+/root/reference/src/loss.py (gen_losses, :4-105) are plain Python graph-construction code.  With this
+module installed as `tensorflow`, those two files are EXEC'D FROM THE REFERENCE TREE and the reference's
+own statements -- its scopes, its flag tests, its chained `net = slim.conv2d(net, ...)`, its lbl/lgt swap,
+its reduce_mean / reduce_sum choices, its arg_scope defaults leaking into un-annotated convs -- decide what
+is computed.  What this file supplies is only the meaning of each individual TF op, written from the TF 1.1
+sources' documented behaviour and NOT from oracle/attn_pool_oracle.py, which the
+fixtures are meant to check:
+
+    op (call site)                                   semantics implemented here
+    ------------------------------------------------ -------------------------------------------------------
+    slim.arg_scope / add_arg_scope                    scope stack of per-op keyword defaults; a dict argument
+                                                      REPLACES the current scope (arg_scope.py)
+    tf.variable_scope(name, default_name)             name stack; default names are uniquified per parent
+                                                      scope: Conv, Conv_1, ... (variable_scope.py)
+    slim.conv2d  (layers.convolution)                 1x1 only: y = x . W[Cin,Cout] (+ biases unless a
+                                                      normalizer_fn is given), then normalizer_fn(y, **params),
+                                                      then activation_fn (DEFAULT tf.nn.relu); variables
+                                                      <scope>/weights, <scope>/biases; weights_regularizer(W)
+                                                      appended to REGULARIZATION_LOSSES
+    slim.batch_norm (is_training default True)        tf.nn.moments over all but the last axis (biased variance),
+                                                      tf.nn.batch_normalization: inv = rsqrt(var+eps)*gamma,
+                                                      y = x*inv + (beta - mean*inv); moving averages updated
+                                                      as mov -= (1-decay)*(mov - batch) into UPDATE_OPS
+    slim.dropout -> tf.nn.dropout                     binary = floor(keep_prob + random_uniform(shape)),
+                                                      y = x / keep_prob * binary; identity if not is_training
+    slim.l2_regularizer(s)                            s * sum(w^2)/2; `None` for s == 0
+    tf.nn.softmax                                     exp(x - max) / sum over the LAST axis
+    tf.reduce_mean / reduce_sum / transpose / reshape / stack / concat / split / unstack / squeeze /
+    expand_dims / where / equal / greater / less / to_float / square / ones / shape
+    tf.image.resize_images (bilinear, TF 1.1 kernel)  scale = in/out as float32, in = i*scale (float32), lower =
+                                                      floor(in), upper = min(ceil(in), size-1), lerp = in - lower
+    tf.losses.softmax_cross_entropy / mean_squared_error / sigmoid_cross_entropy / add_loss
+                                                      per-element losses reduced by compute_weighted_loss:
+                                                      sum(losses*w) / #(elements with w != 0)
+    tf.nn.weighted_cross_entropy_with_logits          (1-z)*x + (1+(q-1)*z) * (log1p(exp(-|x|)) + max(-x,0))
+    tf.nn.sigmoid_cross_entropy_with_logits           max(x,0) - x*z + log1p(exp(-|x|))
+
+Numbers are torch float64 tensors and torch autograd plays tf.gradients.  TF's float32 kernel rounding and
+its RNG streams are NOT modelled (random draws come from a seeded numpy stream that the generator records, so
+that the same dropout mask / uniform draws can be replayed through the oracle and the HIP path).
+"""
+from __future__ import annotations
+
+import contextlib
+import functools
+import math
+import sys
+import types
+from typing import Any, Callable, Dict, List, Optional
+
+import numpy as np
+import torch
+
+DT = torch.float64
+
+
+# ------------------------------------------------------------------------------------------- tensors
+class Dimension(object):
+    def __init__(self, v):
+        self.value = v
+
+    def __int__(self):
+        return int(self.value)
+
+    __index__ = __int__
+
+    def __eq__(self, o):
+        return int(self) == int(o)
+
+    def __hash__(self):
+        return hash(int(self))
+
+    def __repr__(self):
+        return 'Dimension(%d)' % self.value
+
+
+class TensorShape(object):
+    def __init__(self, dims):
+        self._dims = [int(d) for d in dims]
+
+    @property
+    def ndims(self):
+        return len(self._dims)
+
+    def as_list(self):
+        return list(self._dims)
+
+    def num_elements(self):
+        n = 1
+        for d in self._dims:
+            n *= d
+        return n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return TensorShape(self._dims[i])
+        return Dimension(self._dims[i])
+
+    def __len__(self):
+        return len(self._dims)
+
+    def __iter__(self):
+        return iter(Dimension(d) for d in self._dims)
+
+    def __repr__(self):
+        return 'TensorShape(%r)' % (self._dims,)
+
+
+class Tensor(object):
+    """A TF graph tensor, evaluated eagerly: `.v` is a torch tensor (float64, bool or int64)."""
+    __array_priority__ = 1000
+
+    def __init__(self, v, name=None):
+        self.v = v
+        self.name = name
+
+    def get_shape(self):
+        return TensorShape(self.v.shape)
+
+    @property
+    def shape(self):
+        return TensorShape(self.v.shape)
+
+    @property
+    def dtype(self):
+        return self.v.dtype
+
+    def set_shape(self, shape):
+        assert list(self.v.shape) == [int(s) for s in shape]
+
+    def __mul__(self, o):
+        return Tensor(self.v * _raw(o, like=self.v))
+
+    __rmul__ = __mul__
+
+    def __add__(self, o):
+        return Tensor(self.v + _raw(o, like=self.v))
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return Tensor(self.v - _raw(o, like=self.v))
+
+    def __rsub__(self, o):
+        return Tensor(_raw(o, like=self.v) - self.v)
+
+    def __truediv__(self, o):
+        return Tensor(self.v / _raw(o, like=self.v))
+
+    def __rtruediv__(self, o):
+        return Tensor(_raw(o, like=self.v) / self.v)
+
+    def __neg__(self):
+        return Tensor(-self.v)
+
+    def __getitem__(self, idx):
+        return Tensor(self.v[idx])
+
+    def __repr__(self):
+        return 'Tensor(shape=%r, name=%r)' % (list(self.v.shape), self.name)
+
+
+def _raw(x, like=None):
+    """python scalars / lists / numpy / Tensor -> torch tensor (dtype follows `like` for python numbers, as
+    TF's op-def type inference does for `tf.where(v, loss_val, [0] * n)`)."""
+    if isinstance(x, Tensor):
+        return x.v
+    if isinstance(x, torch.Tensor):
+        return x
+    if isinstance(x, Dimension):
+        x = int(x)
+    if isinstance(x, (list, tuple)) and len(x) and isinstance(x[0], Tensor):
+        return torch.stack([t.v for t in x])
+    dt = like.dtype if (like is not None and like.dtype.is_floating_point) else None
+    t = torch.as_tensor(np.asarray(x))
+    if t.dtype.is_floating_point or dt is not None:
+        t = t.to(dt or DT)
+    return t
+
+
+def _axes(axis, nd):
+    if axis is None:
+        return tuple(range(nd))
+    if isinstance(axis, int):
+        axis = [axis]
+    return tuple(a % nd for a in axis)
+
+
+# ------------------------------------------------------------------------------------ graph-level state
+class Graph(object):
+    """Everything a tf.Graph would hold for one build: variables by name, collections, the random source."""
+
+    def __init__(self, value_fn: Callable[[str, List[int], Dict[str, Any]], np.ndarray],
+                 uniform_fn: Callable[[List[int], str], np.ndarray]):
+        self.variables: Dict[str, torch.Tensor] = {}
+        self.var_init: Dict[str, Dict[str, Any]] = {}
+        self.var_order: List[str] = []
+        self.collections: Dict[str, list] = {}
+        self.scope_stack: List[str] = []
+        self.default_name_counts: Dict[str, Dict[str, int]] = {}
+        self.arg_stack: List[Dict[str, Dict[str, Any]]] = [{}]
+        self.value_fn = value_fn
+        self.uniform_fn = uniform_fn
+        self.random_draws: List[Dict[str, Any]] = []
+        self.log: List[str] = []
+
+    def scope_name(self):
+        return '/'.join(self.scope_stack)
+
+    def add_to_collection(self, key, value):
+        self.collections.setdefault(key, []).append(value)
+
+    def get_collection(self, key):
+        return list(self.collections.get(key, []))
+
+    def get_variable(self, name, shape, initializer, regularizer=None, trainable=True):
+        full = (self.scope_name() + '/' if self.scope_stack else '') + name
+        if full in self.variables:
+            raise ValueError('Variable %s already exists (no reuse in this shim)' % full)
+        shape = [int(s) for s in shape]
+        desc = dict(initializer or {'kind': 'unknown'})
+        val = np.asarray(self.value_fn(full, shape, desc), dtype=np.float64).reshape(shape)
+        t = torch.from_numpy(val.copy()).to(DT)
+        if trainable:
+            t.requires_grad_(True)
+        self.variables[full] = t
+        self.var_init[full] = desc
+        self.var_order.append(full)
+        if regularizer is not None:
+            loss = regularizer(Tensor(t))
+            if loss is not None:
+                self.add_to_collection(GraphKeys.REGULARIZATION_LOSSES, loss)
+        return Tensor(t, name=full)
+
+
+_GRAPH: Optional[Graph] = None
+
+
+def set_graph(g: Optional[Graph]):
+    global _GRAPH
+    _GRAPH = g
+
+
+def graph() -> Graph:
+    assert _GRAPH is not None, 'tf1_shim: no Graph installed (set_graph)'
+    return _GRAPH
+
+
+class GraphKeys(object):
+    LOSSES = 'losses'
+    REGULARIZATION_LOSSES = 'regularization_losses'
+    UPDATE_OPS = 'update_ops'
+    TRAINABLE_VARIABLES = 'trainable_variables'
+
+
+# ---------------------------------------------------------------------------------- scopes (tf / slim)
+class _VarScope(object):
+    def __init__(self, name):
+        self.name = name
+
+
+@contextlib.contextmanager
+def variable_scope(name_or_scope=None, default_name=None, values=None, reuse=None):
+    g = graph()
+    if name_or_scope is None:
+        parent = g.scope_name()
+        counts = g.default_name_counts.setdefault(parent, {})
+        k = counts.get(default_name, 0)
+        counts[default_name] = k + 1
+        name = default_name if k == 0 else '%s_%d' % (default_name, k)
+    else:
+        name = name_or_scope.name if isinstance(name_or_scope, _VarScope) else name_or_scope
+    g.scope_stack.append(name)
+    try:
+        yield _VarScope(g.scope_name())
+    finally:
+        g.scope_stack.pop()
+
+
+@contextlib.contextmanager
+def name_scope(name=None, default_name=None, values=None):
+    yield name
+
+
+def _op_key(op):
+    return getattr(op, '_arg_scope_key', None) or (op.__module__ + '.' + op.__name__)
+
+
+@contextlib.contextmanager
+def arg_scope(list_ops_or_scope, **kwargs):
+    g = graph()
+    if isinstance(list_ops_or_scope, dict):
+        if kwargs:
+            raise ValueError('When attempting to re-use a scope by suppling a dictionary, kwargs must be empty.')
+        g.arg_stack.append({k: dict(v) for k, v in list_ops_or_scope.items()})
+        try:
+            yield list_ops_or_scope
+        finally:
+            g.arg_stack.pop()
+        return
+    if not isinstance(list_ops_or_scope, (list, tuple)):
+        raise TypeError('list_ops_or_scope must either be a list/tuple or reused scope (i.e. dict)')
+    cur = {k: dict(v) for k, v in g.arg_stack[-1].items()}
+    for op in list_ops_or_scope:
+        key = _op_key(op)
+        if not getattr(op, '_has_arg_scope', False):
+            raise ValueError('%s is not decorated with @add_arg_scope' % key)
+        merged = dict(cur.get(key, {}))
+        merged.update(kwargs)
+        cur[key] = merged
+    g.arg_stack.append(cur)
+    try:
+        yield cur
+    finally:
+        g.arg_stack.pop()
+
+
+def add_arg_scope(func):
+    key = func.__module__ + '.' + func.__name__
+
+    @functools.wraps(func)
+    def wrapper(*args, **kwargs):
+        defaults = graph().arg_stack[-1].get(key, {}) if _GRAPH is not None else {}
+        if defaults:
+            merged = dict(defaults)
+            merged.update(kwargs)
+            kwargs = merged
+        return func(*args, **kwargs)
+
+    wrapper._arg_scope_key = key
+    wrapper._has_arg_scope = True
+    return wrapper
+
+
+# ------------------------------------------------------------------------------------------ initializers
+def random_normal_initializer(mean=0.0, stddev=1.0, seed=None, dtype=None):
+    return {'kind': 'random_normal', 'mean': float(mean), 'stddev': float(stddev)}
+
+
+def zeros_initializer(dtype=None):
+    return {'kind': 'zeros'}
+
+
+def ones_initializer(dtype=None):
+    return {'kind': 'ones'}
+
+
+def constant_initializer(value=0, dtype=None):
+    return {'kind': 'constant', 'value': float(value)}
+
+
+def variance_scaling_initializer(factor=2.0, mode='FAN_IN', uniform=False, seed=None, dtype=None):
+    # tf.contrib.layers: truncated normal with stddev = sqrt(1.3 * factor / n), n = fan_in for FAN_IN
+    return {'kind': 'variance_scaling', 'factor': float(factor), 'mode': mode, 'uniform': bool(uniform),
+            'truncated_normal_stddev': 'sqrt(1.3*factor/n)'}
+
+
+def xavier_initializer(uniform=True, seed=None, dtype=None):
+    return {'kind': 'xavier', 'uniform': bool(uniform)}
+
+
+# ------------------------------------------------------------------------------------------------ slim ops
+def l2_regularizer(scale, scope=None):
+    if isinstance(scale, (int, float)) and scale == 0.:
+        return lambda _: None
+
+    def l2(weights):
+        return Tensor(float(scale) * (weights.v ** 2).sum() / 2.0)       # scale * tf.nn.l2_loss(w)
+    return l2
+
+
+@add_arg_scope
+def batch_norm(inputs, decay=0.999, center=True, scale=False, epsilon=0.001, activation_fn=None,
+               param_initializers=None, param_regularizers=None, updates_collections=GraphKeys.UPDATE_OPS,
+               is_training=True, reuse=None, variables_collections=None, outputs_collections=None,
+               trainable=True, batch_weights=None, fused=False, data_format='NHWC',
+               zero_debias_moving_mean=False, scope=None):
+    g = graph()
+    x = inputs.v
+    c = x.shape[-1]
+    with variable_scope(scope, 'BatchNorm', [inputs], reuse=reuse):
+        beta = g.get_variable('beta', [c], zeros_initializer(), trainable=trainable).v if center else None
+        gamma = g.get_variable('gamma', [c], ones_initializer(), trainable=trainable).v if scale else None
+        moving_mean = g.get_variable('moving_mean', [c], zeros_initializer(), trainable=False).v
+        moving_variance = g.get_variable('moving_variance', [c], ones_initializer(), trainable=False).v
+        if is_training:
+            axes = tuple(range(x.dim() - 1))
+            mean = x.mean(dim=axes)                                            # tf.nn.moments
+            variance = ((x - mean) ** 2).mean(dim=axes)
+            g.add_to_collection(updates_collections or GraphKeys.UPDATE_OPS,
+                                ('moving_mean', (moving_mean - (1 - decay) * (moving_mean - mean)).detach()))
+            g.add_to_collection(updates_collections or GraphKeys.UPDATE_OPS,
+                                ('moving_variance',
+                                 (moving_variance - (1 - decay) * (moving_variance - variance)).detach()))
+        else:
+            mean, variance = moving_mean, moving_variance
+        inv = torch.rsqrt(variance + epsilon)                                   # tf.nn.batch_normalization
+        if gamma is not None:
+            inv = inv * gamma
+        y = x * inv + ((beta - mean * inv) if beta is not None else (-mean * inv))
+    out = Tensor(y)
+    if activation_fn is not None:
+        out = activation_fn(out)
+    return out
+
+
+@add_arg_scope
+def conv2d(inputs, num_outputs, kernel_size, stride=1, padding='SAME', data_format=None, rate=1,
+           activation_fn='__default_relu__', normalizer_fn=None, normalizer_params=None,
+           weights_initializer=None, weights_regularizer=None, biases_initializer='__default_zeros__',
+           biases_regularizer=None, reuse=None, variables_collections=None, outputs_collections=None,
+           trainable=True, scope=None):
+    g = graph()
+    if activation_fn == '__default_relu__':
+        activation_fn = relu                              # layers.convolution: activation_fn=nn.relu
+    if biases_initializer == '__default_zeros__':
+        biases_initializer = zeros_initializer()
+    if weights_initializer is None:
+        weights_initializer = xavier_initializer()
+    ks = [kernel_size, kernel_size] if isinstance(kernel_size, int) else list(kernel_size)
+    if ks != [1, 1] or stride != 1 or rate != 1:
+        raise NotImplementedError('tf1_shim.conv2d: only the 1x1 stride-1 convolutions of the head')
+    x = inputs.v
+    cin = x.shape[-1]
+    cout = int(num_outputs)
+    with variable_scope(scope, 'Conv', [inputs], reuse=reuse):
+        w = g.get_variable('weights', [1, 1, cin, cout], dict(weights_initializer, fan_in=cin, fan_out=cout),
+                           regularizer=weights_regularizer, trainable=trainable)
+        y = torch.matmul(x, w.v.reshape(cin, cout))
+        if normalizer_fn is None and biases_initializer is not None:
+            b = g.get_variable('biases', [cout], biases_initializer, regularizer=biases_regularizer,
+                               trainable=trainable)
+            y = y + b.v                                    # nn.bias_add
+        out = Tensor(y)
+        if normalizer_fn is not None:
+            out = normalizer_fn(out, **(normalizer_params or {}))
+        if activation_fn is not None:
+            out = activation_fn(out)
+    return out
+
+
+@add_arg_scope
+def dropout(inputs, keep_prob=0.5, noise_shape=None, is_training=True, outputs_collections=None, scope=None):
+    if not is_training:
+        return inputs                                      # utils.smart_cond -> identity
+    return nn_dropout(inputs, keep_prob)
+
+
+@add_arg_scope
+def max_pool2d(*a, **k):
+    raise NotImplementedError
+
+
+@add_arg_scope
+def avg_pool2d(*a, **k):
+    raise NotImplementedError
+
+
+@add_arg_scope
+def fully_connected(*a, **k):
+    raise NotImplementedError
+
+
+def one_hot_encoding(labels, num_classes, on_value=1.0, off_value=0.0, outputs_collections=None, scope=None):
+    lab = _raw(labels).long()
+    out = torch.full((lab.shape[0], int(num_classes)), float(off_value), dtype=DT)
+    out[torch.arange(lab.shape[0]), lab] = float(on_value)
+    return Tensor(out)
+
+
+# --------------------------------------------------------------------------------------------------- tf.nn
+def relu(x, name=None):
+    return Tensor(torch.clamp(_raw(x), min=0))
+
+
+def softmax(logits, dim=-1, name=None):
+    x = _raw(logits)
+    e = torch.exp(x - x.max(dim=dim, keepdim=True).values)
+    return Tensor(e / e.sum(dim=dim, keepdim=True))
+
+
+def nn_dropout(x, keep_prob, noise_shape=None, seed=None, name=None):
+    g = graph()
+    xv = _raw(x)
+    u = g.uniform_fn(list(xv.shape), 'dropout')
+    g.random_draws.append({'kind': 'dropout', 'keep_prob': float(keep_prob), 'uniform': u})
+    random_tensor = float(keep_prob) + torch.from_numpy(np.asarray(u, dtype=np.float64))
+    binary_tensor = torch.floor(random_tensor)
+    return Tensor(xv / float(keep_prob) * binary_tensor)        # math_ops.div(x, keep_prob) * binary_tensor
+
+
+def sigmoid_cross_entropy_with_logits(_sentinel=None, labels=None, logits=None, name=None):
+    x, z = _raw(logits), _raw(labels).to(DT)
+    return Tensor(torch.clamp(x, min=0) - x * z + torch.log1p(torch.exp(-x.abs())))
+
+
+def weighted_cross_entropy_with_logits(targets, logits, pos_weight, name=None):
+    x, z = _raw(logits), _raw(targets).to(DT)
+    log_weight = 1 + (float(pos_weight) - 1) * z
+    return Tensor((1 - z) * x + log_weight * (torch.log1p(torch.exp(-x.abs())) + torch.clamp(-x, min=0)))
+
+
+def softmax_cross_entropy_with_logits(_sentinel=None, labels=None, logits=None, dim=-1, name=None):
+    x, z = _raw(logits), _raw(labels).to(DT)
+    sh = x - x.max(dim=-1, keepdim=True).values
+    lsm = sh - torch.log(torch.exp(sh).sum(dim=-1, keepdim=True))
+    return Tensor(-(z * lsm).sum(dim=-1))
+
+
+# ------------------------------------------------------------------------------------------- tf.* array ops
+def reshape(t, shape, name=None):
+    return Tensor(_raw(t).reshape([int(s) for s in shape]))
+
+
+def transpose(t, perm=None, name=None):
+    v = _raw(t)
+    if perm is None:
+        perm = list(range(v.dim()))[::-1]
+    if len(perm) != v.dim():
+        raise ValueError('transpose: perm %r does not match a rank-%d tensor' % (perm, v.dim()))
+    return Tensor(v.permute(*perm))
+
+
+def stack(values, axis=0, name=None):
+    return Tensor(torch.stack([_raw(v) for v in values], dim=axis))
+
+
+def unstack(value, num=None, axis=0, name=None):
+    return [Tensor(t) for t in torch.unbind(_raw(value), dim=axis)]
+
+
+def concat(values, axis, name=None):
+    return Tensor(torch.cat([_raw(v) for v in values], dim=axis))
+
+
+def split(value, num_or_size_splits, axis=0, num=None, name=None):
+    v = _raw(value)
+    if isinstance(num_or_size_splits, (list, tuple)):
+        return [Tensor(t) for t in torch.split(v, [int(s) for s in num_or_size_splits], dim=axis)]
+    n = int(num_or_size_splits)
+    if v.shape[axis] % n:
+        raise ValueError('split: dimension %d not divisible by %d' % (v.shape[axis], n))
+    return [Tensor(t) for t in torch.split(v, v.shape[axis] // n, dim=axis)]
+
+
+def squeeze(t, axis=None, name=None, squeeze_dims=None):
+    v = _raw(t)
+    axis = squeeze_dims if axis is None else axis
+    if axis is None:
+        return Tensor(v.squeeze())
+    for a in sorted(_axes(axis, v.dim()), reverse=True):
+        if v.shape[a] != 1:
+            raise ValueError('squeeze: dimension %d is %d, not 1' % (a, v.shape[a]))
+        v = v.squeeze(a)
+    return Tensor(v)
+
+
+def expand_dims(t, axis=None, name=None, dim=None):
+    v = _raw(t)
+    axis = dim if axis is None else axis
+    if axis < 0:
+        axis = v.dim() + 1 + axis
+    return Tensor(v.unsqueeze(axis))
+
+
+def reduce_mean(t, axis=None, keep_dims=False, name=None, reduction_indices=None):
+    v = _raw(t)
+    ax = _axes(reduction_indices if axis is None else axis, v.dim())
+    return Tensor(v.sum(dim=ax, keepdim=keep_dims) / float(np.prod([v.shape[a] for a in ax])))
+
+
+def reduce_sum(t, axis=None, keep_dims=False, name=None, reduction_indices=None):
+    if isinstance(t, (list, tuple)):            # a python list of scalars is packed into a vector first
+        v = torch.stack([_raw(e).to(DT).reshape(()) for e in t])
+    else:
+        v = _raw(t)
+    ax = _axes(reduction_indices if axis is None else axis, v.dim())
+    return Tensor(v.sum(dim=ax, keepdim=keep_dims))
+
+
+def where(condition, x=None, y=None, name=None):
+    c = _raw(condition).bool()
+    xv = _raw(x)
+    yv = _raw(y, like=xv)
+    if c.dim() == 1 and xv.dim() > 1:
+        c = c.reshape([-1] + [1] * (xv.dim() - 1))
+    return Tensor(torch.where(c, xv, yv))
+
+
+def equal(a, b, name=None):
+    av = _raw(a)
+    return Tensor(av == _raw(b, like=av))
+
+
+def greater(a, b, name=None):
+    av = _raw(a)
+    return Tensor(av > _raw(b, like=av))
+
+
+def less(a, b, name=None):
+    av = _raw(a)
+    return Tensor(av < _raw(b, like=av))
+
+
+def to_float(t, name=None):
+    return Tensor(_raw(t).to(DT))
+
+
+def square(t, name=None):
+    v = _raw(t)
+    return Tensor(v * v)
+
+
+def shape(t, name=None):
+    return list(_raw(t).shape)
+
+
+def ones(shape_, dtype=None, name=None):
+    return Tensor(torch.ones([int(s) for s in shape_], dtype=DT))
+
+
+def zeros(shape_, dtype=None, name=None):
+    return Tensor(torch.zeros([int(s) for s in shape_], dtype=DT))
+
+
+def random_uniform(shape_, minval=0, maxval=None, dtype=None, seed=None, name=None):
+    g = graph()
+    maxval = 1.0 if maxval is None else maxval
+    u = np.asarray(g.uniform_fn([int(s) for s in shape_], 'random_uniform'), dtype=np.float64)
+    g.random_draws.append({'kind': 'random_uniform', 'uniform': u})
+    return Tensor(torch.from_numpy(u * (maxval - minval) + minval))
+
+
+def argmax(t, axis=None, name=None, dimension=None):
+    return Tensor(torch.argmax(_raw(t), dim=dimension if axis is None else axis))
+
+
+def identity(t, name=None):
+    return t
+
+
+# ---------------------------------------------------------------------------------------------- tf.image
+def resize_images(images, size, method=0, align_corners=False):
+    """ResizeBilinear as the TF 1.1 CPU kernel computes it (core/kernels/resize_bilinear_op.cc +
+    image_resizer_state.h, align_corners=False): scale and source coordinates in FLOAT32."""
+    if method != 0 or align_corners:
+        raise NotImplementedError
+    v = _raw(images)
+    squeeze0 = v.dim() == 3
+    if squeeze0:
+        v = v.unsqueeze(0)
+    n, h, w, c = v.shape
+    oh, ow = int(size[0]), int(size[1])
+    if (oh, ow) == (h, w):
+        return images                                   # resize_images returns the input unchanged
+
+    def weights(out_size, in_size):
+        scale = np.float32(in_size) / np.float32(out_size)
+        lo, hi, lerp = [], [], []
+        for i in range(out_size):
+            src = np.float32(i) * scale                 # float32 product
+            lo.append(int(np.floor(src)))
+            hi.append(min(int(np.ceil(src)), in_size - 1))
+            lerp.append(float(np.float32(src - np.floor(src))))
+        return lo, hi, torch.tensor(lerp, dtype=DT)
+
+    y0, y1, fy = weights(oh, h)
+    x0, x1, fx = weights(ow, w)
+    fy = fy.reshape(1, oh, 1, 1)
+    fx = fx.reshape(1, 1, ow, 1)
+    tl, tr = v[:, y0][:, :, x0], v[:, y0][:, :, x1]
+    bl, br = v[:, y1][:, :, x0], v[:, y1][:, :, x1]
+    top = tl + (tr - tl) * fx                            # compute_lerp
+    bot = bl + (br - bl) * fx
+    out = top + (bot - top) * fy
+    return Tensor(out[0] if squeeze0 else out)
+
+
+# ---------------------------------------------------------------------------------------------- tf.losses
+def add_loss(loss, loss_collection=GraphKeys.LOSSES):
+    if loss_collection:
+        graph().add_to_collection(loss_collection, loss if isinstance(loss, Tensor) else Tensor(_raw(loss).to(DT)))
+
+
+def compute_weighted_loss(losses, weights=1.0, scope=None, loss_collection=GraphKeys.LOSSES):
+    lv = _raw(losses).to(DT)
+    wv = _raw(weights).to(DT) if not isinstance(weights, (int, float)) else torch.tensor(float(weights), dtype=DT)
+    wb = torch.broadcast_to(wv, lv.shape) if wv.dim() == 0 or wv.shape == lv.shape else \
+        torch.broadcast_to(wv.reshape(list(wv.shape) + [1] * (lv.dim() - wv.dim())), lv.shape)
+    total_loss = (lv * wb).sum()                                           # _scale_losses
+    num_present = (wb != 0).to(DT).sum()                                   # _num_present
+    mean_loss = torch.where(num_present > 0, total_loss / torch.clamp(num_present, min=1.0),
+                            torch.zeros_like(total_loss))                  # _safe_mean
+    out = Tensor(mean_loss)
+    add_loss(out, loss_collection)
+    return out
+
+
+def softmax_cross_entropy(onehot_labels, logits, weights=1.0, label_smoothing=0, scope=None,
+                          loss_collection=GraphKeys.LOSSES):
+    assert label_smoothing == 0
+    losses = softmax_cross_entropy_with_logits(labels=onehot_labels, logits=logits)
+    return compute_weighted_loss(losses, weights, scope, loss_collection)
+
+
+def mean_squared_error(labels, predictions, weights=1.0, scope=None, loss_collection=GraphKeys.LOSSES):
+    d = _raw(predictions) - _raw(labels).to(DT)
+    return compute_weighted_loss(Tensor(d * d), weights, scope, loss_collection)
+
+
+def sigmoid_cross_entropy(multi_class_labels, logits, weights=1.0, label_smoothing=0, scope=None,
+                          loss_collection=GraphKeys.LOSSES):
+    assert label_smoothing == 0
+    losses = sigmoid_cross_entropy_with_logits(labels=to_float(multi_class_labels), logits=logits)
+    return compute_weighted_loss(losses, weights, scope, loss_collection)
+
+
+def get_losses(scope=None, loss_collection=GraphKeys.LOSSES):
+    return graph().get_collection(loss_collection)
+
+
+def get_regularization_losses(scope=None):
+    return graph().get_collection(GraphKeys.REGULARIZATION_LOSSES)
+
+
+# ------------------------------------------------------------------------------- module objects to install
+def build_modules() -> Dict[str, types.ModuleType]:
+    """Returns {'tensorflow': module, ...} ready for sys.modules."""
+    tf = types.ModuleType('tensorflow')
+    for fn in (reshape, transpose, stack, unstack, concat, split, squeeze, expand_dims, reduce_mean, reduce_sum,
+               where, equal, greater, less, to_float, square, shape, ones, zeros, random_uniform, argmax,
+               identity, variable_scope, name_scope, random_normal_initializer, zeros_initializer,
+               ones_initializer, constant_initializer):
+        setattr(tf, fn.__name__, fn)
+    tf.GraphKeys = GraphKeys
+    tf.float32 = 'float32'
+    tf.Tensor = Tensor
+    nn = types.ModuleType('tensorflow.nn')
+    nn.relu, nn.softmax, nn.dropout = relu, softmax, nn_dropout
+    nn.sigmoid_cross_entropy_with_logits = sigmoid_cross_entropy_with_logits
+    nn.weighted_cross_entropy_with_logits = weighted_cross_entropy_with_logits
+    nn.softmax_cross_entropy_with_logits = softmax_cross_entropy_with_logits
+    tf.nn = nn
+    image = types.ModuleType('tensorflow.image')
+    image.resize_images = resize_images
+    tf.image = image
+    losses = types.ModuleType('tensorflow.losses')
+    for fn in (add_loss, compute_weighted_loss, softmax_cross_entropy, mean_squared_error, sigmoid_cross_entropy,
+               get_losses, get_regularization_losses):
+        setattr(losses, fn.__name__, fn)
+    tf.losses = losses
+    logging = types.ModuleType('tensorflow.logging')
+    logging.info = lambda *a, **k: graph().log.append(str(a[0]) if a else '') if _GRAPH is not None else None
+    tf.logging = logging
+    tf.get_collection = lambda key, scope=None: graph().get_collection(key)
+    tf.add_to_collection = lambda key, v: graph().add_to_collection(key, v)
+
+    slim = types.ModuleType('tensorflow.contrib.slim')
+    for fn in (arg_scope, add_arg_scope, conv2d, batch_norm, dropout, max_pool2d, avg_pool2d, fully_connected,
+               l2_regularizer, variance_scaling_initializer, xavier_initializer, one_hot_encoding):
+        setattr(slim, fn.__name__, fn)
+    slim.losses = losses
+    slim.softmax = lambda logits, scope=None: softmax(logits)      # default argument of the backbone builders
+    utils = types.ModuleType('tensorflow.contrib.slim.utils')
+    utils.collect_named_outputs = lambda collections, alias, outputs: outputs
+    utils.convert_collection_to_dict = lambda c: {}
+    slim.utils = utils
+    contrib = types.ModuleType('tensorflow.contrib')
+    contrib.slim = slim
+    tf.contrib = contrib
+    return {'tensorflow': tf, 'tensorflow.contrib': contrib, 'tensorflow.contrib.slim': slim,
+            'tensorflow.nn': nn, 'tensorflow.losses': losses}

@@ -26,19 +26,19 @@ def test_hip_matches_golden_fixture(gpu, path):
     from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
     d = np.load(path)
     train = bool(d['train'])
-    if train:
-        pytest.skip('the fixture mask comes from torch RNG; dropout parity is covered with the '
-                    'kernel\'s own mask in test_attn_pool_gpu.py')
+    # a training-mode fixture carries its own dropout mask: replayed through APA_FLAG_RNG_EXTERNAL
+    seed = cof.pack_keep_mask(torch.from_numpy(d['mask']), device=gpu) if train else 0
+    kp = float(d['keep']) if train else 1.0
     fused = 'Xatt' not in d.files
     X = torch.from_numpy(d['X']).to(gpu)
     Xatt = X if fused else torch.from_numpy(d['Xatt']).to(gpu)
     Wa, ba, Wt, bt = (torch.from_numpy(d[k]).to(gpu) for k in ('Wa', 'ba', 'Wt', 'bt'))
     labels = torch.from_numpy(d['labels']).to(gpu)
-    flags = cof.attn_flags(bool(d['softmax']), bool(d['relu']), False)
-    logits, att, zs, ab, _, ws = cof.attn_pool_fwd(X, Xatt, Wa, ba, Wt, bt, flags=flags)
+    flags = cof.attn_flags(bool(d['softmax']), bool(d['relu']), train)
+    logits, att, zs, ab, _, ws = cof.attn_pool_fwd(X, Xatt, Wa, ba, Wt, bt, flags=flags, keep_prob=kp, seed=seed)
     loss, G, _, pred = cof.softmax_xent_fwd_bwd(logits, labels, want_pred=True)
     dX, dXatt, dWa, dba, dWt, dbt = cof.attn_pool_bwd(X, Xatt, Wa, ba, Wt, bt, att, zs, ab, G,
-                                                      flags=flags, workspace=ws)
+                                                      flags=flags, keep_prob=kp, seed=seed, workspace=ws)
     assert np.abs(logits.cpu().numpy() - d['logits']).max() <= 1e-3          # north_star tolerance
     assert _rel(logits.cpu().numpy(), d['logits']) < 2e-5
     assert _rel(att.cpu().numpy().reshape(d['att'].shape), d['att']) < 2e-5
@@ -118,13 +118,18 @@ def test_head_module_autograd_matches_oracle_cfg002(gpu):
     p = {k: v.detach().cpu().double().requires_grad_(True) for k, v in head.named_parameters()}
     lr, _ = orc.attentional_pooling(Xr, None, None, [p['att_weights']], [p['att_biases']],
                                     [p['td_weights']], [p['td_biases']], orc.AttnFlags())
-    tr = orc.action_softmax_xent(lr, labels, 393) + orc.l2_regularizer([p['att_weights'], p['td_weights']], 5e-4)
+    # the regulariser covers the PoseLogits conv weights too, although the pose head is pruned from the data path
+    # (REGULARIZATION_LOSSES of the reference graph: tests/golden/ref_head_cfg002_train.npz)
+    tr = orc.action_softmax_xent(lr, labels, 393) + orc.l2_regularizer(
+        [p['pose_w1'], p['pose_w2'], p['att_weights'], p['td_weights']], 5e-4)
     tr.backward()
     assert abs(float(total) - float(tr)) < 1e-5 * float(tr)
     assert _rel(Xd.grad.cpu().numpy(), Xr.grad.numpy()) < 5e-5
     for k in ('att_weights', 'att_biases', 'td_weights', 'td_biases'):
         assert _rel(getattr(head, k).grad.cpu().numpy(), p[k].grad.numpy()) < 5e-5, k
-    assert head.pose_w1.grad is None          # cfg 002: the pose head is pruned from the graph
+    # cfg 002: the pose head is pruned from the data path; only the weight decay reaches its weights
+    assert torch.allclose(head.pose_w1.grad, 5e-4 * head.pose_w1.detach(), rtol=1e-6, atol=0)
+    assert head.pose_b1.grad is None
     apa_config.reset_cfg()
 
 

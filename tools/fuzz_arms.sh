@@ -1,8 +1,11 @@
 #!/bin/bash
 # the random-shape sweeps once per A/B arm of the library (the fallback kernels are real code paths for the
-# shapes the fast ones do not cover)
+# shapes the fast ones do not cover).  The product build has no run-time knobs: this script rebuilds the library
+# with -DAPA_ABLATION first (knob() then reads the environment) and restores the product build when done.
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 cd $R
+make -C attentionalpoolingaction_amd/csrc clean >/dev/null && make -C attentionalpoolingaction_amd/csrc -j16 ABLATE=1 >/dev/null 2>&1 || exit 1
+trap 'make -C attentionalpoolingaction_amd/csrc clean >/dev/null; make -C attentionalpoolingaction_amd/csrc -j16 >/dev/null 2>&1' EXIT
 m1() { echo "== $*"; env "$@" timeout 300 python tools/fuzz_attn_pool.py 120 13 2>&1 | grep -E "^FAIL|cases," | cut -c1-260 | head -6
        env "$@" timeout 300 python tools/fuzz_all.py 50 13 step,bf16m1 2>&1 | grep -E "^FAIL|cases," | cut -c1-260 | head -6; }
 dense() { echo "== $*"; env "$@" timeout 300 python tools/fuzz_all.py 70 13 perclass,pose 2>&1 | grep -E "^FAIL|cases," | cut -c1-260 | head -6; }
@@ -12,7 +15,6 @@ m1 APA_M1_LOGITS2=0
 m1 APA_M1_LOGITS_XENT=0
 m1 APA_M1_GEMV_BWD2=0 APA_M1_KEEP_BITS=0
 dense APA_PC_FUSED=0
-dense APA_PC_ZT_DMA=0
 dense APA_GEMM_GLDS=0
 dense APA_GEMM_FAST=0
 dense APA_POSE_BWD_ROWS=0 APA_POSE_PL_FAST=0
