@@ -53,9 +53,64 @@ __global__ __launch_bounds__(256) void momentum_sgd_kernel(SgdSegs s, const floa
   }
 }
 
+// out[i] = ((p0[i] + p1[i]) + p2[i] ...) * scale: TRAIN.ITER_SIZE accumulation (src/train.py:529-566:
+// ref = g0; ref += g1; ...; apply(ref / ITER_SIZE)) of micro-batch gradients that were produced side by side.
+struct AccParts {
+  const float* p[APA_ACC_MAX_PARTS];
+  int n;
+};
+__global__ __launch_bounds__(256) void accumulate_kernel(AccParts parts, float* __restrict__ out, size_t n,
+                                                         float scale) {
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  const size_t nv = n / 4;
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < nv; v += (size_t)gridDim.x * 256) {
+    f4u acc = *reinterpret_cast<const f4u*>(parts.p[0] + v * 4);
+    for (int k = 1; k < parts.n; ++k) {
+      const f4u g = *reinterpret_cast<const f4u*>(parts.p[k] + v * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += g[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] *= scale;
+    *reinterpret_cast<f4u*>(out + v * 4) = acc;
+  }
+  if (blockIdx.x == 0) {
+    for (size_t i = nv * 4 + threadIdx.x; i < n; i += 256) {
+      float acc = parts.p[0][i];
+      for (int k = 1; k < parts.n; ++k) acc += parts.p[k][i];
+      out[i] = acc * scale;
+    }
+  }
+}
+
 }  // namespace apa
 
 using namespace apa;
+
+extern "C" int apa_accumulate_gradients(float* out, const float* const* parts, int nparts, size_t n,
+                                        float scale, void* stream) {
+  if (!out || !parts || nparts < 1 || nparts > APA_ACC_MAX_PARTS) {
+    set_error("apa_accumulate_gradients: bad arguments (nparts=%d, max %d)", nparts, APA_ACC_MAX_PARTS);
+    return APA_ERR_INVALID_ARG;
+  }
+  AccParts a;
+  a.n = nparts;
+  for (int k = 0; k < nparts; ++k) {
+    if (!parts[k]) {
+      set_error("apa_accumulate_gradients: parts[%d] is NULL", k);
+      return APA_ERR_INVALID_ARG;
+    }
+    a.p[k] = parts[k];
+  }
+  if (n == 0) return APA_OK;
+  size_t nb = (n / 4 + 255) / 256;
+  if (nb < 1) nb = 1;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)nb), dim3(256), 0, static_cast<hipStream_t>(stream), a, out,
+                     n, scale);
+  APA_LAUNCH_CHECK("accumulate_kernel");
+  return APA_OK;
+}
 
 extern "C" int apa_momentum_sgd_step(int nseg, float* const* weights, const size_t* sizes,
                                      const float* weight_decay, const float* grad_flat,

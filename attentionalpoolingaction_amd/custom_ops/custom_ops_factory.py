@@ -88,6 +88,7 @@ _SIGNATURES = {
     'apa_attn_head_eval_step': (c_int, [c_void_p] * 15 + [c_size_t] + [c_int] * 6 + [c_uint, c_int, c_void_p]),
     'apa_momentum_sgd_step': (c_int, [c_int, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_float),
                                       c_void_p, c_void_p, c_float, c_float, c_float, c_void_p]),
+    'apa_accumulate_gradients': (c_int, [c_void_p, POINTER(c_void_p), c_int, c_size_t, c_float, c_void_p]),
     'apa_prof_event_create': (c_int, [POINTER(c_void_p)]),
     'apa_prof_event_destroy': (c_int, [c_void_p]),
     'apa_prof_event_record': (c_int, [c_void_p, c_void_p]),
@@ -869,6 +870,20 @@ def momentum_sgd_step(weights, weight_decay, grad_flat, acc_flat, lr, momentum=0
 # --------------------------------------------------------------------------------------------
 # measurement hooks (bench.py)
 # --------------------------------------------------------------------------------------------
+def accumulate_gradients(out: torch.Tensor, parts, scale: float, stream: Optional[int] = None) -> None:
+    """out = (parts[0] + parts[1] + ...) * scale, summed in that order (apa_accumulate_gradients: TRAIN.ITER_SIZE
+    accumulation of micro-batch buckets, src/train.py:529-566)."""
+    lib = load_library()
+    n = out.numel()
+    arr = (c_void_p * len(parts))(*[_dev_ptr(p_, 'part', torch.float32) for p_ in parts])
+    for p_ in parts:
+        if p_.numel() != n:
+            raise ApaError('accumulate_gradients: every part must have out.numel() elements')
+    rc = lib.apa_accumulate_gradients(_dev_ptr(out, 'out', torch.float32), arr, len(parts), n, float(scale),
+                                      _stream_ptr() if stream is None else stream)
+    _check(rc, 'apa_accumulate_gradients')
+
+
 class KernelTimer:
     """Per-step event pairs for the two streaming kernels of the M == 1 head (m1s_pool_fwd_kernel,
     m1s_bwd_main_kernel).  `hooks(i)` is the apa_hooks struct to pass to step i: the library launches

@@ -176,6 +176,71 @@ class GradientAccumulator:
         return True
 
 
+class OverlappedMicroBatches:
+    """The TRAIN.ITER_SIZE micro-batches of ONE update in flight side by side (round 3).
+
+    The reference recipe for cfg 002 / 003 is `ITER_SIZE: 2` (experiments/002_MPII_ResNet_withAttention.yaml;
+    src/train.py:529-566): two independent micro-batches, their gradients summed, one apply.  At the reference's
+    per-GPU batch the head step is two HBM-streaming passes (~31 us) plus a chain of five latency-bound kernels
+    (finalize -> logits -> xent -> backward head ... column sums, ~22 us on a handful of CUs: 42 % of the step,
+    DESIGN.md section 3.3).  Here micro-batch i runs on its own HIP stream with its own workspace, dropout counter
+    and gradient bucket; the compute stream then forms bucket = (g0 + g1 + ...) / ITER_SIZE in one launch.
+
+    What it buys, measured on MI355X (N = 32 per micro-batch, fp32, bench.py extra.cfg002_train_iter_size): the
+    lanes run nearly in lockstep -- pooling beside pooling, chain beside chain, backward beside backward (device
+    timeline from the dispatch events) -- so what overlaps is one chain with the other:
+    99-102 us per update against 109-110 us back to back (-8 %), per-image step fraction 0.354 -> 0.385.  The
+    hoped-for pairing "streaming pass of B underneath the chain of A" (forced with a cross-stream event after A's
+    pooling pass, eagerly and inside a hipGraph) measured WORSE (110-118 us): the chain kernels are bound by
+    memory latency, and beside a kernel that saturates HBM their loads take about twice as long, while two
+    event operations per lane cost the host 12 us.  That variant was removed again.  On this chip the way to
+    amortise the chain is a larger pass, not concurrency: the same two micro-batches as ONE call over 2N images
+    (memory is no constraint with 288 GB) take 80 us, 0.48 of the HBM roofline (bench.py reports it next to these figures).
+
+    Same kernels, same inputs, a fixed summation order: the result is bit-identical to running the micro-batches
+    one after the other through `GradientAccumulator` (tests/test_head_gpu.py).  `steppers[i]` is the
+    `cof.HeadTrainStep` of lane i (its gradient views must point into `lane_buckets[i]`)."""
+
+    def __init__(self, steppers: Sequence, lane_buckets: Sequence[torch.Tensor], out_bucket: torch.Tensor, device):
+        from .custom_ops import custom_ops_factory as cof
+        assert len(steppers) == len(lane_buckets) >= 1
+        self._cof = cof
+        self.steppers = list(steppers)
+        self.lane_buckets = list(lane_buckets)
+        self.out = out_bucket
+        self.main = torch.cuda.current_stream(device)
+        self.sides = [torch.cuda.Stream(device) for _ in steppers[1:]]
+        self.start = torch.cuda.Event()
+        self.done = [torch.cuda.Event() for _ in steppers[1:]]
+
+    def run(self, steppers: Optional[Sequence] = None) -> None:
+        """Enqueue one update's worth of micro-batches.  `steppers` overrides the lanes' steppers for this call
+        (e.g. rotating input buffers); every lane keeps its own stream."""
+        st = self.steppers if steppers is None else steppers
+        self.start.record(self.main)                 # the lanes start after whatever precedes on the compute stream
+        for side in self.sides:                      # (the optimizer update of the previous iteration)
+            side.wait_event(self.start)
+        st[0].run(stream=self.main.cuda_stream)
+        for s_, side, ev in zip(st[1:], self.sides, self.done):
+            s_.run(stream=side.cuda_stream)
+            ev.record(side)
+        for ev in self.done:
+            self.main.wait_event(ev)
+        self._cof.accumulate_gradients(self.out, self.lane_buckets, 1.0 / len(st), stream=self.main.cuda_stream)
+
+    def run_sequential(self, steppers: Optional[Sequence] = None) -> None:
+        """The same update with the micro-batches one after the other on the compute stream (the schedule of
+        `GradientAccumulator`): the yardstick the overlapped form is measured and checked against."""
+        st = self.steppers if steppers is None else steppers
+        for s_ in st:
+            s_.run(stream=self.main.cuda_stream)
+        self._cof.accumulate_gradients(self.out, self.lane_buckets, 1.0 / len(st), stream=self.main.cuda_stream)
+
+    def close(self) -> None:
+        for side in self.sides:
+            side.synchronize()
+
+
 class MomentumSGD:
     """tf.train.MomentumOptimizer(lr, momentum) (src/train.py:90-94): acc = m*acc + g;
     w -= lr*acc (no Nesterov, no dampening) on the flat bucket layout, with the slim L2

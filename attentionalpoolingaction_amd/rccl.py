@@ -51,6 +51,8 @@ def load_rccl() -> ctypes.CDLL:
     lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
                                   ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+    lib.ncclCommCount.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+    lib.ncclCommUserRank.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
     _lib = lib
     return lib
 
@@ -102,6 +104,32 @@ class RcclCommunicator:
                                                 t.numel(), _DTYPES[t.dtype], _NCCL_SUM, self.comm,
                                                 ctypes.c_void_p(st)), 'ncclAllReduce')
         return t
+
+    def count(self) -> int:
+        """ncclCommCount: the number of ranks RCCL itself sees in this communicator."""
+        n = ctypes.c_int(-1)
+        _check(self.lib, self.lib.ncclCommCount(self.comm, ctypes.byref(n)), 'ncclCommCount')
+        return int(n.value)
+
+    def user_rank(self) -> int:
+        r = ctypes.c_int(-1)
+        _check(self.lib, self.lib.ncclCommUserRank(self.comm, ctypes.byref(r)), 'ncclCommUserRank')
+        return int(r.value)
+
+    def measure_all_reduce_us(self, numel: int, iters: int = 20, warm: int = 5) -> float:
+        """Average device time of one in-stream all-reduce of `numel` fp32 elements (back-to-back launches between
+        two events on the current stream): the figure a trainer weighs against the cost of hiding it."""
+        buf = torch.zeros(numel, dtype=torch.float32, device=self.device)
+        for _ in range(warm):
+            self.all_reduce_(buf)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(self.device)
+        e0.record()
+        for _ in range(iters):
+            self.all_reduce_(buf)
+        e1.record()
+        torch.cuda.synchronize(self.device)
+        return e0.elapsed_time(e1) * 1e3 / iters
 
     def close(self) -> None:
         if self.comm:

@@ -45,6 +45,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+OVERLAP_COST_US = 12.6   # measured cost of the two-stream schedule itself on one rank (profiles/r02_overlap_1rank.md)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
 L3_BYTES = 256 << 20    # Infinity Cache
 
@@ -74,8 +75,9 @@ def parse_args():
     ap.add_argument('--overlap', default='auto', choices=['auto', 'on', 'off'],
                     help='N > 1: reduce dWt|dbt (99.7 %% of the bytes) on a communication stream with its own '
                          'RCCL communicator, between the grad-ready and td-weights-ready hooks (apa_hooks), '
-                         'and only dWa|dba (8 KB) on the compute stream (deploy.OverlappedGradientSum).  auto = on '
-                         'with --comm rccl, off (one in-stream bucket) with --comm torch')
+                         'and only dWa|dba (8 KB) on the compute stream (deploy.OverlappedGradientSum).  auto (with '
+                         '--comm rccl) = decided from a MEASUREMENT at start-up: on iff one in-stream all-reduce of '
+                         'the bucket takes longer than the two-stream choreography costs (OVERLAP_COST_US)')
     ap.add_argument('--comm', default='rccl', choices=['rccl', 'torch', 'gloo'],
                     help='N > 1 gradient sum: direct in-stream ncclAllReduce through librccl (default), '
                          'torch.distributed.all_reduce over RCCL, or over gloo (host-staged; lets two ranks '
@@ -89,7 +91,12 @@ def parse_args():
     ap.add_argument('--per-op-calls', action='store_true',
                     help='drive the step as three separately marshalled calls instead of one '
                          'apa_attn_head_train_step call: same kernels, more host time per step')
+    ap.add_argument('--iter-size', type=int, default=2,
+                    help='extra.cfg002_train_iter_size: TRAIN.ITER_SIZE micro-batches per update (the cfg 002 / 003 '
+                         'YAMLs say 2), run side by side on separate streams (deploy.OverlappedMicroBatches) and, as '
+                         'the yardstick, one after the other; 1 = skip')
     ap.add_argument('--no-extra', action='store_true', help='skip the `extra` workloads')
+    ap.add_argument('--extra-only', default='', help='comma-separated subset of the extra workloads (experiments)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=10.0)
     ap.add_argument('--traffic-bytes', type=float, default=None,
@@ -238,6 +245,69 @@ class HeadWorkload:
                           out=(self.dX[r], None, self.dWa, self.dba, self.dWt, self.dbt), hooks=h)
 
 
+class IterSizeWorkload:
+    """One UPDATE of the reference recipe: TRAIN.ITER_SIZE micro-batches of the headline step (per-GPU batch N each)
+    whose gradients are summed and divided by ITER_SIZE (src/train.py:529-566).  Lane l has its own gradient
+    bucket, workspace and dropout counter; the feature maps rotate over the same kind of buffer sets as the
+    headline workload.  `run_overlapped` puts the lanes on separate HIP streams (deploy.OverlappedMicroBatches),
+    `run_sequential` runs them back to back on one stream; same kernels and results either way."""
+
+    def __init__(self, cof, args, dev, N, lanes):
+        from attentionalpoolingaction_amd import deploy
+        H, C, K = args.hw, args.channels, args.classes
+        P = H * H
+        self.N, self.lanes = N, lanes
+        tdtype = torch.float32 if args.dtype == 'f32' else torch.bfloat16
+        esz = 4 if args.dtype == 'f32' else 2
+        per_set = 2 * N * P * C * esz
+        self.rotate = max(2 * lanes + 1, -(-int(1.5 * L3_BYTES) // per_set))
+        g = torch.Generator(device=dev).manual_seed(42)
+        gw = torch.Generator(device='cpu').manual_seed(42)
+        self.Wa = (torch.randn(C, 1, generator=gw) / C ** 0.5).to(dev)
+        self.ba = torch.zeros(1, device=dev)
+        self.Wt = (torch.randn(C, K, generator=gw) / C ** 0.5).to(dev)
+        self.bt = torch.zeros(K, device=dev)
+        self.labels = [torch.randint(0, K, (N,), generator=gw).to(dev) for _ in range(lanes)]
+        self.flags = cof.attn_flags(args.softmax_att, False, True)
+        sizes = [C, 1, C * K, K]
+        self.bucket = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        self.lane_buckets = [torch.zeros_like(self.bucket) for _ in range(lanes)]
+        self.ws = [torch.empty((cof.attn_pool_workspace_bytes(N, P, C, C, K, 1, self.flags),), dtype=torch.uint8,
+                               device=dev) for _ in range(lanes)]
+        self.ctr = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(lanes)]
+        self.X = [torch.relu(torch.randn(N, P, C, generator=g, device=dev)).to(tdtype) for _ in range(self.rotate)]
+        self.dX = [torch.empty_like(x) for x in self.X]
+        self._steppers = {}
+        self.cof, self.args, self.sizes = cof, args, sizes
+        self.sched = deploy.OverlappedMicroBatches([self._stepper(l, l) for l in range(lanes)], self.lane_buckets,
+                                                   self.bucket, dev)
+        self.i = 0
+
+    def _stepper(self, s, lane):
+        if (s, lane) not in self._steppers:
+            C, K = self.args.channels, self.args.classes
+            b, o, v = self.lane_buckets[lane], 0, []
+            for n in self.sizes:
+                v.append(b[o:o + n])
+                o += n
+            self._steppers[(s, lane)] = self.cof.HeadTrainStep(
+                self.X[s], self.X[s], self.Wa, self.ba, self.Wt, self.bt, self.labels[lane],
+                (self.dX[s], None, v[0].view(C, 1), v[1], v[2].view(C, K), v[3]), flags=self.flags,
+                keep_prob=self.args.keep_prob, seed=42 + lane, offset=self.ctr[lane], workspace=self.ws[lane])
+        return self._steppers[(s, lane)]
+
+    def _next(self):
+        st = [self._stepper((self.i * self.lanes + l) % self.rotate, l) for l in range(self.lanes)]
+        self.i += 1
+        return st
+
+    def run_overlapped(self):
+        self.sched.run(self._next())
+
+    def run_sequential(self):
+        self.sched.run_sequential(self._next())
+
+
 def timed_loops(step, barrier, steps, min_ms, repeats, reduce_max):
     """>= `repeats` loops of `steps` steps, each bracketed by barrier(); until >= min_ms in total.
     Every rank takes the same number of loops (the per-loop time is MAX-reduced over ranks)."""
@@ -312,15 +382,14 @@ def main():
     # all-reduce starts on a side stream underneath the streaming pass; dWa|dba (8 KB) follow on the
     # main stream once the call is done.
     comm = comm_td = None
+    comm_info = None
+    bucket_numel = C + 1 + C * K + K
     if dist is not None and args.comm == 'rccl':
         from attentionalpoolingaction_amd import rccl
         ok = 1
         try:
             comm = rccl.RcclCommunicator(rank, max(world, 1), dev, group=None)
             comm.all_reduce_(torch.zeros(8, device=dev))      # first call builds the rings
-            if args.overlap != 'off' and not args.graph:      # one communicator per stream
-                comm_td = rccl.RcclCommunicator(rank, max(world, 1), dev, group=None)
-                comm_td.all_reduce_(torch.zeros(8, device=dev))
             torch.cuda.synchronize()
         except Exception as e:                                 # noqa: BLE001 -- any failure -> fallback
             print('direct RCCL unavailable on rank {}: {}'.format(rank, e), file=sys.stderr)
@@ -328,13 +397,48 @@ def main():
         flag = torch.tensor([ok], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)            # every rank takes the same branch
         if int(flag.item()) == 0:                              # fall back to torch.distributed's RCCL
-            for c in (comm, comm_td):
-                if c is not None:
-                    c.close()
-            comm = comm_td = None
+            if comm is not None:
+                comm.close()
+            comm = None
             args.comm = 'torch'
             dist.destroy_process_group()
             dist.init_process_group('nccl', device_id=dev)
+        else:
+            # What RCCL itself reports, and what the bucket's all-reduce costs on THIS node: the overlap decision is
+            # taken from this measurement (every rank uses the slowest rank's figure), not from an estimate.
+            ar_us = comm.measure_all_reduce_us(bucket_numel)
+            t_ar = torch.tensor([ar_us], dtype=torch.float64)
+            dist.all_reduce(t_ar, op=dist.ReduceOp.MAX)
+            ar_us = float(t_ar.item())
+            want_overlap = (args.overlap == 'on' or (args.overlap == 'auto' and ar_us > OVERLAP_COST_US)) and not args.graph
+            comm_info = {'ranks': comm.count(), 'user_rank': comm.user_rank(),
+                         'allreduce_bucket_bytes': bucket_numel * 4, 'allreduce_us': round(ar_us, 2),
+                         'overlap': 'on' if want_overlap else 'off',
+                         'overlap_rule': '--overlap {}: on iff the measured in-stream all-reduce of the bucket (max over '
+                                         'ranks) exceeds the {} us the two-stream schedule itself costs'.format(
+                                             args.overlap, OVERLAP_COST_US)}
+            if want_overlap:                                   # one communicator per stream
+                comm_td = rccl.RcclCommunicator(rank, max(world, 1), dev, group=None)
+                comm_td.all_reduce_(torch.zeros(8, device=dev))
+                torch.cuda.synchronize()
+    if dist is not None and comm is None:
+        # torch.distributed transports (RCCL through torch, or gloo for the single-GPU functional check)
+        buf = torch.zeros(bucket_numel, dtype=torch.float32, device=dev)
+        for _ in range(3):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        t_ar = torch.tensor([(time.perf_counter() - t0) / 10 * 1e6], dtype=torch.float64,
+                            device=dev if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(t_ar, op=dist.ReduceOp.MAX)
+        comm_info = {'ranks': dist.get_world_size(), 'user_rank': dist.get_rank(),
+                     'allreduce_bucket_bytes': bucket_numel * 4, 'allreduce_us': round(float(t_ar.item()), 2),
+                     'overlap': 'on' if args.overlap == 'on' and not args.graph else 'off',
+                     'overlap_rule': 'torch.distributed transport: two async buckets only with --overlap on'}
+        del buf
 
     # the overlapped schedule needs the bucket views before the workload exists: build the workload
     # first without hooks, then attach them to its steppers
@@ -490,6 +594,7 @@ def main():
                 'host_calls_per_step': 3 if args.per_op_calls else 1,
                 'comm': None if dist is None else ('librccl ncclAllReduce, in-stream' if comm is not None
                                                    else 'torch.distributed ' + dist.get_backend()),
+                'comm_detail': comm_info,
                 'allreduce': ('none' if dist is None else
                               'dWt|dbt on a communication stream (own communicator) between the grad-ready and '
                               'td-weights-ready hooks; dWa|dba in-stream' if overlap is not None else
@@ -530,7 +635,11 @@ def main():
         del work
         torch.cuda.empty_cache()
 
+        only = set(k for k in args.extra_only.split(',') if k)
+
         def run_extra(key, builder, **kw):
+            if only and key not in only:
+                return
             try:
                 fn, info = builder(cof, dev, **kw)
                 s, reps = bd.timed(fn, 50, 5, min_ms=args.min_ms, repeats=args.repeats)
@@ -545,6 +654,8 @@ def main():
         run_extra('hmdb51_rank1_bf16_train', bd.build_rank1, N=32, H=14, K=51, dtype='bf16')
         # the headline step far outside every cache: N = 512 (1.6 GB of features per pass, no rotation needed)
         try:
+            if only and 'cfg002_train_n512' not in only:
+                raise KeyError('skipped')
             big = HeadWorkload(cof, args, dev, rank, world, 512, 1)
             for _ in range(3):
                 big.compute()
@@ -565,9 +676,57 @@ def main():
                                  'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                  'frac': round(1.0 * 512 * P * C * esz / (bf_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
             del big
+        except KeyError:
+            pass
         except Exception as e:                                 # noqa: BLE001
             extra['cfg002_train_n512'] = {'error': '{}: {}'.format(type(e).__name__, e)}
         torch.cuda.empty_cache()
+        # the reference recipe's update: ITER_SIZE micro-batches of the headline step, side by side vs back to back
+        if args.iter_size > 1 and not args.eval_mode and (not only or 'cfg002_train_iter_size' in only):
+            try:
+                it = IterSizeWorkload(cof, args, dev, N, args.iter_size)
+                L = args.iter_size
+                res = {}
+                for name, fn in (('overlapped', it.run_overlapped), ('sequential', it.run_sequential)):
+                    for _ in range(10):
+                        fn()
+                    p_, _ = timed_loops(fn, torch.cuda.synchronize, max(20, args.steps // L), args.min_ms, args.repeats,
+                                        lambda x: x)
+                    s_ = _median(p_)
+                    res[name] = {'us_per_update': round(s_ * 1e6, 2), 'images_per_sec': round(L * N / s_, 1),
+                                 'step_roofline_frac': round(L * 3.0 * N * P * C * esz / s_ / 1e9 / HBM_PEAK_GBS, 4),
+                                 'repeats': len(p_)}
+                it.sched.close()
+                del it
+                torch.cuda.empty_cache()
+                # the same ITER_SIZE x N images as ONE call (per-GPU batch L*N, ITER_SIZE 1): what 288 GB of HBM allow
+                one = HeadWorkload(cof, args, dev, rank, world, L * N, 0)
+                for _ in range(10):
+                    one.compute()
+                p_, _ = timed_loops(one.compute, torch.cuda.synchronize, max(20, args.steps // L), args.min_ms,
+                                    args.repeats, lambda x: x)
+                s_ = _median(p_)
+                res['one_pass'] = {'us_per_update': round(s_ * 1e6, 2), 'images_per_sec': round(L * N / s_, 1),
+                                   'step_roofline_frac': round(L * 3.0 * N * P * C * esz / s_ / 1e9 / HBM_PEAK_GBS, 4),
+                                   'repeats': len(p_)}
+                del one
+                extra['cfg002_train_iter_size'] = {
+                    'workload': 'one UPDATE of the reference recipe (TRAIN.ITER_SIZE = {}: experiments/002...yaml, '
+                                'src/train.py:529-566): {} micro-batches of the headline step (per-GPU batch {} each) + '
+                                'gradient accumulation (one launch); overlapped = each micro-batch on its own HIP '
+                                'stream, workspace, bucket and dropout counter (deploy.OverlappedMicroBatches); '
+                                'sequential = back to back on one stream.  Same kernels, bit-identical gradients '
+                                '(tests/test_head_gpu.py)'.format(L, L, N),
+                    'iter_size': L, 'overlapped': res['overlapped'], 'sequential': res['sequential'],
+                    'one_pass_batch_{}'.format(L * N): res['one_pass'],
+                    'step_roofline_frac': res['overlapped']['step_roofline_frac'],
+                    'note': 'step_roofline_frac = ITER_SIZE x 3 x N x P x C x 4 algorithmic bytes per update / time '
+                            '/ 8 TB/s (the accumulation launch is inside the time, its 9.6 MB are not in the bytes); '
+                            'one_pass = the same images as one call with ITER_SIZE 1 (mathematically the same update '
+                            'for this head, not bit-identical: one reduction over all rows)'}
+            except Exception as e:                             # noqa: BLE001
+                extra['cfg002_train_iter_size'] = {'error': '{}: {}'.format(type(e).__name__, e)}
+            torch.cuda.empty_cache()
         out['extra'] = extra
 
     if rank == 0:

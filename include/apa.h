@@ -421,6 +421,17 @@ int apa_momentum_sgd_step(int nseg, float* const* weights, const size_t* sizes,
                           float lr, float momentum, float grad_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * TRAIN.ITER_SIZE accumulation (src/train.py:529-566: `ref = grad` on the first micro-step, `ref += grad` on the
+ * following ones, `apply_gradients(ref / ITER_SIZE)` on the last) for micro-batches whose gradients were written
+ * into separate flat buckets (deploy.OverlappedMicroBatches runs them on separate streams):
+ *     out[i] = ((parts[0][i] + parts[1][i]) + ...) * scale           same summation order as the reference
+ * parts: HOST array of nparts device pointers (f32 [n] each; out may alias parts[0]); one launch, any alignment.
+ */
+#define APA_ACC_MAX_PARTS 8
+int apa_accumulate_gradients(float* out, const float* const* parts, int nparts, size_t n, float scale,
+                             void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Measurement helpers (bench.py): HIP events owned by the library's HIP runtime, for the prof_*
  * members of apa_hooks.
  */

@@ -1235,6 +1235,10 @@ def test_bench_two_ranks_sharing_one_gpu_over_gloo(gpu):
     assert d['scaling'] == 'weak' and d['value'] > 0 and 'cpu_baseline' not in d
     assert abs(d['value'] - 64 / (d['ms_per_step'] * 1e-3)) < 0.01 * d['value']   # whole-job images / max-rank time
     assert 'gloo' in d['config']['comm']
+    # what the communicator itself reports, and the measurement the overlap decision is taken from
+    cd = d['config']['comm_detail']
+    assert cd['ranks'] == 2 and cd['allreduce_bucket_bytes'] == (2048 + 1 + 2048 * 393 + 393) * 4
+    assert cd['allreduce_us'] > 0 and cd['overlap'] in ('on', 'off')
 
 
 def test_bench_prints_one_json_line_with_the_contract_fields(gpu):
@@ -1256,6 +1260,12 @@ def test_bench_prints_one_json_line_with_the_contract_fields(gpu):
             assert k in d, k
         assert d['unit'] == 'images/sec' and d['steps'] == 20 and d['warmup'] == 3 and d['n_gpus'] == 1
         assert d['vs_baseline'] is None and d['dtype'] == 'f32' and 'workload' in d['config']
+        if '--force-dist' in extra:      # a one-rank RCCL group: ncclCommCount and the measured bucket all-reduce
+            cd = d['config']['comm_detail']
+            assert cd['ranks'] == 1 and cd['allreduce_us'] > 0
+            assert cd['overlap'] == ('on' if cd['allreduce_us'] > 12.6 else 'off')
+        else:
+            assert d['config']['comm_detail'] is None
         r = d['roofline']
         assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
         assert 0.2 < r['frac'] < 1.0 and d['value'] > 2000          # BASELINE target: >= 2000 img/s
@@ -1270,3 +1280,75 @@ def test_bench_prints_one_json_line_with_the_contract_fields(gpu):
                       'cfg002_train_n512'):
                 assert 'error' not in d['extra'][k], d['extra'][k]
                 assert d['extra'][k]['ms_per_step'] > 0 and 0.0 < d['extra'][k]['roofline']['frac'] < 1.0
+            it = d['extra']['cfg002_train_iter_size']
+            assert 'error' not in it, it
+            assert it['iter_size'] == 2 and 0.2 < it['overlapped']['step_roofline_frac'] < 1.0
+            assert it['overlapped']['us_per_update'] < 1.05 * it['sequential']['us_per_update']
+            assert it['one_pass_batch_64']['us_per_update'] < it['sequential']['us_per_update']
+
+
+@pytest.mark.parametrize('lanes,dtype', [(2, torch.float32), (3, torch.bfloat16)])
+def test_overlapped_micro_batches_equal_the_sequential_gradient_accumulator(gpu, lanes, dtype):
+    """TRAIN.ITER_SIZE (src/train.py:529-566): the micro-batches of one update on separate streams
+    (deploy.OverlappedMicroBatches) give BIT-IDENTICAL accumulated gradients, dX and losses to the same micro-batches
+    run one after the other through deploy.GradientAccumulator."""
+    from attentionalpoolingaction_amd import deploy
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    N, P, C, K = 8, 49, 2048, 51
+    g = torch.Generator().manual_seed(5)
+    Wa, ba = (torch.randn(C, 1, generator=g) / 45).to(gpu), torch.zeros(1, device=gpu)
+    Wt, bt = (torch.randn(C, K, generator=g) / 45).to(gpu), (torch.randn(K, generator=g) * 0.1).to(gpu)
+    Xs = [torch.relu(torch.randn(N, P, C, generator=g)).to(gpu).to(dtype) for _ in range(lanes)]
+    labels = [torch.randint(0, K, (N,), generator=g).to(gpu) for _ in range(lanes)]
+    flags = cof.attn_flags(False, False, True)
+    sizes = [C, 1, C * K, K]
+
+    def views(flat):
+        o, v = 0, []
+        for n in sizes:
+            v.append(flat[o:o + n])
+            o += n
+        return v[0].view(C, 1), v[1], v[2].view(C, K), v[3]
+
+    def build(lane_buckets, dXs, ctrs):
+        st = []
+        for l in range(lanes):
+            dWa, dba, dWt, dbt = views(lane_buckets[l])
+            st.append(cof.HeadTrainStep(Xs[l], Xs[l], Wa, ba, Wt, bt, labels[l], (dXs[l], None, dWa, dba, dWt, dbt),
+                                        flags=flags, keep_prob=0.2, seed=42 + l, offset=ctrs[l]))
+        return st
+
+    def fresh():
+        return ([torch.zeros(sum(sizes), device=gpu) for _ in range(lanes)], [torch.empty_like(x) for x in Xs],
+                [torch.zeros(1, dtype=torch.int64, device=gpu) for _ in range(lanes)])
+
+    # (a) the overlapped schedule, three updates in a row (the dropout counters advance)
+    lb, dXa, ctr = fresh()
+    out_a = torch.zeros(sum(sizes), device=gpu)
+    sched = deploy.OverlappedMicroBatches(build(lb, dXa, ctr), lb, out_a, gpu)
+    hist_a = []
+    for _ in range(3):
+        sched.run()
+        torch.cuda.synchronize()
+        hist_a.append((out_a.clone(), [d.clone() for d in dXa], [s.loss.clone() for s in sched.steppers]))
+    sched.close()
+    assert [int(c) for c in ctr] == [3] * lanes
+    # (b) the same micro-batches one at a time, accumulated by deploy.GradientAccumulator
+    lb2, dXb, ctr2 = fresh()
+    work = torch.zeros(sum(sizes), device=gpu)
+    bucket = deploy.GradientBucket({'flat': (sum(sizes),)}, gpu)
+    acc = deploy.GradientAccumulator(bucket, lanes)
+    st2 = build([work] * lanes, dXb, ctr2)          # every micro-step writes the ONE working bucket
+    for u in range(3):
+        ready = False
+        for l in range(lanes):
+            st2[l].run()
+            torch.cuda.synchronize()
+            bucket.flat.copy_(work)
+            ready = acc.step()
+        assert ready
+        got_flat, got_dX, got_loss = hist_a[u]
+        assert torch.equal(bucket.flat, got_flat)
+        for l in range(lanes):
+            assert torch.equal(dXb[l], got_dX[l]) and torch.equal(st2[l].loss, got_loss[l])
+    assert float(hist_a[0][0].abs().max()) > 0 and not torch.equal(hist_a[0][0], hist_a[1][0])
