@@ -216,9 +216,26 @@ int set_lds(K kernel, size_t shm) {
 }
 }  // namespace
 
+// dynamic LDS a block may ask for on the current device (160 KB on gfx950; 64 KB parts exist): queried once per
+// thread, so a channel count whose accumulator rows do not fit is refused with APA_ERR_UNSUPPORTED instead of
+// failing inside hipFuncSetAttribute / the launch
+static size_t max_block_lds() {
+  static thread_local size_t cached = 0;
+  if (!cached) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0)
+      cached = (size_t)v;
+    else
+      cached = 64 * 1024;
+  }
+  return cached;
+}
+
 bool m1g_supported(int C, int dtype) {
   const int epv = dtype == APA_DTYPE_BF16 ? 8 : 4;
-  return C >= epv && C % epv == 0 && (size_t)4 * C * 4 + 64 <= 150 * 1024;   // 4 accumulator rows in LDS
+  const size_t cap = max_block_lds() < 150 * 1024 ? max_block_lds() : (size_t)150 * 1024;
+  return C >= epv && C % epv == 0 && (size_t)4 * C * 4 + 64 <= cap;   // 4 accumulator rows in LDS
 }
 
 int m1g_launch_pool_fwd(int dtype, int C, bool fused, bool train, int nblk, hipStream_t st, const void* X,

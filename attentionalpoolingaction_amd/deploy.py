@@ -104,7 +104,8 @@ class OverlappedGradientSum:
     The two waits are the `grad_ready_event` / `td_weights_ready_event` members of `apa_hooks`
     (include/apa.h): `self.hooks` is that struct and has to be handed to every forward / backward call
     of the head explicitly (`cof.attn_pool_fwd(..., hooks=ogs.hooks)`, `cof.attn_pool_bwd(..., hooks=
-    ogs.hooks)`, `cof.HeadTrainStep(..., hooks=ogs.hooks)`) -- nothing is registered per thread, so the
+    ogs.hooks)`, `cof.HeadTrainStep(..., hooks=ogs.hooks)`; through the nn.Module surface:
+    `network_fn.head.hooks = ogs.hooks`) -- nothing is registered per thread, so the
     schedule also holds when autograd runs the backward on its engine thread.  Each stream drives its own communicator: two collectives of one communicator
     must not be in flight at the same time.  Every rank enqueues them in the same order.  Same sums
     as `sum_clone_gradients` (model_deploy.py:421-451), only the schedule differs."""

@@ -83,13 +83,14 @@ class AttentionalPoolingFunction(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, X, Xatt, Wa, ba, Wt, bt, flags, keep_prob, seed, offset, want_topdown):
+    def forward(ctx, X, Xatt, Wa, ba, Wt, bt, flags, keep_prob, seed, offset, want_topdown, hooks=None):
         Xc = X.contiguous()
         fused = Xatt is None
         Xa = Xc if fused else Xatt.contiguous()
         logits, att, zsave, abar, topdown, ws = cof.attn_pool_fwd(
             Xc, Xa, Wa.contiguous(), ba.contiguous(), Wt.contiguous(), bt.contiguous(),
-            flags=flags, keep_prob=keep_prob, seed=seed, offset=offset, want_topdown=want_topdown)
+            flags=flags, keep_prob=keep_prob, seed=seed, offset=offset, want_topdown=want_topdown, hooks=hooks)
+        ctx.hooks = hooks
         saved = [Xc, Xa, Wa, ba, Wt, bt, att, zsave]
         ctx.has_abar = abar is not None
         if abar is not None:
@@ -117,11 +118,11 @@ class AttentionalPoolingFunction(torch.autograd.Function):
         dX, dXatt, dWa, dba, dWt, dbt = cof.attn_pool_bwd(
             Xc, Xa, Wa.contiguous(), ba.contiguous(), Wt.contiguous(), bt.contiguous(), att, zsave,
             abar, dlogits.contiguous().float(), flags=flags, keep_prob=keep_prob, seed=seed,
-            offset=offset, workspace=ctx.ws)
+            offset=offset, workspace=ctx.ws, hooks=ctx.hooks)
         dX = dX.view(ctx.xshape)
         if dXatt is not None:
             dXatt = dXatt.view(ctx.xatt_shape)
-        return dX, dXatt, dWa, dba, dWt, dbt, None, None, None, None, None
+        return dX, dXatt, dWa, dba, dWt, dbt, None, None, None, None, None, None
 
 
 class AttentionalPoolingCatFunction(torch.autograd.Function):
@@ -130,14 +131,15 @@ class AttentionalPoolingCatFunction(torch.autograd.Function):
     (apa_attn_pool_fwd_cat / apa_attn_pool_bwd_cat); `Xatt is None` = attention from X itself."""
 
     @staticmethod
-    def forward(ctx, X, Xatt, Xext, Wa, ba, Wt, bt, flags, keep_prob, seed, offset):
+    def forward(ctx, X, Xatt, Xext, Wa, ba, Wt, bt, flags, keep_prob, seed, offset, hooks=None):
         Xc = X.contiguous()
         fused = Xatt is None
         Xa = Xc if fused else Xatt.contiguous()
         Xe = Xext.contiguous().float()
         logits, att, zsave, abar, zext, ws = cof.attn_pool_fwd_cat(
             Xc, Xa, Xe, Wa.contiguous(), ba.contiguous(), Wt.contiguous(), bt.contiguous(), flags=flags,
-            keep_prob=keep_prob, seed=seed, offset=offset)
+            keep_prob=keep_prob, seed=seed, offset=offset, hooks=hooks)
+        ctx.hooks = hooks
         ctx.save_for_backward(Xc, Xa, Xe, Wa, ba, Wt, bt, att, zsave, abar, zext)
         ctx.fused = fused
         ctx.cfg = (flags, keep_prob, seed, offset)
@@ -155,10 +157,10 @@ class AttentionalPoolingCatFunction(torch.autograd.Function):
         dX, dXatt, dXext, dWa, dba, dWt, dbt = cof.attn_pool_bwd_cat(
             Xc, Xa, Xe, zext, Wa.contiguous(), ba.contiguous(), Wt.contiguous(), bt.contiguous(), att, zsave,
             abar, dlogits.contiguous().float(), flags=flags, keep_prob=keep_prob, seed=seed, offset=offset,
-            workspace=ctx.ws)
+            workspace=ctx.ws, hooks=ctx.hooks)
         xs, xas, xes = ctx.shapes
         return (dX.view(xs), None if dXatt is None else dXatt.view(xas), dXext.view(xes), dWa, dba, dWt, dbt,
-                None, None, None, None)
+                None, None, None, None, None)
 
 
 class PoseHeadFunction(torch.autograd.Function):
@@ -196,13 +198,14 @@ class PoseAttentionFunction(torch.autograd.Function):
     pooling op's buffer instead of autograd summing two [N,P,2048] tensors."""
 
     @staticmethod
-    def forward(ctx, X, W1, b1, W2, b2, Wa, ba, Wt, bt, flags, keep_prob, seed, offset, want_topdown):
+    def forward(ctx, X, W1, b1, W2, b2, Wa, ba, Wt, bt, flags, keep_prob, seed, offset, want_topdown, hooks=None):
         Xc = X.contiguous()
         W1c, W2c, Wac, Wtc = W1.contiguous(), W2.contiguous(), Wa.contiguous(), Wt.contiguous()
         Ppre, Pl, pws = cof.pose_head_fwd(Xc, W1c, b1.contiguous(), W2c, b2.contiguous())
         logits, att, zsave, abar, topdown, aws = cof.attn_pool_fwd(
             Xc, Ppre, Wac, ba.contiguous(), Wtc, bt.contiguous(), flags=flags, keep_prob=keep_prob,
-            seed=seed, offset=offset, want_topdown=want_topdown)
+            seed=seed, offset=offset, want_topdown=want_topdown, hooks=hooks)
+        ctx.hooks = hooks
         ctx.save_for_backward(Xc, W1c, W2c, Ppre, Wac, ba, Wtc, bt, att, zsave, abar)
         ctx.cfg = (flags, keep_prob, seed, offset)
         ctx.ws = (pws, aws)
@@ -220,7 +223,7 @@ class PoseAttentionFunction(torch.autograd.Function):
         pws, aws = ctx.ws
         dPl_c = None if dPl is None else dPl.contiguous().float()
         if dlogits is None and dPl_c is None:
-            return (None,) * 14
+            return (None,) * 15
         dX = dZ = dWa = dba = dWt = dbt = None
         if dlogits is not None:
             epv = 4 if Xc.dtype == torch.float32 else 8
@@ -228,7 +231,7 @@ class PoseAttentionFunction(torch.autograd.Function):
             dX, dZ, dWa, dba, dWt, dbt = cof.attn_pool_bwd(
                 Xc, Ppre, Wa, ba.contiguous(), Wt, bt.contiguous(), att, zsave, abar,
                 dlogits.contiguous().float(), flags=flags, keep_prob=keep_prob, seed=seed, offset=offset,
-                workspace=aws, dxatt_rank1=rank1)
+                workspace=aws, dxatt_rank1=rank1, hooks=ctx.hooks)
             if rank1:
                 dX, dW1, db1, dW2, db2 = cof.pose_head_bwd(Xc, W1, W2, Ppre, dPl_c, None, dX=dX, accumulate_dX=True,
                                                            workspace=pws, ws_from_fwd=True,
@@ -239,18 +242,18 @@ class PoseAttentionFunction(torch.autograd.Function):
         else:
             dX, dW1, db1, dW2, db2 = cof.pose_head_bwd(Xc, W1, W2, Ppre, dPl_c, None, workspace=pws,
                                                        ws_from_fwd=True)
-        return (dX.view(ctx.xshape), dW1, db1, dW2, db2, dWa, dba, dWt, dbt, None, None, None, None, None)
+        return (dX.view(ctx.xshape), dW1, db1, dW2, db2, dWa, dba, dWt, dbt, None, None, None, None, None, None)
 
 
 def attentional_pooling(X, Xatt, Wa, ba, Wt, bt, *, softmax_att=False, relu_att=False,
                         is_training=False, keep_prob=0.2, seed=0, offset=0, want_topdown=False,
-                        relu_input=False):
+                        relu_input=False, hooks=None):
     """`relu_input=True`: X is the backbone's pre-activation map; the op computes with max(X, 0) and
     returns the gradient w.r.t. the pre-activation (APA_FLAG_RELU_INPUT, include/apa.h)."""
     flags = cof.attn_flags(softmax_att, relu_att, is_training, relu_input)
     return AttentionalPoolingFunction.apply(X, Xatt, Wa, ba, Wt, bt, flags,
                                             keep_prob if is_training else 1.0, seed, offset,
-                                            want_topdown)
+                                            want_topdown, hooks)
 
 
 class AttentionalPoolingHead(nn.Module):
@@ -295,6 +298,9 @@ class AttentionalPoolingHead(nn.Module):
             raise ValueError('arg_scope must be one of %s' % sorted(self.ARG_SCOPES))
         self.arg_scope = arg_scope
         self._replay_mask = None      # replay_dropout_mask(): an externally drawn keep mask for the next forward
+        # apa_hooks (cof.make_hooks / deploy.OverlappedGradientSum.hooks) handed to every pooling call of this
+        # head, forward and backward, also when autograd runs the backward on its engine thread
+        self.hooks = None
         self.fuse_pose_attention = fuse_pose_attention   # cfg 003: one autograd node for pose head + pooling
         net = cfg.NET
         if not net.USE_POSE_PRELOGITS_BASED_ATTENTION:
@@ -476,7 +482,8 @@ class AttentionalPoolingHead(nn.Module):
             logits, att, pose_logits, topdown = PoseAttentionFunction.apply(
                 last_conv, self.pose_w1, self.pose_b1, self.pose_w2, self.pose_b2, self.att_weights,
                 self.att_biases, self.td_weights, self.td_biases, flags,
-                self.keep_prob if self.is_training else 1.0, self._dropout_seed(), offset, self.want_topdown)
+                self.keep_prob if self.is_training else 1.0, self._dropout_seed(), offset, self.want_topdown,
+                self.hooks)
             self._replay_mask = None
             end_points['PoseLogits'] = pose_logits
             end_points['PosePrelogitsBasedAttention'] = att.view(n, h, w, -1)
@@ -498,7 +505,7 @@ class AttentionalPoolingHead(nn.Module):
         n, h, w = last_conv.shape[0], last_conv.shape[1], last_conv.shape[2]
         C = self.in_channels
         kw = dict(softmax_att=self.softmax_att, relu_att=self.relu_att, is_training=self.is_training,
-                  keep_prob=self.keep_prob, seed=self.seed, offset=offset)    # seed: see below (replay mask)
+                  keep_prob=self.keep_prob, seed=self.seed, offset=offset, hooks=self.hooks)    # seed: see below
 
         xext = None
         if self.with_pose_feat:
@@ -531,9 +538,24 @@ class AttentionalPoolingHead(nn.Module):
             # points never form the top-down tensor, so the concatenation is made as the reference makes it
             # (tf.concat, :295 -- a copy, not arithmetic) and the plain op runs on it with the map itself as its
             # separate attention input; the dropout mask is then the flat stream over the [N,H,W,C+J] tensor
-            x_td = torch.cat([last_conv, xext.to(last_conv.dtype)], dim=-1)
+            # The kernels read whole 16-byte vectors: C + J is padded with zero channels (and the top-down weights
+            # with zero rows) to the next multiple of 4 fp32 / 8 bf16 channels -- J = 13 keypoints work.  (The pose
+            # logits ride in the feature dtype here: bf16 features round them to bf16, the split-channel M == 1 ops
+            # keep them in fp32.)
+            vec = 4 if last_conv.dtype == torch.float32 else 8
+            td_pad = (-(C + xext.shape[-1])) % vec
+            parts = [last_conv, xext.to(last_conv.dtype)]
+            if td_pad:
+                parts.append(last_conv.new_zeros(n, h, w, td_pad))
+            x_td = torch.cat(parts, dim=-1)
             xatt_td = last_conv if self.single_layer else pose_pre
             cat_op = False
+            if td_pad and self._replay_mask is not None:
+                m_ = self._replay_mask
+                self._replay_mask = torch.cat([m_, m_.new_zeros(tuple(m_.shape[:-1]) + (td_pad,))], dim=-1)
+        else:
+            td_pad = 0
+        pad_rows = (lambda w_: torch.cat([w_, w_.new_zeros(td_pad, w_.shape[1])], dim=0)) if td_pad else (lambda w_: w_)
         # the dropout key of every pooling pass below: the head's own seed, or the one-shot replay mask
         seed = self._dropout_seed(split_at=C if (self.with_pose_feat and cat_op) else None)
         kw['seed'] = seed
@@ -542,11 +564,11 @@ class AttentionalPoolingHead(nn.Module):
             flags = cof.attn_flags(self.softmax_att, self.relu_att, self.is_training)
             logits, att = AttentionalPoolingCatFunction.apply(
                 last_conv, xatt, xext, self.att_weights, self.att_biases, self.td_weights, self.td_biases,
-                flags, self.keep_prob if self.is_training else 1.0, seed, offset)
+                flags, self.keep_prob if self.is_training else 1.0, seed, offset, self.hooks)
             end_points['PosePrelogitsBasedAttention'] = att.view(n, h, w, -1)    # :287
         elif self.rank == 1:
             logits, att, topdown = attentional_pooling(
-                x_td, xatt_td, self.att_weights, self.att_biases, self.td_weights, self.td_biases,
+                x_td, xatt_td, self.att_weights, self.att_biases, pad_rows(self.td_weights), self.td_biases,
                 want_topdown=self.want_topdown, relu_input=preactivation, **kw)
             end_points['PosePrelogitsBasedAttention'] = att.view(n, h, w, -1)    # :287
             if topdown is not None:
@@ -570,10 +592,10 @@ class AttentionalPoolingHead(nn.Module):
                     flags = cof.attn_flags(self.softmax_att, self.relu_att, self.is_training)
                     lg_r, att_r = AttentionalPoolingCatFunction.apply(
                         last_conv, xatt, xext, wa_r, ba_r, wts[r], bts[r], flags,
-                        self.keep_prob if self.is_training else 1.0, seed, offset)
+                        self.keep_prob if self.is_training else 1.0, seed, offset, self.hooks)
                     td_r = None
                 else:
-                    lg_r, att_r, td_r = attentional_pooling(x_td, xatt_td, wa_r, ba_r, wts[r], bts[r],
+                    lg_r, att_r, td_r = attentional_pooling(x_td, xatt_td, wa_r, ba_r, pad_rows(wts[r]), bts[r],
                                                             want_topdown=self.want_topdown, **kw)
                 logits = lg_r if logits is None else logits + lg_r
                 atts.append(att_r.view(n, h, w, -1))

@@ -1352,3 +1352,66 @@ def test_overlapped_micro_batches_equal_the_sequential_gradient_accumulator(gpu,
         for l in range(lanes):
             assert torch.equal(dXb[l], got_dX[l]) and torch.equal(st2[l].loss, got_loss[l])
     assert float(hist_a[0][0].abs().max()) > 0 and not torch.equal(hist_a[0][0], hist_a[1][0])
+
+
+def test_module_surface_hands_apa_hooks_to_the_kernels_and_pose_feat_with_13_keypoints(gpu):
+    """(a) `head.hooks` reaches the forward AND the backward pooling call made by autograd (the grad-ready event is
+    recorded by the library during backward); results are unaffected.  (b) _WITH_POSE_FEAT + per-class maps with
+    J = 13 keypoints: C + J is not a whole number of 16-byte vectors, the literal concat is zero-padded."""
+    from attentionalpoolingaction_amd import config as apa_config, nets_factory
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    cfg = apa_config.reset_cfg()
+    apa_config.cfg_from_dict({'NET': {'USE_POSE_PRELOGITS_BASED_ATTENTION': True,
+                                      'USE_POSE_PRELOGITS_BASED_ATTENTION_SINGLE_LAYER_ATT': True}})
+    fn = nets_factory.get_network_fn('resnet_v1_101', 51, 16, cfg, is_training=True, device=gpu, in_channels=256)
+    g = torch.Generator().manual_seed(3)
+    X = torch.relu(torch.randn(4, 5, 5, 256, generator=g)).to(gpu)
+    labels = torch.randint(0, 51, (4,), generator=g).to(gpu)
+
+    def run(hooks):
+        fn.head._step = 0
+        fn.head.hooks = hooks
+        for p_ in fn.head.parameters():
+            p_.grad = None
+        Xd = X.clone().requires_grad_(True)
+        logits, _ = fn(Xd)
+        torch.nn.functional.cross_entropy(logits, labels).backward()
+        return logits.detach().clone(), Xd.grad.clone(), fn.head.td_weights.grad.clone()
+    base = run(None)
+    t0, ready, tdw = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    tdw.record()
+    ready.record()
+    torch.cuda.synchronize()
+    t0.record()
+    hooked = run(cof.make_hooks(grad_ready=ready, td_weights_ready=tdw))
+    torch.cuda.synchronize()
+    assert t0.elapsed_time(ready) > 0.0          # re-recorded by the backward call, after t0
+    for a, b in zip(base, hooked):
+        assert torch.equal(a, b)
+    apa_config.reset_cfg()
+    # (b)
+    cfg = apa_config.reset_cfg()
+    apa_config.cfg_from_dict({'NET': {'USE_POSE_PRELOGITS_BASED_ATTENTION': True,
+                                      'USE_POSE_PRELOGITS_BASED_ATTENTION_SINGLE_LAYER_ATT': True,
+                                      'USE_POSE_PRELOGITS_BASED_ATTENTION_PER_CLASS': True,
+                                      'USE_POSE_PRELOGITS_BASED_ATTENTION_WITH_POSE_FEAT': True}})
+    J, K, C = 13, 20, 64
+    fn = nets_factory.get_network_fn('resnet_v1_101', K, J, cfg, is_training=False, device=gpu, in_channels=C)
+    head = fn.head
+    with torch.no_grad():
+        for p_ in head.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) / max(p_.shape[0], 1) ** 0.5 if p_.dim() >= 2
+                     else torch.randn(p_.shape, generator=g) * 0.1)
+    X = torch.relu(torch.randn(2, 3, 4, C, generator=g))
+    Xd = X.to(gpu).requires_grad_(True)
+    logits, ep = fn(Xd)
+    logits.sum().backward()
+    p = {k: v.detach().cpu().double() for k, v in head.named_parameters()}
+    Xr = X.double().requires_grad_(True)
+    pre, pl = orc.pose_logits_head(Xr, p['pose_w1'], p['pose_b1'], p['pose_w2'], p['pose_b2'])
+    lr, _ = orc.attentional_pooling(Xr, pre, pl, [p['att_weights']], [p['att_biases']], [p['td_weights']],
+                                    [p['td_biases']], orc.AttnFlags(per_class=True, with_pose_feat=True))
+    lr.sum().backward()
+    assert _rel(logits.detach().cpu().numpy(), lr.detach().numpy()) < 5e-5
+    assert _rel(Xd.grad.cpu().numpy(), Xr.grad.numpy()) < 1e-4
+    apa_config.reset_cfg()
