@@ -390,6 +390,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(FastParams p) {
 // ---------------------------------------------------------------------------------------------
 constexpr int IMG = TM * TK;   // 8192 elements = 16 KiB per operand image
 
+// LDS-DMA from inline asm: the builtin makes hipcc guard every LDS read with s_waitcnt vmcnt(0), which drains a
+// ring deeper than two stages; here the waits are counted by hand (ring_wait_barrier)
+__device__ __forceinline__ void glds16_ring(const void* gsrc, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 template <bool KM>
 __device__ __forceinline__ long glds_src_offset(int g, int lane, long ld, int r0, int rlim) {
   if (!KM) {
@@ -663,6 +671,210 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_glds64_kernel(FastParams p) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Ring variant for the products with FEW tiles (round 3): one block per CU, 8 waves, a (2 MT x 16) x 128
+// block tile chosen so that ALL tiles are resident at once (tiles <= CUs), and a ring of 3-4 LDS stages fed by
+// LDS-DMA issued from inline asm with counted vmcnt waits.
+// Why: the two-stage kernels above are bound by the LATENCY of their own staging, not by MFMA, LDS or HBM
+// bandwidth -- a block has exactly one K tile in flight while it multiplies the other, a DMA round trip takes
+// ~1 us under load, so a block advances one K tile per microsecond whatever it does in between (32 K tiles of
+// the pose-head forward product = 32-33 us measured, MFMA busy 21 %, waves parked in s_waitcnt 54 %; a
+// skeleton of the same pipeline with constant addresses and no MFMAs runs at the same pace -- DESIGN.md 3.5).
+// Two resident blocks per CU do not help a block go faster, they only fill the second tile round.  More K
+// tiles in flight per block do: with NST stages NST-1 tiles are outstanding and the pace becomes
+// max(latency / (NST-1), LDS / MFMA time of a tile).  LDS (160 KB) then limits the CU to one block, so the tile
+// must be tall enough that one round covers the product: 160 x 128 for the pose-head forward product (240
+// tiles), 128 x 128 for the per-class maps with K = 393 (196 tiles).
+// A is k-contiguous ([M][K]); B k-major ([K][N], weights) or k-contiguous.  Wave (wm, wn) of a 2 x 4 grid owns
+// MT x 2 MFMA tiles: MT + 2 fragment reads per 2 MT MFMAs (the 4 x 4 layout above: 8 per 16).
+// ---------------------------------------------------------------------------------------------
+static int gemm_cu_count() {
+  static thread_local int cus = 0;
+  if (!cus) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      cus = v;
+    else
+      cus = 256;
+  }
+  return cus;
+}
+
+template <int MT> struct RingCfg {
+  static constexpr int TMR = 2 * MT * 16;                    // rows of the block tile
+  static constexpr int A_EL = TMR * TK;                      // shorts
+  static constexpr int STAGE_EL = A_EL + IMG;                // + [128][64] B image
+  static constexpr int NST = (STAGE_EL * 2 * 4 <= 150 * 1024) ? 4 : 3;
+  static constexpr int NBLK = TMR / 8 + 16;                  // KiB-blocks (DMA wave-instructions) per stage
+  static constexpr int C_LO = NBLK / 8, N_HI = NBLK % 8;     // waves < N_HI issue C_LO + 1 of them
+  static constexpr size_t LDS_BYTES = (size_t)NST * STAGE_EL * 2;
+  static_assert((size_t)TMR * (TN + 4) * 4 <= LDS_BYTES, "epilogue staging fits in the ring");
+};
+
+template <int CNT>
+__device__ __forceinline__ void ring_wait_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(CNT) : "memory");
+}
+
+template <typename TC, bool B_KM, int MT>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_ring_kernel(FastParams p) {
+  typedef RingCfg<MT> R;
+  extern __shared__ __attribute__((aligned(16))) short smem[];
+  typedef __attribute__((address_space(3))) void* lptr;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int ntm = (p.M + R::TMR - 1) / R::TMR, ntn = (p.N + TN - 1) / TN;
+  const int tile = xcd_remap(blockIdx.x, ntm * ntn);   // neighbouring tiles (same A panel) share an XCD
+  const int m0 = (tile / ntn) * R::TMR, n0 = (tile % ntn) * TN;
+  const int nk = p.K / TK;
+
+  // this wave's KiB-blocks of a stage: b = wave, wave + 8, ...  (b < TMR/8: A rows 8b..; else B block b - TMR/8)
+  constexpr int NMINE = R::C_LO + (R::N_HI ? 1 : 0);
+  const bf16_t* src[NMINE];
+  uint32_t dst[NMINE];
+  long step[NMINE];
+#pragma unroll
+  for (int j = 0; j < NMINE; ++j) {
+    const int b = wave + 8 * j;
+    if (b < R::TMR / 8) {
+      src[j] = static_cast<const bf16_t*>(p.A) + glds_src_offset<false>(b, lane, p.lda, m0, p.M);
+      dst[j] = (uint32_t)b * 1024u;
+      step[j] = TK;
+    } else {
+      const int g = min(b - R::TMR / 8, 15);
+      src[j] = static_cast<const bf16_t*>(p.B) + glds_src_offset<B_KM>(g, lane, p.ldb, n0, p.N);
+      dst[j] = (uint32_t)(R::A_EL * 2) + (uint32_t)g * 1024u;
+      step[j] = B_KM ? (long)TK * p.ldb : (long)TK;
+    }
+  }
+  const bool extra = wave < R::N_HI;              // block-uniform per wave: issues slot C_LO as well
+  const uint32_t lds0 = (uint32_t)(size_t)(lptr)smem;
+  auto issue = [&](int t) {
+    const uint32_t st = lds0 + (uint32_t)((t % R::NST) * R::STAGE_EL * 2);
+#pragma unroll
+    for (int j = 0; j < R::C_LO; ++j) glds16_ring(src[j] + (long)t * step[j], st + dst[j]);
+    if (R::N_HI && extra) glds16_ring(src[NMINE - 1] + (long)t * step[NMINE - 1], st + dst[NMINE - 1]);
+  };
+
+  f32x4 acc[MT][2];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int t = 0; t < R::NST - 1; ++t)
+    if (t < nk) issue(t);
+  for (int t = 0; t < nk; ++t) {
+    // tile t has landed once at most the pieces of the NST-2 younger tiles are outstanding (vmcnt counts in
+    // issue order); the barrier publishes everybody's pieces and frees the stage read in iteration t-1
+    const int younger = min(R::NST - 2, nk - 1 - t);
+    if (extra) {
+      if (younger >= 2) ring_wait_barrier<2 * (R::C_LO + 1)>();
+      else if (younger == 1) ring_wait_barrier<R::C_LO + 1>();
+      else ring_wait_barrier<0>();
+    } else {
+      if (younger >= 2) ring_wait_barrier<2 * R::C_LO>();
+      else if (younger == 1) ring_wait_barrier<R::C_LO>();
+      else ring_wait_barrier<0>();
+    }
+    if (t + R::NST - 1 < nk) issue(t + R::NST - 1);
+    const short* a_img = smem + (t % R::NST) * R::STAGE_EL;
+    const short* b_img = a_img + R::A_EL;
+#pragma unroll
+    for (int ks = 0; ks < TK / 32; ++ks) {
+      bf16x8 af[MT], bf[2];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[i] = fragment_sw<false>(a_img, (wm * MT + i) * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = fragment_sw<B_KM>(b_img, wn * 32 + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with the last stage
+
+  // epilogue: the tile goes through LDS as fp32 [TMR][132] and leaves as 16-byte row segments (store8)
+  TC* C = static_cast<TC*>(p.C);
+  const int l16 = lane & 15, kb = lane >> 4;
+  uint32_t h0 = 0, h1 = 0;
+  if (p.drop_c) rng_key_dev_x(p.seed, p.offset_dev ? *p.offset_dev : p.offset, p.thresh, h0, h1);
+  if (p.vec_epi) {
+    float* stage = reinterpret_cast<float*>(smem);
+    constexpr int LDS_C = TN + 4;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          stage[((wm * MT + i) * 16 + 4 * kb + r) * LDS_C + wn * 32 + j * 16 + l16] = acc[i][j][r];
+    __syncthreads();
+    for (int v = tid; v < R::TMR * 16; v += 512) {
+      const int row = v >> 4, c8 = (v & 15) * 8;
+      const int grow = m0 + row, gcol = n0 + c8;
+      if (grow >= p.M || gcol >= p.Nout) continue;
+      const float4 x0 = *reinterpret_cast<const float4*>(stage + row * LDS_C + c8);
+      const float4 x1 = *reinterpret_cast<const float4*>(stage + row * LDS_C + c8 + 4);
+      store8<TC>(p, C, grow, gcol, x0, x1, h0, h1);
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wn * 32 + j * 16 + l16;
+    if (col >= p.Nout) continue;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + (wm * MT + i) * 16 + 4 * kb + r;
+        if (row < p.M) store1<TC>(p, C, row, col, acc[i][j][r], bv, h0, h1);
+      }
+  }
+}
+
+template <typename TC, bool B_KM, int MT>
+int launch_ring(const FastParams& p, hipStream_t st) {
+  typedef RingCfg<MT> R;
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<TC, B_KM, MT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)R::LDS_BYTES));
+    attr_set = true;
+  }
+  const int tiles = ((p.M + R::TMR - 1) / R::TMR) * ((p.N + TN - 1) / TN);
+  hipLaunchKernelGGL((gemm_bf16_ring_kernel<TC, B_KM, MT>), dim3(tiles), dim3(512), R::LDS_BYTES, st, p);
+  APA_LAUNCH_CHECK("gemm_bf16_ring_kernel");
+  return APA_OK;
+}
+
+// smallest tile height (MT row tiles per wave row, block rows = 32 MT) whose tile count fits one round of the
+// chip; 0 = none does (the two-stage kernels take the product)
+static int ring_pick_mt(int M, int N, int cus) {
+  const int ntn = (N + TN - 1) / TN;
+  for (int mt = 4; mt <= 8; ++mt)
+    if ((long)((M + 32 * mt - 1) / (32 * mt)) * ntn <= cus) return mt;
+  return 0;
+}
+
+template <typename TC, bool B_KM>
+int launch_ring_mt(const FastParams& p, int mt, hipStream_t st) {
+  switch (mt) {
+    case 4: return launch_ring<TC, B_KM, 4>(p, st);
+    case 5: return launch_ring<TC, B_KM, 5>(p, st);
+    case 6: return launch_ring<TC, B_KM, 6>(p, st);
+    case 7: return launch_ring<TC, B_KM, 7>(p, st);
+    default: return launch_ring<TC, B_KM, 8>(p, st);
+  }
+}
+
 template <typename TC, bool A_KM, bool B_KM>
 int launch_glds64(const FastParams& p, int splits, hipStream_t st) {
   const size_t shm = (size_t)2 * (IMG + IMGB64) * sizeof(short);   // 49 152 B
@@ -802,6 +1014,15 @@ int gemm_bf16_launch(const GemmDesc& d, int splits, int k_per_split, hipStream_t
     // tile shape: with fewer than ~2.5 tiles of 128 x 128 per CU the ragged last round dominates and
     // the 128 x 64 variant (twice the tiles, three blocks per CU) wins -- measured on the pose head:
     // 294 tiles 38.2 -> 32.6 us, 96 x 3 splits 40.0 -> 35.2 us, but 784 tiles 34.4 -> 37.4 us
+    // few tiles, A k-contiguous, no split-K: the ring kernel (one resident round, 3-4 K tiles in flight)
+    static const int use_ring = knob("APA_GEMM_RING", 1);
+    if (use_ring && d.a_kc && splits == 1 && d.K / TK >= 4) {
+      const int mt = ring_pick_mt(d.M, d.N, gemm_cu_count());
+      if (mt) {
+        if (d.tc == 1) return d.b_kc ? launch_ring_mt<bf16_t, false>(p, mt, st) : launch_ring_mt<bf16_t, true>(p, mt, st);
+        return d.b_kc ? launch_ring_mt<float, false>(p, mt, st) : launch_ring_mt<float, true>(p, mt, st);
+      }
+    }
     static const int bn_env = knob("APA_GEMM_BN", 0);
     const long tiles128 = (long)((d.M + TM - 1) / TM) * ((d.N + TN - 1) / TN) * splits;
     const int bn = bn_env ? bn_env : (tiles128 < 640 ? 64 : 128);
