@@ -5,10 +5,11 @@ tag=${1:-r01}
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 mkdir -p $R/profiles
-for wl in cfg003 perclass; do
-  O=$R/gpurun_out/prof_${tag}_$wl; rm -rf $O; mkdir -p $O
+for wl in cfg003 perclass "perclass --classes 393"; do
+  name=$(echo $wl | sed 's/ --classes //')
+  O=$R/gpurun_out/prof_${tag}_$name; rm -rf $O; mkdir -p $O
   rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python $R/tools/bench_dense.py --workload $wl > $O/bench.log 2>&1
-  python - "$O" "$R/profiles/${tag}_${wl}" "$wl" <<'PY'
+  python - "$O" "$R/profiles/${tag}_${name}" "$wl" <<'PY'
 import csv, glob, json, os, sys
 out_dir, prefix, wl = sys.argv[1:4]
 f = glob.glob(os.path.join(out_dir, '**', '*kernel_stats.csv'), recursive=True)[0]

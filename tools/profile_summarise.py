@@ -83,8 +83,8 @@ def main():
             f.write('\nroofline (bench line): {} GB/s = {} of {} GB/s on {} B per launch\n'.format(
                 rl.get('achieved'), rl.get('frac'), rl.get('peak'), rl.get('alg_bytes_per_launch')))
         f.write('\nrocprofv3 kernel durations include ~1.5 us of dispatch overhead per kernel (an empty kernel '
-                'reads 1.5 us min / 4.6 us median under the profiler, tools/ubench.hip), so the small kernels look '
-                'bigger here than their marginal cost in the un-profiled step (tools/kbench.cpp ablation).\n\n')
+                'reads 1.5 us min / 4.6 us median under the profiler, measured in round 2), so the small kernels look '
+                'bigger here than their marginal cost in the un-profiled step.\n\n')
         f.write('HBM traffic per launch (PMC, separate passes): see `{}_pmc_traffic.json`\n'.format(tag))
         for k, v in traffic.items():
             if k != '_how':
