@@ -614,7 +614,7 @@ def main():
                 'kernel_median_us': round(_median(kb) * 1e3, 3),
                 'timer': 'hipExtLaunchKernel start/stop events around the dispatch, {} live steps, nothing '
                          'subtracted (reads ~1.2 us above rocprofv3\'s begin->end of the same kernel: '
-                         'profiles/r02_summary.md)'.format(len(kb)),
+                         'profiles/r03_summary.md)'.format(len(kb)),
                 'rocprofv3': rocprof_reference('bwd_main', alg_bytes),
             },
             'roofline_fwd': {
