@@ -229,14 +229,18 @@ def fam_catfeat(rnd, i):
     single_layer, two_layer, train = rnd.random() < 0.5, rnd.random() < 0.4, rnd.random() < 0.5
     N, H = rnd.choice([2, 3, 5]), rnd.choice([2, 3, 7, 14, 15])
     K, J = rnd.choice([2, 7, 51, 130, 393]), rnd.choice([1, 3, 7, 16, 20])
+    act = rnd.choice(['id', 'softmax', 'relu'])          # softmax: the extra channels enter the correction term
+    ext = train and rnd.random() < 0.35                  # replay an externally drawn mask (APA_FLAG_RNG_EXTERNAL)
     global LAST
-    LAST = desc = dict(N=N, H=H, K=K, J=J, single_layer=single_layer, two_layer=two_layer, train=train)
+    LAST = desc = dict(N=N, H=H, K=K, J=J, single_layer=single_layer, two_layer=two_layer, train=train, act=act, ext=ext)
     C = 2048
     cfg = apa_config.reset_cfg()
     apa_config.cfg_from_dict({'MODEL_NAME': 'resnet_v1_101', 'NET': {
         'USE_POSE_PRELOGITS_BASED_ATTENTION': True,
         'USE_POSE_PRELOGITS_BASED_ATTENTION_SINGLE_LAYER_ATT': single_layer,
         'USE_POSE_PRELOGITS_BASED_ATTENTION_WITH_POSE_FEAT': True,
+        'USE_POSE_PRELOGITS_BASED_ATTENTION_SOFTMAX_ATT': act == 'softmax',
+        'USE_POSE_PRELOGITS_BASED_ATTENTION_RELU_ATT': act == 'relu',
         'USE_POSE_PRELOGITS_BASED_ATTENTION_WITH_POSE_FEAT_2LAYER': two_layer}})
     fn = nets_factory.get_network_fn('resnet_v1_101', K, J, cfg, is_training=train, device=gpu)
     head = fn.head
@@ -255,10 +259,13 @@ def fam_catfeat(rnd, i):
     labels = torch.randint(0, K, (N,), generator=g)
     Xd = X.to(gpu).requires_grad_(True)
     step0 = head._step
+    mask = None
+    if ext:
+        mask = (torch.rand(N, H, H, C + J, generator=g) < head.keep_prob).to(torch.uint8)
+        head.replay_dropout_mask(mask.to(gpu))
     logits, ep = fn(Xd)
     torch.nn.functional.cross_entropy(logits, labels.to(gpu)).backward()
-    mask = None
-    if train:
+    if train and not ext:
         m = cof.dropout_mask((N * H * H * (C + J),), head.keep_prob, head.seed, step0).cpu()
         mask = torch.cat([m[:N * H * H * C].view(N, H, H, C), m[N * H * H * C:].view(N, H, H, J)], dim=-1)
     p = {k: v.detach().cpu().double().requires_grad_(True) for k, v in head.named_parameters()}
@@ -266,7 +273,8 @@ def fam_catfeat(rnd, i):
     pre, pl = orc.pose_logits_head(Xr, p['pose_w1'], p['pose_b1'], p['pose_w2'], p['pose_b2'])
     lr, _ = orc.attentional_pooling(
         Xr, pre, pl, [p['att_weights']], [p['att_biases']], [p['td_weights']], [p['td_biases']],
-        orc.AttnFlags(single_layer_att=single_layer, with_pose_feat=True, with_pose_feat_2layer=two_layer),
+        orc.AttnFlags(single_layer_att=single_layer, with_pose_feat=True, with_pose_feat_2layer=two_layer,
+                      softmax_att=act == 'softmax', relu_att=act == 'relu'),
         is_training=train, keep_prob=head.keep_prob, dropout_mask=mask,
         pose_feat_w=p.get('pose_feat_weights'),
         pose_feat_bn=(p['pose_feat_bn_gamma'], p['pose_feat_bn_beta']) if two_layer else None)

@@ -49,7 +49,9 @@ def main():
             # tiny K makes dX tiny: a floor of 1e-6 x the scale of dWt keeps fp32 noise out of the verdict)
             floor = 1e-6 * float(ref['dWt'].abs().max())
             for k in ('dX', 'dWa', 'dba', 'dWt', 'dbt') + (() if fused else ('dXatt',)):
-                T._close(got[k].reshape(ref[k].shape), ref[k], 5e-5, k, atol=floor)
+                # (the softmax's d(ba) is a sum of dZ that cancels exactly: its noise scales with |dZ|, i.e. with dWa)
+                at = max(floor, 1e-5 * float(ref['dWa'].abs().max())) if (softmax and k == 'dba') else floor
+                T._close(got[k].reshape(ref[k].shape), ref[k], 5e-5, k, atol=at)
         except Exception as e:                                   # noqa: BLE001
             bad += 1
             print('FAIL', desc, type(e).__name__, str(e)[:300])
