@@ -8,7 +8,7 @@
     src/config.py, the shipped experiments/*.yaml and the backbones' arg_scope functions) from the
     reference tree behind a float64 stand-in for the ~40 TF/slim symbols they call
     (tests/golden/tf1_shim.py, written from TF's documented op semantics, independent of this file)
-    and commits the results as tests/golden/ref_head_*.npz / ref_losses.npz: 37 head configurations
+    and commits the results as tests/golden/ref_head_*.npz / ref_losses.npz: 39 head configurations
     (cfg 002 / 003 from their YAML, softmax / relu / per-class / rank 2-3 / _WITH_POSE_FEAT(+_2LAYER)
     under four arg-scopes / video frame pooling / temporal attention / separate pose tap, training
     mode with the recorded dropout mask) and 12 gen_losses cases.

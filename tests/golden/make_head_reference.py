@@ -216,6 +216,10 @@ HEAD_CASES = [
     # shape = the conv5 map [N,H,W,C] (or [B,F,H,W,C] video); K classes
     dict(name='cfg002_eval', yaml='002_MPII_ResNet_withAttention.yaml', train=False, shape=(3, 5, 5, 128), K=393),
     dict(name='cfg002_train', yaml='002_MPII_ResNet_withAttention.yaml', train=True, shape=(3, 5, 5, 128), K=393),
+    # the real channel count: in evaluation mode these run through the hash-free STREAMING kernels on the GPU
+    dict(name='cfg002_eval_c2048', yaml='002_MPII_ResNet_withAttention.yaml', train=False, shape=(3, 4, 4, 2048), K=51),
+    dict(name='softmax_eval_c2048', train=False, shape=(2, 3, 5, 2048), K=20, train_cfg=NOPOSE,
+         net=dict(SL, **{P + '_SOFTMAX_ATT': True})),
     dict(name='cfg002_refinit', yaml='002_MPII_ResNet_withAttention.yaml', train=True, shape=(2, 4, 4, 64), K=393,
          values='init'),
     dict(name='cfg002_dropout_half', yaml='002_MPII_ResNet_withAttention.yaml', train=True, shape=(2, 4, 5, 64),
