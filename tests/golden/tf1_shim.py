@@ -680,6 +680,91 @@ def resize_images(images, size, method=0, align_corners=False):
     return Tensor(out[0] if squeeze0 else out)
 
 
+# ---------------------------------------------------------------------------------------------- label path ops
+# (src/preprocess_pipeline.py: _replay_augmentation and the normalise / resize lines; evaluated in FLOAT32
+#  -- set_float_dtype(torch.float32) -- because that graph is float32 and its truncations depend on it)
+def set_float_dtype(dt):
+    """The float type of every tensor the stand-in creates (float64 for the head graphs, float32 for the label
+    pipeline)."""
+    global DT
+    DT = dt
+
+
+_DTYPES = {'float32': None, 'uint8': torch.uint8, 'int32': torch.int32, 'int64': torch.int64, 'bool': torch.bool}
+
+
+def cast(t, dtype, name=None):
+    """tf.cast: float -> integer truncates toward zero; 'float32' maps to the stand-in's float type."""
+    v = _raw(t)
+    if dtype not in _DTYPES:
+        raise NotImplementedError('cast to %r' % (dtype,))
+    return Tensor(v.to(_DTYPES[dtype] or DT))
+
+
+def to_int32(t, name=None):
+    return cast(t, 'int32')
+
+
+def constant(value, dtype=None, name=None):
+    return Tensor(_raw(value))
+
+
+def tf_tuple(tensors, name=None):
+    return list(tensors)
+
+
+def cond(pred, true_fn=None, false_fn=None, name=None, fn1=None, fn2=None):
+    p = bool(_raw(pred).item()) if not isinstance(pred, bool) else pred
+    return (true_fn or fn1)() if p else (false_fn or fn2)()
+
+
+def tf_slice(input_, begin, size, name=None):
+    """tf.slice: begin/size per dimension (size -1 = to the end); out-of-range requests are an error."""
+    v = _raw(input_)
+    b = [int(x) for x in _raw(begin).tolist()]
+    s = [int(x) for x in _raw(size).tolist()]
+    if len(b) != v.dim() or len(s) != v.dim():
+        raise ValueError('slice: begin/size of length %d/%d for a rank-%d tensor' % (len(b), len(s), v.dim()))
+    idx = []
+    for d, (bi, si) in enumerate(zip(b, s)):
+        if si == -1:
+            si = v.shape[d] - bi
+        if bi < 0 or si < 0 or bi + si > v.shape[d]:
+            raise ValueError('slice: [%d, %d) outside dimension %d of size %d' % (bi, bi + si, d, v.shape[d]))
+        idx.append(slice(bi, bi + si))
+    return Tensor(v[tuple(idx)])
+
+
+def reduce_min(t, axis=None, keep_dims=False, name=None):
+    v = _raw(t)
+    return Tensor(v.amin(dim=_axes(axis, v.dim()), keepdim=keep_dims))
+
+
+def reduce_max(t, axis=None, keep_dims=False, name=None):
+    v = _raw(t)
+    return Tensor(v.amax(dim=_axes(axis, v.dim()), keepdim=keep_dims))
+
+
+def flip_left_right(image):
+    """tf.image.flip_left_right: reverse the width axis of a [height, width, channels] image."""
+    v = _raw(image)
+    if v.dim() != 3:
+        raise ValueError('flip_left_right: rank-%d input' % v.dim())
+    return Tensor(torch.flip(v, dims=[1]))
+
+
+def convert_image_dtype(image, dtype, saturate=False, name=None):
+    """tf.image.convert_image_dtype, integer -> float: cast, then MULTIPLY by 1 / dtype.max (image_ops_impl.py)."""
+    v = _raw(image)
+    if dtype != 'float32':
+        raise NotImplementedError
+    if v.dtype.is_floating_point:
+        return Tensor(v.to(DT))
+    if v.dtype != torch.uint8:
+        raise NotImplementedError
+    return Tensor(v.to(DT) * torch.tensor(1.0 / 255, dtype=DT))
+
+
 # ---------------------------------------------------------------------------------------------- tf.losses
 def add_loss(loss, loss_collection=GraphKeys.LOSSES):
     if loss_collection:
@@ -736,8 +821,11 @@ def build_modules() -> Dict[str, types.ModuleType]:
                identity, variable_scope, name_scope, random_normal_initializer, zeros_initializer,
                ones_initializer, constant_initializer):
         setattr(tf, fn.__name__, fn)
+    for fn in (cast, to_int32, constant, cond, reduce_min, reduce_max):
+        setattr(tf, fn.__name__, fn)
+    tf.slice, tf.tuple = tf_slice, tf_tuple
     tf.GraphKeys = GraphKeys
-    tf.float32 = 'float32'
+    tf.float32, tf.uint8, tf.int32, tf.int64, tf.bool = 'float32', 'uint8', 'int32', 'int64', 'bool'
     tf.Tensor = Tensor
     nn = types.ModuleType('tensorflow.nn')
     nn.relu, nn.softmax, nn.dropout = relu, softmax, nn_dropout
@@ -747,6 +835,8 @@ def build_modules() -> Dict[str, types.ModuleType]:
     tf.nn = nn
     image = types.ModuleType('tensorflow.image')
     image.resize_images = resize_images
+    image.flip_left_right = flip_left_right
+    image.convert_image_dtype = convert_image_dtype
     tf.image = image
     losses = types.ModuleType('tensorflow.losses')
     for fn in (add_loss, compute_weighted_loss, softmax_cross_entropy, mean_squared_error, sigmoid_cross_entropy,
