@@ -283,3 +283,49 @@ def exponential_decay_lr(base_lr: float, global_step: int, decay_steps: int, dec
     if staircase:
         e = float(int(e))
     return base_lr * (decay_rate ** e)
+
+
+def decay_steps(cfg, num_samples_per_epoch: int, num_clones: int) -> int:
+    """The step count between two learning-rate drops, src/train.py:42-48: TRAIN.NUM_STEPS_PER_DECAY when it
+    is positive, else int(samples / (BATCH_SIZE * clones * ITER_SIZE) * NUM_EPOCHS_PER_DECAY) -- one "step"
+    is one parameter update, i.e. ITER_SIZE micro-batches on every clone."""
+    if cfg.TRAIN.NUM_STEPS_PER_DECAY > 0:
+        return int(cfg.TRAIN.NUM_STEPS_PER_DECAY)
+    return int(num_samples_per_epoch / (cfg.TRAIN.BATCH_SIZE * num_clones * cfg.TRAIN.ITER_SIZE)
+               * cfg.TRAIN.NUM_EPOCHS_PER_DECAY)
+
+
+def configure_learning_rate(cfg, num_samples_per_epoch: int, num_clones: int, global_step: int) -> float:
+    """_configure_learning_rate (src/train.py:29-69) evaluated at `global_step` (the number of parameter
+    updates applied so far).  'exponential' is the staircase decay, 'fixed' the constant rate; the reference's
+    'polynomial' branch (power 1, no cycle) is the linear ramp to END_LEARNING_RATE."""
+    kind = cfg.TRAIN.LEARNING_RATE_DECAY_TYPE
+    if kind == 'exponential':
+        return exponential_decay_lr(cfg.TRAIN.LEARNING_RATE, global_step,
+                                    decay_steps(cfg, num_samples_per_epoch, num_clones),
+                                    cfg.TRAIN.LEARNING_RATE_DECAY_RATE, staircase=True)
+    if kind == 'fixed':
+        return float(cfg.TRAIN.LEARNING_RATE)
+    if kind == 'polynomial':
+        n = decay_steps(cfg, num_samples_per_epoch, num_clones)
+        t = min(global_step, n) / float(n)
+        return (cfg.TRAIN.LEARNING_RATE - cfg.TRAIN.END_LEARNING_RATE) * (1.0 - t) + cfg.TRAIN.END_LEARNING_RATE
+    raise ValueError('learning_rate_decay_type [%s] was not recognized' % kind)
+
+
+def configure_optimizer(cfg, params: Dict[str, torch.Tensor], bucket: GradientBucket, learning_rate: float,
+                        regularized: Sequence[str] = ()):
+    """_configure_optimizer (src/train.py:72-105) for the optimisers this library implements as one fused
+    launch: 'momentum' (cfgs 001-003: MomentumOptimizer(lr, TRAIN.MOMENTUM)) and 'sgd' (momentum 0).  The L2
+    regulariser's gradient (TRAIN.WEIGHT_DECAY on `regularized`) is folded into the same launch."""
+    kind = cfg.TRAIN.OPTIMIZER
+    if kind == 'momentum':
+        momentum = float(cfg.TRAIN.MOMENTUM)
+    elif kind == 'sgd':
+        momentum = 0.0
+    elif kind in ('adam', 'rmsprop'):
+        raise NotImplementedError('TRAIN.OPTIMIZER %r: only momentum / sgd have a fused update here' % kind)
+    else:
+        raise ValueError('Optimizer [%s] was not recognized' % kind)
+    return MomentumSGD(params, bucket, lr=learning_rate, momentum=momentum,
+                       weight_decay=float(cfg.TRAIN.WEIGHT_DECAY), regularized=regularized)

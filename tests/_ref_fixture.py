@@ -24,10 +24,13 @@ def case_id(path):
 
 
 class HeadFixture(object):
-    def __init__(self, path):
-        d = np.load(path)
-        self.arrays = {k: d[k] for k in d.files if k != 'meta'}
-        self.meta = json.loads(str(d['meta']))
+    def __init__(self, path=None, arrays=None, meta=None):
+        if path is not None:
+            d = np.load(path)
+            arrays = {k: d[k] for k in d.files if k != 'meta'}
+            meta = json.loads(str(d['meta']))
+        self.arrays = arrays
+        self.meta = meta
         self.name = self.meta['case']
         self.f32_keys = set(self.meta['f32_keys'])
         self.variables = {}
@@ -172,6 +175,49 @@ def run_oracle(fx: HeadFixture, dtype=torch.float64):
         out['out/update/moving_mean'] = (mm - (1 - decay) * (mm - mean))[None]
         out['out/update/moving_variance'] = (mv - (1 - decay) * (mv - var))[None]
     return {k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in out.items()}
+
+
+def train_fixture_paths():
+    return sorted(glob.glob(os.path.join(GOLD, 'ref_train_*.npz')))
+
+
+class TrainFixture(object):
+    """tests/golden/ref_train_<case>.npz (make_train_reference.py: the reference's model_deploy.py + the training
+    pieces of src/train.py): initial variables, the batches in dequeue order, per session.run the summed clone
+    gradients, per parameter update the learning rate / loss / variables."""
+
+    def __init__(self, path):
+        d = np.load(path)
+        self.arrays = {k: d[k] for k in d.files if k != 'meta'}
+        self.meta = json.loads(str(d['meta']))
+        self.name = self.meta['case']
+        self.f32_keys = set(self.meta['f32_keys'])
+
+    def initial_variables(self):
+        return {vn: self.arrays['var0/' + vn].astype(np.float64) for vn in self.meta['var_order']}
+
+    def tol(self, key, tight=1e-11):
+        return 2e-7 if key in self.f32_keys else tight
+
+    def clone_fixture(self, variables, batch, draw, weight_decay=0.0):
+        """The head fixture of ONE clone in ONE run: `variables` {tf name: value} are the current weights, `batch`
+        / `draw` index this file's batches / dropout draws.  clone_fn (src/train.py:395-398) concatenates the
+        label tensors over the batch axis."""
+        m = self.meta
+        a = {'in/images': self.arrays['batch/%d/images' % batch],
+             'in/labels_action': self.arrays['batch/%d/labels_action' % batch]}
+        lp = self.arrays['batch/%d/labels_pose' % batch]
+        a['in/labels_pose'] = lp.reshape((-1,) + lp.shape[2:])
+        lv = self.arrays['batch/%d/labels_pose_valid' % batch]
+        a['in/labels_pose_valid'] = lv.reshape((-1,) + lv.shape[2:])
+        for vn, v in variables.items():
+            a['var/' + vn] = np.asarray(v, dtype=np.float64)
+        a['rand/0/keep_bits'] = self.arrays['rand/%d/keep_bits' % draw]
+        meta = dict(case='%s/batch%d' % (self.name, batch), f32_keys=[], var_order=m['var_order'],
+                    trainable=m['var_order'], num_classes=m['num_classes'],
+                    num_pose_keypoints=m['num_pose_keypoints'], is_training=True, model=m['model'], net=m['net'],
+                    train_cfg=m['train_cfg'], weight_decay=weight_decay, draws=[m['draws'][draw]], reg_only_grad=[])
+        return HeadFixture(arrays=a, meta=meta)
 
 
 def _cfg_for(fx):

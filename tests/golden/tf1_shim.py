@@ -164,6 +164,19 @@ class Tensor(object):
         return 'Tensor(shape=%r, name=%r)' % (list(self.v.shape), self.name)
 
 
+class _OpRef(object):
+    def __init__(self, name):
+        self.name = name
+
+
+class Variable(Tensor):
+    """tf.Variable: `.name` carries the ':0' output suffix, `.op.name` does not."""
+
+    def __init__(self, v, full_name):
+        Tensor.__init__(self, v, name=full_name + ':0')
+        self.op = _OpRef(full_name)
+
+
 def _raw(x, like=None):
     """python scalars / lists / numpy / Tensor -> torch tensor (dtype follows `like` for python numbers, as
     TF's op-def type inference does for `tf.where(v, loss_val, [0] * n)`)."""
@@ -201,7 +214,10 @@ class Graph(object):
         self.var_order: List[str] = []
         self.collections: Dict[str, list] = {}
         self.scope_stack: List[str] = []
-        self.default_name_counts: Dict[str, Dict[str, int]] = {}
+        self.reuse_stack: List[bool] = []
+        self.name_stack: List[str] = []                 # tf.name_scope (only used to tag LOSSES per clone)
+        self.created: Dict[str, 'Variable'] = {}        # variables created in the CURRENT run of the graph
+        self.default_name_counts: Dict[str, int] = {}     # variable_scopes_count of the variable store
         self.arg_stack: List[Dict[str, Dict[str, Any]]] = [{}]
         self.value_fn = value_fn
         self.uniform_fn = uniform_fn
@@ -214,27 +230,53 @@ class Graph(object):
     def add_to_collection(self, key, value):
         self.collections.setdefault(key, []).append(value)
 
-    def get_collection(self, key):
-        return list(self.collections.get(key, []))
+    def get_collection(self, key, scope=None):
+        items = list(self.collections.get(key, []))
+        if scope:                                       # tf.get_collection(key, scope): re.match(scope, item.name)
+            items = [i for i in items if (getattr(i, 'name', None) or '').startswith(scope)]
+        return items
+
+    def name_scope_prefix(self):
+        return ''.join(n + '/' for n in self.name_stack if n)
+
+    def begin_run(self):
+        """A new evaluation of the same graph (one `session.run`): the variables keep their values, everything
+        derived from them (collections, regularisation losses) is rebuilt by running the graph code again."""
+        self.collections = {}
+        self.created = {}
+        self.default_name_counts = {}
 
     def get_variable(self, name, shape, initializer, regularizer=None, trainable=True):
         full = (self.scope_name() + '/' if self.scope_stack else '') + name
-        if full in self.variables:
-            raise ValueError('Variable %s already exists (no reuse in this shim)' % full)
+        reuse = any(self.reuse_stack)
+        if full in self.created:
+            if not reuse:
+                raise ValueError('Variable %s already exists, disallowed. Did you mean to set reuse=True?' % full)
+            return self.created[full]
+        if reuse:
+            raise ValueError('Variable %s does not exist, or was not created with tf.get_variable()' % full)
         shape = [int(s) for s in shape]
-        desc = dict(initializer or {'kind': 'unknown'})
-        val = np.asarray(self.value_fn(full, shape, desc), dtype=np.float64).reshape(shape)
-        t = torch.from_numpy(val.copy()).to(DT)
+        if full in self.variables:                      # a later run of the same graph: the stored value
+            t = self.variables[full]
+            assert list(t.shape) == shape, full
+        else:
+            desc = dict(initializer or {'kind': 'unknown'})
+            val = np.asarray(self.value_fn(full, shape, desc), dtype=np.float64).reshape(shape)
+            t = torch.from_numpy(val.copy()).to(DT)
+            if trainable:
+                t.requires_grad_(True)
+            self.variables[full] = t
+            self.var_init[full] = desc
+            self.var_order.append(full)
+        var = Variable(t, full)
+        self.created[full] = var
         if trainable:
-            t.requires_grad_(True)
-        self.variables[full] = t
-        self.var_init[full] = desc
-        self.var_order.append(full)
-        if regularizer is not None:
+            self.add_to_collection(GraphKeys.TRAINABLE_VARIABLES, var)
+        if regularizer is not None:                     # applied once, where the variable is created
             loss = regularizer(Tensor(t))
             if loss is not None:
                 self.add_to_collection(GraphKeys.REGULARIZATION_LOSSES, loss)
-        return Tensor(t, name=full)
+        return var
 
 
 _GRAPH: Optional[Graph] = None
@@ -265,25 +307,56 @@ class _VarScope(object):
 
 @contextlib.contextmanager
 def variable_scope(name_or_scope=None, default_name=None, values=None, reuse=None):
+    """tf.variable_scope, including the bookkeeping that decides the names of UNNAMED layers (variable_scope.py:
+    _get_unique_variable_scope / open_variable_scope / close_variable_subscopes): every opened scope is counted
+    under its full name; a default name takes the first suffix ('', '_1', '_2', ...) whose count is zero; leaving
+    a scope resets the counts of all its sub-scopes -- which is why the second clone of a model, re-entering the
+    same named scopes with reuse=True, finds 'Conv' again and not 'Conv_1'."""
     g = graph()
+    counts = g.default_name_counts
+    saved = list(g.scope_stack)
     if name_or_scope is None:
         parent = g.scope_name()
-        counts = g.default_name_counts.setdefault(parent, {})
-        k = counts.get(default_name, 0)
-        counts[default_name] = k + 1
-        name = default_name if k == 0 else '%s_%d' % (default_name, k)
+        full = lambda n: (parent + '/' + n) if parent else n
+        name = default_name
+        idx = 0
+        while counts.get(full(name), 0) > 0:
+            idx += 1
+            name = '%s_%d' % (default_name, idx)
+        g.scope_stack.append(name)
+    elif isinstance(name_or_scope, _VarScope):           # a captured scope is re-entered by its ABSOLUTE name
+        g.scope_stack[:] = [p for p in name_or_scope.name.split('/') if p]
     else:
-        name = name_or_scope.name if isinstance(name_or_scope, _VarScope) else name_or_scope
-    g.scope_stack.append(name)
+        g.scope_stack.append(name_or_scope)
+    opened = g.scope_name()
+    counts[opened] = counts.get(opened, 0) + 1
+    g.reuse_stack.append(bool(reuse))
     try:
-        yield _VarScope(g.scope_name())
+        yield _VarScope(opened)
     finally:
-        g.scope_stack.pop()
+        for k in list(counts):
+            if not opened or k.startswith(opened + '/'):
+                counts[k] = 0
+        g.scope_stack[:] = saved
+        g.reuse_stack.pop()
+
+
+def get_variable_scope():
+    return _VarScope(graph().scope_name())
 
 
 @contextlib.contextmanager
 def name_scope(name=None, default_name=None, values=None):
-    yield name
+    """yields the scope's full name with the trailing '/', as TF does ('' for the empty scope)"""
+    if _GRAPH is None:
+        yield name
+        return
+    g = graph()
+    g.name_stack.append(name or '')
+    try:
+        yield g.name_scope_prefix()
+    finally:
+        g.name_stack.pop()
 
 
 def _op_key(op):
@@ -765,10 +838,230 @@ def convert_image_dtype(image, dtype, saturate=False, name=None):
     return Tensor(v.to(DT) * torch.tensor(1.0 / 255, dtype=DT))
 
 
+# ---------------------------------------------------------------------------------------- training graph
+# src/train.py builds ONE graph and then calls session.run on different fetches (train_ops[i]); what a fetch
+# evaluates depends on graph dependencies.  The model part of the graph is evaluated eagerly here, so a
+# `session.run` is modelled as: dequeue fresh batches, run the (reference) model-building code again on them
+# with the variables' current values (Graph.begin_run), then execute the fetched ops.  Ops and tensors that
+# are built ONCE by the reference's training code (assign / assign_add / group / control_dependencies /
+# apply_gradients / with_dependencies) are lazy nodes evaluated per run, each at most once per run.
+class Run(object):
+    """one session.run: memo of what has been evaluated"""
+
+    def __init__(self, session):
+        self.session = session
+        self.done: Dict[int, Any] = {}
+
+
+class Node(object):
+    """A lazy graph node: `deps` run first (control inputs), then `fn(run)`; memoised per run."""
+
+    def __init__(self, fn, deps=(), name=None, shape=None):
+        self.fn = fn
+        self.deps = list(deps) + list(_CONTROL_DEPS[-1]) if _CONTROL_DEPS else list(deps)
+        self.name = name
+        self._shape = shape
+
+    def eval(self, run):
+        k = id(self)
+        if k not in run.done:
+            for d in self.deps:
+                d.eval(run)
+            run.done[k] = self.fn(run)
+        return run.done[k]
+
+    # the tensor surface the reference's accumulation block touches
+    def get_shape(self):
+        return TensorShape(self._shape)
+
+    def __truediv__(self, o):
+        return Node(lambda run: self.eval(run) / _lazy_value(o, run), shape=self._shape)
+
+
+_CONTROL_DEPS: List[List[Node]] = []
+
+
+def _lazy_value(x, run):
+    if isinstance(x, Node):
+        return x.eval(run)
+    if isinstance(x, Tensor):
+        return x.v
+    return x
+
+
+@contextlib.contextmanager
+def control_dependencies(ops):
+    _CONTROL_DEPS.append((list(_CONTROL_DEPS[-1]) if _CONTROL_DEPS else []) + list(ops))
+    try:
+        yield
+    finally:
+        _CONTROL_DEPS.pop()
+
+
+def group(*ops, **kw):
+    return Node(lambda run: None, deps=ops, name=kw.get('name'))
+
+
+def with_dependencies(dependencies, output_tensor, name=None):
+    return Node(lambda run: _lazy_value(output_tensor, run), deps=dependencies, name=name)
+
+
+class LocalVariable(Node):
+    """slim.local_variable(initial_value, name=...): a non-trainable variable; reading it is a lazy node."""
+
+    def __init__(self, initial_value, name=None):
+        self.value = torch.as_tensor(np.asarray(initial_value)).to(DT).clone()
+        Node.__init__(self, lambda run: self.value, name=name, shape=list(self.value.shape))
+        self.deps = []                                    # the read op is created with the variable
+
+    def eval(self, run):                                  # never memoised: a read sees the latest assignment
+        return self.value
+
+    def assign(self, t):
+        def fn(run):
+            self.value = _lazy_value(t, run).detach().clone()
+        return Node(fn, name='assign')
+
+    def assign_add(self, t):
+        def fn(run):
+            self.value = self.value + _lazy_value(t, run).detach()
+        return Node(fn, name='assign_add')
+
+
+def local_variable(initial_value, name=None, **kw):
+    return LocalVariable(initial_value, name=(graph().scope_name() + '/' if graph().scope_stack else '') + (name or ''))
+
+
+class GlobalStep(LocalVariable):
+    def __init__(self):
+        LocalVariable.__init__(self, np.zeros((), dtype=np.int64), name='global_step')
+        self.value = torch.zeros((), dtype=torch.int64)
+
+
+def exponential_decay(learning_rate, global_step, decay_steps, decay_rate, staircase=False, name=None):
+    """tf.train.exponential_decay: lr * rate ** (step / decay_steps), the exponent floored when staircase
+    (learning_rate_decay.py; computed in float32 there, in the stand-in's float type here)."""
+    def fn(run):
+        p = _lazy_value(global_step, run).to(DT) / float(decay_steps)
+        if staircase:
+            p = torch.floor(p)
+        return torch.tensor(float(learning_rate), dtype=DT) * torch.tensor(float(decay_rate), dtype=DT) ** p
+    return Node(fn, name=name, shape=[])
+
+
+def polynomial_decay(learning_rate, global_step, decay_steps, end_learning_rate=0.0001, power=1.0, cycle=False,
+                     name=None):
+    """tf.train.polynomial_decay, cycle=False: step = min(step, decay_steps);
+    (lr - end) * (1 - step / decay_steps) ** power + end."""
+    assert not cycle
+
+    def fn(run):
+        step = torch.clamp(_lazy_value(global_step, run).to(DT), max=float(decay_steps))
+        return (float(learning_rate) - float(end_learning_rate)) * (1.0 - step / float(decay_steps)) ** float(power) \
+            + float(end_learning_rate)
+    return Node(fn, name=name, shape=[])
+
+
+class MomentumOptimizer(object):
+    """tf.train.MomentumOptimizer (training_ops ApplyMomentum, use_nesterov=False):
+         accum = momentum * accum + grad;  var -= lr * accum;   then global_step += 1."""
+
+    def __init__(self, learning_rate, momentum, use_locking=False, name='Momentum', use_nesterov=False):
+        assert not use_nesterov
+        self.learning_rate, self.momentum, self.name = learning_rate, float(momentum), name
+        self.slots: Dict[str, torch.Tensor] = {}
+        self.applied = 0
+
+    def compute_gradients(self, loss, var_list=None, **kw):
+        if kw:
+            raise NotImplementedError(sorted(kw))
+        vs = list(var_list) if var_list is not None else graph().get_collection(GraphKeys.TRAINABLE_VARIABLES)
+        gs = torch.autograd.grad(_raw(loss), [v.v for v in vs], retain_graph=True, allow_unused=True)
+        return [(None if g_ is None else Tensor(g_), v) for g_, v in zip(gs, vs)]
+
+    def apply_gradients(self, grads_and_vars, global_step=None, name=None):
+        gvs = list(grads_and_vars)
+
+        def fn(run):
+            lr = _lazy_value(self.learning_rate, run)
+            with torch.no_grad():
+                for g_, v in gvs:
+                    if g_ is None:
+                        continue
+                    gval = _lazy_value(g_, run).detach()
+                    acc = self.slots.get(v.op.name)
+                    acc = gval.clone() if acc is None else self.momentum * acc + gval     # slot starts at zero
+                    self.slots[v.op.name] = acc
+                    v.v -= lr * acc
+                if global_step is not None:
+                    global_step.value = global_step.value + 1
+            self.applied += 1
+        return Node(fn, name=name or self.name)
+
+
+class GradientDescentOptimizer(MomentumOptimizer):
+    def __init__(self, learning_rate, use_locking=False, name='GradientDescent'):
+        MomentumOptimizer.__init__(self, learning_rate, 0.0, name=name)
+
+
+class Session(object):
+    """`before_run()` is the per-run rebuild of the eager part of the graph (fresh batches)."""
+
+    def __init__(self, before_run: Callable[[], None]):
+        self.before_run = before_run
+        self.runs = 0
+
+    def run(self, fetches, options=None, run_metadata=None, feed_dict=None):
+        self.before_run()
+        self.runs += 1
+        run = Run(self)
+        single = not isinstance(fetches, (list, tuple))
+        out = []
+        for f in ([fetches] if single else fetches):
+            val = _lazy_value(f, run)
+            out.append(val.detach().numpy().copy() if isinstance(val, torch.Tensor) else val)
+        return out[0] if single else out
+
+
+def add_n(inputs, name=None):
+    vs = [_raw(i) for i in inputs]
+    out = vs[0]
+    for v in vs[1:]:
+        out = out + v
+    return Tensor(out)
+
+
+def div(x, y, name=None):
+    xv = _raw(x)
+    return Tensor(xv / _raw(y, like=xv))
+
+
+@contextlib.contextmanager
+def device(device_name_or_function=None):
+    yield
+
+
+def trainable_variables():
+    return graph().get_collection(GraphKeys.TRAINABLE_VARIABLES)
+
+
+@add_arg_scope
+def model_variable(*a, **k):
+    raise NotImplementedError
+
+
+@add_arg_scope
+def variable(*a, **k):
+    raise NotImplementedError
+
+
 # ---------------------------------------------------------------------------------------------- tf.losses
 def add_loss(loss, loss_collection=GraphKeys.LOSSES):
     if loss_collection:
-        graph().add_to_collection(loss_collection, loss if isinstance(loss, Tensor) else Tensor(_raw(loss).to(DT)))
+        t = loss if isinstance(loss, Tensor) else Tensor(_raw(loss).to(DT))
+        if t.name is None:                                # tagged with the enclosing name scope ('clone_1/...'),
+            t.name = graph().name_scope_prefix() + 'loss'  # which is what tf.get_collection(LOSSES, scope) filters on
+        graph().add_to_collection(loss_collection, t)
 
 
 def compute_weighted_loss(losses, weights=1.0, scope=None, loss_collection=GraphKeys.LOSSES):
@@ -824,6 +1117,20 @@ def build_modules() -> Dict[str, types.ModuleType]:
     for fn in (cast, to_int32, constant, cond, reduce_min, reduce_max):
         setattr(tf, fn.__name__, fn)
     tf.slice, tf.tuple = tf_slice, tf_tuple
+    for fn in (add_n, div, device, trainable_variables, get_variable_scope, control_dependencies, group):
+        setattr(tf, fn.__name__, fn)
+    train = types.ModuleType('tensorflow.train')
+    train.exponential_decay = exponential_decay
+    train.polynomial_decay = polynomial_decay
+    train.MomentumOptimizer = MomentumOptimizer
+    train.GradientDescentOptimizer = GradientDescentOptimizer
+    tf.train = train
+    summary = types.ModuleType('tensorflow.summary')
+    summary.scalar = lambda *a, **k: None
+    summary.histogram = lambda *a, **k: None
+    tf.summary = summary
+    tf.IndexedSlices = type('IndexedSlices', (), {})
+    tf.NodeDef = type('NodeDef', (), {})
     tf.GraphKeys = GraphKeys
     tf.float32, tf.uint8, tf.int32, tf.int64, tf.bool = 'float32', 'uint8', 'int32', 'int64', 'bool'
     tf.Tensor = Tensor
@@ -846,7 +1153,7 @@ def build_modules() -> Dict[str, types.ModuleType]:
     logging = types.ModuleType('tensorflow.logging')
     logging.info = lambda *a, **k: graph().log.append(str(a[0]) if a else '') if _GRAPH is not None else None
     tf.logging = logging
-    tf.get_collection = lambda key, scope=None: graph().get_collection(key)
+    tf.get_collection = lambda key, scope=None: graph().get_collection(key, scope)
     tf.add_to_collection = lambda key, v: graph().add_to_collection(key, v)
 
     slim = types.ModuleType('tensorflow.contrib.slim')
@@ -854,6 +1161,7 @@ def build_modules() -> Dict[str, types.ModuleType]:
                l2_regularizer, variance_scaling_initializer, xavier_initializer, one_hot_encoding):
         setattr(slim, fn.__name__, fn)
     slim.losses = losses
+    slim.model_variable, slim.variable, slim.local_variable = model_variable, variable, local_variable
     slim.softmax = lambda logits, scope=None: softmax(logits)      # default argument of the backbone builders
     utils = types.ModuleType('tensorflow.contrib.slim.utils')
     utils.collect_named_outputs = lambda collections, alias, outputs: outputs
