@@ -9,9 +9,11 @@ cfg.EPS and resized to FINAL_POSE_HMAP_SIDE^2 (:194-207), then split back into f
 This script exec's that file (and src/config.py) from /root/reference behind the TF1 stand-in
 (tests/golden/tf1_shim.py, in FLOAT32 mode: the label graph is float32 and its crop truncations depend on
 it) and runs `train_preprocess_pipeline` itself.  What is stubbed, and why that does not weaken the pin:
-  * `custom_ops.custom_ops_factory.pose_to_heatmap` -- the compiled OpenCV op (pose_to_heatmap.cc), which is
-    not buildable here.  The stub records the arguments the reference passes (canvas width max(200, side),
-    out_channels, do_gauss_blur=False, marker_wd_ratio = cfg.HEATMAP_MARKER_WD_RATIO) and returns either
+  * the compiled OpenCV op behind `tf.load_op_library('pose_to_heatmap.so')` (pose_to_heatmap.cc), which is
+    not buildable here; its python wrapper (src/custom_ops/custom_ops_factory.py:20-28: *= 255.0, cast to uint8)
+    IS the reference's, exec'd from its file.  The op stand-in records the arguments the reference passes
+    (canvas width max(200, side), out_channels, do_gauss_blur=False, marker_wd_ratio =
+    cfg.HEATMAP_MARKER_WD_RATIO) and returns a FLOAT canvas: either
       - the canvas of oracle/labels_eval_oracle.py's restatement of the op for those arguments (cases
         'raster_*': the raster RULE itself stays unpinned -- cv::circle is third-party; everything AFTER
         the canvas is the reference's code), or
@@ -102,7 +104,8 @@ def load_pipeline():
     calls = []
     state = {}
 
-    def pose_to_heatmap(pl, im_ht, im_wd, out_wd, out_channels=16, do_gauss_blur=True, marker_wd_ratio=0.1):
+    def pose_to_heatmap_op(pl, im_ht, im_wd, out_wd, out_channels=16, do_gauss_blur=True, marker_wd_ratio=0.1):
+        """stand-in of the compiled op (pose_to_heatmap.cc): FLOAT canvas in [0, 1] + valid flags"""
         args = dict(im_ht=int(tfs._raw(im_ht)), im_wd=int(tfs._raw(im_wd)), out_wd=int(out_wd),
                     out_channels=int(out_channels), do_gauss_blur=bool(do_gauss_blur),
                     marker_wd_ratio=float(marker_wd_ratio))
@@ -110,15 +113,26 @@ def load_pipeline():
         hm, valid = state['canvas_fn'](np.asarray(tfs._raw(pl)), args, len(calls) - 1)
         return tfs.Tensor(torch.from_numpy(hm)), tfs.Tensor(torch.from_numpy(valid))
 
-    cof = types.ModuleType('custom_ops.custom_ops_factory')
-    cof.pose_to_heatmap = pose_to_heatmap
-    cof.render_pose = cof.render_objects = cof.extract_glimpse = None
+    # the reference's OWN python wrapper (src/custom_ops/custom_ops_factory.py:20-28: set_shape, *= 255.0, cast
+    # to uint8) around the op stand-in: tf.load_op_library hands back a namespace with the op
+    tf = sys.modules['tensorflow']
+    tf.load_op_library = lambda path: types.SimpleNamespace(
+        pose_to_heatmap=pose_to_heatmap_op, zero_out_channels=None, render_pose=None, render_objects=None)
+    cof = mhr._exec_ref(os.path.join(REF, 'src', 'custom_ops', 'custom_ops_factory.py'),
+                        'custom_ops.custom_ops_factory')
     pkg = types.ModuleType('custom_ops')
     pkg.__path__ = []
     pkg.custom_ops_factory = cof
     sys.modules['custom_ops'] = pkg
     sys.modules['custom_ops.custom_ops_factory'] = cof
     pp = mhr._exec_ref(os.path.join(REF, 'src', 'preprocess_pipeline.py'), 'refpreproc')
+    replay = pp._replay_augmentation
+
+    def spy(H, aug_info):                                  # records the uint8 canvas stack the replay receives
+        state['canvas_u8'] = tfs._raw(H).numpy().copy()
+        assert state['canvas_u8'].dtype == np.uint8
+        return replay(H, aug_info)
+    pp._replay_augmentation = spy
     return cfgmod, pp, calls, state
 
 
@@ -144,22 +158,22 @@ def run_case(cfgmod, pp, calls, state, c):
         else:
             poses.append(np.full((3 * J,), -1, dtype=np.int64))
 
-    canvases = []
 
     def canvas_fn(pl, args, idx):
         if c['kind'] == 'raster':
-            hm, valid = leo.pose_to_heatmap_py_wrapper(
+            hm, valid = leo.pose_to_heatmap(
                 pl, args['im_ht'], args['im_wd'], args['out_wd'], out_channels=args['out_channels'],
                 do_gauss_blur=args['do_gauss_blur'], marker_wd_ratio=args['marker_wd_ratio'])
+            hm = np.asarray(hm, dtype=np.float32)
             valid = np.asarray(valid, dtype=bool)
         else:
             out_ht = int(args['im_ht'] * args['out_wd'] * 1.0 / args['im_wd'])      # pose_to_heatmap.cc:52
             r = _rs('canvas', c['name'], idx)
             coarse = r.rand(out_ht // 8 + 2, args['out_wd'] // 8 + 2, args['out_channels'])
             hm = np.kron(coarse, np.ones((8, 8, 1)))[:out_ht, :args['out_wd']]
-            hm = (20 + 200 * hm + 10 * r.rand(*hm.shape)).astype(np.uint8)            # min > 0, max < 255
+            u8 = (20 + 200 * hm + 10 * r.rand(*hm.shape)).astype(np.uint8)           # min > 0, max < 255
+            hm = ((u8.astype(np.float32) + np.float32(0.5)) / np.float32(255.0))      # the wrapper's *255 -> uint8 gives u8 back
             valid = r.rand(args['out_channels']) < 0.7
-        canvases.append(hm)
         return hm, valid
 
     state['canvas_fn'] = canvas_fn
@@ -210,7 +224,7 @@ def run_case(cfgmod, pp, calls, state, c):
         'in/pose': pose_pad,
         'in/n_vals': np.asarray([p.size for p in poses], dtype=np.int32),
         'in/geom': np.asarray([im_ht, im_wd, aug_ht, aug_wd, oy, ox, ch, cw, int(c['flip'])], dtype=np.int32),
-        'in/canvas': np.concatenate(canvases, axis=-1),                     # uint8 [h, w, J*T] (:172)
+        'in/canvas': state['canvas_u8'],                                    # uint8 [h, w, J*T] (:172)
         'meta': np.asarray(json.dumps({
             'kind': c['kind'], 'T': T, 'J': J, 'side': c['side'], 'eps': float(cfg.EPS),
             'calls': list(calls), 'image_preprocessing_fn_saw': seen, 'raises': err,
@@ -228,6 +242,7 @@ def run_case(cfgmod, pp, calls, state, c):
 def generate():
     prev = tfs.DT
     tfs.set_float_dtype(torch.float32)
+    tfs.set_graph(tfs.Graph(None, None))                # scopes only: the label graph has no variables / randomness
     try:
         cfgmod, pp, calls, state = load_pipeline()
         import copy
@@ -243,6 +258,7 @@ def generate():
         return blobs
     finally:
         tfs.set_float_dtype(prev)
+        tfs.set_graph(None)
 
 
 if __name__ == '__main__':

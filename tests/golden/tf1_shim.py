@@ -130,7 +130,7 @@ class Tensor(object):
         return self.v.dtype
 
     def set_shape(self, shape):
-        assert list(self.v.shape) == [int(s) for s in shape]
+        assert len(shape) == self.v.dim() and all(s is None or int(s) == d for s, d in zip(shape, self.v.shape))
 
     def __mul__(self, o):
         return Tensor(self.v * _raw(o, like=self.v))

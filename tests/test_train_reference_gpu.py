@@ -53,7 +53,7 @@ def test_hip_training_loop_matches_reference(gpu, path):
         ts = [table[vn] for vn in m['var_order']]
         gs = torch.autograd.grad(sum(losses), ts, allow_unused=True)
         grads = {vn: (torch.zeros_like(t) if g is None else g) for vn, t, g in zip(m['var_order'], ts, gs)}
-        return grads, [float(l) for l in losses]
+        return grads, [float(l.detach()) for l in losses]
 
     def on_run(r, run, params, bucket, clone_losses):
         for vn in m['grad_vars']:
