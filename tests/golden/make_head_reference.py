@@ -220,6 +220,14 @@ HEAD_CASES = [
     dict(name='cfg002_eval_c2048', yaml='002_MPII_ResNet_withAttention.yaml', train=False, shape=(3, 4, 4, 2048), K=51),
     dict(name='softmax_eval_c2048', train=False, shape=(2, 3, 5, 2048), K=20, train_cfg=NOPOSE,
          net=dict(SL, **{P + '_SOFTMAX_ATT': True})),
+    # training mode at the real channel count with the LIBRARY'S OWN dropout mask (see `libmask` in run_head_case):
+    # on the GPU these run the hot streaming kernels with their counter hash, no replay
+    dict(name='cfg002_train_c2048_libmask', yaml='002_MPII_ResNet_withAttention.yaml', train=True,
+         shape=(2, 3, 3, 2048), K=20, libmask=(42, 0)),
+    dict(name='softmax_train_c2048_libmask', train=True, shape=(2, 2, 3, 2048), K=12, train_cfg=NOPOSE,
+         net=dict(SL, **{P + '_SOFTMAX_ATT': True}), libmask=(7, 3)),
+    dict(name='relu_train_c2048_libmask', train=True, shape=(3, 2, 2, 2048), K=12, train_cfg=NOPOSE,
+         net=dict(SL, **{P + '_RELU_ATT': True, 'DROPOUT': 0.5}), libmask=(1234567, 11)),
     dict(name='cfg002_refinit', yaml='002_MPII_ResNet_withAttention.yaml', train=True, shape=(2, 4, 4, 64), K=393,
          values='init'),
     dict(name='cfg002_dropout_half', yaml='002_MPII_ResNet_withAttention.yaml', train=True, shape=(2, 4, 5, 64),
@@ -299,7 +307,21 @@ def run_head_case(cfgmod, nf, lossmod, defaults, case):
     wd = float(cfg.TRAIN.WEIGHT_DECAY)
     train = case['train']
 
-    g = tfs.Graph(make_value_fn(name, case.get('values', 'trained')), make_uniform_fn(name))
+    uniform_fn = make_uniform_fn(name)
+    if case.get('libmask'):
+        # the dropout uniforms are derived from the LIBRARY'S OWN keep mask for (seed, offset) (apa_keep_mask.py):
+        # floor(keep_prob + U) reproduces that mask, so the product can be run with its own counter hash -- its
+        # hot streaming kernels -- against what the reference's code computes for the very same mask
+        import apa_keep_mask
+        seed, offset = case['libmask']
+        d = float(cfg.NET.DROPOUT)
+        keep_prob = 0.2 if d < 0 else 1.0 - d                  # nets_factory.py:143-146
+
+        def uniform_fn(shape, what):
+            assert what == 'dropout'
+            keep = apa_keep_mask.keep_mask(shape, keep_prob, seed, offset)
+            return np.where(keep == 1, 0.9, 0.1)
+    g = tfs.Graph(make_value_fn(name, case.get('values', 'trained')), uniform_fn)
     tfs.set_graph(g)
     r = _rs(name, 'inputs')
     shape = case['shape']
@@ -424,6 +446,8 @@ def run_head_case(cfgmod, nf, lossmod, defaults, case):
                 var_order=g.var_order, trainable=trainable, reg_only_grad=reg_only, seeded_vars=seeded, var_init=g.var_init, draws=draws,
                 n_losses=len(losses), n_reg_losses=len(regs), f32_keys=f32_keys,
                 end_points=sorted(k for k in out if k.startswith('out/ep/')), values=case.get('values', 'trained'))
+    if case.get('libmask'):
+        meta['libmask'] = list(case['libmask'])
     out['meta'] = np.array(json.dumps(meta, sort_keys=True, default=str))
     tfs.set_graph(None)
     return out

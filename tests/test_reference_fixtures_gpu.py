@@ -24,6 +24,7 @@ def _rel(got, exp, floor=1e-30):
 
 def _run_product(fx, gpu, **head_kw):
     from attentionalpoolingaction_amd import config as apa_config, loss as apa_loss
+    head_kw_replay = head_kw.pop('force_replay', False)
     tap = None
     if fx.pose_tap is not None:                                  # a backbone that returns its end points by name
         tap = torch.from_numpy(fx.arrays['in/pose_tap']).to(gpu).requires_grad_(True)
@@ -38,7 +39,11 @@ def _run_product(fx, gpu, **head_kw):
     head = network_fn.head
     images = torch.from_numpy(fx.arrays['in/images']).to(gpu).requires_grad_(True)
     mask = fx.dropout_mask()
-    if mask is not None:
+    if mask is not None and fx.meta.get('libmask') and not head_kw_replay:
+        # the fixture's mask IS the library's own stream for (seed, offset): no replay, the head's counter hash
+        # -- and with it the hot streaming kernels -- regenerates it
+        head.seed, head._step = int(fx.meta['libmask'][0]), int(fx.meta['libmask'][1])
+    elif mask is not None:
         head.replay_dropout_mask(torch.from_numpy(mask).to(gpu))
     logits, ep = network_fn(images)
     tc = fx.meta['train_cfg']
@@ -77,7 +82,7 @@ def test_hip_head_matches_reference_fixture(gpu, path):
     exp_losses = fx.expected('out/losses')
     assert len(r['losses']) == len(exp_losses)
     for got, exp in zip(r['losses'], exp_losses):
-        assert abs(float(got) - exp) <= 2e-5 * max(abs(exp), 1e-3)
+        assert abs(float(got.detach()) - exp) <= 2e-5 * max(abs(exp), 1e-3)
     assert abs(float(r['reg']) - fx.expected('out/reg_losses').sum()) <= 1e-5 * fx.expected('out/reg_losses').sum()
     assert abs(float(r['total']) - float(fx.expected('out/total'))) <= 2e-5 * float(fx.expected('out/total'))
     assert _rel(r['images'].grad.cpu().numpy(), fx.expected('grad/images')) < 5e-5
@@ -97,6 +102,32 @@ def test_hip_head_matches_reference_fixture(gpu, path):
         head = r['head']                                   # UPDATE_OPS of the _2LAYER batch-norm ran with the step
         assert _rel(head.pose_feat_bn_moving_mean.cpu().numpy(), fx.expected('out/update/moving_mean')[0]) < 1e-5
         assert _rel(head.pose_feat_bn_moving_variance.cpu().numpy(), fx.expected('out/update/moving_variance')[0]) < 1e-5
+
+
+LIBMASK = [p for p in HEAD_PATHS if rf.HeadFixture(p).meta.get('libmask')]
+
+
+@pytest.mark.parametrize('path', LIBMASK, ids=rf.case_id)
+def test_library_dropout_stream_is_the_mask_the_reference_ran_with(gpu, path):
+    """The `*_libmask` fixtures: the reference's code was run with tf.nn.dropout uniforms derived from the
+    numpy twin of the library's counter hash (tests/golden/apa_keep_mask.py).  (1) apa_dropout_mask on the GPU
+    gives exactly the fixture's keep bits, so (2) test_hip_head_matches_reference_fixture above ran these cases
+    on the product's OWN stream -- the streaming kernels at C = 2048, forward and backward -- and (3) the
+    replay of the same bits through APA_FLAG_RNG_EXTERNAL (generic kernels) lands on the same numbers."""
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    fx = rf.HeadFixture(path)
+    seed, offset = fx.meta['libmask']
+    want = fx.dropout_mask()
+    assert len(LIBMASK) >= 3 and want.shape[-1] == 2048
+    got = cof.dropout_mask(want.shape, fx.keep_prob, seed, offset, device=gpu).cpu().numpy()
+    assert np.array_equal(got, want)
+    own = _run_product(fx, gpu)
+    rep = _run_product(fx, gpu, force_replay=True)
+    exp = fx.expected('out/logits')
+    for r in (own, rep):
+        assert _rel(r['logits'].detach().cpu().numpy(), exp) < 2e-5
+        assert _rel(r['images'].grad.cpu().numpy(), fx.expected('grad/images')) < 5e-5
+    assert _rel(own['logits'].detach().cpu().numpy(), rep['logits'].detach().cpu().numpy()) < 1e-5
 
 
 @pytest.mark.parametrize('name', ['cfg002_eval', 'cfg002_train', 'cfg003_train', 'softmax_train', 'perclass_train',
@@ -199,7 +230,7 @@ def test_hip_gen_losses_match_reference(gpu, case):
     apa_config.reset_cfg()
     assert len(losses) == m['n_losses']
     for got, exp in zip(losses, case['losses']):
-        assert abs(float(got) - exp) <= 2e-5 * max(abs(exp), 1e-3)
+        assert abs(float(got.detach()) - exp) <= 2e-5 * max(abs(exp), 1e-3)
     if losses and sum(losses).requires_grad:
         sum(losses).backward()
     zero = lambda t: torch.zeros_like(t) if t.grad is None else t.grad
