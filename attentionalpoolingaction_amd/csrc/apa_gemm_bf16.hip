@@ -712,9 +712,14 @@ template <int MT> struct RingCfg {
   static_assert((size_t)TMR * (TN + 4) * 4 <= LDS_BYTES, "epilogue staging fits in the ring");
 };
 
+// The wait is the BUILTIN (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14]) so that the
+// compiler's own wait-count bookkeeping knows the LDS queue is empty here: with an opaque asm wait it treated
+// the loop-carried fragment reads conservatively and put `lgkmcnt(0)` in front of the first MFMA group of every
+// tile, i.e. waited for the reads it had just issued.  The barrier stays raw (no implied vmcnt(0)).
 template <int CNT>
 __device__ __forceinline__ void ring_wait_barrier() {
-  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(CNT) : "memory");
+  __builtin_amdgcn_s_waitcnt((CNT & 0xF) | ((CNT >> 4) << 14) | (0x7 << 4) | (0 << 8));
+  asm volatile("s_barrier" ::: "memory");
 }
 
 template <typename TC, bool B_KM, int MT>
@@ -764,13 +769,32 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_ring_kernel(FastParams p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Software pipeline over the two 32-wide k steps of a tile: the fragments of step 1 are read while the
+  // MFMAs of step 0 run, the tile hand-over (wait + barrier + next DMA) sits BETWEEN the two MFMA groups, and
+  // the step-0 fragments of the next tile are read under the MFMAs of step 1 -- every LDS read has ten MFMAs
+  // of this wave (and the other wave of the SIMD) to hide behind.  (The straightforward loop -- wait, barrier,
+  // read, multiply -- left the compiler re-using fragment registers: one exposed LDS round trip per two MFMAs,
+  // 0.85 us per tile against 0.27 us of MFMA time.)
+  static_assert(TK / 32 == 2, "two k steps per tile");
+  auto load_frags = [&](int t, int ks, bf16x8 (&af)[MT], bf16x8 (&bf)[2]) {
+    const short* a_img = smem + (t % R::NST) * R::STAGE_EL;
+    const short* b_img = a_img + R::A_EL;
 #pragma unroll
-  for (int t = 0; t < R::NST - 1; ++t)
-    if (t < nk) issue(t);
-  for (int t = 0; t < nk; ++t) {
-    // tile t has landed once at most the pieces of the NST-2 younger tiles are outstanding (vmcnt counts in
-    // issue order); the barrier publishes everybody's pieces and frees the stage read in iteration t-1
-    const int younger = min(R::NST - 2, nk - 1 - t);
+    for (int i = 0; i < MT; ++i) af[i] = fragment_sw<false>(a_img, (wm * MT + i) * 16, ks, lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bf[j] = fragment_sw<B_KM>(b_img, wn * 32 + j * 16, ks, lane);
+  };
+  auto mma = [&](const bf16x8 (&af)[MT], const bf16x8 (&bf)[2]) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+  };
+  // tile `want` has landed once at most the pieces of the `younger` tiles issued after it are outstanding (vmcnt
+  // counts in issue order); lgkmcnt(0): this wave's fragment reads of the tile about to be recycled are home;
+  // the barrier publishes everybody's pieces and frees that tile's stage
+  auto hand_over = [&](int younger) {
     if (extra) {
       if (younger >= 2) ring_wait_barrier<2 * (R::C_LO + 1)>();
       else if (younger == 1) ring_wait_barrier<R::C_LO + 1>();
@@ -780,23 +804,40 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_ring_kernel(FastParams p) {
       else if (younger == 1) ring_wait_barrier<R::C_LO>();
       else ring_wait_barrier<0>();
     }
-    if (t + R::NST - 1 < nk) issue(t + R::NST - 1);
-    const short* a_img = smem + (t % R::NST) * R::STAGE_EL;
-    const short* b_img = a_img + R::A_EL;
+  };
+  bf16x8 af0[MT], bf0[2], af1[MT], bf1[2];
 #pragma unroll
-    for (int ks = 0; ks < TK / 32; ++ks) {
-      bf16x8 af[MT], bf[2];
+  for (int t = 0; t < R::NST - 1; ++t)
+    if (t < nk) issue(t);
+  hand_over(min(R::NST - 2, nk - 1));
+  if (R::NST - 1 < nk) issue(R::NST - 1);
+  load_frags(0, 0, af0, bf0);
+  // an opaque use of the step-0 fragments BEFORE the step-1 reads are issued: the compiler does not count LDS
+  // returns across the loop's back edge and waits with lgkmcnt(0) at the first use -- placed here that wait
+  // covers reads issued ten MFMAs ago (all but home), placed after the step-1 reads it would wait for those too
+  auto settle = [&](bf16x8 (&af)[MT], bf16x8 (&bf)[2]) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = fragment_sw<false>(a_img, (wm * MT + i) * 16, ks, lane);
+    for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(af[i]));
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bf[j] = fragment_sw<B_KM>(b_img, wn * 32 + j * 16, ks, lane);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-    }
+    for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(bf[j]));
+  };
+  for (int t = 0; t + 1 < nk; ++t) {                // the last tile is peeled: one state on the loop's back edge
+    settle(af0, bf0);
+    load_frags(t, 1, af1, bf1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(af0, bf0);
+    __builtin_amdgcn_sched_barrier(0);
+    hand_over(min(R::NST - 2, nk - 2 - t));         // tile t + 1 is in; tile t's stage is free
+    if (t + R::NST < nk) issue(t + R::NST);
+    load_frags(t + 1, 0, af0, bf0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(af1, bf1);
+    __builtin_amdgcn_sched_barrier(0);
   }
+  load_frags(nk - 1, 1, af1, bf1);
+  __builtin_amdgcn_sched_barrier(0);
+  mma(af0, bf0);
+  mma(af1, bf1);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with the last stage
 
   // epilogue: the tile goes through LDS as fp32 [TMR][132] and leaves as 16-byte row segments (store8)
