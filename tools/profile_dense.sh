@@ -25,4 +25,5 @@ with open(prefix + '_summary.md', 'w') as o:
             o.write('| `{}` | {} | {:.2f} | {} |\n'.format(r['Name'].replace('(anonymous namespace)::', '').split('(')[0][:100], r['Calls'], float(r['AverageNs']) / 1e3, r['Percentage']))
 print(open(prefix + '_summary.md').read())
 PY
+  cp $R/profiles/${tag}_${name}_summary.md $R/gpurun_out/ 2>/dev/null   # gpurun merges gpurun_out/ back, not profiles/
 done
