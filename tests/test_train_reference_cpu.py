@@ -200,3 +200,67 @@ def test_generator_reproduces_a_committed_training_fixture():
         for k in list(sys.modules):
             if k not in saved:
                 del sys.modules[k]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the same reference loop with the clones as PROCESSES: world_size-2 gloo, one rank per clone of the reference
+# ---------------------------------------------------------------------------------------------------------------
+def _gloo_clone_worker(rank, world, port, path, out_dir):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        tf_ = rf.TrainFixture(path)
+        m = tf_.meta
+        cfg = product_cfg(tf_)
+        dc = deploy.DeploymentConfig()                                     # rank / world from the process group
+        assert dc.num_clones == m['num_clones'] == world and dc.clone_index == rank
+        names = m['var_order']
+        params = {vn: torch.from_numpy(v) for vn, v in tf_.initial_variables().items()}
+        bucket = deploy.GradientBucket({vn: params[vn].shape for vn in names}, 'cpu', dtype=torch.float64)
+        accum = deploy.GradientAccumulator(bucket, cfg.TRAIN.ITER_SIZE)
+        opt = deploy.configure_optimizer(cfg, params, bucket, cfg.TRAIN.LEARNING_RATE,
+                                         regularized=[vn for vn in names if vn.endswith('/weights')])
+        step_no = 0
+        for step in m['steps']:
+            lr = deploy.configure_learning_rate(cfg, m['num_samples'], world, step_no)
+            for r in step['runs']:
+                run = m['runs'][r]
+                grads, _ = oracle_clone_gradients(tf_, {vn: p.numpy() for vn, p in params.items()},
+                                                  run['batches'][rank], run['draws'][rank])   # THIS clone's batch
+                for vn in names:
+                    bucket.views[vn].copy_(torch.from_numpy(np.asarray(grads[vn])).reshape(params[vn].shape)
+                                           * dc.clone_loss_scale)
+                if accum.step():                    # ITER_SIZE local micro-steps, ONE all-reduce per update
+                    deploy.sum_clone_gradients(bucket, dc)
+                    opt.step(lr=lr)
+                    step_no += 1
+        np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), **{vn: p.numpy() for vn, p in params.items()})
+    finally:
+        dist.destroy_process_group()
+        apa_config.reset_cfg()
+
+
+@pytest.mark.parametrize('name', ['cfg002_2clones_iter2', 'cfg002_2clones_iter2_dropout'])
+def test_two_gloo_ranks_replay_the_reference_two_clone_loop(tmp_path, name):
+    """Each rank plays one clone of the reference run (its own batches and dropout masks, oracle gradients),
+    accumulates ITER_SIZE micro-steps LOCALLY and all-reduces once per update (the reference sums the
+    clone gradients every run and accumulates the sums -- the same numbers, one collective instead of ITER_SIZE).
+    Both ranks must hold the reference's variables after the last update."""
+    import socket
+    import torch.multiprocessing as mp
+    path = os.path.join(rf.GOLD, 'ref_train_%s.npz' % name)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_gloo_clone_worker, args=(2, port, path, str(tmp_path)), nprocs=2, join=True)
+    tf_ = rf.TrainFixture(path)
+    last = len(tf_.meta['steps']) - 1
+    r0, r1 = np.load(tmp_path / 'rank0.npz'), np.load(tmp_path / 'rank1.npz')
+    for vn in tf_.meta['var_order']:
+        assert np.array_equal(r0[vn], r1[vn]), vn                          # replicas stay identical
+        key = 'step/%d/var/%s' % (last, vn)
+        exp = tf_.arrays[key]
+        assert np.abs(r0[vn] - exp).max() <= tf_.tol(key) * max(np.abs(exp).max(), 1e-30) + 1e-15, key
