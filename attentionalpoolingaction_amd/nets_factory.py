@@ -787,15 +787,7 @@ def get_network_fn(name: str, num_classes: int, num_pose_keypoints: int, cfg,
         net = resnet_v1.ResNetV1(name, final_relu=not fuse_final_relu).to(device)
         net.train(is_training)
         if cfg.NET.TRAIN_TOP_BN:
-            # resnet_v1.py:191-204: every batch-norm but the root block's runs with is_training=False
-            # and trainable=False (moving statistics, frozen gamma / beta)
-            root_bn = net.conv1.bn if net.conv1 is not None else None
-            for m in net.modules():
-                if isinstance(m, nn.BatchNorm2d) and m is not root_bn:
-                    m.eval()
-                    m.train = lambda mode=True, _m=m: _m      # stays frozen through later .train() calls
-                    for p_ in m.parameters():
-                        p_.requires_grad_(False)
+            resnet_v1.freeze_all_but_root_batch_norm(net)      # resnet_v1.py:191-204
 
         def backbone(images, _net=net, _dt=backbone_dtype):
             if _dt is None:

@@ -48,6 +48,39 @@ def max_pool_same(x: torch.Tensor, k: int, s: int) -> torch.Tensor:
     return F.max_pool2d(x, k, s)
 
 
+class SlimBatchNorm2d(nn.BatchNorm2d):
+    """slim.batch_norm's moving statistics: the moving VARIANCE is updated with the batch variance exactly as
+    tf.nn.moments returns it (biased, / n) -- nn.BatchNorm2d feeds the unbiased estimate (/ (n - 1)) into
+    running_var.  The normalisation itself is identical; the update is corrected after the fact (a few
+    C-sized operations, no extra pass over the activations).  Found by running the reference's graph code
+    (tests/golden/make_backbone_reference.py)."""
+
+    def forward(self, x):
+        if not (self.training and self.track_running_stats):
+            return super().forward(x)
+        n = x.numel() // x.shape[1]
+        keep = 1.0 - self.momentum
+        old = self.running_var * keep
+        y = super().forward(x)
+        if n > 1:
+            with torch.no_grad():
+                self.running_var.sub_(old).mul_((n - 1.0) / n).add_(old)
+        return y
+
+
+def freeze_all_but_root_batch_norm(net: 'ResNetV1') -> None:
+    """cfg.NET.TRAIN_TOP_BN (models/slim/nets/resnet_v1.py:191-204): every batch norm but the root block's runs
+    with is_training=False and trainable=False -- moving statistics, frozen gamma / beta -- also through later
+    `.train()` calls."""
+    root_bn = net.conv1.bn if net.conv1 is not None else None
+    for m in net.modules():
+        if isinstance(m, nn.BatchNorm2d) and m is not root_bn:
+            m.eval()
+            m.train = lambda mode=True, _m=m: _m
+            for p_ in m.parameters():
+                p_.requires_grad_(False)
+
+
 class ConvBN(nn.Module):
     """slim.conv2d under resnet_arg_scope: conv (no bias) + batch_norm [+ relu]; `same=True` is
     resnet_utils.conv2d_same."""
@@ -55,7 +88,7 @@ class ConvBN(nn.Module):
     def __init__(self, cin, cout, k, stride=1, relu=True):
         super().__init__()
         self.conv = nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=False)
-        self.bn = nn.BatchNorm2d(cout, eps=BN_EPS, momentum=1.0 - BN_DECAY)
+        self.bn = SlimBatchNorm2d(cout, eps=BN_EPS, momentum=1.0 - BN_DECAY)
         self.relu = relu
 
     def forward(self, x):

@@ -45,6 +45,7 @@ that the same dropout mask / uniform draws can be replayed through the oracle an
 """
 from __future__ import annotations
 
+import collections as collections_module
 import contextlib
 import functools
 import math
@@ -303,6 +304,7 @@ class GraphKeys(object):
 class _VarScope(object):
     def __init__(self, name):
         self.name = name
+        self.original_name_scope = name + '/'            # what slim hands to collect_named_outputs
 
 
 @contextlib.contextmanager
@@ -495,15 +497,19 @@ def conv2d(inputs, num_outputs, kernel_size, stride=1, padding='SAME', data_form
     if weights_initializer is None:
         weights_initializer = xavier_initializer()
     ks = [kernel_size, kernel_size] if isinstance(kernel_size, int) else list(kernel_size)
-    if ks != [1, 1] or stride != 1 or rate != 1:
-        raise NotImplementedError('tf1_shim.conv2d: only the 1x1 stride-1 convolutions of the head')
     x = inputs.v
     cin = x.shape[-1]
     cout = int(num_outputs)
-    with variable_scope(scope, 'Conv', [inputs], reuse=reuse):
-        w = g.get_variable('weights', [1, 1, cin, cout], dict(weights_initializer, fan_in=cin, fan_out=cout),
+    general = ks != [1, 1] or stride != 1 or rate != 1
+    with variable_scope(scope, 'Conv', [inputs], reuse=reuse) as sc:
+        w = g.get_variable('weights', ks + [cin, cout],
+                           dict(weights_initializer, fan_in=cin * ks[0] * ks[1], fan_out=cout * ks[0] * ks[1])
+                           if general else dict(weights_initializer, fan_in=cin, fan_out=cout),
                            regularizer=weights_regularizer, trainable=trainable)
-        y = torch.matmul(x, w.v.reshape(cin, cout))
+        if general:
+            y = _conv2d_nhwc(x, w.v, int(stride), int(rate), padding)
+        else:
+            y = torch.matmul(x, w.v.reshape(cin, cout))
         if normalizer_fn is None and biases_initializer is not None:
             b = g.get_variable('biases', [cout], biases_initializer, regularizer=biases_regularizer,
                                trainable=trainable)
@@ -513,7 +519,60 @@ def conv2d(inputs, num_outputs, kernel_size, stride=1, padding='SAME', data_form
             out = normalizer_fn(out, **(normalizer_params or {}))
         if activation_fn is not None:
             out = activation_fn(out)
-    return out
+    return collect_named_outputs(outputs_collections, sc.original_name_scope, out)
+
+
+def _same_pad(size, k_eff, s):
+    """TF 'SAME': out = ceil(size / s); total = max((out - 1) s + k_eff - size, 0), split low = total // 2"""
+    out = -(-size // s)
+    total = max((out - 1) * s + k_eff - size, 0)
+    return total // 2, total - total // 2
+
+
+def _conv2d_nhwc(x, w_hwio, stride, rate, padding):
+    """tf.nn.convolution on NHWC / HWIO (Conv2D; atrous via dilation), 'SAME' or 'VALID'"""
+    assert x.dim() == 4
+    kh, kw = int(w_hwio.shape[0]), int(w_hwio.shape[1])
+    xn = x.permute(0, 3, 1, 2)
+    if padding == 'SAME':
+        pt, pb = _same_pad(xn.shape[2], (kh - 1) * rate + 1, stride)
+        pl, pr = _same_pad(xn.shape[3], (kw - 1) * rate + 1, stride)
+        xn = torch.nn.functional.pad(xn, (pl, pr, pt, pb))
+    elif padding != 'VALID':
+        raise ValueError(padding)
+    y = torch.nn.functional.conv2d(xn, w_hwio.permute(3, 2, 0, 1), stride=stride, dilation=rate)
+    return y.permute(0, 2, 3, 1)
+
+
+def collect_named_outputs(collections, alias, outputs):
+    """slim.utils.collect_named_outputs: tags the tensor with `alias` (trailing '/' dropped) and files it"""
+    if collections:
+        if alias[-1] == '/':
+            alias = alias[:-1]
+        outputs.alias = alias
+        for c in ([collections] if isinstance(collections, str) else collections):
+            graph().add_to_collection(c, outputs)
+    return outputs
+
+
+def convert_collection_to_dict(collection):
+    return collections_module.OrderedDict((t.alias, t) for t in graph().get_collection(collection))
+
+
+def last_dimension(shape, min_rank=1):
+    dims = shape.as_list()
+    if len(dims) < min_rank:
+        raise ValueError('rank of shape must be at least %d not: %d' % (min_rank, len(dims)))
+    return dims[-1]
+
+
+def pad(tensor, paddings, mode='CONSTANT', name=None):
+    assert mode == 'CONSTANT'
+    v = _raw(tensor)
+    flat = []
+    for lo, hi in reversed([[int(a), int(b)] for a, b in paddings]):
+        flat += [lo, hi]
+    return Tensor(torch.nn.functional.pad(v, flat))
 
 
 @add_arg_scope
@@ -524,8 +583,21 @@ def dropout(inputs, keep_prob=0.5, noise_shape=None, is_training=True, outputs_c
 
 
 @add_arg_scope
-def max_pool2d(*a, **k):
-    raise NotImplementedError
+def max_pool2d(inputs, kernel_size, stride=2, padding='VALID', data_format='NHWC', outputs_collections=None,
+               scope=None):
+    """slim.max_pool2d (nn.max_pool): 'SAME' padding never wins the maximum"""
+    ks = [kernel_size, kernel_size] if isinstance(kernel_size, int) else list(kernel_size)
+    st = [stride, stride] if isinstance(stride, int) else list(stride)
+    xn = _raw(inputs).permute(0, 3, 1, 2)
+    if padding == 'SAME':
+        pt, pb = _same_pad(xn.shape[2], ks[0], st[0])
+        pl, pr = _same_pad(xn.shape[3], ks[1], st[1])
+        xn = torch.nn.functional.pad(xn, (pl, pr, pt, pb), value=float('-inf'))
+    elif padding != 'VALID':
+        raise ValueError(padding)
+    y = torch.nn.functional.max_pool2d(xn, ks, st).permute(0, 2, 3, 1)
+    with variable_scope(scope, 'MaxPool2D', [inputs]) as sc:
+        return collect_named_outputs(outputs_collections, sc.original_name_scope, Tensor(y))
 
 
 @add_arg_scope
@@ -1164,8 +1236,10 @@ def build_modules() -> Dict[str, types.ModuleType]:
     slim.model_variable, slim.variable, slim.local_variable = model_variable, variable, local_variable
     slim.softmax = lambda logits, scope=None: softmax(logits)      # default argument of the backbone builders
     utils = types.ModuleType('tensorflow.contrib.slim.utils')
-    utils.collect_named_outputs = lambda collections, alias, outputs: outputs
-    utils.convert_collection_to_dict = lambda c: {}
+    utils.collect_named_outputs = collect_named_outputs
+    utils.convert_collection_to_dict = convert_collection_to_dict
+    utils.last_dimension = last_dimension
+    tf.pad = pad
     slim.utils = utils
     contrib = types.ModuleType('tensorflow.contrib')
     contrib.slim = slim

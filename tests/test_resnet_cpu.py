@@ -93,3 +93,98 @@ def test_resnet101_structure_and_tf_names():
     w = np.random.RandomState(0).randn(7, 7, 3, 64).astype(np.float32)
     net.load_tf_variables({'resnet_v1_101/conv1/weights': w}, strict=False)
     assert np.array_equal(net.conv1.conv.weight.detach().numpy(), w.transpose(3, 2, 0, 1))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the whole backbone against the reference's own graph code (tests/golden/make_backbone_reference.py executes
+# models/slim/nets/resnet_v1.py + resnet_utils.py behind the TF1 stand-in): variable table, every end point's
+# shape, the block4 tap, batch-norm moving statistics after a training step, cfg.NET.TRAIN_TOP_BN
+# ---------------------------------------------------------------------------------------------------------------
+import importlib.util
+import json
+import os
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+_BZ = np.load(os.path.join(GOLD, 'ref_backbone.npz'))
+BACKBONE_CASES = json.loads(str(_BZ['cases']))
+
+
+def _variable_value():
+    spec = importlib.util.spec_from_file_location('apa_backbone_values', os.path.join(GOLD, 'make_backbone_reference.py'))
+    src = open(spec.origin).read()
+    ns = {'np': np, 'zlib': __import__('zlib')}
+    start = src.index('def variable_value(')
+    exec(src[start:src.index('\n\n\ndef load_backbone_reference')], ns)      # the documented formula, nothing else
+    return ns['variable_value']
+
+
+@pytest.mark.parametrize('name', BACKBONE_CASES)
+def test_backbone_matches_reference_graph(name):
+    m = json.loads(str(_BZ[name + '/meta']))
+    value = _variable_value()
+    net = rn.ResNetV1(m['model']).double()
+    table = net.tf_variable_map()
+    # the reference built exactly these variables (+ the ImageNet `logits` conv, which the head does not use)
+    ref_vars = [v for v in m['var_order'] if '/logits/' not in v]
+    assert sorted(ref_vars) == sorted(table)
+    for vn in ref_vars:
+        mod, attr = table[vn]
+        shape = m['var_shapes'][vn]
+        got = list(getattr(mod, attr).shape)
+        assert (got == [shape[3], shape[2], shape[0], shape[1]]) if len(shape) == 4 else (got == shape), vn
+    net.load_tf_variables({vn: value(name, vn, m['var_shapes'][vn]) for vn in ref_vars})
+    net.train(m['is_training'])
+    if m['train_top_bn']:
+        rn.freeze_all_but_root_batch_norm(net)
+    images = torch.from_numpy(_BZ[name + '/in/images'].astype(np.float64))
+    eps = {}
+    with torch.no_grad():
+        out = net(images, end_points=eps)
+    exp = _BZ[name + '/out/block4'].astype(np.float64)
+    assert list(out.shape) == list(exp.shape) == m['end_points'][m['tap']]['shape']
+    assert np.abs(out.numpy() - exp).max() <= 2e-6 * np.abs(exp).max()                  # float32-stored fixture
+    for b in range(1, 5):                                                              # every block's end point
+        key = '%s/block%d' % (m['model'], b)
+        st = m['end_points'][key]
+        v = eps[key].numpy()
+        assert list(v.shape) == st['shape']
+        assert abs(v.sum() - st['sum']) <= 1e-9 * max(abs(st['sum']), st['sumsq'] ** 0.5)
+        assert abs((v * v).sum() - st['sumsq']) <= 1e-9 * st['sumsq']
+    if m['is_training']:
+        # UPDATE_OPS: moving = moving - (1 - decay) (moving - batch statistic), batch VARIANCE as tf.nn.moments
+        # computes it (biased)
+        bns = [mod for mod in net.modules() if isinstance(mod, torch.nn.BatchNorm2d)]
+        first = net.conv1.bn
+        assert np.abs(first.running_mean.numpy() - _BZ[name + '/out/update/moving_mean/first']).max() < 1e-9
+        assert np.abs(first.running_var.numpy() - _BZ[name + '/out/update/moving_variance/first']).max() < 1e-9 * 1e4
+        if not m['train_top_bn']:
+            last = net.blocks[-1][-1].conv3.bn
+            assert m['n_updates']['moving_mean'] == len(bns)
+            assert np.abs(last.running_mean.numpy() - _BZ[name + '/out/update/moving_mean/last']).max() < 1e-9
+            assert np.abs(last.running_var.numpy() - _BZ[name + '/out/update/moving_variance/last']).max() < 1e-9
+        else:
+            assert m['n_updates']['moving_mean'] == 1            # only the root block's batch norm trains
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference'), reason='the reference tree only exists in the build container')
+def test_backbone_generator_reproduces_a_committed_case():
+    import sys
+    saved, saved_path = dict(sys.modules), list(sys.path)
+    try:
+        spec = importlib.util.spec_from_file_location('make_backbone_reference',
+                                                      os.path.join(GOLD, 'make_backbone_reference.py'))
+        gen = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(gen)
+        blobs = gen.generate(names=['resnet_v1_50_even_eval'])
+        for k, v in blobs.items():
+            if k == 'cases':
+                continue
+            if k.endswith('/meta'):
+                assert json.loads(str(v)) == json.loads(str(_BZ[k]))
+            else:
+                assert np.array_equal(v, _BZ[k]), k
+    finally:
+        sys.path[:] = saved_path
+        for k in list(sys.modules):
+            if k not in saved:
+                del sys.modules[k]
