@@ -52,23 +52,7 @@ CASES = [
 ]
 
 
-def variable_value(case, name, shape):
-    r = np.random.RandomState(zlib.crc32(('%s|%s' % (case, name)).encode()) & 0x7fffffff)
-    leaf = name.rsplit('/', 1)[1]
-    if leaf == 'weights':
-        fan_in = int(np.prod(shape[:-1]))
-        v = r.randn(*shape) * np.sqrt(2.0 / fan_in)
-    elif leaf == 'biases':
-        v = 0.1 * r.randn(*shape)
-    elif leaf == 'gamma':
-        v = 1.0 + 0.1 * r.randn(*shape)
-    elif leaf in ('beta', 'moving_mean'):
-        v = 0.1 * r.randn(*shape)
-    elif leaf == 'moving_variance':
-        v = 1.0 + 0.1 * np.abs(r.randn(*shape))
-    else:
-        raise ValueError(name)
-    return v.astype(np.float32).astype(np.float64)
+from backbone_values import variable_value          # noqa: E402  (the documented formula, shared with the test)
 
 
 def load_backbone_reference():

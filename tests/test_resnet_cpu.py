@@ -110,12 +110,10 @@ BACKBONE_CASES = json.loads(str(_BZ['cases']))
 
 
 def _variable_value():
-    spec = importlib.util.spec_from_file_location('apa_backbone_values', os.path.join(GOLD, 'make_backbone_reference.py'))
-    src = open(spec.origin).read()
-    ns = {'np': np, 'zlib': __import__('zlib')}
-    start = src.index('def variable_value(')
-    exec(src[start:src.index('\n\n\ndef load_backbone_reference')], ns)      # the documented formula, nothing else
-    return ns['variable_value']
+    spec = importlib.util.spec_from_file_location('apa_backbone_values', os.path.join(GOLD, 'backbone_values.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.variable_value
 
 
 @pytest.mark.parametrize('name', BACKBONE_CASES)
