@@ -56,7 +56,7 @@ class SlimBatchNorm2d(nn.BatchNorm2d):
     (tests/golden/make_backbone_reference.py)."""
 
     def forward(self, x):
-        if not (self.training and self.track_running_stats):
+        if not (self.training and self.track_running_stats) or self.momentum is None:
             return super().forward(x)
         n = x.numel() // x.shape[1]
         keep = 1.0 - self.momentum
