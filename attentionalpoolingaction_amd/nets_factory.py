@@ -662,8 +662,8 @@ class SpatialMeanFunction(torch.autograd.Function):
 
 class BaselineHead(nn.Module):
     """cfg 001 (`experiments/001_MPII_ResNet.yaml`, no attention): the slim ResNet's own head --
-    global average pool, dropout, 1x1 conv `resnet_v1_101/logits` (models/slim/nets/resnet_v1.py:206-217
-    with the dropout of nets_factory.py:143-146 forwarded as dropout_keep_prob).  Not the hot path: it is
+    global average pool, dropout, 1x1 conv `resnet_v1_101/logits` (models/slim/nets/resnet_v1.py:206-217; the
+    dropout exists only when cfg.NET.DROPOUT >= 0, nets_factory.py:127-129).  Not the hot path: it is
     the plumbing baseline of BASELINE configs[0].  In eval mode it IS the attentional-pooling op with
     a constant attention map (mean_p X . W + b, one streaming pass in HIP).  In training the dropout
     sits between the pooled vector and the classifier: the pooled vector z comes from SpatialMeanFunction,
@@ -675,7 +675,11 @@ class BaselineHead(nn.Module):
     def __init__(self, num_classes: int, cfg, in_channels: int = 2048, is_training: bool = False, seed: int = 42):
         super().__init__()
         self.num_classes = num_classes
-        self.keep_prob = dropout_keep_prob(cfg)
+        # The backbone's own dropout is only configured when cfg.NET.DROPOUT >= 0 (nets_factory.py:127-129:
+        # `kwargs['dropout_keep_prob'] = 1 - DROPOUT`); with the default DROPOUT = -1 -- the shipped cfg 001 --
+        # nothing is passed and resnet_v1_101's default keep probability 1.0 applies: NO dropout.  (The 0.2 rule
+        # of :143-146 is an arg-scope for the slim.dropout calls of the attention head only.)
+        self.keep_prob = 1.0 if cfg.NET.DROPOUT < 0 else 1.0 - float(cfg.NET.DROPOUT)
         self.is_training = is_training
         self.seed = seed
         self._step = 0

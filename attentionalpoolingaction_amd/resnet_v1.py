@@ -59,12 +59,17 @@ class SlimBatchNorm2d(nn.BatchNorm2d):
         if not (self.training and self.track_running_stats) or self.momentum is None:
             return super().forward(x)
         n = x.numel() // x.shape[1]
-        keep = 1.0 - self.momentum
-        old = self.running_var * keep
-        y = super().forward(x)
-        if n > 1:
-            with torch.no_grad():
-                self.running_var.sub_(old).mul_((n - 1.0) / n).add_(old)
+        # the op updates (and autograd keeps a reference to) a COPY of the moving variance; the module's buffer
+        # then receives the corrected update -- editing the buffer the op saw in place would invalidate the
+        # tensor the backward pass saved
+        seen = self.running_var.clone()
+        y = F.batch_norm(x, self.running_mean, seen, self.weight, self.bias, True, self.momentum, self.eps)
+        with torch.no_grad():
+            old = self.running_var * (1.0 - self.momentum)
+            unbias = (n - 1.0) / n if n > 1 else 1.0
+            self.running_var.copy_((seen - old) * unbias + old)
+            if self.num_batches_tracked is not None:
+                self.num_batches_tracked += 1
         return y
 
 

@@ -100,6 +100,116 @@ def run_case(rv1, nf, c):
     return out
 
 
+# ------------------------------------------------------------------------------------------------------------
+# BASELINE configs[0] end to end: experiments/001_MPII_ResNet.yaml through the reference's get_network_fn with the
+# REAL backbone (no stub), gen_losses and tf.gradients -- images in, logits / losses / gradients out.
+# ------------------------------------------------------------------------------------------------------------
+E2E_CASES = [
+    dict(name='cfg001_train_e2e', yaml='001_MPII_ResNet.yaml', shape=(4, 49, 65, 3), K=7, is_training=True),
+    dict(name='cfg001_eval_e2e', yaml='001_MPII_ResNet.yaml', shape=(2, 65, 49, 3), K=7, is_training=False),
+    # NET.DROPOUT >= 0 IS forwarded to the backbone (nets_factory.py:127-129): keep 0.5 on the pooled vector
+    dict(name='cfg001_train_dropout_e2e', yaml='001_MPII_ResNet.yaml', shape=(4, 49, 65, 3), K=7, is_training=True,
+         net={'DROPOUT': 0.5}, libmask=(42, 0)),
+]
+FULL_GRADS = ['resnet_v1_101/logits/weights', 'resnet_v1_101/logits/biases', 'resnet_v1_101/conv1/BatchNorm/gamma',
+              'resnet_v1_101/conv1/BatchNorm/beta', 'resnet_v1_101/block4/unit_3/bottleneck_v1/conv3/BatchNorm/gamma',
+              'resnet_v1_101/block1/unit_1/bottleneck_v1/shortcut/BatchNorm/beta']
+
+
+def run_e2e_case(cfgmod, nf, lossmod, rv1, defaults, c):
+    import copy
+    name = c['name']
+    mhr.reset_cfg(cfgmod, defaults)
+    cfg = cfgmod.cfg
+    cfgmod.cfg_from_file(os.path.join(REF, 'experiments', c['yaml']))
+    mhr.merge(cfg.NET, c.get('net', {}))
+    K, J = c['K'], 16
+    wd = float(cfg.TRAIN.WEIGHT_DECAY)
+    count = [0]
+
+    def uniform_fn(shape, what):
+        # the LIBRARY'S OWN keep mask for (seed, offset) as tf.nn.dropout's uniforms (see make_head_reference.py,
+        # `libmask`): the product then runs this case on its own counter hash, nothing replayed
+        import apa_keep_mask
+        assert what == 'dropout' and count[0] == 0
+        count[0] += 1
+        seed, offset = c['libmask']
+        keep = apa_keep_mask.keep_mask(shape, 1.0 - float(cfg.NET.DROPOUT), seed, offset)
+        return np.where(keep == 1, 0.9, 0.1)
+
+    g = tfs.Graph(lambda vn, shape, desc: variable_value(name, vn, shape), uniform_fn)
+    tfs.set_graph(g)
+    nf.networks_map['resnet_v1_101'] = rv1.resnet_v1_101                 # the real backbone
+    r = np.random.RandomState(zlib.crc32(('%s|images' % name).encode()) & 0x7fffffff)
+    images_np = (r.randn(*c['shape']) * 50.0).astype(np.float32)
+    labels = r.randint(0, K, size=(c['shape'][0],))
+    images = tfs.Tensor(torch.from_numpy(images_np.astype(np.float64)).requires_grad_(True))
+    network_fn = nf.get_network_fn(cfg.MODEL_NAME, K, J, cfg, weight_decay=wd, is_training=c['is_training'])
+    logits, end_points = network_fn(images)
+    lossmod.gen_losses(tfs.Tensor(torch.from_numpy(labels)), logits, cfg.TRAIN.LOSS_FN_ACTION, K,
+                       cfg.TRAIN.LOSS_FN_ACTION_WT, None, None, '', None, cfg.TRAIN.LOSS_FN_POSE_WT, end_points, cfg)
+    losses = g.get_collection(tfs.GraphKeys.LOSSES)
+    regs = g.get_collection(tfs.GraphKeys.REGULARIZATION_LOSSES)
+    total = sum(l.v for l in losses) + sum(l.v for l in regs)
+    total.backward()
+    weights = [vn for vn in g.var_order if vn.endswith('/weights')]
+    assert len(regs) == len(weights)                                      # one L2 term per conv `weights`
+    reg_groups = {'backbone': 0.0, 'logits': 0.0, 'PoseLogits': 0.0}
+    for vn, l in zip(weights, regs):
+        key = 'PoseLogits' if vn.startswith('PoseLogits/') else ('logits' if '/logits/' in vn else 'backbone')
+        reg_groups[key] += float(l.v.detach())
+    out = {'in/images': images_np, 'in/labels_action': labels.astype(np.int64),
+           'out/logits': logits.v.detach().numpy(), 'out/losses': np.array([float(l.v.detach()) for l in losses]),
+           'out/total': np.float64(float(total.detach())), 'grad/images': images.v.grad.numpy().astype(np.float32)}
+    grad_stats = {}
+    for vn in g.var_order:
+        v = g.variables[vn]
+        if v.requires_grad:
+            gr = np.zeros(v.shape) if v.grad is None else v.grad.numpy()
+            data = gr - (wd * v.detach().numpy() if vn.endswith('/weights') else 0.0)      # without the L2 term
+            grad_stats[vn] = dict(sum=float(data.sum()), sumsq=float((data * data).sum()), none=v.grad is None)
+            if vn in FULL_GRADS:
+                out['grad/var/' + vn] = data
+    draws = []
+    for i, d in enumerate(g.random_draws):
+        keep = np.floor(d['keep_prob'] + d['uniform']).astype(np.uint8)
+        out['rand/%d/keep_bits' % i] = np.packbits(keep.reshape(-1))
+        draws.append({'kind': d['kind'], 'keep_prob': d['keep_prob'], 'shape': list(keep.shape)})
+    updates = {}
+    for kind, val in g.get_collection(tfs.GraphKeys.UPDATE_OPS):
+        updates.setdefault(kind, []).append(val.numpy())
+    if updates:
+        out['out/update/moving_mean/first'] = updates['moving_mean'][0]
+        out['out/update/moving_variance/first'] = updates['moving_variance'][0]
+        out['out/update/moving_mean/last'] = updates['moving_mean'][-1]
+        out['out/update/moving_variance/last'] = updates['moving_variance'][-1]
+    meta = dict(case=name, model=cfg.MODEL_NAME, num_classes=K, is_training=c['is_training'], weight_decay=wd,
+                dropout=float(cfg.NET.DROPOUT), libmask=list(c['libmask']) if c.get('libmask') else None, reg_groups=reg_groups, grad_stats=grad_stats, draws=draws,
+                var_order=g.var_order, var_shapes={vn: list(g.variables[vn].shape) for vn in g.var_order},
+                end_points=sorted(k for k, t in end_points.items() if isinstance(t, tfs.Tensor)),
+                n_losses=len(losses), n_updates={k: len(v) for k, v in updates.items()},
+                train_cfg={k: cfg.TRAIN[k] for k in ('LOSS_FN_POSE', 'LOSS_FN_ACTION', 'LOSS_FN_ACTION_WT',
+                                                     'WEIGHT_DECAY')})
+    out['meta'] = np.array(json.dumps(meta, sort_keys=True, default=str))
+    tfs.set_graph(None)
+    return out
+
+
+def generate_e2e(names=None):
+    import copy
+    cfgmod, nf, rv1 = load_backbone_reference()
+    lossmod = sys.modules['refloss']
+    defaults = copy.deepcopy(cfgmod.cfg)
+    blobs = {}
+    for c in E2E_CASES:
+        if names is None or c['name'] in names:
+            for k, v in run_e2e_case(cfgmod, nf, lossmod, rv1, defaults, c).items():
+                blobs['%s/%s' % (c['name'], k)] = v
+    blobs['cases'] = np.array(json.dumps([c['name'] for c in E2E_CASES if names is None or c['name'] in names]))
+    mhr.reset_cfg(cfgmod, defaults)
+    return blobs
+
+
 def generate(names=None):
     _cfgmod, nf, rv1 = load_backbone_reference()
     blobs = {}
@@ -119,4 +229,13 @@ if __name__ == '__main__':
         m = json.loads(str(blobs[c['name'] + '/meta']))
         print('%-26s block4 %s  %d variables  %d end points' % (
             c['name'], m['end_points'][m['tap']]['shape'], len(m['var_order']), len(m['end_points'])))
+    print('wrote', path, os.path.getsize(path), 'bytes')
+    blobs = generate_e2e()
+    path = os.path.join(HERE, 'ref_cfg001_e2e.npz')
+    np.savez_compressed(path, **blobs)
+    for c in E2E_CASES:
+        m = json.loads(str(blobs[c['name'] + '/meta']))
+        print('%-26s logits %s  losses %s  reg %s  draws %d' % (
+            c['name'], list(blobs[c['name'] + '/out/logits'].shape), blobs[c['name'] + '/out/losses'].round(4).tolist(),
+            {k: round(v, 4) for k, v in m['reg_groups'].items()}, len(m['draws'])))
     print('wrote', path, os.path.getsize(path), 'bytes')

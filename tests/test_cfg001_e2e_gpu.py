@@ -1,0 +1,125 @@
+"""BASELINE configs[0] end to end -- images in, logits / loss / gradients out -- against the reference's own graph:
+tests/golden/ref_cfg001_e2e.npz is produced by executing the reference's get_network_fn (real resnet_v1_101 from
+models/slim/nets/resnet_v1.py, no stub), gen_losses and tf.gradients on experiments/001_MPII_ResNet.yaml
+(tests/golden/make_backbone_reference.py).  The product runs its torch-ROCm backbone (MIOpen, fp32), the HIP
+head and the HIP loss; 101 layers of fp32 convolutions against a float64 graph, hence the looser tolerances.
+
+What the reference showed for this configuration: no dropout with the shipped YAML (NET.DROPOUT = -1 is not
+forwarded to the backbone), dropout on the pooled vector when NET.DROPOUT >= 0; the PoseLogits convs are built and
+regularised although nothing consumes them (their L2 term is the only part of the reference's total loss this
+configuration does not carry: `reg_groups['PoseLogits']`)."""
+import importlib.util
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from attentionalpoolingaction_amd import config as apa_config, loss as apa_loss, nets_factory
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+Z = np.load(os.path.join(GOLD, 'ref_cfg001_e2e.npz'))
+CASES = json.loads(str(Z['cases']))
+
+
+def _values():
+    spec = importlib.util.spec_from_file_location('apa_backbone_values', os.path.join(GOLD, 'backbone_values.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.variable_value
+
+
+def _rel(a, b, floor=1e-30):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), floor))
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_cfg001_images_to_gradients_match_reference_graph(gpu, name):
+    m = json.loads(str(Z[name + '/meta']))
+    value = _values()
+    K, wd, train = m['num_classes'], m['weight_decay'], m['is_training']
+    cfg = apa_config.reset_cfg()
+    apa_config.cfg_from_dict({'MODEL_NAME': m['model'], 'NET': {'DROPOUT': m['dropout']},
+                              'TRAIN': {'LOSS_FN_POSE': '', 'WEIGHT_DECAY': wd}})
+    assert not cfg.NET.USE_POSE_PRELOGITS_BASED_ATTENTION
+    fn = nets_factory.get_network_fn(m['model'], K, 16, cfg, weight_decay=wd, is_training=train, device=gpu,
+                                     with_backbone=True)
+    net, head = fn.backbone, fn.head
+    table = net.tf_variable_map()
+    used = net.load_tf_variables({vn: value(name, vn, m['var_shapes'][vn]) for vn in table})
+    pre = m['model'] + '/logits/'
+    with torch.no_grad():
+        head.logits_weights.copy_(torch.from_numpy(value(name, pre + 'weights', m['var_shapes'][pre + 'weights'])
+                                                   .reshape(2048, K)).to(gpu))
+        head.logits_biases.copy_(torch.from_numpy(value(name, pre + 'biases', [K])).to(gpu))
+    # every variable of the reference graph is either loaded above or belongs to the unused PoseLogits convs
+    rest = [vn for vn in m['var_order'] if vn not in used and not vn.startswith(pre)]
+    assert rest and all(vn.startswith('PoseLogits/') for vn in rest)
+    assert (head.keep_prob == 1.0) == (m['dropout'] < 0) and len(m['draws']) == (0 if m['dropout'] < 0 or not train else 1)
+    if m['libmask']:
+        head.seed, head._step = int(m['libmask'][0]), int(m['libmask'][1])
+    images = torch.from_numpy(Z[name + '/in/images']).to(gpu).requires_grad_(True)
+    logits, ep = fn(images)
+    exp = Z[name + '/out/logits']
+    assert _rel(logits.detach().cpu().numpy(), exp) < 2e-3
+    assert np.array_equal(logits.detach().cpu().numpy().argmax(1), exp.argmax(1))
+    losses = apa_loss.gen_losses(torch.from_numpy(Z[name + '/in/labels_action']).to(gpu), logits, 'softmax-xentropy', K,
+                                 1.0, None, None, '', None, 1.0, ep, cfg)
+    assert len(losses) == 1 and abs(float(losses[0].detach()) - Z[name + '/out/losses'][0]) <= 2e-3 * Z[name + '/out/losses'][0]
+    # slim's L2 terms: 0.5 wd |w|^2 over every conv `weights` of the backbone and the logits conv
+    convs = [getattr(mod, attr) for vn, (mod, attr) in table.items() if vn.endswith('/weights')]
+    reg_backbone = sum(float((w.detach().double() ** 2).sum()) for w in convs) * 0.5 * wd
+    assert abs(reg_backbone - m['reg_groups']['backbone']) <= 1e-6 * m['reg_groups']['backbone']
+    reg_logits = float((head.logits_weights.detach().double() ** 2).sum()) * 0.5 * wd
+    assert abs(reg_logits - m['reg_groups']['logits']) <= 1e-6 * m['reg_groups']['logits']
+    assert [w.shape for w in fn.regularized_weights()] == [head.logits_weights.shape]
+    if not train:
+        apa_config.reset_cfg()
+        return
+    sum(losses).backward()
+
+    def cosine(a, b):
+        a, b = np.asarray(a, dtype=np.float64).ravel(), np.asarray(b, dtype=np.float64).ravel()
+        return float(a @ b / np.sqrt((a @ a) * (b @ b)))
+    # fp32 convolutions and batch statistics through 101 layers against the float64 graph: ReLU gates near zero
+    # flip, so deep gradients are compared by direction and size, not element by element (the SAME module in
+    # float64 matches the reference to 1e-8: tests/test_resnet_cpu.py::test_cfg001_backbone_forward_backward_float64)
+    gi, ei = images.grad.cpu().numpy(), Z[name + '/grad/images']
+    assert cosine(gi, ei) > 0.99 and abs(np.linalg.norm(gi) / np.linalg.norm(ei) - 1.0) < 0.05
+    full = {vn[len('grad/var/'):]: Z[name + '/' + vn] for vn in
+            [k[len(name) + 1:] for k in Z.files if k.startswith(name + '/grad/var/')]}
+    for vn, expg in full.items():
+        if vn.startswith(pre):
+            got = (head.logits_weights if vn.endswith('weights') else head.logits_biases).grad.cpu().numpy()
+        else:
+            mod, attr = table[vn]
+            got = getattr(mod, attr).grad.cpu().numpy()
+        if vn.startswith(pre):
+            assert _rel(got.reshape(expg.shape), expg) < 2e-2, vn           # the head's own gradients: tight
+        else:
+            assert cosine(got, expg) > 0.98, vn
+    # gradient checksums of EVERY backbone variable (the data part, without the L2 term)
+    worst, n_checked = 0.0, 0
+    for vn, (mod, attr) in table.items():
+        st = m['grad_stats'].get(vn)
+        if st is None:
+            continue                                        # moving statistics
+        g = getattr(mod, attr).grad
+        if st['none']:
+            assert g is None or float(g.abs().max()) == 0.0, vn
+            continue
+        gg = g.double().cpu().numpy()
+        worst = max(worst, abs(float((gg * gg).sum()) - st['sumsq']) / st['sumsq'])
+        n_checked += 1
+    assert n_checked == 312 and worst < 0.1, worst       # gradient ENERGY of every trainable backbone variable
+    # batch-norm moving statistics after the step (first and last layer)
+    assert _rel(net.conv1.bn.running_mean.cpu().numpy(), Z[name + '/out/update/moving_mean/first']) < 1e-4
+    assert _rel(net.conv1.bn.running_var.cpu().numpy(), Z[name + '/out/update/moving_variance/first']) < 1e-4
+    last = net.blocks[-1][-1].conv3.bn
+    assert _rel(last.running_mean.cpu().numpy(), Z[name + '/out/update/moving_mean/last']) < 5e-3
+    assert _rel(last.running_var.cpu().numpy(), Z[name + '/out/update/moving_variance/last']) < 5e-3
+    apa_config.reset_cfg()

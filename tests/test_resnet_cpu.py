@@ -186,3 +186,84 @@ def test_backbone_generator_reproduces_a_committed_case():
         for k in list(sys.modules):
             if k not in saved:
                 del sys.modules[k]
+
+
+def test_slim_batch_norm_trains_like_batch_norm_with_the_tf_moving_variance():
+    """forward / backward identical to nn.BatchNorm2d in training mode (the backward pass must survive the
+    corrected moving-variance update); moving variance from the BIASED batch variance (tf.nn.moments)."""
+    torch.manual_seed(0)
+    bn = rn.SlimBatchNorm2d(8, eps=1e-5, momentum=0.003).double()
+    ref = torch.nn.BatchNorm2d(8, eps=1e-5, momentum=0.003).double()
+    x = torch.randn(3, 8, 5, 4, dtype=torch.float64, requires_grad=True)
+    x2 = x.detach().clone().requires_grad_(True)
+    y, y2 = bn(x), ref(x2)
+    y.square().sum().backward()
+    y2.square().sum().backward()
+    assert torch.allclose(y, y2) and torch.allclose(x.grad, x2.grad)
+    assert torch.allclose(bn.running_mean, ref.running_mean)
+    v = x.detach().var((0, 2, 3), unbiased=False)
+    assert torch.allclose(bn.running_var, 0.997 * torch.ones(8, dtype=torch.float64) + 0.003 * v)
+    assert not torch.allclose(bn.running_var, ref.running_var)        # nn.BatchNorm2d used the unbiased estimate
+    bn(x.detach().requires_grad_(True)).sum().backward()              # and a second step
+    assert int(bn.num_batches_tracked) == 2
+    bn.eval()
+    assert torch.allclose(bn(x.detach()), torch.nn.functional.batch_norm(x.detach(), bn.running_mean, bn.running_var,
+                                                                       bn.weight, bn.bias, False, 0.0, 1e-5))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE configs[0] end to end in float64 on the CPU: the backbone module forward AND backward against the
+# reference's get_network_fn + gen_losses + tf.gradients run on experiments/001_MPII_ResNet.yaml
+# (tests/golden/ref_cfg001_e2e.npz).  The head (mean pool, dropout, logits conv) and the loss are written in
+# plain torch here -- the HIP head and loss take their place in tests/test_cfg001_e2e_gpu.py.
+# ---------------------------------------------------------------------------------------------------------------
+_EZ = np.load(os.path.join(GOLD, 'ref_cfg001_e2e.npz'))
+E2E_CASES = json.loads(str(_EZ['cases']))
+
+
+@pytest.mark.parametrize('name', E2E_CASES)
+def test_cfg001_backbone_forward_backward_float64(name):
+    m = json.loads(str(_EZ[name + '/meta']))
+    value = _variable_value()
+    K, train = m['num_classes'], m['is_training']
+    net = rn.ResNetV1(m['model']).double()
+    table = net.tf_variable_map()
+    net.load_tf_variables({vn: value(name, vn, m['var_shapes'][vn]) for vn in table})
+    net.train(train)
+    pre = m['model'] + '/logits/'
+    W = torch.from_numpy(value(name, pre + 'weights', m['var_shapes'][pre + 'weights']).reshape(2048, K)).requires_grad_(True)
+    b = torch.from_numpy(value(name, pre + 'biases', [K])).requires_grad_(True)
+    images = torch.from_numpy(_EZ[name + '/in/images'].astype(np.float64)).requires_grad_(True)
+    z = net(images).mean(dim=(1, 2))
+    if m['draws']:                                         # NET.DROPOUT >= 0: dropout on the pooled vector
+        d = m['draws'][0]
+        keep = np.unpackbits(_EZ[name + '/rand/0/keep_bits'])[:int(np.prod(d['shape']))].reshape(z.shape)
+        z = z / d['keep_prob'] * torch.from_numpy(keep.astype(np.float64))
+    logits = z @ W + b
+    exp = _EZ[name + '/out/logits']
+    assert np.abs(logits.detach().numpy() - exp).max() <= 1e-9 * np.abs(exp).max()
+    labels = torch.from_numpy(_EZ[name + '/in/labels_action'])
+    loss = torch.nn.functional.cross_entropy(logits, labels)
+    assert abs(float(loss.detach()) - _EZ[name + '/out/losses'][0]) <= 1e-9 * _EZ[name + '/out/losses'][0]
+    if not train:
+        return
+    loss.backward()
+    expg = _EZ[name + '/grad/images'].astype(np.float64)
+    assert np.abs(images.grad.numpy() - expg).max() <= 2e-6 * np.abs(expg).max()          # float32-stored
+    for k in [k for k in _EZ.files if k.startswith(name + '/grad/var/')]:
+        vn = k[len(name + '/grad/var/'):]
+        got = (W.grad if vn.endswith('logits/weights') else b.grad) if vn.startswith(pre) else \
+            getattr(*table[vn]).grad
+        e = _EZ[k]
+        assert np.abs(got.numpy().reshape(e.shape) - e).max() <= 1e-8 * max(np.abs(e).max(), 1e-30), vn
+    for vn, (mod, attr) in table.items():                  # every variable of the backbone, by checksum
+        st = m['grad_stats'].get(vn)
+        if st is None:
+            continue
+        g = getattr(mod, attr).grad
+        if st['none']:
+            assert g is None or float(g.abs().max()) == 0.0
+            continue
+        gg = g.numpy()
+        assert abs(float((gg * gg).sum()) - st['sumsq']) <= 1e-8 * st['sumsq'], vn
+        assert abs(float(gg.sum()) - st['sum']) <= 1e-7 * st['sumsq'] ** 0.5 * gg.size ** 0.5 + 1e-12, vn
