@@ -670,11 +670,24 @@ class BaselineHead(nn.Module):
     and dropout + classifier are the pooling op again on z seen as a 1 x 1 map (P = 1: its dropout on the
     "features" is the dropout on z, same counter-based mask stream, `cof.dropout_mask((N, C), ...)`)."""
 
-    TF_NAMES = {'logits_weights': 'logits/weights', 'logits_biases': 'logits/biases'}
+    TF_NAMES = {'logits_weights': 'logits/weights', 'logits_biases': 'logits/biases',
+                'pose_w1': 'PoseLogits/ExtraConv2d_1x1/weights', 'pose_b1': 'PoseLogits/ExtraConv2d_1x1/biases',
+                'pose_w2': 'PoseLogits/Conv2d_1c_1x1/weights', 'pose_b2': 'PoseLogits/Conv2d_1c_1x1/biases'}
 
-    def __init__(self, num_classes: int, cfg, in_channels: int = 2048, is_training: bool = False, seed: int = 42):
+    def __init__(self, num_classes: int, cfg, in_channels: int = 2048, is_training: bool = False, seed: int = 42,
+                 num_pose_keypoints: int = 16):
         super().__init__()
         self.num_classes = num_classes
+        # The PoseLogits convs are built in EVERY configuration (nets_factory.py:147-160), this one included: nothing
+        # consumes them here, but they are variables of the graph (checkpoints carry them) and their weights sit in
+        # REGULARIZATION_LOSSES -- the reference's total loss and weight decay include them
+        # (tests/golden/ref_cfg001_e2e.npz: reg_groups['PoseLogits']).  Same initialisers as AttentionalPoolingHead.
+        cp = AttentionalPoolingHead.POSE_PRELOGITS
+        self.pose_w1 = nn.Parameter(torch.randn(in_channels, cp) * 0.001)
+        self.pose_b1 = nn.Parameter(torch.zeros(cp))
+        self.pose_w2 = nn.Parameter(torch.nn.init.trunc_normal_(
+            torch.empty(cp, max(num_pose_keypoints, 1)), 0.0, 1.0, -2.0, 2.0) * (2.6 / cp) ** 0.5)
+        self.pose_b2 = nn.Parameter(torch.zeros(max(num_pose_keypoints, 1)))
         # The backbone's own dropout is only configured when cfg.NET.DROPOUT >= 0 (nets_factory.py:127-129:
         # `kwargs['dropout_keep_prob'] = 1 - DROPOUT`); with the default DROPOUT = -1 -- the shipped cfg 001 --
         # nothing is passed and resnet_v1_101's default keep probability 1.0 applies: NO dropout.  (The 0.2 rule
@@ -695,7 +708,7 @@ class BaselineHead(nn.Module):
         self._step = int(state.get('dropout_step', 0)) if state else 0
 
     def regularized_weights(self):
-        return [self.logits_weights]
+        return [self.logits_weights, self.pose_w1, self.pose_w2]
 
     def forward(self, last_conv: torch.Tensor):
         n, h, w = last_conv.shape[0], last_conv.shape[1], last_conv.shape[2]
@@ -808,7 +821,7 @@ def get_network_fn(name: str, num_classes: int, num_pose_keypoints: int, cfg,
     else:   # cfg 001: the backbone's own average-pool + logits head
         head_kwargs.pop('arg_scope', None)
         head = BaselineHead(num_classes, cfg, in_channels=channels, is_training=is_training,
-                            seed=head_seed).to(device)
+                            seed=head_seed, num_pose_keypoints=num_pose_keypoints).to(device)
     temporal = None
     if cfg.NET.USE_TEMPORAL_ATT:
         # 'TemporalAttention/Conv/{weights,biases}': 1x1 conv K->1, N(0,1e-3) weights; the bias is

@@ -6,8 +6,7 @@ head and the HIP loss; 101 layers of fp32 convolutions against a float64 graph, 
 
 What the reference showed for this configuration: no dropout with the shipped YAML (NET.DROPOUT = -1 is not
 forwarded to the backbone), dropout on the pooled vector when NET.DROPOUT >= 0; the PoseLogits convs are built and
-regularised although nothing consumes them (their L2 term is the only part of the reference's total loss this
-configuration does not carry: `reg_groups['PoseLogits']`)."""
+regularised although nothing consumes them (BaselineHead carries them as parameters for that reason)."""
 import importlib.util
 import json
 import os
@@ -56,9 +55,14 @@ def test_cfg001_images_to_gradients_match_reference_graph(gpu, name):
         head.logits_weights.copy_(torch.from_numpy(value(name, pre + 'weights', m['var_shapes'][pre + 'weights'])
                                                    .reshape(2048, K)).to(gpu))
         head.logits_biases.copy_(torch.from_numpy(value(name, pre + 'biases', [K])).to(gpu))
-    # every variable of the reference graph is either loaded above or belongs to the unused PoseLogits convs
+    # the PoseLogits convs the reference also builds here (unused, but variables of the graph and regularised)
     rest = [vn for vn in m['var_order'] if vn not in used and not vn.startswith(pre)]
-    assert rest and all(vn.startswith('PoseLogits/') for vn in rest)
+    assert sorted(rest) == sorted(v for k, v in head.TF_NAMES.items() if k.startswith('pose_'))
+    with torch.no_grad():
+        for attr, vn in head.TF_NAMES.items():
+            if attr.startswith('pose_'):
+                t = getattr(head, attr)
+                t.copy_(torch.from_numpy(value(name, vn, m['var_shapes'][vn]).reshape(tuple(t.shape))).to(gpu))
     assert (head.keep_prob == 1.0) == (m['dropout'] < 0) and len(m['draws']) == (0 if m['dropout'] < 0 or not train else 1)
     if m['libmask']:
         head.seed, head._step = int(m['libmask'][0]), int(m['libmask'][1])
@@ -76,7 +80,10 @@ def test_cfg001_images_to_gradients_match_reference_graph(gpu, name):
     assert abs(reg_backbone - m['reg_groups']['backbone']) <= 1e-6 * m['reg_groups']['backbone']
     reg_logits = float((head.logits_weights.detach().double() ** 2).sum()) * 0.5 * wd
     assert abs(reg_logits - m['reg_groups']['logits']) <= 1e-6 * m['reg_groups']['logits']
-    assert [w.shape for w in fn.regularized_weights()] == [head.logits_weights.shape]
+    reg_head = float(apa_loss.l2_regularization(fn.regularized_weights(), wd).detach())
+    assert abs(reg_head - (m['reg_groups']['logits'] + m['reg_groups']['PoseLogits'])) <= 1e-5 * reg_head
+    total = float(losses[0].detach()) + reg_backbone + reg_head          # == the reference's total loss
+    assert abs(total - float(Z[name + '/out/total'])) <= 2e-3 * float(Z[name + '/out/total'])
     if not train:
         apa_config.reset_cfg()
         return
