@@ -681,7 +681,7 @@ class BaselineHead(nn.Module):
         # The PoseLogits convs are built in EVERY configuration (nets_factory.py:147-160), this one included: nothing
         # consumes them here, but they are variables of the graph (checkpoints carry them) and their weights sit in
         # REGULARIZATION_LOSSES -- the reference's total loss and weight decay include them
-        # (tests/golden/ref_cfg001_e2e.npz: reg_groups['PoseLogits']).  Same initialisers as AttentionalPoolingHead.
+        # (tests/golden/ref_e2e.npz: reg_groups['PoseLogits']).  Same initialisers as AttentionalPoolingHead.
         cp = AttentionalPoolingHead.POSE_PRELOGITS
         self.pose_w1 = nn.Parameter(torch.randn(in_channels, cp) * 0.001)
         self.pose_b1 = nn.Parameter(torch.zeros(cp))

@@ -110,8 +110,17 @@ E2E_CASES = [
     # NET.DROPOUT >= 0 IS forwarded to the backbone (nets_factory.py:127-129): keep 0.5 on the pooled vector
     dict(name='cfg001_train_dropout_e2e', yaml='001_MPII_ResNet.yaml', shape=(4, 49, 65, 3), K=7, is_training=True,
          net={'DROPOUT': 0.5}, libmask=(42, 0)),
+    # BASELINE configs[1] / [2] at small size, images in: backbone -> conv5 tap -> attention head -> losses.  The head's
+    # dropout (keep 0.2 on the [N,h,w,2048] map) runs on the library's own mask for (seed, offset).
+    dict(name='cfg002_train_e2e', yaml='002_MPII_ResNet_withAttention.yaml', shape=(4, 49, 65, 3), K=7,
+         is_training=True, libmask=(42, 0)),
+    dict(name='cfg003_train_e2e', yaml='003_MPII_ResNet_withPoseAttention.yaml', shape=(4, 49, 65, 3), K=7,
+         is_training=True, libmask=(43, 5)),
 ]
-FULL_GRADS = ['resnet_v1_101/logits/weights', 'resnet_v1_101/logits/biases', 'resnet_v1_101/conv1/BatchNorm/gamma',
+FULL_GRADS = ['PosePrelogitsBasedAttention/Conv2d_PrePose_Attn/weights', 'PosePrelogitsBasedAttention/Conv2d_PrePose_Attn/biases',
+              'PosePrelogitsBasedAttention/Conv/weights', 'PosePrelogitsBasedAttention/Conv/biases',
+              'PoseLogits/Conv2d_1c_1x1/weights', 'PoseLogits/Conv2d_1c_1x1/biases', 'PoseLogits/ExtraConv2d_1x1/biases',
+              'resnet_v1_101/logits/weights', 'resnet_v1_101/logits/biases', 'resnet_v1_101/conv1/BatchNorm/gamma',
               'resnet_v1_101/conv1/BatchNorm/beta', 'resnet_v1_101/block4/unit_3/bottleneck_v1/conv3/BatchNorm/gamma',
               'resnet_v1_101/block1/unit_1/bottleneck_v1/shortcut/BatchNorm/beta']
 
@@ -134,7 +143,10 @@ def run_e2e_case(cfgmod, nf, lossmod, rv1, defaults, c):
         assert what == 'dropout' and count[0] == 0
         count[0] += 1
         seed, offset = c['libmask']
-        keep = apa_keep_mask.keep_mask(shape, 1.0 - float(cfg.NET.DROPOUT), seed, offset)
+        d = float(cfg.NET.DROPOUT)
+        attention = bool(cfg.NET.USE_POSE_PRELOGITS_BASED_ATTENTION)
+        keep_prob = (0.2 if d < 0 else 1.0 - d) if attention else 1.0 - d      # head rule (:143-146) / backbone kwarg (:127-129)
+        keep = apa_keep_mask.keep_mask(shape, keep_prob, seed, offset)
         return np.where(keep == 1, 0.9, 0.1)
 
     g = tfs.Graph(lambda vn, shape, desc: variable_value(name, vn, shape), uniform_fn)
@@ -146,21 +158,36 @@ def run_e2e_case(cfgmod, nf, lossmod, rv1, defaults, c):
     images = tfs.Tensor(torch.from_numpy(images_np.astype(np.float64)).requires_grad_(True))
     network_fn = nf.get_network_fn(cfg.MODEL_NAME, K, J, cfg, weight_decay=wd, is_training=c['is_training'])
     logits, end_points = network_fn(images)
+    use_pose = bool(cfg.TRAIN.LOSS_FN_POSE)
+    lab_pose = valid = None
+    if use_pose:
+        pl = end_points['PoseLogits']
+        lab_pose = mhr.f32(r.rand(*pl.v.shape))
+        valid = r.rand(pl.v.shape[0], J) > 0.3
     lossmod.gen_losses(tfs.Tensor(torch.from_numpy(labels)), logits, cfg.TRAIN.LOSS_FN_ACTION, K,
-                       cfg.TRAIN.LOSS_FN_ACTION_WT, None, None, '', None, cfg.TRAIN.LOSS_FN_POSE_WT, end_points, cfg)
+                       cfg.TRAIN.LOSS_FN_ACTION_WT,
+                       tfs.Tensor(torch.from_numpy(lab_pose)) if use_pose else None,
+                       end_points['PoseLogits'] if use_pose else None, cfg.TRAIN.LOSS_FN_POSE if use_pose else '',
+                       tfs.Tensor(torch.from_numpy(valid)) if use_pose else None,
+                       cfg.TRAIN.LOSS_FN_POSE_WT, end_points, cfg)
     losses = g.get_collection(tfs.GraphKeys.LOSSES)
     regs = g.get_collection(tfs.GraphKeys.REGULARIZATION_LOSSES)
     total = sum(l.v for l in losses) + sum(l.v for l in regs)
     total.backward()
     weights = [vn for vn in g.var_order if vn.endswith('/weights')]
     assert len(regs) == len(weights)                                      # one L2 term per conv `weights`
-    reg_groups = {'backbone': 0.0, 'logits': 0.0, 'PoseLogits': 0.0}
+    reg_groups = {'backbone': 0.0, 'logits': 0.0, 'PoseLogits': 0.0, 'attention': 0.0}
     for vn, l in zip(weights, regs):
-        key = 'PoseLogits' if vn.startswith('PoseLogits/') else ('logits' if '/logits/' in vn else 'backbone')
+        key = 'PoseLogits' if vn.startswith('PoseLogits/') else ('attention' if vn.startswith('PosePrelogits') else (
+            'logits' if '/logits/' in vn else 'backbone'))
         reg_groups[key] += float(l.v.detach())
     out = {'in/images': images_np, 'in/labels_action': labels.astype(np.int64),
            'out/logits': logits.v.detach().numpy(), 'out/losses': np.array([float(l.v.detach()) for l in losses]),
-           'out/total': np.float64(float(total.detach())), 'grad/images': images.v.grad.numpy().astype(np.float32)}
+           'out/total': np.float64(float(total.detach())), 'grad/images': images.v.grad.numpy().astype(np.float32),
+           'out/block4': end_points[cfg.MODEL_NAME + '/block4'].v.detach().numpy().astype(np.float32)}
+    if use_pose:
+        out['in/labels_pose'] = lab_pose.astype(np.float32)
+        out['in/labels_pose_valid'] = valid
     grad_stats = {}
     for vn in g.var_order:
         v = g.variables[vn]
@@ -169,7 +196,7 @@ def run_e2e_case(cfgmod, nf, lossmod, rv1, defaults, c):
             data = gr - (wd * v.detach().numpy() if vn.endswith('/weights') else 0.0)      # without the L2 term
             grad_stats[vn] = dict(sum=float(data.sum()), sumsq=float((data * data).sum()), none=v.grad is None)
             if vn in FULL_GRADS:
-                out['grad/var/' + vn] = data
+                out['grad/var/' + vn] = data.astype(np.float32) if data.size > 4096 else data   # big ones at float32
     draws = []
     for i, d in enumerate(g.random_draws):
         keep = np.floor(d['keep_prob'] + d['uniform']).astype(np.uint8)
@@ -184,15 +211,20 @@ def run_e2e_case(cfgmod, nf, lossmod, rv1, defaults, c):
         out['out/update/moving_mean/last'] = updates['moving_mean'][-1]
         out['out/update/moving_variance/last'] = updates['moving_variance'][-1]
     meta = dict(case=name, model=cfg.MODEL_NAME, num_classes=K, is_training=c['is_training'], weight_decay=wd,
-                dropout=float(cfg.NET.DROPOUT), libmask=list(c['libmask']) if c.get('libmask') else None, reg_groups=reg_groups, grad_stats=grad_stats, draws=draws,
+                dropout=float(cfg.NET.DROPOUT), attention=bool(cfg.NET.USE_POSE_PRELOGITS_BASED_ATTENTION),
+                net={k: v for k, v in cfg.NET.items() if not isinstance(v, dict)}, libmask=list(c['libmask']) if c.get('libmask') else None, reg_groups=reg_groups, grad_stats=grad_stats, draws=draws,
                 var_order=g.var_order, var_shapes={vn: list(g.variables[vn].shape) for vn in g.var_order},
                 end_points=sorted(k for k, t in end_points.items() if isinstance(t, tfs.Tensor)),
                 n_losses=len(losses), n_updates={k: len(v) for k, v in updates.items()},
-                train_cfg={k: cfg.TRAIN[k] for k in ('LOSS_FN_POSE', 'LOSS_FN_ACTION', 'LOSS_FN_ACTION_WT',
-                                                     'WEIGHT_DECAY')})
-    out['meta'] = np.array(json.dumps(meta, sort_keys=True, default=str))
+                train_cfg={k: cfg.TRAIN[k] for k in ('LOSS_FN_POSE', 'LOSS_FN_POSE_WT', 'LOSS_FN_POSE_SAMPLED',
+                                                     'LOSS_FN_ACTION', 'LOSS_FN_ACTION_WT', 'WEIGHT_DECAY')})
+    out['meta'] = np.frombuffer(json.dumps(meta, sort_keys=True, default=str).encode(), dtype=np.uint8)   # utf-8 bytes
     tfs.set_graph(None)
     return out
+
+
+def e2e_meta(blobs, name):
+    return json.loads(bytes(blobs[name + '/meta']).decode())
 
 
 def generate_e2e(names=None):
@@ -231,10 +263,10 @@ if __name__ == '__main__':
             c['name'], m['end_points'][m['tap']]['shape'], len(m['var_order']), len(m['end_points'])))
     print('wrote', path, os.path.getsize(path), 'bytes')
     blobs = generate_e2e()
-    path = os.path.join(HERE, 'ref_cfg001_e2e.npz')
+    path = os.path.join(HERE, 'ref_e2e.npz')
     np.savez_compressed(path, **blobs)
     for c in E2E_CASES:
-        m = json.loads(str(blobs[c['name'] + '/meta']))
+        m = e2e_meta(blobs, c['name'])
         print('%-26s logits %s  losses %s  reg %s  draws %d' % (
             c['name'], list(blobs[c['name'] + '/out/logits'].shape), blobs[c['name'] + '/out/losses'].round(4).tolist(),
             {k: round(v, 4) for k, v in m['reg_groups'].items()}, len(m['draws'])))
