@@ -441,36 +441,67 @@ template <int KG>
 __global__ __launch_bounds__(256) void m1_logits2_kernel(const float* __restrict__ z,
                                                          const float* __restrict__ Wt,
                                                          float* __restrict__ part, int N, int C,
-                                                         int K) {
+                                                         int K, int nsub) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][2*KG tiles][256]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 15, kq = lane >> 4;
   const int cx = blockIdx.x, gx = blockIdx.y, n0 = blockIdx.z * 32;
-  const int cw = cx * 64 + wave * 16;
   const int ktiles = (K + 15) >> 4;
   const int na = min(n0 + r, N - 1), nb = min(n0 + 16 + r, N - 1);   // rows >= N: discarded at the store
-
-  // ---- one batch of loads: B fragments (Wt), A fragments (z) ----
-  float bw[KG][4];
+  int colj[KG];
 #pragma unroll
-  for (int j = 0; j < KG; ++j) {
-    const int col = min(min(gx * KG + j, ktiles - 1) * 16 + r, K - 1);   // surplus tiles / columns:
-#pragma unroll                                                            // recomputed, discarded
-    for (int e = 0; e < 4; ++e) bw[j][e] = Wt[(size_t)(cw + 4 * kq + e) * K + col];
-  }
-  const float4 a0 = *reinterpret_cast<const float4*>(z + (size_t)na * C + cw + 4 * kq);
-  const float4 a1 = *reinterpret_cast<const float4*>(z + (size_t)nb * C + cw + 4 * kq);
+  for (int j = 0; j < KG; ++j)                                          // surplus tiles / columns:
+    colj[j] = min(min(gx * KG + j, ktiles - 1) * 16 + r, K - 1);       // recomputed, discarded
 
+  // nsub 64-channel sub-chunks per block (1 at small N: one batch of loads, one round trip; 4 at N >= 128, where
+  // the C/64 partial copies of the logits -- 25.7 MB at N = 512 -- are what the kernel and its reducer move):
+  // the operands of sub-chunk s + 1 are requested before the MFMAs of sub-chunk s
+  struct Ops { float bw[KG][4]; float4 a0, a1; };
+  auto load_ops = [&](int s_, Ops& q) {
+    const int cw = (cx * nsub + s_) * 64 + wave * 16;
+#pragma unroll
+    for (int j = 0; j < KG; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) q.bw[j][e] = Wt[(size_t)(cw + 4 * kq + e) * K + colj[j]];
+    q.a0 = *reinterpret_cast<const float4*>(z + (size_t)na * C + cw + 4 * kq);
+    q.a1 = *reinterpret_cast<const float4*>(z + (size_t)nb * C + cw + 4 * kq);
+  };
+  auto settle = [&](Ops& q) {
+#pragma unroll
+    for (int j = 0; j < KG; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(q.bw[j][e]));
+    asm volatile("" : "+v"(q.a0.x), "+v"(q.a0.y), "+v"(q.a0.z), "+v"(q.a0.w));
+    asm volatile("" : "+v"(q.a1.x), "+v"(q.a1.y), "+v"(q.a1.z), "+v"(q.a1.w));
+  };
   f32x4 acc0[KG], acc1[KG];
 #pragma unroll
   for (int j = 0; j < KG; ++j) { acc0[j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[j] = acc0[j]; }
-  const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+  auto multiply = [&](const Ops& q) {
+    const float av0[4] = {q.a0.x, q.a0.y, q.a0.z, q.a0.w}, av1[4] = {q.a1.x, q.a1.y, q.a1.z, q.a1.w};
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < 4; ++e) {
 #pragma unroll
-    for (int j = 0; j < KG; ++j) {
-      acc0[j] = mfma16(av0[e], bw[j][e], acc0[j]);
-      acc1[j] = mfma16(av1[e], bw[j][e], acc1[j]);
+      for (int j = 0; j < KG; ++j) {
+        acc0[j] = mfma16(av0[e], q.bw[j][e], acc0[j]);
+        acc1[j] = mfma16(av1[e], q.bw[j][e], acc1[j]);
+      }
+    }
+  };
+  Ops PA, PB;
+  load_ops(0, PA);
+  if (nsub == 1) {
+    multiply(PA);
+  } else {
+    for (int s_ = 0; s_ < nsub; s_ += 2) {
+      settle(PA);
+      if (s_ + 1 < nsub) load_ops(s_ + 1, PB);
+      multiply(PA);
+      if (s_ + 1 < nsub) {
+        settle(PB);
+        if (s_ + 2 < nsub) load_ops(s_ + 2, PA);
+        multiply(PB);
+      }
     }
   }
   // ---- fixed-order sum of the 4 waves' 16-channel shares, then one store per element ----
@@ -680,6 +711,241 @@ __global__ __launch_bounds__(256) void m1_bwd_head_kernel(
 }
 
 // --------------------------------------------------------------------------------------------
+// B12v3: the same two products for MORE THAN ONE 32-image tile (N > 32).  The kernel above handles a tile as
+// "request every operand, wait, multiply": with one tile that is one memory round trip per block, with 16 tiles
+// (N = 512) it is sixteen of them back to back at 4 waves per CU -- 48 us for 10.5 us of fp32 MFMA work.  Here the
+// operands of tile t + 1 are in flight while tile t is multiplied (two register sets, the loop unrolled by two),
+// and nothing inside the loop waits for memory that is not needed yet:
+//   * the wait for a tile's operands sits in an opaque `asm("" : "+v")` use placed BEFORE the next tile's loads
+//     are issued (the compiler does not count returns across a loop's back edge: where it would put the wait
+//     by itself -- at the first MFMA -- it waits for the loads just issued as well);
+//   * role 0's exchange through `red` uses raw barriers with an LDS-only wait (`__syncthreads` is a fence: it
+//     waits for every outstanding global load, i.e. for the prefetch);
+//   * sn[n] = G[n,:].bt and dbt[k] = sum_n abar[n] G[n,k] are computed FROM THE FRAGMENTS a block holds anyway
+//     (the four waves of a block cover whole rows / all columns of G) by one owner block per tile / by block 0,
+//     instead of from extra global loads that are consumed -- waited for -- on the spot.
+// Same MFMA sequence per output as the one-tile kernel; sn and dbt change their (fixed) summation order.
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ void raw_barrier_lds() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int UG>
+__global__ __launch_bounds__(256) void m1_bwd_head_tiles_kernel(
+    const float* __restrict__ G, const float* __restrict__ Wt, const float* __restrict__ zsave,
+    const float* __restrict__ abar, const float* __restrict__ bt, float* __restrict__ dz,
+    float* __restrict__ dWt, float* __restrict__ dbt, float* __restrict__ sn, int N, int C, int K,
+    float* __restrict__ loss, float lscale) {
+  __shared__ float red[4 * 2 * 256];
+  __shared__ float sred[4][32];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, kq = lane >> 4;
+  const int role = blockIdx.x & 1, b = blockIdx.x >> 1, c0 = b * 16, nslab = gridDim.x >> 1;
+  const int ntiles = (N + 31) >> 5;
+
+  if (role == 0) {
+    // ------------------------------ dz + sn ------------------------------
+    f4u bq[UG], btq[UG];
+    int colc[UG];
+#pragma unroll
+    for (int j = 0; j < UG; ++j) {
+      const int col0 = 16 * (wave + 4 * j) + 4 * kq;
+      colc[j] = min(col0, K - 4);   // ragged / surplus groups re-read the row's last 4 columns ...
+      f4u v = *reinterpret_cast<const f4u*>(Wt + (size_t)(c0 + r) * K + colc[j]);
+      f4u w = *reinterpret_cast<const f4u*>(bt + colc[j]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float keep = (colc[j] + e >= col0) ? 1.f : 0.f;   // ... masked: each k once
+        v[e] *= keep;
+        w[e] *= keep;
+      }
+      bq[j] = v;
+      btq[j] = w;
+    }
+    auto load_tile = [&](int t, f4u (&q0)[UG], f4u (&q1)[UG]) {
+      const float* g0 = G + (size_t)min(32 * t + r, N - 1) * K;        // rows >= N: discarded at the store
+      const float* g1 = G + (size_t)min(32 * t + 16 + r, N - 1) * K;
+#pragma unroll
+      for (int j = 0; j < UG; ++j) {
+        q0[j] = *reinterpret_cast<const f4u*>(g0 + colc[j]);
+        q1[j] = *reinterpret_cast<const f4u*>(g1 + colc[j]);
+      }
+    };
+    auto settle = [&](f4u (&q0)[UG], f4u (&q1)[UG]) {
+#pragma unroll
+      for (int j = 0; j < UG; ++j) {
+        asm volatile("" : "+v"(q0[j]));
+        asm volatile("" : "+v"(q1[j]));
+      }
+    };
+    auto do_tile = [&](int t, const f4u (&q0)[UG], const f4u (&q1)[UG]) {
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < UG; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a0 = mfma16(q0[j][e], bq[j][e], a0);
+          a1 = mfma16(q1[j][e], bq[j][e], a1);
+        }
+      }
+      // sn of this tile's 32 rows: one owner block per tile, from the fragments (each wave holds a quarter of
+      // the k groups of rows r and 16 + r; lanes of one row differ in kq)
+      const bool owner = (t % nslab) == b;
+      float s0 = 0.f, s1 = 0.f;
+      if (owner) {
+#pragma unroll
+        for (int j = 0; j < UG; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            s0 = fmaf(q0[j][e], btq[j][e], s0);
+            s1 = fmaf(q1[j][e], btq[j][e], s1);
+          }
+        s0 += __shfl_xor(s0, 16); s0 += __shfl_xor(s0, 32);
+        s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+      }
+      if (t > 0) raw_barrier_lds();   // the previous tile's readers of red / sred are done
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        red[(wave * 2 + 0) * 256 + (kq * 4 + reg) * 16 + r] = a0[reg];
+        red[(wave * 2 + 1) * 256 + (kq * 4 + reg) * 16 + r] = a1[reg];
+      }
+      if (owner && kq == 0) {
+        sred[wave][r] = s0;
+        sred[wave][16 + r] = s1;
+      }
+      raw_barrier_lds();
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int row = tid >> 4, col = tid & 15;
+        const float s = (red[(0 * 2 + ni) * 256 + tid] + red[(1 * 2 + ni) * 256 + tid]) +
+                        (red[(2 * 2 + ni) * 256 + tid] + red[(3 * 2 + ni) * 256 + tid]);
+        const int n = 32 * t + ni * 16 + row;
+        if (n < N) dz[(size_t)n * C + c0 + col] = s;
+      }
+      if (owner && tid < 32 && 32 * t + tid < N)
+        sn[32 * t + tid] = (sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid]);
+    };
+    f4u A0[UG], A1[UG], B0[UG], B1[UG];
+    load_tile(0, A0, A1);
+    for (int t = 0; t < ntiles; t += 2) {
+      settle(A0, A1);
+      if (t + 1 < ntiles) load_tile(t + 1, B0, B1);
+      do_tile(t, A0, A1);
+      if (t + 1 < ntiles) {
+        settle(B0, B1);
+        if (t + 2 < ntiles) load_tile(t + 2, A0, A1);
+        do_tile(t + 1, B0, B1);
+      }
+    }
+    return;
+  }
+
+  // ------------------------------ dWt + dbt ------------------------------
+  const int ktiles = (K + 15) >> 4;
+  int gcol[UG];
+#pragma unroll
+  for (int j = 0; j < UG; ++j)   // surplus tiles recompute the last one; columns >= K are clamped
+    gcol[j] = min(min(wave + 4 * j, ktiles - 1) * 16 + r, K - 1);   // (both discarded at the store)
+  f32x4 wacc[UG];
+  float dacc[UG];
+#pragma unroll
+  for (int j = 0; j < UG; ++j) { wacc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; dacc[j] = 0.f; }
+  const bool dbt_owner = b == 0;          // block 0's four waves hold every column of G
+  const bool do_loss = loss != nullptr && b == 0;
+  float lrow = 0.f;
+  if (do_loss) {   // the slot orders of the one-tile kernel (bit-identical loss for every N)
+    if (N <= 64) {
+      if (wave == 2 && lane < N) lrow = loss[1 + lane];
+    } else {
+      for (int i = tid; i < N; i += 256) lrow += loss[1 + i];
+    }
+  }
+  // Loads only -- nothing that consumes a loaded value (a multiply by the row's live flag would make the compiler
+  // wait for the load on the spot); rows >= N are zeroed when the tile is multiplied.  The 9 + UG scalar loads of
+  // a 4-row group (their address arithmetic included) cost about as much issue time as the group's UG MFMAs, and
+  // with one wave per SIMD nothing else fills the gap: the NEXT tile's row group u is requested right behind
+  // the MFMAs of the current tile's row group u, so the two overlap.
+  struct TileRegs { float az[8], ab[8], bg[UG][8]; };
+  auto load_group = [&](int t, int u, TileRegs& q) {
+    const size_t nc = (size_t)min(32 * t + 4 * u + kq, N - 1);
+    q.az[u] = zsave[nc * C + c0 + r];
+    q.ab[u] = abar[nc];
+    const float* grow = G + nc * K;
+#pragma unroll
+    for (int j = 0; j < UG; ++j) q.bg[j][u] = grow[gcol[j]];
+  };
+  auto settle = [&](TileRegs& q) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      asm volatile("" : "+v"(q.az[u]));
+      asm volatile("" : "+v"(q.ab[u]));
+#pragma unroll
+      for (int j = 0; j < UG; ++j) asm volatile("" : "+v"(q.bg[j][u]));
+    }
+  };
+  auto do_tile = [&](int t, const TileRegs& q, TileRegs& nxt, bool has_next) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float live = 32 * t + 4 * u + kq < N ? 1.f : 0.f;   // rows >= N contribute nothing
+      const float az = q.az[u] * live, ab = q.ab[u] * live;
+#pragma unroll
+      for (int j = 0; j < UG; ++j) wacc[j] = mfma16(az, q.bg[j][u], wacc[j]);
+      if (dbt_owner) {
+#pragma unroll
+        for (int j = 0; j < UG; ++j) dacc[j] = fmaf(ab, q.bg[j][u], dacc[j]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (has_next) load_group(t + 1, u, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  TileRegs TA, TB;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) load_group(0, u, TA);
+  for (int t = 0; t < ntiles; t += 2) {
+    settle(TA);
+    do_tile(t, TA, TB, t + 1 < ntiles);
+    if (t + 1 < ntiles) {
+      settle(TB);
+      do_tile(t + 1, TB, TA, t + 2 < ntiles);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < UG; ++j) {
+    const int col = (wave + 4 * j) * 16 + r;
+    if (col < K) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+        dWt[(size_t)(c0 + kq * 4 + reg) * K + col] = wacc[j][reg];
+    }
+    if (dbt_owner) {                       // rows 4u + kq of every tile: sum the four kq lanes of a column
+      float d = dacc[j];
+      d += __shfl_xor(d, 16);
+      d += __shfl_xor(d, 32);
+      if (kq == 0 && col < K && wave + 4 * j < ktiles) dbt[col] = d;
+    }
+  }
+  if (do_loss) {   // block-uniform; `red` is unused by this role
+    if (N <= 64) {
+      if (wave == 2) {
+        red[lane] = lrow;
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+          float t = 0.f;
+          for (int w = 0; w < 32; ++w) t += (0.f + red[w]) + red[w + 32];
+          loss[0] = t * lscale;
+        }
+      }
+    } else {
+      lrow = wave_sum(lrow);
+      if (lane == 0) red[wave] = lrow;
+      __syncthreads();
+      if (tid == 0) loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) * lscale;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------
 // B4: dwa[c] = sum_b pdwa[b][c] (fixed order), dba = sum_b pdba[b].
 // grid = ceil(C/32) blocks of 1024 threads: 32 row groups x 32 columns, 128-byte row segments.
 // The last kernel of the backward call: optionally advances the HBM dropout counter.
@@ -780,12 +1046,17 @@ int m1_logits(const float* z, const float* Wt, const float* abar, const float* b
 bool m1_logits2_supported(int C, int K) { return C % 64 == 0 && K >= 1; }
 size_t m1_logits2_ws_bytes(int N, int C, int K) { return (size_t)(C / 64) * N * K * sizeof(float); }
 
+// 64-channel sub-chunks summed inside a block: 1 while the kernel is a latency chain (N < 128), 4 where the partial
+// copies of the logits are what it moves (C / 256 instead of C / 64 of them)
+static int logits2_nsub(int N, int C) { return (N >= 128 && C % 256 == 0) ? 4 : 1; }
+
 static int launch_logits2(const float* z, const float* Wt, float* part_ws, int N, int C, int K, hipStream_t st) {
   constexpr int KG = 7;
   const int ktiles = (K + 15) / 16;
-  dim3 grid(C / 64, (ktiles + KG - 1) / KG, (N + 31) / 32);
+  const int nsub = logits2_nsub(N, C);
+  dim3 grid(C / (64 * nsub), (ktiles + KG - 1) / KG, (N + 31) / 32);
   const size_t shm = (size_t)4 * 2 * KG * 256 * sizeof(float);   // 56 KB
-  hipLaunchKernelGGL((m1_logits2_kernel<KG>), grid, dim3(256), shm, st, z, Wt, part_ws, N, C, K);
+  hipLaunchKernelGGL((m1_logits2_kernel<KG>), grid, dim3(256), shm, st, z, Wt, part_ws, N, C, K, nsub);
   APA_LAUNCH_CHECK("m1_logits2_kernel");
   return APA_OK;
 }
@@ -798,7 +1069,7 @@ int m1_logits2(const float* z, const float* Wt, const float* abar, const float* 
   }
   if (!(dbg_skip() & 8))
   hipLaunchKernelGGL(m1_logits_reduce_kernel, dim3((N * K + 255) / 256), dim3(256), 0, st, part_ws,
-                     abar, bt, logits, N, K, C / 64);
+                     abar, bt, logits, N, K, C / (64 * logits2_nsub(N, C)));
   APA_LAUNCH_CHECK("m1_logits_reduce_kernel");
   return APA_OK;
 }
@@ -817,14 +1088,15 @@ int m1_logits2_xent(const float* z, const float* Wt, const float* abar, const fl
     const int rc = launch_logits2(z, Wt, part_ws, N, C, K, st);
     if (rc != APA_OK) return rc;
   }
+  const int nparts = C / (64 * logits2_nsub(N, C));
 #define APA_LX(NV4)                                                                                  \
   do {                                                                                               \
     if (probs)                                                                                       \
       hipLaunchKernelGGL((m1_logits_xent_kernel<NV4, true>), dim3(N), dim3(256), 0, st, part_ws,     \
-                         abar, bt, labels, logits, loss, G, probs, pred, N, K, C / 64, gscale);      \
+                         abar, bt, labels, logits, loss, G, probs, pred, N, K, nparts, gscale);      \
     else                                                                                             \
       hipLaunchKernelGGL((m1_logits_xent_kernel<NV4, false>), dim3(N), dim3(256), 0, st, part_ws,    \
-                         abar, bt, labels, logits, loss, G, probs, pred, N, K, C / 64, gscale);      \
+                         abar, bt, labels, logits, loss, G, probs, pred, N, K, nparts, gscale);      \
   } while (0)
   if (K <= 128) APA_LX(1);
   else if (K <= 256) APA_LX(2);
@@ -878,6 +1150,18 @@ int m1_bwd_head(const float* G, const float* Wt, const float* zsave, const float
   const int nb = C / 16;
   const int kpb = (K + nb - 1) / nb;
   const int ug = (((K + 15) / 16) + 3) / 4;
+  if (N > 32 && ug <= 7 && knob("APA_M1_BWD_HEAD_TILES", 1)) {   // several image tiles: the pipelined form
+#define APA_BHT(UG)                                                                                      \
+  hipLaunchKernelGGL(m1_bwd_head_tiles_kernel<UG>, dim3(2 * nb), dim3(256), 0, st, G, Wt, zsave, abar, \
+                     bt, dz, dWt, dbt, sn, N, C, K, loss, lscale)
+    if (ug <= 1) APA_BHT(1);
+    else if (ug <= 2) APA_BHT(2);
+    else if (ug <= 4) APA_BHT(4);
+    else APA_BHT(7);
+#undef APA_BHT
+    APA_LAUNCH_CHECK("m1_bwd_head_tiles_kernel");
+    return APA_OK;
+  }
 #define APA_BH(UG)                                                                                \
   hipLaunchKernelGGL(m1_bwd_head_kernel<UG>, dim3(2 * nb), dim3(256), 0, st, G, Wt, zsave, abar, \
                      bt, dz, dWt, dbt, sn, N, C, K, kpb, loss, lscale)
