@@ -296,23 +296,31 @@ __global__ __launch_bounds__(256) void pc_bwd_dw_kernel(
   const int rbeg = blockIdx.y * rows_per_split, rend = min(R, rbeg + rows_per_split);
   const int nk = (rend - rbeg + FK - 1) / FK;
 
-  uint4 av[4], bv[4];
-  uint32_t mb[TRAIN ? 4 : 1];
-  auto load = [&](int t) {
+  // Two tiles ahead through registers: a tile's 9 loads per thread are requested two iterations before they are
+  // parked in LDS (one iteration of MFMAs does not cover a round trip to HBM with 224 blocks streaming X).  The wait
+  // for tile t + 1 sits in an opaque use BEFORE tile t + 2 is requested, and the hand-over barrier waits for LDS
+  // only -- `__syncthreads` is a fence and would wait for the prefetch as well.
+  struct Stage { uint4 av[4], bv[4]; uint32_t mb[TRAIN ? 4 : 1]; };
+  auto load = [&](int t, Stage& q) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int vi = tid + i * 256;
       const int r = rbeg + t * FK + (vi >> 4), m = (vi & 15) * 8;
       const int rc = min(r, rend - 1);
-      const uint4 a = ld16(X + (size_t)rc * C + c0 + m);
-      const uint4 b = ld16(dTdZ + (size_t)rc * 128 + m);
-      if (TRAIN) mb[i] = maskbits[((size_t)rc * C + c0 + m) >> 3];
-      const bool ok = r < rend;
-      av[i] = ok ? a : make_uint4(0u, 0u, 0u, 0u);
-      bv[i] = ok ? b : make_uint4(0u, 0u, 0u, 0u);
+      q.av[i] = ld16(X + (size_t)rc * C + c0 + m);
+      q.bv[i] = ld16(dTdZ + (size_t)rc * 128 + m);
+      if (TRAIN) q.mb[i] = maskbits[((size_t)rc * C + c0 + m) >> 3];
     }
   };
-  auto store = [&](int buf, int t) {
+  auto settle = [&](Stage& q) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      asm volatile("" : "+v"(q.av[i].x), "+v"(q.av[i].y), "+v"(q.av[i].z), "+v"(q.av[i].w));
+      asm volatile("" : "+v"(q.bv[i].x), "+v"(q.bv[i].y), "+v"(q.bv[i].z), "+v"(q.bv[i].w));
+      if (TRAIN) asm volatile("" : "+v"(q.mb[i]));
+    }
+  };
+  auto store = [&](int buf, int t, const Stage& q) {
     short* a0 = smem + buf * STAGE;
     short* a1 = a0 + IMG;
     short* b = a0 + (TRAIN ? 2 : 1) * IMG;
@@ -320,11 +328,15 @@ __global__ __launch_bounds__(256) void pc_bwd_dw_kernel(
     for (int i = 0; i < 4; ++i) {
       const int vi = tid + i * 256;
       const int kk = vi >> 4, m = (vi & 15) * 8;
-      *reinterpret_cast<uint4*>(a0 + kk * LDM + m) = av[i];
-      if (TRAIN) *reinterpret_cast<uint4*>(a1 + kk * LDM + m) = apply_bits8(av[i], mb[i]);
-      *reinterpret_cast<uint4*>(b + kk * LDM + m) = bv[i];
+      const bool ok = rbeg + t * FK + kk < rend;                  // rows past the split: zero operands
+      const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+      const uint4 a = ok ? q.av[i] : z4, bb = ok ? q.bv[i] : z4;
+      *reinterpret_cast<uint4*>(a0 + kk * LDM + m) = a;
+      if (TRAIN) *reinterpret_cast<uint4*>(a1 + kk * LDM + m) = apply_bits8(a, q.mb[i]);
+      *reinterpret_cast<uint4*>(b + kk * LDM + m) = bb;
     }
   };
+  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -332,17 +344,10 @@ __global__ __launch_bounds__(256) void pc_bwd_dw_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (nk > 0) {
-    load(0);
-    store(0, 0);
-  }
-  __syncthreads();
-  for (int t = 0; t < nk; ++t) {
+  auto compute = [&](int t) {
     // half 0 (dT columns) contracts against the MASKED features, half 1 (dZ) against the plain ones
     const short* a_img = smem + (t & 1) * STAGE + ((TRAIN && half == 0) ? IMG : 0);
     const short* b_img = smem + (t & 1) * STAGE + (TRAIN ? 2 : 1) * IMG;
-    const bool more = t + 1 < nk;
-    if (more) load(t + 1);
 #pragma unroll
     for (int ks = 0; ks < FK / 32; ++ks) {
       bf16x8 af[4], bf[4];
@@ -357,8 +362,27 @@ __global__ __launch_bounds__(256) void pc_bwd_dw_kernel(
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
-    if (more) store((t + 1) & 1, t + 1);
-    __syncthreads();
+  };
+  Stage SA, SB;
+  if (nk > 0) {
+    load(0, SA);
+    if (nk > 1) load(1, SB);
+    settle(SA);
+    store(0, 0, SA);
+  }
+  lds_barrier();
+  // iteration t: tile t + 1 (register set `nx`) is parked in LDS after tile t has been multiplied; tile t + 2 is
+  // requested into the set tile t just vacated
+  auto iteration = [&](int t, Stage& nx, Stage& fr) {
+    if (t + 1 < nk) settle(nx);
+    if (t + 2 < nk) load(t + 2, fr);
+    compute(t);
+    if (t + 1 < nk) store((t + 1) & 1, t + 1, nx);
+    lds_barrier();
+  };
+  for (int t = 0; t < nk; t += 2) {
+    iteration(t, SB, SA);
+    if (t + 1 < nk) iteration(t + 1, SA, SB);
   }
   float* out = partial + ((size_t)blockIdx.y * C + c0) * 128;
 #pragma unroll
