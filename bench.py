@@ -168,6 +168,26 @@ def _claim_stdout():
     return real
 
 
+def _self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it: start N ranks of this same command under
+    torch.distributed.run on a free loopback port (the line the module docstring shows) and return its
+    exit status.  The ranks inherit this process's stdout, so rank 0's single JSON line lands where the
+    caller expects it; the launcher's own chatter goes to stderr."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC only on these hosts (RCCL needs it)
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print('bench.py: launching {} ranks: {}'.format(n, ' '.join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def _median(v):
     v = sorted(v)
     return v[len(v) // 2]
@@ -342,14 +362,17 @@ def kernel_times(cof, work, step_with_hooks, barrier, n, base_hooks=None):
 
 def main():
     args = parse_args()
-    real_stdout = _claim_stdout()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` typed as is: become the launcher (one process per GPU, the same
+        # command line the driver would use) and hand this process's stdout to rank 0's JSON line
+        raise SystemExit(_self_launch(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch N>1 with: python -m torch.distributed.run --nproc-per-node N ... '
-                             'bench.py --gpus N (one process per GPU)')
+        raise SystemExit('bench.py --gpus {} started with WORLD_SIZE={}: the two must agree (one process per '
+                         'GPU)'.format(args.gpus, world))
+    real_stdout = _claim_stdout()
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback for the product path)'
     if args.comm == 'gloo':                      # ranks may share a GPU in this mode
         local_rank %= torch.cuda.device_count()

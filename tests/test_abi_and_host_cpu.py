@@ -313,3 +313,36 @@ def test_config_loads_every_shipped_experiment_unchanged():
         apa_config.cfg_from_file(f)
         assert cfg.MODEL_NAME == 'resnet_v1_101' and cfg.TRAIN.BATCH_SIZE == 16
     apa_config.reset_cfg()
+
+
+def test_bench_gpus_n_without_a_launcher_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` typed as is (no WORLD_SIZE in the environment) must become the launcher:
+    N ranks of the same command line under torch.distributed.run on the loopback address, and exit with
+    the launcher's status.  (The 2-rank run itself is `test_bench_two_ranks_sharing_one_gpu_over_gloo[self]`.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen['cmd'], seen['env'] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, 'call', fake_call)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '5', '--warmup', '1'])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen['cmd']
+    assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nnodes=1' in cmd
+    assert cmd[cmd.index('--nproc-per-node') + 1] == '4' and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert cmd[-7].endswith('bench.py') and cmd[-6:] == ['--gpus', '4', '--steps', '5', '--warmup', '1']
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    # a rank started by a launcher with a different world size is a usage error, not a silent 1-GPU run
+    monkeypatch.setenv('WORLD_SIZE', '2')
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert 'must agree' in str(e.value.code)

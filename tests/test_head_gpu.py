@@ -1216,12 +1216,14 @@ def test_yaml_driven_training_loop_matches_cpu_reference_loop(gpu):
     apa_config.reset_cfg()
 
 
-def test_bench_two_ranks_sharing_one_gpu_over_gloo(gpu):
+@pytest.mark.parametrize('launcher', ['torchrun', 'self'])
+def test_bench_two_ranks_sharing_one_gpu_over_gloo(gpu, launcher):
     """The driver's N > 1 launch line (`python -m torch.distributed.run --nproc-per-node N ... bench.py
     --gpus N`) on this single-GPU box: two ranks share the GPU and sum their gradient buckets over gloo
     (`--comm gloo`).  Covers rendezvous on 127.0.0.1, per-rank inputs, the barrier-bracketed timing with
     the max over ranks, whole-job throughput, rank-0-only JSON and the teardown -- everything of the
-    N > 1 flow except the RCCL transport itself."""
+    N > 1 flow except the RCCL transport itself.  `self`: the plain `python bench.py --gpus 2 ...` command,
+    which must start its own ranks and print the same single line."""
     import json
     import socket
     import subprocess
@@ -1231,10 +1233,12 @@ def test_bench_two_ranks_sharing_one_gpu_over_gloo(gpu):
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
-    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-                          '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'),
-                          '--gpus', '2', '--steps', '20', '--warmup', '3', '--comm', 'gloo'],
-                         capture_output=True, text=True, timeout=900, cwd=root)
+    tail = [os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '3', '--comm', 'gloo']
+    head = [sys.executable] if launcher == 'self' else [
+        sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+        '--master-addr', '127.0.0.1', '--master-port', str(port)]
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    out = subprocess.run(head + tail, capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith('{')]
     assert len(lines) == 1, out.stdout[-2000:]
