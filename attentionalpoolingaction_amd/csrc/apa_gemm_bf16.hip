@@ -689,7 +689,8 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_glds64_kernel(FastParams p) 
 // MT x 2 MFMA tiles: MT + 2 fragment reads per 2 MT MFMAs (the 4 x 4 layout above: 8 per 16).
 // ---------------------------------------------------------------------------------------------
 static int gemm_cu_count() {
-  static thread_local int cus = 0;
+  static thread_local PerDevice<int> cus_dev;
+  int& cus = cus_dev.here();
   if (!cus) {
     int dev = 0, v = 0;
     if (hipGetDevice(&dev) == hipSuccess &&
@@ -884,7 +885,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_ring_kernel(FastParams p) {
 template <typename TC, bool B_KM, int MT>
 int launch_ring(const FastParams& p, hipStream_t st) {
   typedef RingCfg<MT> R;
-  static thread_local bool attr_set = false;
+  static thread_local PerDevice<bool> attr_dev; bool& attr_set = attr_dev.here();
   if (!attr_set) {
     APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<TC, B_KM, MT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)R::LDS_BYTES));
@@ -938,7 +939,7 @@ int launch_glds64_layout(const FastParams& p, bool a_km, bool b_km, int splits, 
 template <typename TC, bool A_KM, bool B_KM>
 int launch_glds(const FastParams& p, int splits, hipStream_t st) {
   const size_t shm = (size_t)2 * 2 * OP_ELEMS * sizeof(short);   // epilogue stage needs 67 584 B
-  static thread_local bool attr_set = false;
+  static thread_local PerDevice<bool> attr_dev; bool& attr_set = attr_dev.here();
   if (!attr_set) {
     APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_glds_kernel<TC, A_KM, B_KM>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
@@ -963,7 +964,7 @@ int launch_glds_layout(const FastParams& p, bool a_km, bool b_km, int splits, hi
 template <typename TA, typename TB, typename TC, bool A_KM, bool B_KM>
 int launch(const FastParams& p, int splits, hipStream_t st) {
   const size_t shm = (size_t)2 * 2 * OP_ELEMS * sizeof(short);   // 73 728 B
-  static thread_local bool attr_set = false;
+  static thread_local PerDevice<bool> attr_dev; bool& attr_set = attr_dev.here();
   if (!attr_set) {
     APA_HIP_CHECK(hipFuncSetAttribute(
         reinterpret_cast<const void*>(gemm_bf16_kernel<TA, TB, TC, A_KM, B_KM>),
@@ -1006,7 +1007,7 @@ int gemm_bf16_mid_dropout(const void* A, long lda, const void* B, long ldb, void
   p.drop_mid = 0;
   p.maskbits = maskbits;
   const size_t shm = (size_t)2 * 2 * OP_ELEMS * sizeof(short);
-  static thread_local bool attr_set = false;
+  static thread_local PerDevice<bool> attr_dev; bool& attr_set = attr_dev.here();
   if (!attr_set) {
     APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_glds_kernel<bf16_t, false, false, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));

@@ -14,6 +14,20 @@ namespace apa {
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);
 
+// Per-device memo slots.  A host thread may hipSetDevice between two calls, so whatever a launcher remembers
+// about "the device" (CU count, LDS limit, "hipFuncSetAttribute already done for this kernel") is keyed by the
+// CURRENT device id, not just by the thread.
+constexpr int APA_MAX_DEVICES = 64;
+inline int current_device_slot() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0;
+  return d % APA_MAX_DEVICES;
+}
+template <typename T> struct PerDevice {
+  T v[APA_MAX_DEVICES] = {};
+  T& here() { return v[current_device_slot()]; }
+};
+
 #define APA_HIP_CHECK(expr)                                   \
   do {                                                        \
     hipError_t _e = (expr);                                   \

@@ -220,7 +220,8 @@ int set_lds(K kernel, size_t shm) {
 // thread, so a channel count whose accumulator rows do not fit is refused with APA_ERR_UNSUPPORTED instead of
 // failing inside hipFuncSetAttribute / the launch
 static size_t max_block_lds() {
-  static thread_local size_t cached = 0;
+  static thread_local PerDevice<size_t> cached_dev;
+  size_t& cached = cached_dev.here();
   if (!cached) {
     int dev = 0, v = 0;
     if (hipGetDevice(&dev) == hipSuccess &&

@@ -1119,7 +1119,7 @@ int m1_bwd_small(const float* G, const float* Wt, const float* zsave, const floa
 #define APA_BS(MV)                                                                               \
   do {                                                                                           \
     if (shm > 64 * 1024) {                                                                       \
-      static thread_local bool attr_set = false;                                                 \
+      static thread_local PerDevice<bool> attr_dev; bool& attr_set = attr_dev.here(); \
       if (!attr_set) {                                                                           \
         APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(m1_bwd_small_kernel<MV>), \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \

@@ -59,6 +59,9 @@ struct AccParts {
   const float* p[APA_ACC_MAX_PARTS];
   int n;
 };
+// DIV: out = sum / scale (the reference's own arithmetic, `ref_grad / float(ITER_SIZE)`, IEEE division: differs
+// from sum * (1 / ITER_SIZE) by an ulp when ITER_SIZE is not a power of two); otherwise out = sum * scale.
+template <bool DIV>
 __global__ __launch_bounds__(256) void accumulate_kernel(AccParts parts, float* __restrict__ out, size_t n,
                                                          float scale) {
   typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -71,14 +74,14 @@ __global__ __launch_bounds__(256) void accumulate_kernel(AccParts parts, float* 
       for (int e = 0; e < 4; ++e) acc[e] += g[e];
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] *= scale;
+    for (int e = 0; e < 4; ++e) acc[e] = DIV ? acc[e] / scale : acc[e] * scale;
     *reinterpret_cast<f4u*>(out + v * 4) = acc;
   }
   if (blockIdx.x == 0) {
     for (size_t i = nv * 4 + threadIdx.x; i < n; i += 256) {
       float acc = parts.p[0][i];
       for (int k = 1; k < parts.n; ++k) acc += parts.p[k][i];
-      out[i] = acc * scale;
+      out[i] = DIV ? acc / scale : acc * scale;
     }
   }
 }
@@ -87,17 +90,18 @@ __global__ __launch_bounds__(256) void accumulate_kernel(AccParts parts, float* 
 
 using namespace apa;
 
-extern "C" int apa_accumulate_gradients(float* out, const float* const* parts, int nparts, size_t n,
-                                        float scale, void* stream) {
-  if (!out || !parts || nparts < 1 || nparts > APA_ACC_MAX_PARTS) {
-    set_error("apa_accumulate_gradients: bad arguments (nparts=%d, max %d)", nparts, APA_ACC_MAX_PARTS);
+static int accumulate_launch(const char* who, bool div, float* out, const float* const* parts, int nparts, size_t n,
+                             float scale, void* stream) {
+  if (!out || !parts || nparts < 1 || nparts > APA_ACC_MAX_PARTS || (div && scale == 0.f)) {
+    set_error("%s: bad arguments (nparts=%d, max %d%s)", who, nparts, APA_ACC_MAX_PARTS,
+              div && scale == 0.f ? ", divisor 0" : "");
     return APA_ERR_INVALID_ARG;
   }
   AccParts a;
   a.n = nparts;
   for (int k = 0; k < nparts; ++k) {
     if (!parts[k]) {
-      set_error("apa_accumulate_gradients: parts[%d] is NULL", k);
+      set_error("%s: parts[%d] is NULL", who, k);
       return APA_ERR_INVALID_ARG;
     }
     a.p[k] = parts[k];
@@ -106,10 +110,24 @@ extern "C" int apa_accumulate_gradients(float* out, const float* const* parts, i
   size_t nb = (n / 4 + 255) / 256;
   if (nb < 1) nb = 1;
   if (nb > 1024) nb = 1024;
-  hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)nb), dim3(256), 0, static_cast<hipStream_t>(stream), a, out,
-                     n, scale);
+  if (div)
+    hipLaunchKernelGGL(accumulate_kernel<true>, dim3((unsigned)nb), dim3(256), 0, static_cast<hipStream_t>(stream), a,
+                       out, n, scale);
+  else
+    hipLaunchKernelGGL(accumulate_kernel<false>, dim3((unsigned)nb), dim3(256), 0, static_cast<hipStream_t>(stream), a,
+                       out, n, scale);
   APA_LAUNCH_CHECK("accumulate_kernel");
   return APA_OK;
+}
+
+extern "C" int apa_accumulate_gradients(float* out, const float* const* parts, int nparts, size_t n,
+                                        float scale, void* stream) {
+  return accumulate_launch("apa_accumulate_gradients", false, out, parts, nparts, n, scale, stream);
+}
+
+extern "C" int apa_accumulate_gradients_div(float* out, const float* const* parts, int nparts, size_t n,
+                                            float divisor, void* stream) {
+  return accumulate_launch("apa_accumulate_gradients_div", true, out, parts, nparts, n, divisor, stream);
 }
 
 extern "C" int apa_momentum_sgd_step(int nseg, float* const* weights, const size_t* sizes,

@@ -458,7 +458,7 @@ int pc_fused_forward(const PcFusedWs& f, const void* X, float* Z, float* T, int 
   const float ik = train ? 1.0f / keep_prob : 1.0f;
   const bf16_t* xx = static_cast<const bf16_t*>(X);
   const bf16_t* ww = static_cast<const bf16_t*>(f.WcatT);
-  static thread_local bool attr_set = false;
+  static thread_local PerDevice<bool> attr_dev; bool& attr_set = attr_dev.here();
   if (!attr_set) {
     APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_fwd_zt_dma_kernel<true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_BYTES));
@@ -503,7 +503,7 @@ int pc_fused_dw(const PcFusedWs& f, const void* X, float* dWt, float* dWa, int R
   const bf16_t* x = static_cast<const bf16_t*>(X);
   const bf16_t* g = static_cast<const bf16_t*>(f.dTdZ);
   if (train) {
-    static thread_local bool attr_set = false;
+    static thread_local PerDevice<bool> attr_dev; bool& attr_set = attr_dev.here();
     if (!attr_set) {
       APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_bwd_dw_kernel<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
@@ -512,7 +512,7 @@ int pc_fused_dw(const PcFusedWs& f, const void* X, float* dWt, float* dWa, int R
     hipLaunchKernelGGL(pc_bwd_dw_kernel<true>, dim3(ctiles, S), dim3(256), shm, st, x, g, f.maskbits, f.partial,
                        R, C, rows_per_split);
   } else {
-    static thread_local bool attr_set = false;
+    static thread_local PerDevice<bool> attr_dev; bool& attr_set = attr_dev.here();
     if (!attr_set) {
       APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_bwd_dw_kernel<false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));

@@ -89,6 +89,7 @@ _SIGNATURES = {
     'apa_momentum_sgd_step': (c_int, [c_int, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_float),
                                       c_void_p, c_void_p, c_float, c_float, c_float, c_void_p]),
     'apa_accumulate_gradients': (c_int, [c_void_p, POINTER(c_void_p), c_int, c_size_t, c_float, c_void_p]),
+    'apa_accumulate_gradients_div': (c_int, [c_void_p, POINTER(c_void_p), c_int, c_size_t, c_float, c_void_p]),
     'apa_prof_event_create': (c_int, [POINTER(c_void_p)]),
     'apa_prof_event_destroy': (c_int, [c_void_p]),
     'apa_prof_event_record': (c_int, [c_void_p, c_void_p]),
@@ -870,18 +871,39 @@ def momentum_sgd_step(weights, weight_decay, grad_flat, acc_flat, lr, momentum=0
 # --------------------------------------------------------------------------------------------
 # measurement hooks (bench.py)
 # --------------------------------------------------------------------------------------------
-def accumulate_gradients(out: torch.Tensor, parts, scale: float, stream: Optional[int] = None) -> None:
-    """out = (parts[0] + parts[1] + ...) * scale, summed in that order (apa_accumulate_gradients: TRAIN.ITER_SIZE
-    accumulation of micro-batch buckets, src/train.py:529-566)."""
+ACC_MAX_PARTS = 8      # APA_ACC_MAX_PARTS (include/apa.h)
+
+
+def accumulate_gradients(out: torch.Tensor, parts, scale: Optional[float] = None, stream: Optional[int] = None,
+                         divisor: Optional[float] = None) -> None:
+    """out = (parts[0] + parts[1] + ...) / divisor  -- or  ... * scale --, summed in that order (TRAIN.ITER_SIZE
+    accumulation of micro-batch buckets, src/train.py:529-566).  `divisor=ITER_SIZE` is the reference's own
+    arithmetic (`ref_grad / float(ITER_SIZE)`, apa_accumulate_gradients_div).  More than APA_ACC_MAX_PARTS
+    parts are folded in groups, left to right, so the summation order stays that of the sequential loop."""
+    if (scale is None) == (divisor is None):
+        raise ApaError('accumulate_gradients: give exactly one of scale / divisor')
     lib = load_library()
     n = out.numel()
-    arr = (c_void_p * len(parts))(*[_dev_ptr(p_, 'part', torch.float32) for p_ in parts])
+    parts = list(parts)
     for p_ in parts:
         if p_.numel() != n:
             raise ApaError('accumulate_gradients: every part must have out.numel() elements')
-    rc = lib.apa_accumulate_gradients(_dev_ptr(out, 'out', torch.float32), arr, len(parts), n, float(scale),
-                                      _stream_ptr() if stream is None else stream)
-    _check(rc, 'apa_accumulate_gradients')
+    st = _stream_ptr() if stream is None else stream
+    optr = _dev_ptr(out, 'out', torch.float32)
+
+    def launch(group, last):
+        arr = (c_void_p * len(group))(*[_dev_ptr(p_, 'part', torch.float32) for p_ in group])
+        if last and divisor is not None:
+            rc = lib.apa_accumulate_gradients_div(optr, arr, len(group), n, float(divisor), st)
+        else:
+            rc = lib.apa_accumulate_gradients(optr, arr, len(group), n, float(scale) if last else 1.0, st)
+        _check(rc, 'apa_accumulate_gradients')
+
+    head, rest = parts[:ACC_MAX_PARTS], parts[ACC_MAX_PARTS:]
+    launch(head, not rest)
+    while rest:                               # out already holds the running sum: it leads the next group
+        group, rest = [out] + rest[:ACC_MAX_PARTS - 1], rest[ACC_MAX_PARTS - 1:]
+        launch(group, not rest)
 
 
 class KernelTimer:

@@ -10,7 +10,8 @@ The reference does this in ONE process with towers on /gpu:i and the sum on the 
 each rank owns one MI355X and the sum is a single `all_reduce(SUM)` of one flat fp32 bucket
 ([dWa | dba | dWt | dbt | ...]: 3.2 MB for cfg 002) -- the kernels write their gradients straight
 into views of that bucket, so there is no packing copy.  Backend "nccl" is RCCL on ROCm; the same
-code runs on "gloo" with CPU tensors (tests/test_deploy_gloo.py, world_size 2).
+code runs on "gloo" with CPU tensors (tests/test_deploy_gloo_cpu.py, tests/test_train_reference_cpu.py,
+world_size 2).
 """
 from __future__ import annotations
 
@@ -227,7 +228,8 @@ class OverlappedMicroBatches:
             ev.record(side)
         for ev in self.done:
             self.main.wait_event(ev)
-        self._cof.accumulate_gradients(self.out, self.lane_buckets, 1.0 / len(st), stream=self.main.cuda_stream)
+        self._cof.accumulate_gradients(self.out, self.lane_buckets, divisor=float(len(st)),
+                                       stream=self.main.cuda_stream)
 
     def run_sequential(self, steppers: Optional[Sequence] = None) -> None:
         """The same update with the micro-batches one after the other on the compute stream (the schedule of
@@ -235,7 +237,8 @@ class OverlappedMicroBatches:
         st = self.steppers if steppers is None else steppers
         for s_ in st:
             s_.run(stream=self.main.cuda_stream)
-        self._cof.accumulate_gradients(self.out, self.lane_buckets, 1.0 / len(st), stream=self.main.cuda_stream)
+        self._cof.accumulate_gradients(self.out, self.lane_buckets, divisor=float(len(st)),
+                                       stream=self.main.cuda_stream)
 
     def close(self) -> None:
         for side in self.sides:

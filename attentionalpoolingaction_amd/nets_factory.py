@@ -66,6 +66,27 @@ class EndPoints(dict):
     def __len__(self):
         return len(self.keys())
 
+    # every view agrees with keys(): a lazy entry is evaluated by whoever walks over the values
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def copy(self):
+        c = EndPoints(dict.items(self))
+        c._lazy = dict(self._lazy)
+        return c
+
+    def pop(self, name, *default):
+        if dict.__contains__(self, name):
+            return dict.pop(self, name)
+        if name in self._lazy:
+            return self._lazy.pop(name)()
+        if default:
+            return default[0]
+        raise KeyError(name)
+
 
 ARG_SCOPE_OF = {  # arg_scopes_map (nets_factory.py:69-91): which slim defaults surround the head
     'inception_v3': 'inception_v3', 'inception_v2_tsn': 'inception_v2_tsn', 'resnet_v1_101': 'resnet',
@@ -496,8 +517,14 @@ class AttentionalPoolingHead(nn.Module):
                                                            self.pose_w2, self.pose_b2)
             end_points['PoseLogits'] = pose_logits
         else:   # built by the reference all the same (:147-160), evaluated only if fetched
+            # With the fused input ReLU the shared tap is the backbone's PRE-activation sum: the reference's
+            # PoseLogits convs read the rectified block4 end point (train.py:399-400 fetches it whatever
+            # the head does with it), so rectify inside the thunk -- paid only by a caller that fetches it.
+            pose_needs_relu = preactivation and last_conv_pose is last_conv
+            pose_src = last_conv_pose
             end_points.lazy('PoseLogits', lambda: PoseHeadFunction.apply(
-                last_conv_pose, self.pose_w1, self.pose_b1, self.pose_w2, self.pose_b2)[1])
+                torch.relu(pose_src) if pose_needs_relu else pose_src,
+                self.pose_w1, self.pose_b1, self.pose_w2, self.pose_b2)[1])
         xatt = None if self.single_layer else pose_pre               # :247-250
         offset = self._step
         if self.is_training:

@@ -430,6 +430,11 @@ int apa_momentum_sgd_step(int nseg, float* const* weights, const size_t* sizes,
 #define APA_ACC_MAX_PARTS 8
 int apa_accumulate_gradients(float* out, const float* const* parts, int nparts, size_t n, float scale,
                              void* stream);
+/* The same sum DIVIDED by `divisor` (IEEE fp32 division), i.e. literally `ref_grad / float(ITER_SIZE)`
+ * (src/train.py:560-563): bit-identical to the reference's arithmetic for every ITER_SIZE, where the scale form
+ * differs by an ulp unless ITER_SIZE is a power of two.  divisor == 0 is rejected. */
+int apa_accumulate_gradients_div(float* out, const float* const* parts, int nparts, size_t n, float divisor,
+                                 void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement helpers (bench.py): HIP events owned by the library's HIP runtime, for the prof_*

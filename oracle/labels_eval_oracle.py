@@ -1,12 +1,18 @@
 """CPU oracle for the label generator and the eval consumers -- TEST INFRASTRUCTURE ONLY.
 
-    *** PARITY UNPINNED ***  (see attn_pool_oracle.py; additionally cv::circle / cv::GaussianBlur
-    are OpenCV routines that are absent from this image -- their behaviour is restated from the
-    published algorithm, SURVEY.md Appendix B, and pinned only by the one input the reference
-    supplies: src/custom_ops/test/pose_to_heatmap_op_test.py:10-23, expected valid = [T]*5+[F]*11.)
-    The mAP functions at the end of this file ARE pinned: tests/golden/map_reference.npz holds outputs of the
-    reference's own src/eval/cap_eval_utils.py / src/eval/utils.py executed in the build container
-    (tests/golden/make_map_reference.py), reproduced to 1e-13 with identical tie order.
+    PARITY STATUS: pinned from the raster canvas onwards, restated for the raster itself.
+    * Everything AFTER the canvas -- the op's python wrapper (custom_ops_factory.py:20-28), crop / flip replay,
+      uint8 -> float conversion, min-max normalisation, legacy-bilinear resize (preprocess_pipeline.py:21-45,
+      150-214) -- is held to outputs of the reference's own train_preprocess_pipeline executed in the build
+      container (tests/golden/make_label_reference.py, 14 cases, bit for bit: tests/test_label_reference_cpu.py).
+    * The mAP functions at the end of this file are pinned too: tests/golden/map_reference.npz holds outputs of the
+      reference's src/eval/cap_eval_utils.py / src/eval/utils.py (tests/golden/make_map_reference.py),
+      reproduced to 1e-13 with identical tie order.
+    * cv::circle / cv::GaussianBlur (pose_to_heatmap.cc:83-87) are OpenCV routines; OpenCV is absent from this
+      image and pose_to_heatmap.cc cannot be compiled here.  Their behaviour is restated from OpenCV's published
+      algorithm and checked against the one input the reference supplies
+      (src/custom_ops/test/pose_to_heatmap_op_test.py:10-23, expected valid = [T]*5+[F]*11): that rule alone
+      remains unpinned.
 
 numpy + pure-Python loops (small sizes only).  Citations are relative to /root/reference/.
 """

@@ -10,6 +10,21 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+    config.addinivalue_line('markers', 'regen: re-executes the upstream sources under /root/reference to regenerate '
+                                       'committed fixtures; opt-in with APA_REGEN_FROM_REFERENCE=1 (build container only)')
+
+
+def pytest_collection_modifyitems(config, items):
+    """The regeneration tests EXECUTE third-party code from an absolute path (/root/reference/...).  A plain
+    `pytest` run must not do that by accident: they run only when asked for (APA_REGEN_FROM_REFERENCE=1) and
+    the tree is there."""
+    want = os.environ.get('APA_REGEN_FROM_REFERENCE', '0') == '1' and os.path.isdir('/root/reference')
+    if want:
+        return
+    skip = pytest.mark.skip(reason='regeneration from /root/reference is opt-in: APA_REGEN_FROM_REFERENCE=1')
+    for it in items:
+        if 'regen' in it.keywords:
+            it.add_marker(skip)
 
 
 @pytest.fixture(scope='session')

@@ -346,3 +346,24 @@ def test_bench_gpus_n_without_a_launcher_starts_its_own_ranks(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert 'must agree' in str(e.value.code)
+
+
+def test_end_points_views_agree_on_lazy_entries():
+    """keys() / len() / `in` report a lazy end point, so items() / values() / copy() / pop()
+    must see it as well (an eval dump walking `end_points.items()` would otherwise drop PoseLogits)."""
+    from attentionalpoolingaction_amd.nets_factory import EndPoints
+    calls = []
+    ep = EndPoints()
+    ep['Logits'] = 1
+    ep.lazy('PoseLogits', lambda: calls.append(1) or 7)
+    assert len(ep) == 2 and 'PoseLogits' in ep and list(ep) == ['Logits', 'PoseLogits'] and not calls
+    c = ep.copy()
+    assert not calls and 'PoseLogits' in c and c['PoseLogits'] == 7 and len(calls) == 1
+    assert dict(ep.items()) == {'Logits': 1, 'PoseLogits': 7} and len(calls) == 2     # ep's own thunk, once
+    assert ep.values() == [1, 7] and len(calls) == 2                                    # cached after first access
+    assert {**ep} == {'Logits': 1, 'PoseLogits': 7}
+    ep2 = EndPoints()
+    ep2.lazy('PoseLogits', lambda: 9)
+    assert ep2.pop('PoseLogits') == 9 and 'PoseLogits' not in ep2 and ep2.pop('x', None) is None
+    with pytest.raises(KeyError):
+        ep2.pop('PoseLogits')

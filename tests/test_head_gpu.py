@@ -21,8 +21,11 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize('path', sorted(glob.glob(os.path.join(GOLD, 'attn_*.npz'))),
-                         ids=lambda p: os.path.basename(p)[5:-4])
+                         ids=lambda p: 'regression_pin_' + os.path.basename(p)[5:-4])
 def test_hip_matches_golden_fixture(gpu, path):
+    """REGRESSION PINS: attn_*.npz are outputs of this repo's own oracle (tests/golden/make_golden.py), kept so a
+    change of results is noticed.  The fixtures produced by the reference's code are ref_head_*.npz
+    (tests/test_reference_fixtures_gpu.py)."""
     from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
     d = np.load(path)
     train = bool(d['train'])
@@ -53,6 +56,8 @@ def test_hip_matches_golden_fixture(gpu, path):
 
 
 def test_loss_kernels_match_golden(gpu):
+    """REGRESSION PIN (losses.npz comes from this repo's oracle); the reference-produced loss cases are
+    ref_losses.npz (test_hip_gen_losses_match_reference)."""
     from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
     d = np.load(os.path.join(GOLD, 'losses.npz'))
     Pl = torch.from_numpy(d['pose_Pl']).float().to(gpu)
@@ -821,6 +826,47 @@ def test_backbone_preactivation_tap_matches_explicit_final_relu(gpu):
     apa_config.reset_cfg()
 
 
+def test_pose_logits_fetched_under_the_fused_input_relu_read_the_rectified_map(gpu):
+    """with the backbone's last ReLU folded into the op (preactivation=True on a cfg-002-style
+    head) `last_conv` is the PRE-activation sum.  end_points['PoseLogits'] is built lazily there; the
+    reference's PoseLogits convs read the rectified block4 end point (nets_factory.py:147-160 on
+    resnet_v1.py:108's output; src/train.py:400 fetches it unconditionally), so the fetched value and its
+    gradient must be those of relu(map) -- through .items() / .values() as well as by key."""
+    from attentionalpoolingaction_amd import config as apa_config, nets_factory
+    cfg = apa_config.reset_cfg()
+    apa_config.cfg_from_dict({'MODEL_NAME': 'resnet_v1_101', 'NET': {
+        'USE_POSE_PRELOGITS_BASED_ATTENTION': True,
+        'USE_POSE_PRELOGITS_BASED_ATTENTION_SINGLE_LAYER_ATT': True}})
+    torch.manual_seed(3)
+    head = nets_factory.AttentionalPoolingHead(51, cfg, in_channels=2048, is_training=False).to(gpu)
+    assert head.can_fuse_input_relu()
+    with torch.no_grad():
+        head.pose_w1.copy_(torch.randn(2048, 768, device=gpu) / 45)
+        head.pose_b1.copy_(torch.randn(768, device=gpu) * 0.1)
+        head.pose_w2.copy_(torch.randn(768, 16, device=gpu) / 28)
+        head.att_weights.copy_(torch.randn(2048, 1, device=gpu) / 45)
+        head.td_weights.copy_(torch.randn(2048, 51, device=gpu) / 45)
+    pre = torch.randn(2, 5, 5, 2048, device=gpu).requires_grad_(True)      # about half the entries negative
+    logits, ep = head(pre, preactivation=True)
+    assert 'PoseLogits' in ep and 'PoseLogits' in dict(ep.items()) and len(ep.values()) == len(ep)
+    pl = ep['PoseLogits']
+    pl.square().sum().backward()
+    Xr = torch.relu(pre.detach().double().cpu()).requires_grad_(True)
+    _, pl_ref = orc.pose_logits_head(Xr, head.pose_w1.detach().double().cpu(), head.pose_b1.detach().double().cpu(),
+                                     head.pose_w2.detach().double().cpu(), head.pose_b2.detach().double().cpu())
+    pl_ref.square().sum().backward()
+    assert _rel(pl.detach().cpu().numpy(), pl_ref.detach().numpy()) < 2e-5
+    g_ref = (Xr.grad * (pre.detach().double().cpu() > 0)).numpy()
+    assert _rel(pre.grad.cpu().numpy(), g_ref) < 2e-5
+    # and the logits are those of the rectified map too (the op's own fused ReLU)
+    lr_, _ = orc.attentional_pooling(torch.relu(pre.detach().double().cpu()), None, None,
+                                     [head.att_weights.detach().double().cpu()], [head.att_biases.detach().double().cpu()],
+                                     [head.td_weights.detach().double().cpu()], [head.td_biases.detach().double().cpu()],
+                                     orc.AttnFlags())
+    assert _rel(logits.detach().cpu().numpy(), lr_.numpy()) < 2e-5
+    apa_config.reset_cfg()
+
+
 def test_fused_momentum_sgd_matches_torch_sgd(gpu):
     """apa_momentum_sgd_step == tf.train.MomentumOptimizer + slim L2 on weights only
     (src/train.py:90-94, resnet_utils.py:241) == torch.optim.SGD(momentum, per-group weight_decay);
@@ -1364,6 +1410,29 @@ def test_overlapped_micro_batches_equal_the_sequential_gradient_accumulator(gpu,
         for l in range(lanes):
             assert torch.equal(dXb[l], got_dX[l]) and torch.equal(st2[l].loss, got_loss[l])
     assert float(hist_a[0][0].abs().max()) > 0 and not torch.equal(hist_a[0][0], hist_a[1][0])
+
+
+def test_accumulate_gradients_divides_like_the_reference_and_folds_more_than_eight_parts(gpu):
+    """`ref_grad / float(ITER_SIZE)` (src/train.py:560-563) is a DIVISION -- bit-identical to
+    torch's `.div_` for ITER_SIZE = 3, 5, 7 (where * (1/ITER_SIZE) is an ulp off on some elements) -- and an
+    ITER_SIZE above APA_ACC_MAX_PARTS folds in groups with the sequential summation order."""
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    g = torch.Generator().manual_seed(11)
+    n = 4099                                                   # vector body + scalar tail
+    for k in (2, 3, 5, 7, 8, 9, 11, 17):
+        parts = [torch.randn(n, generator=g).to(gpu) for _ in range(k)]
+        ref = torch.zeros(n, device=gpu)
+        for p_ in parts:
+            ref.add_(p_)
+        out = torch.empty(n, device=gpu)
+        cof.accumulate_gradients(out, parts, divisor=float(k))
+        assert torch.equal(out, ref / float(k)), k
+        cof.accumulate_gradients(out, parts, scale=0.25)
+        assert torch.equal(out, ref * 0.25), k
+    with pytest.raises(cof.ApaError):
+        cof.accumulate_gradients(out, parts, divisor=0.0)
+    with pytest.raises(cof.ApaError):
+        cof.accumulate_gradients(out, parts)
 
 
 def test_module_surface_hands_apa_hooks_to_the_kernels_and_pose_feat_with_13_keypoints(gpu):

@@ -17,7 +17,7 @@ def _t(a, dtype=torch.float64):
 
 
 @pytest.mark.parametrize('path', sorted(glob.glob(os.path.join(GOLD, 'attn_*.npz'))),
-                         ids=lambda p: os.path.basename(p)[5:-4])
+                         ids=lambda p: 'regression_pin_' + os.path.basename(p)[5:-4])
 def test_oracle_matches_golden(path):
     d = np.load(path)
     fused = 'Xatt' not in d.files

@@ -183,7 +183,7 @@ def test_oracle_gen_losses_match_reference(case):
         assert np.array_equal(ep['PoseLossMask'].numpy(), case['PoseLossMask'])
 
 
-@pytest.mark.skipif(not os.path.isdir('/root/reference'), reason='the reference tree only exists in the build container')
+@pytest.mark.regen
 def test_generator_reproduces_the_committed_fixtures():
     """tests/golden/make_head_reference.py is deterministic: re-running it on the reference tree gives the
     committed arrays back bit for bit (two head cases + the loss file)."""

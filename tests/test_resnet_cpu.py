@@ -164,7 +164,7 @@ def test_backbone_matches_reference_graph(name):
             assert m['n_updates']['moving_mean'] == 1            # only the root block's batch norm trains
 
 
-@pytest.mark.skipif(not os.path.isdir('/root/reference'), reason='the reference tree only exists in the build container')
+@pytest.mark.regen
 def test_backbone_generator_reproduces_a_committed_case():
     import sys
     saved, saved_path = dict(sys.modules), list(sys.path)

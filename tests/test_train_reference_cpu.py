@@ -176,7 +176,7 @@ def test_learning_rate_table_matches_the_reference():
     apa_config.reset_cfg()
 
 
-@pytest.mark.skipif(not os.path.isdir('/root/reference'), reason='the reference tree only exists in the build container')
+@pytest.mark.regen
 def test_generator_reproduces_a_committed_training_fixture():
     import importlib.util
     import sys
