@@ -11,6 +11,11 @@ import torch
 from oracle import attn_pool_oracle as orc
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+import sys
+if GOLD not in sys.path:
+    sys.path.insert(0, GOLD)
+import apa_digest          # noqa: E402  (tests/golden: digest / sample / bf16 rounding shared with the generator)
+import apa_keep_mask       # noqa: E402  (numpy twin of the library's dropout stream)
 PRE = 'PosePrelogitsBasedAttention/'
 P = 'USE_POSE_PRELOGITS_BASED_ATTENTION'
 
@@ -19,8 +24,14 @@ def head_fixture_paths():
     return sorted(glob.glob(os.path.join(GOLD, 'ref_head_*.npz')))
 
 
+def big_fixture_paths():
+    """the benchmark-shape cases (make_head_reference.BIG_CASES): inputs by seed, large outputs by digest"""
+    return sorted(glob.glob(os.path.join(GOLD, 'refbig_*.npz')))
+
+
 def case_id(path):
-    return os.path.basename(path)[len('ref_head_'):-4]
+    b = os.path.basename(path)
+    return b[len('refbig_'):-4] if b.startswith('refbig_') else b[len('ref_head_'):-4]
 
 
 class HeadFixture(object):
@@ -33,6 +44,18 @@ class HeadFixture(object):
         self.meta = meta
         self.name = self.meta['case']
         self.f32_keys = set(self.meta['f32_keys'])
+        self.quant = self.meta.get('quant')
+        rnd = apa_digest.bf16_round if self.quant == 'bf16' else (lambda a: a)
+        if 'inseed/images' in self.arrays:
+            # X = round(relu(RandomState(seed).randn(*shape))) -- the generator's first draw from its input stream
+            spec = [int(v) for v in self.arrays['inseed/images']]
+            x = np.random.RandomState(spec[0]).randn(*spec[3:])
+            if spec[1]:
+                x = np.maximum(x, 0)
+            x = apa_digest.bf16_round(x) if spec[2] else x.astype(np.float32).astype(np.float64)
+            chk = self.arrays['insum/images']
+            assert abs(x.sum() - chk[0]) <= 1e-9 * abs(chk[0]) and abs((x ** 2).sum() - chk[1]) <= 1e-12 * chk[1]
+            self.arrays['in/images'] = x.astype(np.float32)
         self.variables = {}
         for vn in self.meta['var_order']:
             if 'var/' + vn in self.arrays:
@@ -42,7 +65,7 @@ class HeadFixture(object):
                 # (make_head_reference.make_value_fn, 'trained' mode): f32(RandomState(seed).randn(*shape)/sqrt(fan_in))
                 spec = self.arrays['varseed/' + vn]
                 seed, fan_in, shape = int(spec[0]), int(spec[1]), [int(s) for s in spec[2:]]
-                v = (np.random.RandomState(seed).randn(*shape) / np.sqrt(fan_in)).astype(np.float32).astype(np.float64)
+                v = rnd((np.random.RandomState(seed).randn(*shape) / np.sqrt(fan_in)).astype(np.float32).astype(np.float64))
                 chk = self.arrays['varsum/' + vn]
                 assert abs(v.sum() - chk[0]) <= 1e-9 * max(1.0, abs(chk[0])) and \
                     abs((v ** 2).sum() - chk[1]) <= 1e-12 * chk[1], 'regenerated %s does not match its checksum' % vn
@@ -73,6 +96,11 @@ class HeadFixture(object):
     def dropout_mask(self):
         """the {0,1} keep mask tf.nn.dropout drew (floor(keep + U)), or None in evaluation mode"""
         for i, dr in enumerate(self.meta['draws']):
+            if dr['kind'] == 'dropout' and 'rand/%d/libmask' % i in self.arrays:
+                seed, offset, count = (int(v) for v in self.arrays['rand/%d/libmask' % i])
+                keep = apa_keep_mask.keep_mask(tuple(dr['shape']), dr['keep_prob'], seed, offset)
+                assert int(keep.sum()) == count
+                return keep
             if dr['kind'] == 'dropout':
                 n = int(np.prod(dr['shape']))
                 bits = np.unpackbits(self.arrays['rand/%d/keep_bits' % i])[:n]
@@ -86,6 +114,29 @@ class HeadFixture(object):
 
     def expected(self, key):
         return self.arrays[key]
+
+    def has(self, key):
+        return key in self.arrays or 'digest/' + key in self.arrays
+
+    def output_keys(self):
+        """every stored output / gradient, whether in full or as digest + sample"""
+        ks = [k for k in self.arrays if k.startswith('out/') or k.startswith('grad/')]
+        ks += [k[len('digest/'):] for k in self.arrays if k.startswith('digest/')]
+        return ks
+
+    def check(self, key, got, tol, what='', floor=1e-30, tol_proj=None):
+        """`got` against the stored value of `key`: in full (max abs error <= tol * max|expected|), or -- for the
+        tensors a benchmark-shape fixture keeps as digest + sample -- the 4096 sampled values at `tol` and the
+        two whole-tensor projections at `tol_proj` (default 4 x tol) of the tensor's l2 norm."""
+        got = np.asarray(got, dtype=np.float64)
+        if 'digest/' + key in self.arrays:
+            apa_digest.check(got, self.arrays['digest/' + key], self.arrays['sample/' + key], tol,
+                             4 * tol if tol_proj is None else tol_proj, what or key)
+            return
+        exp = np.asarray(self.arrays[key], dtype=np.float64)
+        err = float(np.abs(got.reshape(exp.shape) - exp).max()) if exp.size else 0.0
+        scale = max(float(np.abs(exp).max()) if exp.size else 0.0, floor)
+        assert err <= tol * scale, '%s: max abs err %.3e > %.1e * %.3e' % (what or key, err, tol, scale)
 
     def tol(self, key, tight=1e-12):
         """float64-stored tensors are compared at `tight`; the ones stored as float32 at storage rounding"""

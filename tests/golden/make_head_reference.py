@@ -39,6 +39,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import tf1_shim as tfs                                   # noqa: E402
+import apa_digest                                        # noqa: E402
 from make_config_reference import EasyDict               # noqa: E402
 
 REF = '/root/reference'
@@ -137,9 +138,14 @@ def f32(a):
     return np.asarray(a, dtype=np.float32).astype(np.float64)
 
 
-def make_value_fn(case, mode):
+def make_value_fn(case, mode, quant=None):
     """mode 'trained': weights ~ N(0, 1/fan_in), biases ~ N(0, 0.1^2) (so that a 1e-3 absolute tolerance on
-    the logits means something); mode 'init': the reference's own initialisers."""
+    the logits means something); mode 'init': the reference's own initialisers.  quant 'bf16': every value is
+    additionally rounded to a bfloat16-representable number, so the same fixture feeds the fp32 AND the bf16
+    kernels with inputs neither of them has to round."""
+    if quant == 'bf16':
+        inner = make_value_fn(case, mode)
+        return lambda name, shape, desc: apa_digest.bf16_round(inner(name, shape, desc))
 
     def value_fn(name, shape, desc):
         r = _rs(case, name)
@@ -294,8 +300,29 @@ HEAD_CASES = [
 ]
 
 
+# The BENCHMARK shapes (BASELINE configs[1]-[3]: per-GPU batch 32 x 14 x 14 x 2048, K = 393), executed by the same
+# reference code.  Committing 100 MB tensors is not an option, so (big=True):
+#   * the feature map and every large weight are stored as the SEED of their documented generator + checksums,
+#   * the dropout mask is the library's own stream for (seed, offset) (libmask) and is regenerated by its numpy twin,
+#   * tensors above 1 M elements (grad/images, TopDownAttention, dW1) are stored as apa_digest.digest + .sample
+#     (two random projections over every element + 4096 exact values); everything else in full,
+#   * quant='bf16': inputs and variables are bfloat16-representable, so the bf16 kernels run the very same fixture
+#     without an input-rounding term in their error budget.
+# Files are named refbig_<case>.npz (the generic ref_head_* tests glob does not pick them up).
+BIG_CASES = [
+    dict(name='cfg002_train_baseline_libmask', yaml='002_MPII_ResNet_withAttention.yaml', train=True,
+         shape=(32, 14, 14, 2048), K=393, libmask=(42, 5), big=True, quant='bf16'),
+    dict(name='cfg003_train_baseline_libmask', yaml='003_MPII_ResNet_withPoseAttention.yaml', train=True,
+         shape=(32, 14, 14, 2048), K=393, libmask=(42, 9), big=True, quant='bf16', full_limit=1 << 17),
+    dict(name='cfg002_eval_baseline', yaml='002_MPII_ResNet_withAttention.yaml', train=False,
+         shape=(32, 14, 14, 2048), K=393, big=True, quant='bf16', full_limit=1 << 16),
+]
+BIG_FULL = 1 << 20       # big cases: tensors up to this many elements are stored in full (float32)
+
+
 def run_head_case(cfgmod, nf, lossmod, defaults, case):
     name = case['name']
+    big, quant = bool(case.get('big')), case.get('quant')
     reset_cfg(cfgmod, defaults)
     cfg = cfgmod.cfg
     if case.get('yaml'):
@@ -321,14 +348,14 @@ def run_head_case(cfgmod, nf, lossmod, defaults, case):
             assert what == 'dropout'
             keep = apa_keep_mask.keep_mask(shape, keep_prob, seed, offset)
             return np.where(keep == 1, 0.9, 0.1)
-    g = tfs.Graph(make_value_fn(name, case.get('values', 'trained')), uniform_fn)
+    g = tfs.Graph(make_value_fn(name, case.get('values', 'trained'), quant), uniform_fn)
     tfs.set_graph(g)
     r = _rs(name, 'inputs')
     shape = case['shape']
     X = r.randn(*shape)
     if case.get('relu_input', True):
         X = np.maximum(X, 0)                                  # conv5 of the ResNet is post-ReLU
-    X = f32(X)
+    X = apa_digest.bf16_round(X) if quant == 'bf16' else f32(X)
     images = tfs.Tensor(torch.from_numpy(X).requires_grad_(True))
     n_img = int(np.prod(shape[:-3]))
     sp = shape[-3:-1]
@@ -375,12 +402,22 @@ def run_head_case(cfgmod, nf, lossmod, defaults, case):
 
     def put(key, arr, exact=False):
         arr = np.asarray(arr)
+        if big and arr.size > case.get('full_limit', BIG_FULL) and arr.dtype.kind == 'f':
+            out['digest/' + key] = apa_digest.digest(arr)
+            out['sample/' + key] = apa_digest.sample(arr)
+            return
         if arr.dtype == np.float64 and arr.size > BIG and not exact:
             f32_keys.append(key)
             arr = arr.astype(np.float32)
         out[key] = arr
 
-    put('in/images', X.astype(np.float32))
+    if big:   # X = round(relu(RandomState(seed).randn(*shape))): [seed, relu?, bf16?, shape...] + [sum, sum of squares]
+        out['inseed/images'] = np.array([zlib.crc32(('%s|inputs' % name).encode()) & 0x7fffffff,
+                                         int(case.get('relu_input', True)), int(quant == 'bf16')] + list(shape),
+                                        dtype=np.int64)
+        out['insum/images'] = np.array([X.sum(), (X ** 2).sum()])
+    else:
+        put('in/images', X.astype(np.float32))
     if pose_tap is not None:
         put('in/pose_tap', pose_tap.v.detach().numpy().astype(np.float32))
         put('grad/pose_tap', pose_tap.v.grad.numpy())
@@ -401,7 +438,8 @@ def run_head_case(cfgmod, nf, lossmod, defaults, case):
             if vn.endswith('/weights') and wd > 0 and np.array_equal(grad, wd * val) and np.abs(val).max() > 0:
                 reg_only.append(vn)
                 grad = None
-        if grad is None and vn in reg_only and val.size > BIG and case.get('values', 'trained') == 'trained':
+        if (big or (grad is None and vn in reg_only)) and vn.endswith('/weights') and val.size > BIG \
+                and case.get('values', 'trained') == 'trained':
             # ... and whose values are therefore only needed for sum(w^2): stored as the seed of the documented
             # generator (make_value_fn: f32(RandomState(crc32(case|name)).randn(*shape) / sqrt(fan_in))) + checksums
             seeded.append(vn)
@@ -416,7 +454,10 @@ def run_head_case(cfgmod, nf, lossmod, defaults, case):
     for i, d in enumerate(g.random_draws):
         if d['kind'] == 'dropout':
             keep = np.floor(d['keep_prob'] + d['uniform']).astype(np.uint8)     # tf.nn.dropout's binary_tensor
-            put('rand/%d/keep_bits' % i, np.packbits(keep.reshape(-1)))
+            if big and case.get('libmask'):           # regenerated by the reader from (seed, offset): apa_keep_mask
+                put('rand/%d/libmask' % i, np.array(list(case['libmask']) + [int(keep.sum())], dtype=np.int64))
+            else:
+                put('rand/%d/keep_bits' % i, np.packbits(keep.reshape(-1)))
             draws.append({'kind': 'dropout', 'keep_prob': d['keep_prob'], 'shape': list(keep.shape)})
         else:
             put('rand/%d/uniform' % i, d['uniform'].astype(np.float32))
@@ -448,6 +489,7 @@ def run_head_case(cfgmod, nf, lossmod, defaults, case):
                 end_points=sorted(k for k in out if k.startswith('out/ep/')), values=case.get('values', 'trained'))
     if case.get('libmask'):
         meta['libmask'] = list(case['libmask'])
+    meta['big'], meta['quant'] = big, quant
     out['meta'] = np.array(json.dumps(meta, sort_keys=True, default=str))
     tfs.set_graph(None)
     return out
@@ -521,11 +563,11 @@ def main():
     defaults = copy.deepcopy(cfgmod.cfg)
     only = set(sys.argv[1:])
     tot = 0
-    for case in HEAD_CASES:
-        if only and case['name'] not in only:
-            continue
+    for case in HEAD_CASES + BIG_CASES:
+        if (only and case['name'] not in only) or (case.get('big') and not only):
+            continue                          # the benchmark-shape cases take minutes: generated when named
         out = run_head_case(cfgmod, nf, lossmod, defaults, case)
-        dst = os.path.join(HERE, 'ref_head_%s.npz' % case['name'])
+        dst = os.path.join(HERE, ('refbig_%s.npz' if case.get('big') else 'ref_head_%s.npz') % case['name'])
         np.savez_compressed(dst, **out)
         tot += os.path.getsize(dst)
         meta = json.loads(str(out['meta']))

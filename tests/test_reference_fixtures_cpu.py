@@ -212,3 +212,28 @@ def test_generator_reproduces_the_committed_fixtures():
         for k in list(sys.modules):                 # drop the tensorflow / nets / easydict stand-ins again
             if k not in saved:
                 del sys.modules[k]
+
+
+BIG_PATHS = rf.big_fixture_paths()
+
+
+@pytest.mark.parametrize('path', BIG_PATHS, ids=rf.case_id)
+def test_oracle_matches_reference_at_the_benchmark_shape(path):
+    """BASELINE configs[1]-[3] at their real size -- per-GPU batch 32 x 14 x 14 x 2048, K = 393 (cfg 002 training
+    and evaluation, cfg 003 training with the pose head and both losses) -- executed by the reference's own
+    nets_factory.py / loss.py (make_head_reference.BIG_CASES).  Inputs and large weights come back from their
+    seeds, the dropout mask from the library stream's numpy twin; tensors above the storage limit are held as
+    whole-tensor projections + 4096 exact samples (tests/golden/apa_digest.py)."""
+    fx = rf.HeadFixture(path)
+    assert fx.meta['big'] and fx.arrays['in/images'].shape == (32, 14, 14, 2048) and fx.meta['num_classes'] == 393
+    got = rf.run_oracle(fx)
+    keys = fx.output_keys()
+    assert 'grad/images' in keys and 'out/logits' in keys and 'out/ep/TopDownAttention' in keys
+    for key in keys:
+        assert key in got, 'the oracle produces no %s' % key
+        # stored-as-float32 tensors: storage rounding; digests / float64 tensors: float64 round-off of sums over
+        # 12.8 M terms in a different association order
+        fx.check(key, got[key], 1.5e-7 if key in fx.f32_keys else 1e-10, '%s %s' % (fx.name, key), floor=1e-3,
+                 tol_proj=1e-9)
+    for vn in fx.meta['reg_only_grad']:
+        _close(got['grad/var/' + vn], fx.meta['weight_decay'] * fx.variables[vn], 1e-12, vn)

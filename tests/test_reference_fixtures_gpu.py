@@ -25,6 +25,7 @@ def _rel(got, exp, floor=1e-30):
 def _run_product(fx, gpu, **head_kw):
     from attentionalpoolingaction_amd import config as apa_config, loss as apa_loss
     head_kw_replay = head_kw.pop('force_replay', False)
+    in_dtype = head_kw.pop('in_dtype', torch.float32)
     tap = None
     if fx.pose_tap is not None:                                  # a backbone that returns its end points by name
         tap = torch.from_numpy(fx.arrays['in/pose_tap']).to(gpu).requires_grad_(True)
@@ -37,8 +38,8 @@ def _run_product(fx, gpu, **head_kw):
     if network_fn.temporal is not None:
         network_fn.temporal._bias_initialised = True            # the fixture's value, not the 1/F initialiser
     head = network_fn.head
-    images = torch.from_numpy(fx.arrays['in/images']).to(gpu).requires_grad_(True)
-    mask = fx.dropout_mask()
+    images = torch.from_numpy(fx.arrays['in/images']).to(gpu).to(in_dtype).requires_grad_(True)
+    mask = fx.dropout_mask() if not (fx.meta.get('big') and fx.meta.get('libmask') and not head_kw_replay) else True
     if mask is not None and fx.meta.get('libmask') and not head_kw_replay:
         # the fixture's mask IS the library's own stream for (seed, offset): no replay, the head's counter hash
         # -- and with it the hot streaming kernels -- regenerates it
@@ -102,6 +103,82 @@ def test_hip_head_matches_reference_fixture(gpu, path):
         head = r['head']                                   # UPDATE_OPS of the _2LAYER batch-norm ran with the step
         assert _rel(head.pose_feat_bn_moving_mean.cpu().numpy(), fx.expected('out/update/moving_mean')[0]) < 1e-5
         assert _rel(head.pose_feat_bn_moving_variance.cpu().numpy(), fx.expected('out/update/moving_variance')[0]) < 1e-5
+
+
+BIG_PATHS = rf.big_fixture_paths()
+_BIG_CACHE = {}
+
+
+def _big(path):
+    if path not in _BIG_CACHE:               # regenerating 12.8 M normals + the bf16 rounding takes a second or two
+        _BIG_CACHE[path] = rf.HeadFixture(path)
+    return _BIG_CACHE[path]
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('path', BIG_PATHS, ids=rf.case_id)
+def test_hip_head_matches_reference_at_the_benchmark_shape(gpu, path, dtype):
+    """BASELINE configs[1]-[3] at the size bench.py times -- per-GPU batch 32 x 14 x 14 x 2048, K = 393 -- against
+    numbers the REFERENCE'S OWN nets_factory.py / loss.py produced for these inputs (make_head_reference.BIG_CASES;
+    inputs by seed, dropout mask = the library's own stream, large tensors as whole-tensor projections + 4096
+    exact samples).  fp32: the 512-block streaming plan of the timed kernels, north_star's tolerances (logits
+    1e-3 abs / 2e-5 rel, argmax exact, gradients 5e-5).  bf16: the SAME fixture through the bf16 kernels -- its
+    inputs and variables are bf16-representable, so what is measured is the kernels' own rounding (bf16 stores of
+    pose_pre_logits / dX, bf16 MFMA operands): logits within 3e-3 (tests/test_bf16_parity_gpu.py's
+    LOGIT_TOL_BF16), argmax exact on rows whose top-2 margin exceeds twice that, gradients within
+    KAPPA * 2^-8 = 1.2e-2 of max|reference| elementwise and 2e-3 of the l2 norm on the projections."""
+    fx = _big(path)
+    assert fx.quant == 'bf16'
+    bf = dtype == 'bf16'
+    r = _run_product(fx, gpu, in_dtype=torch.bfloat16 if bf else torch.float32)
+    if fx.meta.get('libmask'):                               # the library's stream IS the fixture's mask
+        from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+        seed, offset = fx.meta['libmask']
+        got = cof.dropout_mask(fx.arrays['in/images'].shape, fx.keep_prob, seed, offset, device=gpu).cpu().numpy()
+        assert np.array_equal(got, fx.dropout_mask())
+    exp_logits = fx.expected('out/logits').astype(np.float64)
+    got_logits = r['logits'].detach().float().cpu().numpy().astype(np.float64)
+    err = np.abs(got_logits - exp_logits).max()
+    print('%s %s: logits max abs err %.3e (max |logit| %.3f)' % (fx.name, dtype, err, np.abs(exp_logits).max()))
+    if bf:
+        assert err <= 3e-3
+        top2 = np.sort(exp_logits, axis=1)[:, -2:]
+        sure = (top2[:, 1] - top2[:, 0]) > 6e-3
+        assert sure.sum() >= 24 and np.array_equal(got_logits.argmax(1)[sure], exp_logits.argmax(1)[sure])
+    else:
+        assert err <= 1e-3 and _rel(got_logits, exp_logits) < 2e-5
+        assert np.array_equal(got_logits.argmax(1), exp_logits.argmax(1))
+    tol, tolp = (1.2e-2, 2e-3) if bf else (5e-5, 5e-5)
+    for key in fx.meta['end_points']:
+        name = key[len('out/ep/'):]
+        if name == 'TopDownAttention':
+            continue
+        fx.check(key, r['ep'][name].detach().float().cpu().numpy(), tol, '%s %s' % (dtype, name), floor=1e-6)
+    for got, exp in zip(r['losses'], fx.expected('out/losses')):
+        assert abs(float(got.detach()) - exp) <= (2e-3 if bf else 2e-5) * max(abs(exp), 1e-3)
+    assert abs(float(r['total']) - float(fx.expected('out/total'))) <= (2e-3 if bf else 2e-5) * float(fx.expected('out/total'))
+    fx.check('grad/images', r['images'].grad.float().cpu().numpy(), tol, dtype + ' grad/images', tol_proj=tolp)
+    for vn in fx.meta['trainable']:
+        t = r['table'][vn]
+        if vn in fx.meta['reg_only_grad']:
+            exp = fx.meta['weight_decay'] * fx.variables[vn]
+            assert _rel(t.grad.cpu().numpy(), exp) < 5e-5, vn
+            continue
+        if t.grad is None:
+            assert float(np.abs(fx.expected('grad/var/' + vn)).max()) == 0.0, vn
+            continue
+        fx.check('grad/var/' + vn, t.grad.float().cpu().numpy(), tol, dtype + ' ' + vn, tol_proj=tolp)
+
+
+@pytest.mark.parametrize('path', BIG_PATHS, ids=rf.case_id)
+def test_hip_topdown_endpoint_at_the_benchmark_shape(gpu, path):
+    """end_points['TopDownAttention'] [32, 14, 14, 393] on request (nets_factory.py:309), against the reference's
+    whole-tensor digest; the logits of that (literal, T-materialising) code path once more."""
+    fx = _big(path)
+    r = _run_product(fx, gpu, want_topdown=True)
+    assert _rel(r['logits'].detach().cpu().numpy(), fx.expected('out/logits')) < 2e-5
+    fx.check('out/ep/TopDownAttention', r['ep']['TopDownAttention'].detach().float().cpu().numpy(), 5e-5)
+    fx.check('grad/images', r['images'].grad.cpu().numpy(), 5e-5)
 
 
 LIBMASK = [p for p in HEAD_PATHS if rf.HeadFixture(p).meta.get('libmask')]
