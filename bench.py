@@ -750,6 +750,17 @@ def main():
             except Exception as e:                             # noqa: BLE001
                 extra['cfg002_train_iter_size'] = {'error': '{}: {}'.format(type(e).__name__, e)}
             torch.cuda.empty_cache()
+        # BASELINE configs[1] / [2] END TO END: synthetic 448 x 448 images -> torch-ROCm ResNet-101 (channels-last)
+        # -> HIP head -> loss (-> backward -> update): img/s of the real step and the head's share of it
+        for key, which in (('cfg002_eval_e2e', 'eval002'), ('cfg003_train_e2e', 'train003')):
+            if only and key not in only:
+                continue
+            try:
+                from tools import bench_e2e
+                extra[key] = bench_e2e.run(which, dev)
+            except Exception as e:                             # noqa: BLE001
+                extra[key] = {'error': '{}: {}'.format(type(e).__name__, e)}
+            torch.cuda.empty_cache()
         out['extra'] = extra
 
     if rank == 0:
