@@ -161,6 +161,7 @@ class GradientAccumulator:
         self.bucket = bucket
         self.iter_size = max(1, int(iter_size))
         self.acc = torch.zeros_like(bucket.flat) if self.iter_size > 1 else None
+        self._divisor = torch.full((), float(self.iter_size), dtype=bucket.flat.dtype, device=bucket.flat.device)
         self.micro = 0
 
     def step(self) -> bool:
@@ -172,7 +173,10 @@ class GradientAccumulator:
         self.micro += 1
         if self.micro < self.iter_size:
             return False
-        self.bucket.flat.copy_(self.acc).div_(float(self.iter_size))
+        # `ref_grad / float(ITER_SIZE)` (src/train.py:560-563) is a true division.  torch divides a GPU tensor by
+        # a python scalar as a multiplication by its reciprocal (an ulp off for ITER_SIZE = 3, 5, ...): divide by
+        # a 0-dim tensor on the bucket's device instead, which takes the element-wise IEEE path
+        torch.div(self.acc, self._divisor, out=self.bucket.flat)
         self.acc.zero_()
         self.micro = 0
         return True

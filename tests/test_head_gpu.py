@@ -1426,7 +1426,10 @@ def test_accumulate_gradients_divides_like_the_reference_and_folds_more_than_eig
             ref.add_(p_)
         out = torch.empty(n, device=gpu)
         cof.accumulate_gradients(out, parts, divisor=float(k))
-        assert torch.equal(out, ref / float(k)), k
+        # IEEE division (numpy on the host); NOT torch's `gpu_tensor / python_scalar`, which multiplies by 1/k
+        want = torch.from_numpy(ref.cpu().numpy() / np.float32(k)).to(gpu)
+        assert torch.equal(out, want), k
+        assert torch.equal(out, torch.div(ref, torch.full((), float(k), device=gpu))), k
         cof.accumulate_gradients(out, parts, scale=0.25)
         assert torch.equal(out, ref * 0.25), k
     with pytest.raises(cof.ApaError):

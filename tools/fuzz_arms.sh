@@ -1,11 +1,11 @@
 #!/bin/bash
 # the random-shape sweeps once per A/B arm of the library (the fallback kernels are real code paths for the
 # shapes the fast ones do not cover).  The product build has no run-time knobs: this script rebuilds the library
-# with -DAPA_ABLATION first (knob() then reads the environment) and restores the product build when done.
+# with -DAPA_ABLATION into libapa_hip_ablate.so (knob() then reads the environment) and points APA_LIB_PATH at it.
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 cd $R
-make -C attentionalpoolingaction_amd/csrc clean >/dev/null && make -C attentionalpoolingaction_amd/csrc -j16 ABLATE=1 >/dev/null 2>&1 || exit 1
-trap 'make -C attentionalpoolingaction_amd/csrc clean >/dev/null; make -C attentionalpoolingaction_amd/csrc -j16 >/dev/null 2>&1' EXIT
+make -C attentionalpoolingaction_amd/csrc -j16 ABLATE=1 >/dev/null 2>&1 || exit 1     # libapa_hip_ablate.so, beside the product library
+export APA_LIB_PATH=$R/attentionalpoolingaction_amd/custom_ops/libapa_hip_ablate.so
 m1() { echo "== $*"; env "$@" timeout 300 python tools/fuzz_attn_pool.py 120 13 2>&1 | grep -E "^FAIL|cases," | cut -c1-260 | head -6
        env "$@" timeout 300 python tools/fuzz_all.py 50 13 step,bf16m1 2>&1 | grep -E "^FAIL|cases," | cut -c1-260 | head -6; }
 dense() { echo "== $*"; env "$@" timeout 300 python tools/fuzz_all.py 70 13 perclass,pose 2>&1 | grep -E "^FAIL|cases," | cut -c1-260 | head -6; }
