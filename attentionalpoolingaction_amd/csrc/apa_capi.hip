@@ -217,7 +217,7 @@ extern "C" int apa_attn_pool_fwd(const void* X, const void* Xatt, const float* W
                                  unsigned flags, float keep_prob, uint64_t seed, uint64_t offset,
                                  int dtype, void* stream) {
   return attn_pool_fwd_impl(Hooks(), nullptr, nullptr, X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar, topdown, ws,
-                            ws_bytes, N, P, C, Ca, K, M, flags, keep_prob, seed, offset, dtype, stream);
+                            ws_bytes, N, P, C, Ca, K, M, flags & APA_PUBLIC_FLAGS, keep_prob, seed, offset, dtype, stream);
 }
 
 extern "C" int apa_attn_pool_fwd_ex(const apa_hooks* hooks, const void* X, const void* Xatt,
@@ -227,7 +227,7 @@ extern "C" int apa_attn_pool_fwd_ex(const apa_hooks* hooks, const void* X, const
                                     unsigned flags, float keep_prob, uint64_t seed, uint64_t offset,
                                     int dtype, void* stream) {
   return attn_pool_fwd_impl(Hooks(hooks), nullptr, nullptr, X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar, topdown,
-                            ws, ws_bytes, N, P, C, Ca, K, M, flags, keep_prob, seed, offset, dtype, stream);
+                            ws, ws_bytes, N, P, C, Ca, K, M, flags & APA_PUBLIC_FLAGS, keep_prob, seed, offset, dtype, stream);
 }
 
 static int attn_pool_bwd_impl(const Hooks& hk, const apa_concat_feat* catp, const M1Xent* xf, const void* X, const void* Xatt, const float* Wa, const float* ba,
@@ -309,7 +309,7 @@ extern "C" int apa_attn_pool_bwd(const void* X, const void* Xatt, const float* W
                                  int M, unsigned flags, float keep_prob, uint64_t seed,
                                  uint64_t offset, int dtype, void* stream) {
   return attn_pool_bwd_impl(Hooks(), nullptr, nullptr, X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, dX, dXatt, dWa, dba,
-                            dWt, dbt, ws, ws_bytes, N, P, C, Ca, K, M, flags & ~APA_FLAG_WS_FROM_FWD, keep_prob,
+                            dWt, dbt, ws, ws_bytes, N, P, C, Ca, K, M, flags & APA_PUBLIC_FLAGS & ~APA_FLAG_WS_FROM_FWD, keep_prob,
                             seed, offset, dtype, stream);
 }
 
@@ -321,7 +321,7 @@ extern "C" int apa_attn_pool_bwd_ex(const apa_hooks* hooks, const void* X, const
                                     int C, int Ca, int K, int M, unsigned flags, float keep_prob,
                                     uint64_t seed, uint64_t offset, int dtype, void* stream) {
   return attn_pool_bwd_impl(Hooks(hooks), nullptr, nullptr, X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, dX, dXatt,
-                            dWa, dba, dWt, dbt, ws, ws_bytes, N, P, C, Ca, K, M, flags & ~APA_FLAG_WS_FROM_FWD,
+                            dWa, dba, dWt, dbt, ws, ws_bytes, N, P, C, Ca, K, M, flags & APA_PUBLIC_FLAGS & ~APA_FLAG_WS_FROM_FWD,
                             keep_prob, seed, offset, dtype, stream);
 }
 
@@ -332,8 +332,8 @@ extern "C" int apa_attn_pool_fwd_cat(const apa_concat_feat* cat, const apa_hooks
                                      int C, int Ca, int K, int M, unsigned flags, float keep_prob,
                                      uint64_t seed, uint64_t offset, int dtype, void* stream) {
   return attn_pool_fwd_impl(Hooks(hooks), cat, nullptr, X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar,
-                            topdown, ws, ws_bytes, N, P, C, Ca, K, M, flags, keep_prob, seed, offset, dtype,
-                            stream);
+                            topdown, ws, ws_bytes, N, P, C, Ca, K, M, flags & APA_PUBLIC_FLAGS, keep_prob, seed, offset,
+                            dtype, stream);
 }
 
 extern "C" int apa_attn_pool_bwd_cat(const apa_concat_feat* cat, const apa_hooks* hooks, const void* X,
@@ -345,7 +345,7 @@ extern "C" int apa_attn_pool_bwd_cat(const apa_concat_feat* cat, const apa_hooks
                                      uint64_t seed, uint64_t offset, int dtype, void* stream) {
   return attn_pool_bwd_impl(Hooks(hooks), cat, nullptr, X, Xatt, Wa, ba, Wt, bt, att, zsave, abar, G, dX,
                             dXatt, dWa, dba, dWt, dbt, ws, ws_bytes, N, P, C, Ca, K, M,
-                            flags & ~APA_FLAG_WS_FROM_FWD, keep_prob, seed, offset, dtype, stream);
+                            flags & APA_PUBLIC_FLAGS & ~APA_FLAG_WS_FROM_FWD, keep_prob, seed, offset, dtype, stream);
 }
 
 extern "C" int apa_attn_head_train_step_ex(const apa_hooks* hooks, const void* X, const void* Xatt,
@@ -358,6 +358,7 @@ extern "C" int apa_attn_head_train_step_ex(const apa_hooks* hooks, const void* X
                                            unsigned flags, float keep_prob, uint64_t seed,
                                            uint64_t offset, int dtype, void* stream) {
   const Hooks hk(hooks);
+  flags &= APA_PUBLIC_FLAGS;
   if (!labels || !loss || !G) {
     apa::set_error("apa_attn_head_train_step: null labels / loss / G pointer");
     return APA_ERR_INVALID_ARG;
@@ -400,6 +401,87 @@ extern "C" int apa_attn_head_train_step(const void* X, const void* Xatt, const f
                                      N, P, C, Ca, K, M, flags, keep_prob, seed, offset, dtype, stream);
 }
 
+extern "C" int apa_pose_attn_train_step(const apa_pose_attn_step_io* io, int N, int P, int C, int Cp, int J,
+                                        int K, unsigned flags, float keep_prob, uint64_t seed, uint64_t offset,
+                                        int dtype, void* stream) {
+  if (!io) {
+    set_error("apa_pose_attn_train_step: null io");
+    return APA_ERR_INVALID_ARG;
+  }
+  const apa_pose_attn_step_io& s = *io;
+  if (!s.X || !s.W1 || !s.b1 || !s.W2 || !s.b2 || !s.Wa || !s.ba || !s.Wt || !s.bt || !s.labels ||
+      !s.pose_labels || !s.pose_valid || !s.Ppre || !s.Pl || !s.att || !s.logits || !s.zsave || !s.abar ||
+      !s.loss_action || !s.loss_pose || !s.G || !s.dPl || !s.dZ || !s.dX || !s.dW1 || !s.db1 || !s.dW2 || !s.db2 ||
+      !s.dWa || !s.dba || !s.dWt || !s.dbt || !s.ws_pool || !s.ws_pose) {
+    set_error("apa_pose_attn_train_step: null pointer in apa_pose_attn_step_io (only W1_bf16 may be NULL)");
+    return APA_ERR_INVALID_ARG;
+  }
+  int rc = check_common("apa_pose_attn_train_step", N, P, C, Cp, K, 1, dtype);
+  if (rc != APA_OK) return rc;
+  if (J <= 0) {
+    set_error("apa_pose_attn_train_step: J=%d", J);
+    return APA_ERR_INVALID_ARG;
+  }
+  flags &= APA_PUBLIC_FLAGS & ~(APA_FLAG_WS_FROM_FWD | APA_FLAG_DXATT_RANK1 | APA_FLAG_RELU_INPUT | APA_FLAG_RNG_EXTERNAL);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool train = (flags & APA_FLAG_TRAIN) && keep_prob < 1.0f;
+  const bool fast = pose_step_fast_ok(N, P, C, Cp, J, dtype, s.Ppre, s.W2, s.Wa) && m1_small_supported(C, K) &&
+                    m1_supported(C, Cp, dtype, false) &&
+                    ((reinterpret_cast<uintptr_t>(s.G) | reinterpret_cast<uintptr_t>(s.Wt) |
+                      reinterpret_cast<uintptr_t>(s.zsave)) & 15) == 0;
+  if (!fast) {
+    // the same step as four calls (what a caller without this entry point runs)
+    rc = apa_pose_head_fwd(s.X, s.W1, s.b1, s.W2, s.b2, s.Ppre, s.Pl, s.ws_pose, s.ws_pose_bytes, N, P, C, Cp, J,
+                           dtype, stream);
+    if (rc != APA_OK) return rc;
+    rc = apa_pose_l2_loss_fwd_bwd(s.Pl, s.pose_labels, s.pose_valid, s.loss_pose, s.dPl,
+                                  pose_ws_loss_scratch(s.ws_pose, N, P, C, Cp, J, dtype),
+                                  apa_pose_l2_workspace_bytes(N, P, J), N, P, J, s.pose_wt, s.grad_scale, stream);
+    if (rc != APA_OK) return rc;
+    rc = apa_attn_head_train_step_ex(nullptr, s.X, s.Ppre, s.Wa, s.ba, s.Wt, s.bt, s.labels, s.action_wt,
+                                     s.grad_scale, s.logits, s.att, s.zsave, s.abar, s.loss_action, s.G, s.dX,
+                                     s.dZ, s.dWa, s.dba, s.dWt, s.dbt, s.ws_pool, s.ws_pool_bytes, N, P, C, Cp, K,
+                                     1, flags | APA_FLAG_DXATT_RANK1, keep_prob, seed, offset, dtype, stream);
+    if (rc != APA_OK) return rc;
+    return apa_pose_head_bwd_rank1ext(s.X, s.W1, s.W2, s.Ppre, s.dPl, s.dZ, s.Wa, s.dX, 1 | APA_POSE_WS_FROM_FWD,
+                                      s.dW1, s.db1, s.dW2, s.db2, s.ws_pose, s.ws_pose_bytes, N, P, C, Cp, J, dtype,
+                                      stream);
+  }
+  PoseStepArgs a;
+  a.W1_bf16 = s.W1_bf16;
+  a.wa = s.Wa; a.ba = s.ba; a.att = s.att;
+  a.relu_att = (flags & APA_FLAG_RELU_ATT) && !(flags & APA_FLAG_SOFTMAX_ATT);
+  a.pose_labels = s.pose_labels; a.pose_valid = s.pose_valid; a.dPl = s.dPl;
+  a.pose_wt = s.pose_wt; a.grad_scale = s.grad_scale;
+  rc = pose_fwd_fused(s.X, s.W1, s.b1, s.W2, s.b2, s.Ppre, s.Pl, s.ws_pose, s.ws_pose_bytes, N, P, C, Cp, J, dtype,
+                      a, st);
+  if (rc != APA_OK) return rc;
+  M1Xent xf;
+  xf.labels = s.labels; xf.loss = s.loss_action; xf.G = s.G;
+  xf.lscale = s.action_wt / (float)N;
+  xf.gscale = s.action_wt * s.grad_scale / (float)N;
+  xf.done = false;
+  const Hooks hk;
+  rc = attn_pool_fwd_impl(hk, nullptr, &xf, s.X, s.Ppre, s.Wa, s.ba, s.Wt, s.bt, s.logits, s.att, s.zsave, s.abar,
+                          nullptr, s.ws_pool, s.ws_pool_bytes, N, P, C, Cp, K, 1, flags | APA_IFLAG_ATT_READY,
+                          keep_prob, seed, offset, dtype, stream);
+  if (rc != APA_OK) return rc;
+  if (!xf.done) {
+    rc = apa_softmax_xent_fwd_bwd(s.logits, s.labels, s.loss_action, s.G, nullptr, nullptr, N, K, s.action_wt,
+                                  s.grad_scale, stream);
+    if (rc != APA_OK) return rc;
+  }
+  rc = attn_pool_bwd_impl(hk, nullptr, xf.done ? &xf : nullptr, s.X, s.Ppre, s.Wa, s.ba, s.Wt, s.bt, s.att, s.zsave,
+                          s.abar, s.G, s.dX, s.dZ, s.dWa, s.dba, s.dWt, s.dbt, s.ws_pool, s.ws_pool_bytes, N, P, C,
+                          Cp, K, 1, flags | APA_FLAG_DXATT_RANK1 | APA_FLAG_WS_FROM_FWD | APA_IFLAG_NO_ATT_WGRAD,
+                          keep_prob, seed, offset, dtype, stream);
+  if (rc != APA_OK) return rc;
+  uint64_t* bump = (train && (flags & APA_FLAG_RNG_DEVICE))
+                       ? reinterpret_cast<uint64_t*>(static_cast<uintptr_t>(offset)) : nullptr;
+  return pose_bwd_fused(s.X, s.W1, s.W2, s.Ppre, s.dPl, s.dZ, s.Wa, s.dX, 1, s.dW1, s.db1, s.dW2, s.db2, s.dWa,
+                        s.dba, s.loss_pose, bump, s.ws_pose, s.ws_pose_bytes, N, P, C, Cp, J, dtype, a, st);
+}
+
 extern "C" int apa_attn_head_eval_step(const void* X, const void* Xatt, const float* Wa, const float* ba,
                                        const float* Wt, const float* bt, const int64_t* labels,
                                        float* logits, float* att, float* zsave, float* abar, float* loss,
@@ -414,7 +496,7 @@ extern "C" int apa_attn_head_eval_step(const void* X, const void* Xatt, const fl
     apa::set_error("apa_attn_head_eval_step: labels and loss must be given together");
     return APA_ERR_INVALID_ARG;
   }
-  const unsigned eval_flags = flags & ~(unsigned)APA_FLAG_TRAIN;   // is_training=False: no dropout
+  const unsigned eval_flags = flags & APA_PUBLIC_FLAGS & ~(unsigned)APA_FLAG_TRAIN;   // is_training=False: no dropout
   // without ground truth the softmax / argmax of a row rides on the logits reduction (M == 1, K <= 512)
   M1Xent xf;
   xf.labels = nullptr; xf.loss = nullptr; xf.G = nullptr; xf.gscale = 0.f; xf.lscale = 0.f; xf.done = false;

@@ -177,10 +177,17 @@ __global__ __launch_bounds__(512) void pose_dppre_kernel(const float* __restrict
 constexpr int POSE_RPB_MIN = 16;   // smallest rows-per-block variant (sizes the partial matrix)
 // leading dimension (floats) of the rows kernel's partial matrix: [dW2 | db1 | db2]; with J == 16 the dW2
 // part is padded to 32 floats per thread of the block (permuted layout, see the kernel's epilogue)
-__host__ __device__ static inline size_t pose_rows_ld(int Cp, int J, int nthr) {
-  return (J == 16 ? (size_t)nthr * 32 : (size_t)Cp * J) + Cp + J;
+// ... followed (WA form of the kernel: the fused cfg 003 step) by [dWa (Cp) | dba (1)], padded to 4 floats
+__host__ __device__ static inline size_t pose_rows_dw2(int Cp, int J, int nthr) {
+  return J == 16 ? (size_t)nthr * 32 : (size_t)Cp * J;
 }
-template <typename T, bool R1, bool EXT, int RPB>
+__host__ __device__ static inline size_t pose_rows_ld(int Cp, int J, int nthr) {
+  return pose_rows_dw2(Cp, J, nthr) + Cp + J + Cp + 4;
+}
+// WA (with R1: ext_row = dZ, ext_col = wa): the attention conv's own gradients, dWa[c] = sum_r Ppre[r,c] dZ[r] and
+// dba = sum_r dZ[r], leave with the same partial row -- dZ is a 17th column of dPl as far as dW2 is concerned --
+// so m1_att_gemv_bwd2_kernel's pass over Ppre and its column-sum launch disappear from the cfg 003 step.
+template <typename T, bool R1, bool EXT, int RPB, bool WA = false>
 __global__ __launch_bounds__(512) void pose_bwd_rows_kernel(
     const float* __restrict__ dPl, const float* __restrict__ W2, const T* __restrict__ ext,
     const float* __restrict__ ext_row, const float* __restrict__ ext_col, const T* __restrict__ Ppre,
@@ -245,7 +252,7 @@ __global__ __launch_bounds__(512) void pose_bwd_rows_kernel(
   }
   v2f ecol = {0.f, 0.f};
   if (R1) ecol = v2f{ext_col[c0c], ext_col[c0c + 1]};
-  v2f acc = {0.f, 0.f};
+  v2f acc = {0.f, 0.f}, awa = {0.f, 0.f};
   v2f a[2][8];
 #pragma unroll
   for (int c = 0; c < 2; ++c)
@@ -292,6 +299,7 @@ __global__ __launch_bounds__(512) void pose_bwd_rows_kernel(
     sv += sv_b;
     v2f o = {pp.x > 0.f ? sv.x : 0.f, pp.y > 0.f ? sv.y : 0.f};
     acc += o;
+    if constexpr (WA) awa = __builtin_elementwise_fma(pp, v2f{er, er}, awa);
 #pragma unroll
     for (int h = 0; h < 8; ++h) {
       a[0][h] = __builtin_elementwise_fma(v2f{pp.x, pp.x}, d2[h], a[0][h]);
@@ -308,7 +316,7 @@ __global__ __launch_bounds__(512) void pose_bwd_rows_kernel(
   // to float offset (v * nthr + t) * 4; m1_colsum undoes the permutation when it writes dW2.  (In natural
   // [c][q] order each lane's 128 bytes are contiguous and every store touches 64 different lines: 4.3 us.)
   float* prow = partial + (size_t)blockIdx.x * pose_rows_ld(Cp, J, nthr);
-  const size_t dw2_cols = J == 16 ? (size_t)nthr * 32 : (size_t)Cp * J;
+  const size_t dw2_cols = pose_rows_dw2(Cp, J, nthr);
   {
     if (J == 16) {
       float4* dst = reinterpret_cast<float4*>(prow) + tid;
@@ -331,6 +339,15 @@ __global__ __launch_bounds__(512) void pose_bwd_rows_kernel(
     float sdb = 0.f;
     for (int rr = 0; rr < nrows; ++rr) sdb += s_dpl[rr * 16 + tid];
     prow[dw2_cols + Cp + tid] = sdb;
+  }
+  if constexpr (WA) {
+    float* wrow = prow + dw2_cols + Cp + J;
+    if (active) { wrow[c0] = awa.x; wrow[c0 + 1] = awa.y; }
+    if (tid == 0) {
+      float sdz = 0.f;
+      for (int rr = 0; rr < nrows; ++rr) sdz += s_er[rr];
+      wrow[Cp] = sdz;
+    }
   }
 }
 
@@ -368,14 +385,30 @@ static bool pose_bwd_rows_ok(const float* dPl, const void* Ppre, const void* ext
 // once per block through LDS), KS MFMAs later the 16 x 16 result leaves with the bias added.  HBM-bound
 // on the 9.6 MB pre-logit map.  (Fewer waves per block to cover more CUs -- 98 blocks at N = 32 -- measured slower:
 // 4 / 2 / 1 waves 7.4 / 8.0 / 11.6 us, every block stages the whole of W2.)
-template <int KS>   // k steps of 32: Cp = 32 * KS
+// FUSED (the one-call cfg 003 step, apa_pose_attn_train_step): on the same pass over Ppre
+//   * the attention logits Z[r] = Ppre[r,:] . wa + ba of the pose-prelogits-based attention (nets_factory.py:
+//     247-270, M = 1; id / relu applied, softmax left raw) -- exact fp32 FMAs on the A fragments the lanes already
+//     hold (wa is NOT rounded to bf16), the four k-quarters of a row added across lanes: one launch and one
+//     read of the 9.6 MB map less than m1_att_gemv_fwd_kernel;
+//   * the pose L2 loss of src/loss.py:29-70 on the finished Pl tile: dPl = gcoef * valid * (Pl - lbl) (the
+//     expression of pose_l2_kernel, bit for bit) and one partial sum of valid * (Pl - lbl)^2 per block.
+// W2 staging: a thread converts the k pair (2kp, 2kp + 1) of four columns and writes four 32-bit words (2-way
+// bank aliasing at most, free for ds_write_b32; the 2-byte scatter it replaces showed an LDS conflict ratio of
+// 0.50 in the SQ counters), rows padded by 16 so that the ds_read_b128 fragment reads are conflict-free.
+struct PosePlExtra {
+  const float* wa; const float* ba; float* att; int act;                                   // wa == nullptr: off
+  const float* lbl; const uint8_t* valid; float* dPl; float* lpart; float gcoef; int P;    // lbl == nullptr: off
+};
+template <int KS, bool FUSED>   // k steps of 32: Cp = 32 * KS
 __global__ __launch_bounds__(256) void pose_pl_kernel(const bf16_t* __restrict__ Ppre,
                                                       const float* __restrict__ W2,
                                                       const float* __restrict__ b2, float* __restrict__ Pl,
-                                                      int R, int J) {
+                                                      int R, int J, PosePlExtra x) {
   typedef short bf16x8 __attribute__((ext_vector_type(8)));
-  constexpr int Cp = 32 * KS, LDW = Cp + 8;
+  constexpr int Cp = 32 * KS, LDW = Cp + 16;
   __shared__ __attribute__((aligned(16))) short w2s[16 * LDW];   // [n][k] bf16, zero rows for n >= J
+  __shared__ __attribute__((aligned(16))) float was[FUSED ? Cp : 4];
+  __shared__ float lred[4];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int l16 = lane & 15, kb = lane >> 4;
   const int r0 = (blockIdx.x * 4 + wave) * 16;
@@ -387,18 +420,23 @@ __global__ __launch_bounds__(256) void pose_pl_kernel(const bf16_t* __restrict__
     const uint4 v = ld16(arow + ks * 32);
     af[ks] = __builtin_bit_cast(bf16x8, v);
   }
-  if (J == 16) {   // W2 rows are 64 B: 4 float4 each, every load of the block issued before the first use
-    constexpr int NV = Cp * 4 / 256;             // Cp is a multiple of 256 / 4
-    float4 wv[NV];
+  if (J == 16) {   // W2 rows are 64 B: task = (k pair, column quad), both float4 loads issued before the first use
+    constexpr int NT = Cp * 2 / 256;             // Cp/2 pairs x 4 quads over 256 threads
+    float4 w0[NT], w1[NT];
 #pragma unroll
-    for (int u = 0; u < NV; ++u) wv[u] = *reinterpret_cast<const float4*>(W2 + (size_t)(tid + u * 256) * 4);
+    for (int u = 0; u < NT; ++u) {
+      const int t = tid + u * 256, kp = t >> 2, nq = t & 3;
+      w0[u] = *reinterpret_cast<const float4*>(W2 + (size_t)(2 * kp) * 16 + nq * 4);
+      w1[u] = *reinterpret_cast<const float4*>(W2 + (size_t)(2 * kp + 1) * 16 + nq * 4);
+    }
 #pragma unroll
-    for (int u = 0; u < NV; ++u) {
-      const int v = tid + u * 256, k = v >> 2, n = (v & 3) * 4;
-      w2s[(n + 0) * LDW + k] = (short)f32_to_bf16_bits(wv[u].x);
-      w2s[(n + 1) * LDW + k] = (short)f32_to_bf16_bits(wv[u].y);
-      w2s[(n + 2) * LDW + k] = (short)f32_to_bf16_bits(wv[u].z);
-      w2s[(n + 3) * LDW + k] = (short)f32_to_bf16_bits(wv[u].w);
+    for (int u = 0; u < NT; ++u) {
+      const int t = tid + u * 256, kp = t >> 2, n = (t & 3) * 4;
+      uint32_t* d = reinterpret_cast<uint32_t*>(w2s + n * LDW + 2 * kp);
+      d[0] = pack_bf16x2(w0[u].x, w1[u].x);
+      d[LDW / 2] = pack_bf16x2(w0[u].y, w1[u].y);
+      d[LDW] = pack_bf16x2(w0[u].z, w1[u].z);
+      d[3 * (LDW / 2)] = pack_bf16x2(w0[u].w, w1[u].w);
     }
   } else {
     for (int i = tid; i < 16 * Cp; i += 256) {
@@ -407,6 +445,9 @@ __global__ __launch_bounds__(256) void pose_pl_kernel(const bf16_t* __restrict__
       w2s[n * LDW + k] = (short)f32_to_bf16_bits(v);
     }
   }
+  if (FUSED && x.wa)
+    for (int i = tid; i < Cp / 4; i += 256)
+      *reinterpret_cast<float4*>(was + i * 4) = *reinterpret_cast<const float4*>(x.wa + i * 4);
   __syncthreads();
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -414,13 +455,46 @@ __global__ __launch_bounds__(256) void pose_pl_kernel(const bf16_t* __restrict__
     const bf16x8 bf = *reinterpret_cast<const bf16x8*>(w2s + l16 * LDW + ks * 32 + kb * 8);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], bf, acc, 0, 0, 0);
   }
+  if (FUSED && x.wa) {   // Z of row r0 + l16: this lane's k quarter, then the four quarters across lanes
+    float d = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4 wlo = *reinterpret_cast<const float4*>(was + ks * 32 + kb * 8);
+      const float4 whi = *reinterpret_cast<const float4*>(was + ks * 32 + kb * 8 + 4);
+      float xv[8];
+      Vec<bf16_t>::unpack(__builtin_bit_cast(uint4, af[ks]), xv);
+      d = fmaf(xv[0], wlo.x, d); d = fmaf(xv[1], wlo.y, d); d = fmaf(xv[2], wlo.z, d); d = fmaf(xv[3], wlo.w, d);
+      d = fmaf(xv[4], whi.x, d); d = fmaf(xv[5], whi.y, d); d = fmaf(xv[6], whi.z, d); d = fmaf(xv[7], whi.w, d);
+    }
+    d += __shfl_xor(d, 16);
+    d += __shfl_xor(d, 32);
+    float z = d + x.ba[0];
+    if (x.act == 1) z = fmaxf(z, 0.f);           // 1 = relu attention; a softmax map stays raw here
+    if (kb == 0 && r0 + l16 < R) x.att[r0 + l16] = z;
+  }
+  float lacc = 0.f;
   if (l16 < J) {
     const float bias = b2[l16];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = r0 + 4 * kb + r;
-      if (row < R) Pl[(size_t)row * J + l16] = acc[r] + bias;
+      if (row < R) {
+        const float pl = acc[r] + bias;
+        Pl[(size_t)row * J + l16] = pl;
+        if (FUSED && x.lbl) {
+          const float dd = pl - x.lbl[(size_t)row * J + l16];
+          const float vm = x.valid[(size_t)(row / x.P) * J + l16] ? 1.0f : 0.0f;
+          lacc = fmaf(vm * dd, dd, lacc);
+          x.dPl[(size_t)row * J + l16] = x.gcoef * vm * dd;
+        }
+      }
     }
+  }
+  if (FUSED && x.lbl) {
+    lacc = wave_sum(lacc);
+    if (lane == 0) lred[wave] = lacc;
+    __syncthreads();
+    if (tid == 0) x.lpart[blockIdx.x] = (lred[0] + lred[1]) + (lred[2] + lred[3]);
   }
 }
 
@@ -430,10 +504,31 @@ static bool pose_pl_fast(int Cp, int J, int dtype, const void* Ppre) {
          (reinterpret_cast<uintptr_t>(Ppre) & 15) == 0;
 }
 
+// the skinny product's launch; `x` != nullptr: the fused form (attention logits column and / or pose L2 loss)
+static int pose_pl_launch(const bf16_t* pp, const float* W2, const float* b2, float* Pl, int R, int Cp, int J,
+                          const PosePlExtra* x, hipStream_t st) {
+  const dim3 grid((R + 63) / 64);
+  const PosePlExtra none = {nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0.f, 1};
+#define APA_PL(KSv)                                                                                              \
+  do {                                                                                                           \
+    if (x) hipLaunchKernelGGL((pose_pl_kernel<KSv, true>), grid, dim3(256), 0, st, pp, W2, b2, Pl, R, J, *x);     \
+    else hipLaunchKernelGGL((pose_pl_kernel<KSv, false>), grid, dim3(256), 0, st, pp, W2, b2, Pl, R, J, none);    \
+  } while (0)
+  switch (Cp / 32) {
+    case 8: APA_PL(8); break;
+    case 16: APA_PL(16); break;
+    case 24: APA_PL(24); break;
+    default: APA_PL(32); break;
+  }
+#undef APA_PL
+  APA_LAUNCH_CHECK("pose_pl_kernel");
+  return APA_OK;
+}
+
 struct PosePlan {
   long R;
   int nchunks;
-  size_t off_dppre, off_partial, off_gemm, off_w1b, total;
+  size_t off_dppre, off_partial, off_gemm, off_w1b, off_lpart, total;
 };
 static PosePlan pose_plan(int N, int P, int C, int Cp, int J, int dtype) {
   PosePlan pl;
@@ -452,6 +547,13 @@ static PosePlan pose_plan(int N, int P, int C, int Cp, int J, int dtype) {
   pl.off_gemm = off;    off += align_up(g, 256);
   // bf16 features: a bf16 copy of W1, so the MFMA GEMMs can DMA both operands straight into LDS
   pl.off_w1b = off;     off += align_up((size_t)C * Cp * 2, 256);
+  // fused step: one pose-loss partial per block of the Pl kernel, alive from the forward to the last launch
+  {                     // (its fallback runs apa_pose_l2_loss_fwd_bwd with the same region as scratch)
+    size_t lp = (size_t)((pl.R + 63) / 64) * 4;
+    const size_t l2 = apa_pose_l2_workspace_bytes(N, P, J);
+    if (l2 > lp) lp = l2;
+    pl.off_lpart = off; off += align_up(lp, 256);
+  }
   pl.total = off;
   return pl;
 }
@@ -522,18 +624,8 @@ extern "C" int apa_pose_head_fwd(const void* X, const float* W1, const float* b1
   g1.M = R; g1.N = Cp; g1.K = C; g1.bias = b1; g1.act = 1;
   int rc = gemm_launch(g1, st);
   if (rc != APA_OK) return rc;
-  if (pose_pl_fast(Cp, J, dtype, Ppre)) {   // Pl = Ppre.W2 + b2: skinny product, one wave per 16 rows
-    const dim3 grid((R + 63) / 64);
-    const bf16_t* pp = static_cast<const bf16_t*>(Ppre);
-    switch (Cp / 32) {
-      case 8: hipLaunchKernelGGL(pose_pl_kernel<8>, grid, dim3(256), 0, st, pp, W2, b2, Pl, R, J); break;
-      case 16: hipLaunchKernelGGL(pose_pl_kernel<16>, grid, dim3(256), 0, st, pp, W2, b2, Pl, R, J); break;
-      case 24: hipLaunchKernelGGL(pose_pl_kernel<24>, grid, dim3(256), 0, st, pp, W2, b2, Pl, R, J); break;
-      default: hipLaunchKernelGGL(pose_pl_kernel<32>, grid, dim3(256), 0, st, pp, W2, b2, Pl, R, J); break;
-    }
-    APA_LAUNCH_CHECK("pose_pl_kernel");
-    return APA_OK;
-  }
+  if (pose_pl_fast(Cp, J, dtype, Ppre))   // Pl = Ppre.W2 + b2: skinny product, one wave per 16 rows
+    return pose_pl_launch(static_cast<const bf16_t*>(Ppre), W2, b2, Pl, R, Cp, J, nullptr, st);
   GemmDesc g2;  // Pl = Ppre.W2 + b2
   g2.A = Ppre; g2.lda = Cp; g2.ta = dt_code(dtype); g2.a_kc = true;
   g2.B = W2; g2.ldb = J; g2.tb = 0; g2.b_kc = false;
@@ -562,9 +654,17 @@ static int pose_dw1_splits(int C, int Cp, int R, int dtype) {
 }
 
 // the two dense products of the backward pass: dW1 = X^T . dPpre and dX (+)= dPpre . W1^T
+// fused-step extras of the backward pass (apa_pose_attn_train_step)
+struct PoseBwdFuse {
+  float* dWa = nullptr; float* dba = nullptr;                 // attention conv gradients (rank-1 ext only)
+  const float* aux_src = nullptr; int aux_n = 0; float aux_scale = 0.f; float* aux_dst = nullptr;   // pose loss
+  uint64_t* rng_bump = nullptr;                               // device-side dropout counter to advance
+  const void* W1_bf16 = nullptr;                              // caller-maintained bf16 copy of W1
+};
+
 static int pose_head_bwd_big(const void* X, const float* W1, const void* dPpre, void* dX, int accumulate_dX,
                              float* dW1, char* w, const PosePlan& pl, float* gws, int R, int C, int Cp,
-                             int dtype, hipStream_t st) {
+                             int dtype, hipStream_t st, const void* W1_shadow = nullptr) {
   const int tdt = dt_code(dtype);
   int rc;
   {  // dW1[c,j] = sum_r X[r,c] dPpre[r,j]
@@ -581,8 +681,10 @@ static int pose_head_bwd_big(const void* X, const float* W1, const void* dPpre, 
     GemmDesc g;
     g.A = dPpre; g.lda = Cp; g.ta = tdt; g.a_kc = true;
     int w1_tb = 0;
-    const void* W1op = pose_w1_operand(W1, w + pl.off_w1b, C, Cp, dtype, &w1_tb, st,
-                                       (accumulate_dX & APA_POSE_WS_FROM_FWD) != 0);
+    const void* W1op = W1_shadow;
+    if (W1_shadow && dtype == APA_DTYPE_BF16) w1_tb = 1;
+    else W1op = pose_w1_operand(W1, w + pl.off_w1b, C, Cp, dtype, &w1_tb, st,
+                                (accumulate_dX & APA_POSE_WS_FROM_FWD) != 0);
     g.B = W1op; g.ldb = Cp; g.tb = w1_tb; g.b_kc = true;   // W1 [C][Cp]: n = c rows, k contiguous
     g.C = dX; g.ldc = C; g.tc = tdt;
     g.M = R; g.N = C; g.K = Cp; g.beta = (accumulate_dX & 1) ? 1.f : 0.f;
@@ -595,7 +697,7 @@ static int pose_head_bwd_impl(const void* X, const float* W1, const float* W2, c
                               const float* dPl, const void* dPpre_ext, const float* ext_row,
                               const float* ext_col, void* dX, int accumulate_dX, float* dW1, float* db1,
                               float* dW2, float* db2, void* ws, size_t ws_bytes, int N, int P, int C,
-                              int Cp, int J, int dtype, void* stream) {
+                              int Cp, int J, int dtype, void* stream, const PoseBwdFuse* fuse = nullptr) {
   if (!X || !W1 || !W2 || !Ppre || !dX || !dW1 || !db1 || !dW2 || !db2 || N <= 0 || P <= 0 ||
       C <= 0 || Cp <= 0 || J <= 0) {
     set_error("apa_pose_head_bwd: null pointer or non-positive dimension");
@@ -632,31 +734,53 @@ static int pose_head_bwd_impl(const void* X, const float* W1, const float* W2, c
     const int rpb = pose_rows_per_block(pl.R, nthr2, dtype, dPpre_ext != nullptr && !ext_row);
     const int nblk = (int)((pl.R + rpb - 1) / rpb);
     const size_t lds = pose_rows_lds(rpb, nthr2, dtype, dPpre_ext != nullptr && !ext_row);
-#define APA_ROWS2(T, R1v, EXTv, RPBv)                                                                        \
-  hipLaunchKernelGGL((pose_bwd_rows_kernel<T, R1v, EXTv, RPBv>), dim3(nblk), dim3(nthr2), lds, st, dPl, W2, \
+#define APA_ROWS2(T, R1v, EXTv, RPBv, WAv)                                                                      \
+  hipLaunchKernelGGL((pose_bwd_rows_kernel<T, R1v, EXTv, RPBv, WAv>), dim3(nblk), dim3(nthr2), lds, st, dPl, W2, \
                      static_cast<const T*>(dPpre_ext), ext_row, ext_col, static_cast<const T*>(Ppre),       \
                      static_cast<T*>(dPpre), partial, pl.R, Cp, J)
-#define APA_ROWS(T, R1v, EXTv)                                              \
-  do {                                                                      \
-    if (rpb == 32) APA_ROWS2(T, R1v, EXTv, 32); else APA_ROWS2(T, R1v, EXTv, 16); \
+#define APA_ROWS(T, R1v, EXTv, WAv)                                                   \
+  do {                                                                               \
+    if (rpb == 32) APA_ROWS2(T, R1v, EXTv, 32, WAv); else APA_ROWS2(T, R1v, EXTv, 16, WAv); \
   } while (0)
+    const bool want_wa = fuse && fuse->dWa;
+    if (want_wa && !ext_row) {
+      set_error("apa_pose_head_bwd: the fused dWa / dba outputs need the rank-1 external gradient (internal)");
+      return APA_ERR_INVALID_ARG;
+    }
     if (dtype == APA_DTYPE_F32) {
-      if (ext_row) APA_ROWS(float, true, false);
-      else if (dPpre_ext) APA_ROWS(float, false, true);
-      else APA_ROWS(float, false, false);
+      if (ext_row && want_wa) APA_ROWS(float, true, false, true);
+      else if (ext_row) APA_ROWS(float, true, false, false);
+      else if (dPpre_ext) APA_ROWS(float, false, true, false);
+      else APA_ROWS(float, false, false, false);
     } else {
-      if (ext_row) APA_ROWS(bf16_t, true, false);
-      else if (dPpre_ext) APA_ROWS(bf16_t, false, true);
-      else APA_ROWS(bf16_t, false, false);
+      if (ext_row && want_wa) APA_ROWS(bf16_t, true, false, true);
+      else if (ext_row) APA_ROWS(bf16_t, true, false, false);
+      else if (dPpre_ext) APA_ROWS(bf16_t, false, true, false);
+      else APA_ROWS(bf16_t, false, false, false);
     }
 #undef APA_ROWS2
 #undef APA_ROWS
     APA_LAUNCH_CHECK("pose_bwd_rows_kernel");
-    const int ldp = (int)pose_rows_ld(Cp, J, nthr2), c1 = ldp - Cp - J;
-    int rc = m1_colsum(partial, nullptr, dW2, nullptr, nblk, ldp, ldp, nullptr, st, db1, c1, db2, c1 + Cp,
-                       J == 16 ? nthr2 : 0, Cp);
+    const int ldp = (int)pose_rows_ld(Cp, J, nthr2), c1 = (int)pose_rows_dw2(Cp, J, nthr2);
+    // [dW2 | db1 | db2 (| dWa | dba)]: one fixed-order column sum for all of them; in the fused step the same
+    // launch finishes the pose loss (its block partials) and advances the dropout counter
+    ColsumMore more;
+    int ncol = c1 + Cp + J;
+    if (want_wa) {
+      more.dwa4 = fuse->dWa; more.C3 = c1 + Cp + J;
+      more.dwa5 = fuse->dba; more.C4 = c1 + Cp + J + Cp;
+      ncol = c1 + Cp + J + Cp + 1;
+    }
+    if (fuse) { more.aux_src = fuse->aux_src; more.aux_n = fuse->aux_n; more.aux_scale = fuse->aux_scale; more.aux_dst = fuse->aux_dst; }
+    int rc = m1_colsum(partial, nullptr, dW2, nullptr, nblk, ncol, ldp, fuse ? fuse->rng_bump : nullptr, st, db1, c1,
+                       db2, c1 + Cp, J == 16 ? nthr2 : 0, Cp, fuse ? &more : nullptr);
     if (rc != APA_OK) return rc;
-    return pose_head_bwd_big(X, W1, dPpre, dX, accumulate_dX, dW1, w, pl, gws, R, C, Cp, dtype, st);
+    return pose_head_bwd_big(X, W1, dPpre, dX, accumulate_dX, dW1, w, pl, gws, R, C, Cp, dtype, st,
+                             fuse ? fuse->W1_bf16 : nullptr);
+  }
+  if (fuse) {
+    set_error("apa_pose_head_bwd: the fused step needs the one-pass rows kernel (J <= 16, Cp <= 1024; internal)");
+    return APA_ERR_UNSUPPORTED;
   }
   const int nthr = ((Cp / 4 + 63) / 64) * 64;   // one thread per 4 columns (<= 512: Cp <= 2048)
 #define APA_DPPRE(T, JM)                                                                            \
@@ -695,6 +819,78 @@ static int pose_head_bwd_impl(const void* X, const float* W1, const float* W2, c
   }
   return pose_head_bwd_big(X, W1, dPpre, dX, accumulate_dX, dW1, w, pl, gws, R, C, Cp, dtype, st);
 }
+
+// ---------------------------------------------------------------------------------------------
+// The pose-head halves of the one-call cfg 003 step (apa_pose_attn_train_step, apa_capi.hip)
+// ---------------------------------------------------------------------------------------------
+namespace apa {
+
+void* pose_ws_loss_scratch(void* ws, int N, int P, int C, int Cp, int J, int dtype) {
+  return static_cast<char*>(ws) + pose_plan(N, P, C, Cp, J, dtype).off_lpart;
+}
+
+bool pose_step_fast_ok(int N, int P, int C, int Cp, int J, int dtype, const void* Ppre, const float* W2,
+                       const float* wa) {
+  static const int enabled = knob("APA_POSE_STEP_FUSED", 1);
+  const int nthr = ((Cp / 2 + 63) / 64) * 64;
+  return enabled && dtype == APA_DTYPE_BF16 && J == 16 && pose_pl_fast(Cp, J, dtype, Ppre) &&
+         (reinterpret_cast<uintptr_t>(W2) & 15) == 0 && (reinterpret_cast<uintptr_t>(wa) & 15) == 0 &&
+         Cp % 4 == 0 && Cp <= 1024 && pose_rows_lds(16, nthr, dtype, false) <= 65536 && N > 0 && P > 0 && C > 0;
+}
+
+// Ppre = relu(X.W1 + b1); then ONE launch for Pl = Ppre.W2 + b2, the attention logits Z = Ppre.wa + ba and the
+// pose L2 loss (dPl + block partials kept in the workspace until pose_bwd_fused's last launch sums them)
+int pose_fwd_fused(const void* X, const float* W1, const float* b1, const float* W2, const float* b2, void* Ppre,
+                   float* Pl, void* ws, size_t ws_bytes, int N, int P, int C, int Cp, int J, int dtype,
+                   const PoseStepArgs& a, hipStream_t st) {
+  const PosePlan pl = pose_plan(N, P, C, Cp, J, dtype);
+  if (!ws || ws_bytes < pl.total) {
+    set_error("apa_pose_attn_train_step: pose workspace too small (%zu < %zu)", ws_bytes, pl.total);
+    return APA_ERR_WORKSPACE;
+  }
+  char* w = static_cast<char*>(ws);
+  const int R = (int)pl.R;
+  int w1_tb = 0;
+  const void* W1op = a.W1_bf16;
+  if (W1op) w1_tb = 1;
+  else W1op = pose_w1_operand(W1, w + pl.off_w1b, C, Cp, dtype, &w1_tb, st);
+  GemmDesc g1;  // Ppre = relu(X.W1 + b1)
+  g1.A = X; g1.lda = C; g1.ta = dt_code(dtype); g1.a_kc = true;
+  g1.B = W1op; g1.ldb = Cp; g1.tb = w1_tb; g1.b_kc = false;
+  g1.C = Ppre; g1.ldc = Cp; g1.tc = dt_code(dtype);
+  g1.M = R; g1.N = Cp; g1.K = C; g1.bias = b1; g1.act = 1;
+  int rc = gemm_launch(g1, st);
+  if (rc != APA_OK) return rc;
+  const float denom = (float)N * (float)N * (float)P;          // loss.py:54-62 (apa_pose_l2_loss_fwd_bwd)
+  PosePlExtra x;
+  x.wa = a.wa; x.ba = a.ba; x.att = a.att; x.act = a.relu_att ? 1 : 0;
+  x.lbl = a.pose_labels; x.valid = a.pose_valid; x.dPl = a.dPl;
+  x.lpart = reinterpret_cast<float*>(w + pl.off_lpart);
+  x.gcoef = a.grad_scale * a.pose_wt / denom; x.P = P;
+  return pose_pl_launch(static_cast<const bf16_t*>(Ppre), W2, b2, Pl, R, Cp, J, &x, st);
+}
+
+// dPpre (+ the rank-1 attention-branch gradient dZ (x) wa), dW2, db1, db2, dWa, dba in one pass + one column
+// sum that also finishes the pose loss and advances the dropout counter; then dW1 and dX (+)= dPpre.W1^T
+int pose_bwd_fused(const void* X, const float* W1, const float* W2, const void* Ppre, const float* dPl,
+                   const float* dZ, const float* wa, void* dX, int accumulate_dX, float* dW1, float* db1,
+                   float* dW2, float* db2, float* dWa, float* dba, float* loss_pose, uint64_t* rng_bump,
+                   void* ws, size_t ws_bytes, int N, int P, int C, int Cp, int J, int dtype,
+                   const PoseStepArgs& a, hipStream_t st) {
+  const PosePlan pl = pose_plan(N, P, C, Cp, J, dtype);
+  PoseBwdFuse f;
+  f.dWa = dWa; f.dba = dba;
+  f.aux_src = reinterpret_cast<const float*>(static_cast<char*>(ws) + pl.off_lpart);
+  f.aux_n = (int)((pl.R + 63) / 64);
+  f.aux_scale = 0.5f * a.pose_wt / ((float)N * (float)N * (float)P);
+  f.aux_dst = loss_pose;
+  f.rng_bump = rng_bump;
+  f.W1_bf16 = a.W1_bf16;
+  return pose_head_bwd_impl(X, W1, W2, Ppre, dPl, nullptr, dZ, wa, dX, accumulate_dX, dW1, db1, dW2, db2, ws,
+                            ws_bytes, N, P, C, Cp, J, dtype, st, &f);
+}
+
+}  // namespace apa
 
 extern "C" int apa_pose_head_bwd(const void* X, const float* W1, const float* W2, const void* Ppre,
                                  const float* dPl, const void* dPpre_ext, void* dX, int accumulate_dX,

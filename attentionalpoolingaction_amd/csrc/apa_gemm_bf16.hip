@@ -897,6 +897,221 @@ int launch_ring(const FastParams& p, hipStream_t st) {
   return APA_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wide variant (round 4) for the products whose OUTPUT is wide and whose contraction is short: the pose head's
+// dX (+)= dPpre . W1^T, [6272 x 768] . [768 x 2048] -- only 12 K tiles, so a tile's prologue and its
+// epilogue (read + write of its share of a 25.7 MB bf16 map) weigh as much as its loop, and with 784 tiles of
+// 128 x 128 the second round of the two-stage kernel is half empty (34.3 us against hipBLASLt's 24.0 us,
+// profiles/r03_*).  Here ONE resident round covers the product with (32 MT) x 256 tiles (MT = 7: 28 x 8 = 224
+// tiles for 256 CUs): one block of 8 waves per CU as 2 x 4, wave tile (16 MT) x 64 = MT x 4 MFMA tiles -- MT + 4
+// fragment reads per 4 MT MFMAs (0.39 reads per MFMA against 0.70 in the ring kernel's MT x 2 layout and 0.5 in the
+// 4 x 4 layout: the LDS port was what bounded those loops) and half the operand bytes per flop of a 128-wide
+// tile.  Both operands k-contiguous ([rows][K] row images, 128-byte rows, the same XOR swizzle as above), two
+// LDS stages of (4 MT + 32) KB fed by LDS-DMA from inline asm: the DMA of tile t + 1 is issued right after the
+// barrier that hands over tile t and flies under its MFMAs (one barrier per K tile).  The fp32 tile leaves
+// through LDS in two 128-column halves (it does not fit at once) as 16-byte row segments (store8).
+// ---------------------------------------------------------------------------------------------
+constexpr int TNW = 256;
+template <int MT> struct WideCfg {
+  static constexpr int TMR = 32 * MT;
+  static constexpr int A_EL = TMR * TK, B_EL = TNW * TK;       // shorts per image
+  static constexpr int STAGE_EL = A_EL + B_EL;
+  static constexpr int NBLK = TMR / 8 + TNW / 8;               // KiB-blocks (DMA wave-instructions) per stage
+  static constexpr int C_LO = NBLK / 8, N_HI = NBLK % 8;
+  static constexpr size_t LDS_BYTES = (size_t)2 * STAGE_EL * 2;
+  static_assert((size_t)TMR * (TN + 4) * 4 <= LDS_BYTES, "half-tile epilogue staging fits in the two stages");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+template <typename TC, int MT, bool PIPE>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_wide_kernel(FastParams p) {
+  typedef WideCfg<MT> W;
+  extern __shared__ __attribute__((aligned(16))) short smem[];
+  typedef __attribute__((address_space(3))) void* lptr;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int ntm = (p.M + W::TMR - 1) / W::TMR, ntn = (p.N + TNW - 1) / TNW;
+  const int tile = xcd_remap(blockIdx.x, ntm * ntn);   // the column tiles of one A panel share an XCD
+  const int m0 = (tile / ntn) * W::TMR, n0 = (tile % ntn) * TNW;
+  const int nk = p.K / TK;
+
+  // this wave's KiB-blocks of a stage: b = wave, wave + 8, ...  (b < TMR/8: A rows 8b..; else B rows 8(b - TMR/8)..)
+  constexpr int NMINE = W::C_LO + (W::N_HI ? 1 : 0);
+  const bf16_t* src[NMINE];
+  uint32_t dst[NMINE];
+#pragma unroll
+  for (int j = 0; j < NMINE; ++j) {
+    const int b = wave + 8 * j;
+    if (b < W::TMR / 8) {
+      src[j] = static_cast<const bf16_t*>(p.A) + glds_src_offset<false>(b, lane, p.lda, m0, p.M);
+      dst[j] = (uint32_t)b * 1024u;
+    } else {
+      const int g = min(b - W::TMR / 8, TNW / 8 - 1);
+      src[j] = static_cast<const bf16_t*>(p.B) + glds_src_offset<false>(g, lane, p.ldb, n0, p.N);
+      dst[j] = (uint32_t)(W::A_EL * 2) + (uint32_t)g * 1024u;
+    }
+  }
+  const bool extra = wave < W::N_HI;              // wave-uniform: issues slot C_LO as well
+  const uint32_t lds0 = (uint32_t)(size_t)(lptr)smem;
+  auto issue = [&](int t) {
+    const uint32_t st = lds0 + (uint32_t)((t & 1) * W::STAGE_EL * 2);
+#pragma unroll
+    for (int j = 0; j < W::C_LO; ++j) glds16_ring(src[j] + (long)t * TK, st + dst[j]);
+    if (W::N_HI && extra) glds16_ring(src[NMINE - 1] + (long)t * TK, st + dst[NMINE - 1]);
+  };
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto load_frags = [&](int t, int ks, bf16x8 (&af)[MT], bf16x8 (&bf)[4]) {
+    const short* a_img = smem + (t & 1) * W::STAGE_EL;
+    const short* b_img = a_img + W::A_EL;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bf[j] = fragment_sw<false>(b_img, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af[i] = fragment_sw<false>(a_img, (wm * MT + i) * 16, ks, lane);
+  };
+  auto mma = [&](const bf16x8 (&af)[MT], const bf16x8 (&bf)[4]) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+  };
+  if (!PIPE) {
+    if (nk > 0) issue(0);
+    for (int t = 0; t < nk; ++t) {
+      // my pieces of tile t are home; the barrier publishes everybody's and tells me that every wave is done with
+      // tile t - 1, whose stage the next DMA overwrites
+      ring_wait_barrier<0>();
+      if (t + 1 < nk) issue(t + 1);
+#pragma unroll
+      for (int ks = 0; ks < TK / 32; ++ks) {
+        bf16x8 bf[4], af[MT];
+        load_frags(t, ks, af, bf);
+        mma(af, bf);
+      }
+    }
+  } else {
+    // the ring kernel's two-step software pipeline (see there) on two stages: the fragments of k step 1 are read
+    // under the MFMAs of step 0, the hand-over (wait + barrier + next DMA) sits between the two MFMA groups, step 0
+    // of the next tile is read under the MFMAs of step 1
+    static_assert(TK / 32 == 2, "two k steps per tile");
+    bf16x8 af0[MT], bf0[4], af1[MT], bf1[4];
+    auto settle = [&](bf16x8 (&af)[MT], bf16x8 (&bf)[4]) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(af[i]));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bf[j]));
+    };
+    if (nk > 0) issue(0);
+    ring_wait_barrier<0>();
+    if (1 < nk) issue(1);
+    load_frags(0, 0, af0, bf0);
+    for (int t = 0; t + 1 < nk; ++t) {
+      settle(af0, bf0);
+      load_frags(t, 1, af1, bf1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(af0, bf0);
+      __builtin_amdgcn_sched_barrier(0);
+      ring_wait_barrier<0>();                       // tile t + 1 is in; every wave's reads of tile t are home
+      if (t + 2 < nk) issue(t + 2);
+      load_frags(t + 1, 0, af0, bf0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(af1, bf1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    load_frags(nk - 1, 1, af1, bf1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(af0, bf0);
+    mma(af1, bf1);
+  }
+
+  // epilogue, one 128-column half at a time: fp32 [TMR][132] through LDS, out as 16-byte row segments
+  TC* C = static_cast<TC*>(p.C);
+  const int l16 = lane & 15, kb = lane >> 4;
+  uint32_t h0 = 0, h1 = 0;
+  if (p.drop_c) rng_key_dev_x(p.seed, p.offset_dev ? *p.offset_dev : p.offset, p.thresh, h0, h1);
+  float* stage = reinterpret_cast<float*>(smem);
+  constexpr int LDS_C = TN + 4;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // everyone is done with the LDS contents
+    if ((wn >> 1) == half) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            stage[((wm * MT + i) * 16 + 4 * kb + r) * LDS_C + (wn & 1) * 64 + j * 16 + l16] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (p.vec_epi) {
+      for (int v = tid; v < W::TMR * 16; v += 512) {
+        const int row = v >> 4, c8 = (v & 15) * 8;
+        const int grow = m0 + row, gcol = n0 + half * 128 + c8;
+        if (grow >= p.M || gcol >= p.Nout) continue;
+        const float4 x0 = *reinterpret_cast<const float4*>(stage + row * LDS_C + c8);
+        const float4 x1 = *reinterpret_cast<const float4*>(stage + row * LDS_C + c8 + 4);
+        store8<TC>(p, C, grow, gcol, x0, x1, h0, h1);
+      }
+    } else {
+      for (int v = tid; v < W::TMR * 128; v += 512) {
+        const int row = v >> 7, c = v & 127;
+        const int grow = m0 + row, gcol = n0 + half * 128 + c;
+        if (grow >= p.M || gcol >= p.Nout) continue;
+        store1<TC>(p, C, grow, gcol, stage[row * LDS_C + c], p.bias ? p.bias[gcol] : 0.f, h0, h1);
+      }
+    }
+  }
+}
+
+template <typename TC, int MT, bool PIPE>
+int launch_wide_p(const FastParams& p, hipStream_t st) {
+  typedef WideCfg<MT> W;
+  static thread_local PerDevice<bool> attr_dev; bool& attr_set = attr_dev.here();
+  if (!attr_set) {
+    APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_wide_kernel<TC, MT, PIPE>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS_BYTES));
+    attr_set = true;
+  }
+  const int tiles = ((p.M + W::TMR - 1) / W::TMR) * ((p.N + TNW - 1) / TNW);
+  hipLaunchKernelGGL((gemm_bf16_wide_kernel<TC, MT, PIPE>), dim3(tiles), dim3(512), W::LDS_BYTES, st, p);
+  APA_LAUNCH_CHECK("gemm_bf16_wide_kernel");
+  return APA_OK;
+}
+template <typename TC, int MT>
+int launch_wide(const FastParams& p, hipStream_t st) {
+  static const int pipe = knob("APA_GEMM_WIDE_PIPE", 1);
+#ifdef APA_ABLATION
+  if (!pipe) return launch_wide_p<TC, MT, false>(p, st);
+#endif
+  return launch_wide_p<TC, MT, true>(p, st);
+}
+
+// tile height of the wide kernel: the smallest (32 MT) x 256 tiling that fits one resident round; 0 = none
+static int wide_pick_mt(int M, int N, int cus) {
+  const int ntn = (N + TNW - 1) / TNW;
+  for (int mt = 4; mt <= 7; ++mt)
+    if ((long)((M + 32 * mt - 1) / (32 * mt)) * ntn <= cus) return mt;
+  return 0;
+}
+
+template <typename TC>
+int launch_wide_mt(const FastParams& p, int mt, hipStream_t st) {
+  switch (mt) {
+    case 4: return launch_wide<TC, 4>(p, st);
+    case 5: return launch_wide<TC, 5>(p, st);
+    case 6: return launch_wide<TC, 6>(p, st);
+    default: return launch_wide<TC, 7>(p, st);
+  }
+}
+
 // smallest tile height (MT row tiles per wave row, block rows = 32 MT) whose tile count fits one round of the
 // chip; 0 = none does (the two-stage kernels take the product)
 static int ring_pick_mt(int M, int N, int cus) {
@@ -1057,6 +1272,17 @@ int gemm_bf16_launch(const GemmDesc& d, int splits, int k_per_split, hipStream_t
     // the 128 x 64 variant (twice the tiles, three blocks per CU) wins -- measured on the pose head:
     // 294 tiles 38.2 -> 32.6 us, 96 x 3 splits 40.0 -> 35.2 us, but 784 tiles 34.4 -> 37.4 us
     // few tiles, A k-contiguous, no split-K: the ring kernel (one resident round, 3-4 K tiles in flight)
+    // wide output, short contraction, both operands k-contiguous, no split-K: one resident round of 256-wide tiles
+    static const int use_wide = knob("APA_GEMM_WIDE", 1);
+    if (use_wide && d.a_kc && d.b_kc && splits == 1 && d.N >= 1024 && d.K / TK <= 16 && d.K / TK >= 2) {
+      const int cus = gemm_cu_count();
+      const int mt = wide_pick_mt(d.M, d.N, cus);
+      // worth it only when the one round is reasonably full (else the 128-wide kernels' second block per CU wins)
+      if (mt && (long)((d.M + 32 * mt - 1) / (32 * mt)) * ((d.N + TNW - 1) / TNW) * 4 >= (long)cus * 3) {
+        if (d.tc == 1) return launch_wide_mt<bf16_t>(p, mt, st);
+        return launch_wide_mt<float>(p, mt, st);
+      }
+    }
     static const int use_ring = knob("APA_GEMM_RING", 1);
     if (use_ring && d.a_kc && splits == 1 && d.K / TK >= 4) {
       const int mt = ring_pick_mt(d.M, d.N, gemm_cu_count());

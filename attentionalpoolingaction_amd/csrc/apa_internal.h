@@ -174,6 +174,11 @@ int gemm_bf16_launch(const GemmDesc& d, int splits, int k_per_split, hipStream_t
 // ------------------------------------------------------------------------------------------
 // Fused train step (apa_attn_head_train_step): softmax cross-entropy folded into the logits
 // reduction (forward sets `done` when it ran), batch-mean loss written by the backward head kernel.
+// Library-internal flag bits (never accepted from a caller: every extern "C" entry masks with APA_PUBLIC_FLAGS)
+constexpr unsigned APA_PUBLIC_FLAGS = 0xFFu;
+constexpr unsigned APA_IFLAG_ATT_READY = 1u << 24;      // M == 1, Xatt != X: `att` already holds Z (id / relu applied)
+constexpr unsigned APA_IFLAG_NO_ATT_WGRAD = 1u << 25;   // M == 1 + DXATT_RANK1: dWa / dba / RNG bump done by the caller
+
 struct M1Xent {
   const int64_t* labels;
   float* loss;   // [1+N]
@@ -277,9 +282,35 @@ int m1_logits2_xent(const float* z, const float* Wt, const float* abar, const fl
                     float* probs, int64_t* pred, float* part_ws, int N, int C, int K, hipStream_t st);
 // dwa2 != nullptr: columns [C1, C2) of the partial matrix are summed into dwa2, dwa3 != nullptr: columns
 // [C2, C) into dwa3 (one launch, up to three outputs)
+// apa_dense.hip: the pose-head halves of the one-call cfg 003 step (apa_pose_attn_train_step)
+struct PoseStepArgs {
+  const void* W1_bf16 = nullptr;        // caller-maintained bf16 copy of W1 (nullptr: converted per call)
+  const float* wa = nullptr; const float* ba = nullptr; float* att = nullptr; bool relu_att = false;
+  const float* pose_labels = nullptr; const uint8_t* pose_valid = nullptr; float* dPl = nullptr;
+  float pose_wt = 1.f, grad_scale = 1.f;
+};
+bool pose_step_fast_ok(int N, int P, int C, int Cp, int J, int dtype, const void* Ppre, const float* W2,
+                       const float* wa);
+void* pose_ws_loss_scratch(void* ws, int N, int P, int C, int Cp, int J, int dtype);   // >= apa_pose_l2_workspace_bytes
+int pose_fwd_fused(const void* X, const float* W1, const float* b1, const float* W2, const float* b2, void* Ppre,
+                   float* Pl, void* ws, size_t ws_bytes, int N, int P, int C, int Cp, int J, int dtype,
+                   const PoseStepArgs& a, hipStream_t st);
+int pose_bwd_fused(const void* X, const float* W1, const float* W2, const void* Ppre, const float* dPl,
+                   const float* dZ, const float* wa, void* dX, int accumulate_dX, float* dW1, float* db1,
+                   float* dW2, float* db2, float* dWa, float* dba, float* loss_pose, uint64_t* rng_bump,
+                   void* ws, size_t ws_bytes, int N, int P, int C, int Cp, int J, int dtype,
+                   const PoseStepArgs& a, hipStream_t st);
+
+// `more`: a fourth / fifth output section (columns [C3, C4) -> dwa4, [C4, C) -> dwa5) and an optional scalar
+// reduction aux_dst[0] = aux_scale * sum(aux_src[0 .. aux_n)) done by the launch's last block
+struct ColsumMore {
+  float* dwa4 = nullptr; int C3 = 0;
+  float* dwa5 = nullptr; int C4 = 0;
+  const float* aux_src = nullptr; int aux_n = 0; float aux_scale = 0.f; float* aux_dst = nullptr;
+};
 int m1_colsum(const float* pdwa, const float* pdba, float* dwa, float* dba, int nblk, int C, int ld,
               uint64_t* rng_bump, hipStream_t st, float* dwa2 = nullptr, int C1 = 0, float* dwa3 = nullptr,
-              int C2 = 0, int perm_nthr = 0, int perm_cp = 0);
+              int C2 = 0, int perm_nthr = 0, int perm_cp = 0, const ColsumMore* more = nullptr);
 
 // apa_gemm_bf16.hip: C = (A[:, :64] . B[:, :64]^T) * mask/keep + A[:, 64:] . B[:, 64:]^T  (all bf16, k contiguous)
 int gemm_bf16_mid_dropout(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N,

@@ -814,7 +814,14 @@ int m1_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
     return APA_ERR_UNSUPPORTED;
   }
   int pool_act = act;
-  if (!fused) {
+  if (!fused && (flags & APA_IFLAG_ATT_READY)) {
+    // the fused cfg 003 step: the pose head's Pl kernel already left Z = Xatt . wa + ba (id / relu applied) in att
+    if (act == ACT_SOFTMAX) {
+      hipLaunchKernelGGL(m1_softmax_rows_kernel, dim3(N), dim3(64), 0, st, att, P);
+      APA_LAUNCH_CHECK("m1_softmax_rows_kernel");
+    }
+    pool_act = ACT_ID;
+  } else if (!fused) {
     const long NP = (long)N * P;
     const int nb = (int)((NP + 3) / 4 < 2048 ? (NP + 3) / 4 : 2048);
     if (dtype == APA_DTYPE_F32)
@@ -978,6 +985,15 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
 
   int nred = pl.nblk;
   int cred = C;
+  if (flags & APA_IFLAG_NO_ATT_WGRAD) {
+    // fused cfg 003 step: dWa = Xatt^T dZ and dba = sum dZ ride on the pose head's backward rows kernel (dZ is a
+    // 17th column of dPl there), and its column-sum launch advances the dropout counter
+    if (!rank1 || !small_ok) {
+      set_error("attn_pool M=1: NO_ATT_WGRAD needs the rank-1 dXatt form and the small-K head kernels (internal)");
+      return APA_ERR_UNSUPPORTED;
+    }
+    return APA_OK;
+  }
   if (!fused) {
     const long NP = (long)N * P;
     int nb = (int)((NP + 15) / 16);

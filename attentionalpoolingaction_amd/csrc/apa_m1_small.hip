@@ -950,8 +950,16 @@ __global__ __launch_bounds__(256) void m1_bwd_head_tiles_kernel(
 // grid = ceil(C/32) blocks of 1024 threads: 32 row groups x 32 columns, 128-byte row segments.
 // The last kernel of the backward call: optionally advances the HBM dropout counter.
 // --------------------------------------------------------------------------------------------
-// Columns [0, C1) go to dwa, columns [C1, C2) to dwa2, columns [C2, C) to dwa3 (up to three outputs from
-// one partial matrix, e.g. dW2 | db1 | db2 of the pose head); C1 == C2 == C for a single output.
+// Columns [0, C1) go to dwa, columns [C1, C2) to dwa2, columns [C2, C3) to dwa3, [C3, C4) to dwa4 and
+// [C4, C) to dwa5 (up to five outputs from one partial matrix: dW2 | db1 | db2 | dWa | dba of the cfg 003
+// pose head); C1 == ... == C for a single output.
+// aux (optional): aux_dst[0] = aux_scale * sum(aux_src[0 .. aux_n)) in a fixed order, by the LAST block -- a
+// scalar reduction that would otherwise be a launch of its own (the pose loss of the fused cfg 003 step).
+struct ColsumExtra {
+  float* dwa4 = nullptr; int C3 = 0;
+  float* dwa5 = nullptr; int C4 = 0;
+  const float* aux_src = nullptr; int aux_n = 0; float aux_scale = 0.f; float* aux_dst = nullptr;
+};
 __global__ __launch_bounds__(1024) void m1_colsum_kernel(const float* __restrict__ pdwa,
                                                          const float* __restrict__ pdba,
                                                          float* __restrict__ dwa,
@@ -959,7 +967,7 @@ __global__ __launch_bounds__(1024) void m1_colsum_kernel(const float* __restrict
                                                          int ld, uint64_t* __restrict__ rng_bump,
                                                          float* __restrict__ dwa2, int C1,
                                                          float* __restrict__ dwa3, int C2, int perm_nthr,
-                                                         int perm_cp) {
+                                                         int perm_cp, ColsumExtra x) {
   // perm_nthr > 0: the first section holds the pose head's dW2 partials in the permuted order of
   // pose_bwd_rows_kernel (float4 v of thread t at float4 index v * nthr + t; v = 4 (column & 1) + q / 4)
   __shared__ float red[32][33];
@@ -999,7 +1007,9 @@ __global__ __launch_bounds__(1024) void m1_colsum_kernel(const float* __restrict
         dwa[c] = s;
       }
     } else if (c < C2) dwa2[c - C1] = s;
-    else dwa3[c - C2] = s;
+    else if (c < x.C3) dwa3[c - C2] = s;
+    else if (c < x.C4) x.dwa4[c - x.C3] = s;
+    else x.dwa5[c - x.C4] = s;
   }
   if (blockIdx.x == 0 && pdba) {
     __syncthreads();
@@ -1012,7 +1022,20 @@ __global__ __launch_bounds__(1024) void m1_colsum_kernel(const float* __restrict
       float s = 0.f;
       for (int w = 0; w < 16; ++w) s += red[0][w];
       dba[0] = s;
-      if (rng_bump) *rng_bump += 1;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && rng_bump) *rng_bump += 1;
+  if (x.aux_src && blockIdx.x == gridDim.x - 1) {
+    __syncthreads();
+    float a = 0.f;
+    for (int b = threadIdx.x; b < x.aux_n; b += 1024) a += x.aux_src[b];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) red[1][threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float s = 0.f;
+      for (int w = 0; w < 16; ++w) s += red[1][w];
+      x.aux_dst[0] = s * x.aux_scale;
     }
   }
 }
@@ -1177,11 +1200,18 @@ int m1_bwd_head(const float* G, const float* Wt, const float* zsave, const float
 
 int m1_colsum(const float* pdwa, const float* pdba, float* dwa, float* dba, int nblk, int C, int ld,
               uint64_t* rng_bump, hipStream_t st, float* dwa2, int C1, float* dwa3, int C2, int perm_nthr,
-              int perm_cp) {
+              int perm_cp, const ColsumMore* more) {
   if (!dwa2) C1 = C;
   if (!dwa3) C2 = C;
+  ColsumExtra x;
+  x.C3 = C; x.C4 = C;
+  if (more) {
+    if (more->dwa4) { x.dwa4 = more->dwa4; x.C3 = more->C3; }
+    if (more->dwa5) { x.dwa5 = more->dwa5; x.C4 = more->C4; }
+    x.aux_src = more->aux_src; x.aux_n = more->aux_n; x.aux_scale = more->aux_scale; x.aux_dst = more->aux_dst;
+  }
   hipLaunchKernelGGL(m1_colsum_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, pdwa, pdba, dwa, dba,
-                     nblk, C, ld, rng_bump, dwa2, C1, dwa3, C2, perm_nthr, perm_cp);
+                     nblk, C, ld, rng_bump, dwa2, C1, dwa3, C2, perm_nthr, perm_cp, x);
   APA_LAUNCH_CHECK("m1_colsum_kernel");
   return APA_OK;
 }

@@ -13,6 +13,7 @@
 namespace apa {
 
 struct SgdSegs {
+  bf16_t* shadow[APA_SGD_MAX_SEGMENTS];   // optional bf16 copy of the UPDATED weights (nullptr: none)
   float* w[APA_SGD_MAX_SEGMENTS];
   unsigned long long off[APA_SGD_MAX_SEGMENTS + 1];   // element offsets into the flat buffers
   float wd[APA_SGD_MAX_SEGMENTS];
@@ -31,6 +32,7 @@ __global__ __launch_bounds__(256) void momentum_sgd_kernel(SgdSegs s, const floa
   const float* __restrict__ g = grad + o;
   float* __restrict__ a = acc + o;
   const float wd = s.wd[sg];
+  bf16_t* __restrict__ sh = s.shadow[sg];
   const size_t nv = n / 4;
   for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < nv; v += (size_t)gridDim.x * 256) {
     f4u wv = *reinterpret_cast<const f4u*>(w + v * 4);
@@ -43,12 +45,18 @@ __global__ __launch_bounds__(256) void momentum_sgd_kernel(SgdSegs s, const floa
     }
     *reinterpret_cast<f4u*>(a + v * 4) = av;
     *reinterpret_cast<f4u*>(w + v * 4) = wv;
+    if (sh) {   // the bf16 operand copy the MFMA products read (pose-head W1): kept current by the update itself
+      typedef unsigned u2u __attribute__((ext_vector_type(2), aligned(4)));
+      *reinterpret_cast<u2u*>(sh + v * 4) = u2u{pack_bf16x2(wv[0], wv[1]), pack_bf16x2(wv[2], wv[3])};
+    }
   }
   if (blockIdx.x == 0) {
     for (size_t i = nv * 4 + threadIdx.x; i < n; i += 256) {
       const float av = fmaf(momentum, a[i], fmaf(wd, w[i], g[i] * gscale));
       a[i] = av;
-      w[i] = fmaf(-lr, av, w[i]);
+      const float wn = fmaf(-lr, av, w[i]);
+      w[i] = wn;
+      if (sh) sh[i].v = (uint16_t)f32_to_bf16_bits(wn);
     }
   }
 }
@@ -130,13 +138,12 @@ extern "C" int apa_accumulate_gradients_div(float* out, const float* const* part
   return accumulate_launch("apa_accumulate_gradients_div", true, out, parts, nparts, n, divisor, stream);
 }
 
-extern "C" int apa_momentum_sgd_step(int nseg, float* const* weights, const size_t* sizes,
-                                     const float* weight_decay, const float* grad_flat,
-                                     float* acc_flat, float lr, float momentum, float grad_scale,
-                                     void* stream) {
+static int sgd_launch(const char* who, int nseg, float* const* weights, const size_t* sizes,
+                      const float* weight_decay, const float* grad_flat, float* acc_flat, float lr, float momentum,
+                      float grad_scale, void* const* bf16_shadow, void* stream) {
   if (nseg <= 0 || nseg > APA_SGD_MAX_SEGMENTS || !weights || !sizes || !weight_decay || !grad_flat ||
       !acc_flat) {
-    set_error("apa_momentum_sgd_step: bad arguments (nseg=%d, max %d)", nseg, APA_SGD_MAX_SEGMENTS);
+    set_error("%s: bad arguments (nseg=%d, max %d)", who, nseg, APA_SGD_MAX_SEGMENTS);
     return APA_ERR_INVALID_ARG;
   }
   SgdSegs s;
@@ -144,10 +151,15 @@ extern "C" int apa_momentum_sgd_step(int nseg, float* const* weights, const size
   size_t o = 0, biggest = 0;
   for (int i = 0; i < nseg; ++i) {
     if (!weights[i]) {
-      set_error("apa_momentum_sgd_step: weights[%d] is NULL", i);
+      set_error("%s: weights[%d] is NULL", who, i);
       return APA_ERR_INVALID_ARG;
     }
     s.w[i] = weights[i];
+    s.shadow[i] = bf16_shadow ? static_cast<bf16_t*>(bf16_shadow[i]) : nullptr;
+    if (s.shadow[i] && (reinterpret_cast<uintptr_t>(s.shadow[i]) & 3)) {
+      set_error("%s: bf16_shadow[%d] must be 4-byte aligned", who, i);
+      return APA_ERR_INVALID_ARG;
+    }
     s.off[i] = o;
     s.wd[i] = weight_decay[i];
     o += sizes[i];
@@ -158,8 +170,24 @@ extern "C" int apa_momentum_sgd_step(int nseg, float* const* weights, const size
   size_t nbx = (biggest / 4 + 255) / 256;
   if (nbx < 1) nbx = 1;
   if (nbx > 1024) nbx = 1024;
-  hipLaunchKernelGGL(momentum_sgd_kernel, dim3((unsigned)nbx, nseg), dim3(256), 0,
+  hipLaunchKernelGGL(momentum_sgd_kernel, dim3((unsigned)nbx, (unsigned)nseg), dim3(256), 0,
                      static_cast<hipStream_t>(stream), s, grad_flat, acc_flat, lr, momentum, grad_scale);
   APA_LAUNCH_CHECK("momentum_sgd_kernel");
   return APA_OK;
+}
+
+extern "C" int apa_momentum_sgd_step(int nseg, float* const* weights, const size_t* sizes,
+                                     const float* weight_decay, const float* grad_flat,
+                                     float* acc_flat, float lr, float momentum, float grad_scale,
+                                     void* stream) {
+  return sgd_launch("apa_momentum_sgd_step", nseg, weights, sizes, weight_decay, grad_flat, acc_flat, lr, momentum,
+                    grad_scale, nullptr, stream);
+}
+
+extern "C" int apa_momentum_sgd_step_shadow(int nseg, float* const* weights, const size_t* sizes,
+                                            const float* weight_decay, const float* grad_flat, float* acc_flat,
+                                            float lr, float momentum, float grad_scale, void* const* bf16_shadow,
+                                            void* stream) {
+  return sgd_launch("apa_momentum_sgd_step_shadow", nseg, weights, sizes, weight_decay, grad_flat, acc_flat, lr,
+                    momentum, grad_scale, bf16_shadow, stream);
 }

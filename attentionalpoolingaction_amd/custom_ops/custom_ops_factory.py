@@ -88,6 +88,11 @@ _SIGNATURES = {
     'apa_attn_head_eval_step': (c_int, [c_void_p] * 15 + [c_size_t] + [c_int] * 6 + [c_uint, c_int, c_void_p]),
     'apa_momentum_sgd_step': (c_int, [c_int, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_float),
                                       c_void_p, c_void_p, c_float, c_float, c_float, c_void_p]),
+    'apa_momentum_sgd_step_shadow': (c_int, [c_int, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_float),
+                                             c_void_p, c_void_p, c_float, c_float, c_float, POINTER(c_void_p),
+                                             c_void_p]),
+    'apa_pose_attn_train_step': (c_int, [c_void_p] + [c_int] * 6 + [c_uint, c_float, ctypes.c_uint64,
+                                                                    ctypes.c_uint64, c_int, c_void_p]),
     'apa_accumulate_gradients': (c_int, [c_void_p, POINTER(c_void_p), c_int, c_size_t, c_float, c_void_p]),
     'apa_accumulate_gradients_div': (c_int, [c_void_p, POINTER(c_void_p), c_int, c_size_t, c_float, c_void_p]),
     'apa_prof_event_create': (c_int, [POINTER(c_void_p)]),
@@ -811,6 +816,82 @@ class HeadTrainStep:
             _check(rc, 'apa_attn_head_train_step')
 
 
+class ApaPoseAttnStepIO(ctypes.Structure):
+    """`apa_pose_attn_step_io` of include/apa.h (field order is the ABI)."""
+    _fields_ = ([(n, c_void_p) for n in ('X', 'W1', 'b1', 'W2', 'b2', 'W1_bf16', 'Wa', 'ba', 'Wt', 'bt', 'labels',
+                                          'pose_labels', 'pose_valid')] +
+                [('action_wt', c_float), ('pose_wt', c_float), ('grad_scale', c_float)] +
+                [(n, c_void_p) for n in ('Ppre', 'Pl', 'att', 'logits', 'zsave', 'abar', 'loss_action', 'loss_pose',
+                                          'G', 'dPl', 'dZ', 'dX', 'dW1', 'db1', 'dW2', 'db2', 'dWa', 'dba', 'dWt',
+                                          'dbt')] +
+                [('ws_pool', c_void_p), ('ws_pool_bytes', c_size_t), ('ws_pose', c_void_p),
+                 ('ws_pose_bytes', c_size_t)])
+
+
+class PoseAttnTrainStep:
+    """apa_pose_attn_train_step bound to caller-owned buffers: the whole cfg 003 head step (PoseLogits head ->
+    attention from pose_pre_logits -> dropout + pooling -> pose L2 + softmax cross-entropy -> every gradient) as ONE
+    foreign call, like the reference's one sess.run per step (src/train.py:529-566).
+
+    `params = (W1, b1, W2, b2, Wa, ba, Wt, bt)` fp32; `grads = (dX, dW1, db1, dW2, db2, dWa, dba, dWt, dbt)`;
+    `w1_bf16`: optional bf16 copy of W1 the caller keeps current (momentum_sgd_step(..., shadows=...)).
+    Outputs as attributes: Ppre, Pl, att, logits, zsave, abar, loss_action [1+N], loss_pose [1], G, dPl, dZ."""
+
+    def __init__(self, X, params, labels, pose_labels, pose_valid, grads, *, flags=0, keep_prob=1.0, seed=0,
+                 offset=0, action_wt=1.0, pose_wt=1.0, grad_scale=1.0, w1_bf16=None):
+        self.lib = load_library()
+        W1, b1, W2, b2, Wa, ba, Wt, bt = params
+        dX, dW1, db1, dW2, db2, dWa, dba, dWt, dbt = grads
+        N, C = X.shape[0], X.shape[-1]
+        P = X.numel() // (N * C)
+        Cp, J, K = W1.shape[1], W2.shape[1], Wt.shape[1]
+        dev, f32 = X.device, torch.float32
+        if tuple(W1.shape) != (C, Cp) or Wa.numel() != Cp or tuple(Wt.shape) != (C, K):
+            raise ApaError('PoseAttnTrainStep: W1 [C,Cp], Wa [Cp,1], Wt [C,K] expected')
+        if pose_valid.dtype == torch.bool:
+            pose_valid = pose_valid.to(torch.uint8)
+        new = lambda *shape, dt=f32: torch.empty(shape, dtype=dt, device=dev)
+        self.Ppre, self.Pl, self.att = new(N, P, Cp, dt=X.dtype), new(N, P, J), new(N, P, 1)
+        self.logits, self.zsave, self.abar = new(N, K), new(N, C), new(N)
+        self.loss_action, self.loss_pose = new(1 + N), new(1)
+        self.G, self.dPl, self.dZ = new(N, K), new(N, P, J), new(N * P)
+        dt = _feat_dtype(X)
+        seed, off, flags = _rng_key(seed, offset, flags)
+        if flags & APA_FLAG_RNG_EXTERNAL:
+            raise ApaError('PoseAttnTrainStep: an external keep mask is served by the per-op entry points')
+        self.ws_pool = torch.empty((max(int(self.lib.apa_attn_pool_workspace_bytes(N, P, C, Cp, K, 1, flags)), 16),),
+                                   dtype=torch.uint8, device=dev)
+        self.ws_pose = torch.empty((max(int(self.lib.apa_pose_head_workspace_bytes(N, P, C, Cp, J, dt)), 16),),
+                                   dtype=torch.uint8, device=dev)
+        self._keep = (X, params, labels, pose_labels, pose_valid, grads, offset, w1_bf16)
+        io = ApaPoseAttnStepIO()
+        io.X = _dev_ptr(X, 'X')
+        for name, t in (('W1', W1), ('b1', b1), ('W2', W2), ('b2', b2), ('Wa', Wa), ('ba', ba), ('Wt', Wt), ('bt', bt),
+                        ('pose_labels', pose_labels), ('dW1', dW1), ('db1', db1), ('dW2', dW2), ('db2', db2),
+                        ('dWa', dWa), ('dba', dba), ('dWt', dWt), ('dbt', dbt)):
+            setattr(io, name, _dev_ptr(t, name, f32))
+        io.W1_bf16 = None if w1_bf16 is None else _dev_ptr(w1_bf16, 'w1_bf16', torch.bfloat16)
+        if w1_bf16 is not None and w1_bf16.numel() != W1.numel():
+            raise ApaError('PoseAttnTrainStep: w1_bf16 must have W1\'s element count')
+        io.labels = _dev_ptr(labels, 'labels', torch.int64)
+        io.pose_valid = _dev_ptr(pose_valid, 'pose_valid', torch.uint8)
+        if pose_labels.numel() != N * P * J or pose_valid.numel() != N * J or labels.numel() != N:
+            raise ApaError('PoseAttnTrainStep: labels [N], pose_labels [N,P,J], pose_valid [N,J] expected')
+        io.action_wt, io.pose_wt, io.grad_scale = float(action_wt), float(pose_wt), float(grad_scale)
+        io.dX = _dev_ptr(dX, 'dX', X.dtype)
+        for name in ('Ppre', 'Pl', 'att', 'logits', 'zsave', 'abar', 'loss_action', 'loss_pose', 'G', 'dPl', 'dZ'):
+            setattr(io, name, getattr(self, name).data_ptr())
+        io.ws_pool, io.ws_pool_bytes = self.ws_pool.data_ptr(), self.ws_pool.numel()
+        io.ws_pose, io.ws_pose_bytes = self.ws_pose.data_ptr(), self.ws_pose.numel()
+        self._io = io
+        self._args = [ctypes.addressof(io), N, P, C, Cp, J, K, flags, float(keep_prob), int(seed), off, dt]
+
+    def run(self, stream: Optional[int] = None) -> None:
+        rc = self.lib.apa_pose_attn_train_step(*self._args, _stream_ptr() if stream is None else stream)
+        if rc != 0:
+            _check(rc, 'apa_pose_attn_train_step')
+
+
 class HeadEvalStep:
     """apa_attn_head_eval_step bound to caller-owned inputs: forward + softmax probabilities + argmax
     (+ per-example loss when `labels` is given) as ONE foreign call (eval.py:181-197).  Outputs:
@@ -851,9 +932,11 @@ class HeadEvalStep:
             _check(rc, 'apa_attn_head_eval_step')
 
 
-def momentum_sgd_step(weights, weight_decay, grad_flat, acc_flat, lr, momentum=0.9, grad_scale=1.0):
+def momentum_sgd_step(weights, weight_decay, grad_flat, acc_flat, lr, momentum=0.9, grad_scale=1.0, shadows=None):
     """One fused launch: acc = m*acc + (grad_scale*g + wd_i*w_i); w_i -= lr*acc for every parameter.
-    `weights`: list of fp32 device tensors in bucket order; `weight_decay`: one float per tensor."""
+    `weights`: list of fp32 device tensors in bucket order; `weight_decay`: one float per tensor.
+    `shadows`: optional list (one entry per tensor, None = no shadow) of bf16 device tensors that receive the
+    UPDATED weights rounded to bf16 in the same launch (apa_momentum_sgd_step_shadow: the pose head's W1)."""
     lib = load_library()
     n = len(weights)
     ptrs = (c_void_p * n)(*[_dev_ptr(w, 'weights[%d]' % i, torch.float32) for i, w in enumerate(weights)])
@@ -863,6 +946,16 @@ def momentum_sgd_step(weights, weight_decay, grad_flat, acc_flat, lr, momentum=0
     if grad_flat.numel() != total or acc_flat.numel() != total:
         raise ValueError('flat buffers hold {} / {} elements, parameters {}'.format(
             grad_flat.numel(), acc_flat.numel(), total))
+    if shadows is not None and any(t is not None for t in shadows):
+        for w_, t in zip(weights, shadows):
+            if t is not None and (t.dtype != torch.bfloat16 or t.numel() != w_.numel() or not t.is_contiguous()):
+                raise ApaError('momentum_sgd_step: a shadow must be a contiguous bf16 tensor of its weight\'s size')
+        sh = (c_void_p * n)(*[None if t is None else _dev_ptr(t, 'shadow', torch.bfloat16) for t in shadows])
+        _check(lib.apa_momentum_sgd_step_shadow(
+            n, ptrs, sizes, wds, _dev_ptr(grad_flat, 'grad_flat', torch.float32),
+            _dev_ptr(acc_flat, 'acc_flat', torch.float32), lr, momentum, grad_scale, sh, _stream_ptr()),
+            'apa_momentum_sgd_step_shadow')
+        return
     _check(lib.apa_momentum_sgd_step(n, ptrs, sizes, wds, _dev_ptr(grad_flat, 'grad_flat', torch.float32),
                                      _dev_ptr(acc_flat, 'acc_flat', torch.float32), lr, momentum,
                                      grad_scale, _stream_ptr()), 'apa_momentum_sgd_step')

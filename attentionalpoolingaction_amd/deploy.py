@@ -257,7 +257,11 @@ class MomentumSGD:
     (`apa_momentum_sgd_step`); CPU tensors (the gloo tests) take the equivalent torch expressions."""
 
     def __init__(self, params: Dict[str, torch.Tensor], bucket: GradientBucket, lr: float,
-                 momentum: float = 0.9, weight_decay: float = 0.0, regularized: Sequence[str] = ()):
+                 momentum: float = 0.9, weight_decay: float = 0.0, regularized: Sequence[str] = (),
+                 bf16_shadows: Optional[Dict[str, torch.Tensor]] = None):
+        """`bf16_shadows` {name: bf16 tensor}: operand copies the bf16 MFMA products read (the pose head's W1 for
+        `cof.PoseAttnTrainStep(w1_bf16=...)`), rewritten from the updated weights by the update's own launch."""
+        self.shadows = dict(bf16_shadows or {})
         self.params = params
         self.bucket = bucket
         self.lr = lr
@@ -271,7 +275,8 @@ class MomentumSGD:
         ws = [self.params[n].data for n in self.bucket.names]
         if self.bucket.flat.is_cuda:
             from .custom_ops import custom_ops_factory as cof
-            cof.momentum_sgd_step(ws, self.wd, self.bucket.flat, self.acc, lr, self.momentum, grad_scale)
+            sh = [self.shadows.get(n) for n in self.bucket.names] if self.shadows else None
+            cof.momentum_sgd_step(ws, self.wd, self.bucket.flat, self.acc, lr, self.momentum, grad_scale, shadows=sh)
             return
         o = 0
         for w, wd in zip(ws, self.wd):
@@ -281,6 +286,8 @@ class MomentumSGD:
             a.mul_(self.momentum).add_(g)
             w.add_(a, alpha=-lr)
             o += n
+        for name, t in self.shadows.items():
+            t.copy_(self.params[name].data.reshape(t.shape))
 
 
 def exponential_decay_lr(base_lr: float, global_step: int, decay_steps: int, decay_rate: float,

@@ -211,6 +211,60 @@ int apa_attn_head_eval_step(const void* X, const void* Xatt, const float* Wa, co
                             int64_t* pred, void* ws, size_t ws_bytes, int N, int P, int C, int Ca, int K,
                             int M, unsigned flags, int dtype, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * One host call for the whole cfg 003 head step (003_MPII_ResNet_withPoseAttention.yaml): what the reference
+ * runs as one sess.run of   PoseLogits head (nets_factory.py:147-160) -> attention from pose_pre_logits
+ * (:247-270, M = 1) -> dropout + top-down conv + attention-weighted mean (:296-328) -> pose L2 +
+ * softmax cross-entropy (src/loss.py:11-80) -> tf.gradients of both w.r.t. every head variable and conv5.
+ * Same results as the sequence apa_pose_head_fwd, apa_pose_l2_loss_fwd_bwd, apa_attn_head_train_step
+ * (APA_FLAG_DXATT_RANK1), apa_pose_head_bwd_rank1ext -- which is what it runs when the fused kernels do not
+ * serve the shape -- but inside one call neighbouring ops share launches (bf16 features, J = 16,
+ * Cp in {256,512,768,1024}, K <= 512): the Pl product also emits the attention logits and the pose loss
+ * gradient; the pose head's backward rows pass also emits dWa / dba; its column-sum launch also finishes the
+ * pose loss and advances the dropout counter: 18 -> 13 launches at the benchmark shape.
+ * io->W1_bf16 (optional): a bf16 copy of W1 [C,Cp] the caller keeps current (apa_momentum_sgd_step_shadow
+ * rewrites it in the optimizer's own launch); NULL = converted inside the call.
+ * All pointers device memory; X/Ppre/dX of `dtype`, everything else f32 (labels int64, pose_valid uint8).
+ * flags: APA_FLAG_SOFTMAX_ATT / RELU_ATT / TRAIN / RNG_DEVICE as for apa_attn_pool_fwd.
+ */
+typedef struct apa_pose_attn_step_io {
+  const void* X;            /* [N,P,C]                                                   */
+  const float* W1;          /* [C,Cp]   PoseLogits/ExtraConv2d_1x1                       */
+  const float* b1;          /* [Cp]                                                      */
+  const float* W2;          /* [Cp,J]   PoseLogits/Conv2d_1c_1x1                         */
+  const float* b2;          /* [J]                                                       */
+  const void* W1_bf16;      /* optional bf16 [C,Cp] copy of W1, or NULL                  */
+  const float* Wa;          /* [Cp,1]   Conv2d_PrePose_Attn                              */
+  const float* ba;          /* [1]                                                       */
+  const float* Wt;          /* [C,K]    top-down conv                                    */
+  const float* bt;          /* [K]                                                       */
+  const int64_t* labels;    /* [N]                                                       */
+  const float* pose_labels; /* [N,P,J]                                                   */
+  const uint8_t* pose_valid;/* [N,J]                                                     */
+  float action_wt, pose_wt, grad_scale;
+  /* activations (outputs) */
+  void* Ppre;               /* [N,P,Cp] dtype                                            */
+  float* Pl;                /* [N,P,J]                                                   */
+  float* att;               /* [N,P]                                                     */
+  float* logits;            /* [N,K]                                                     */
+  float* zsave;             /* [N,C]                                                     */
+  float* abar;              /* [N]                                                       */
+  float* loss_action;       /* [1+N]  (as apa_attn_head_train_step)                      */
+  float* loss_pose;         /* [1]                                                       */
+  /* gradients (outputs) */
+  float* G;                 /* [N,K]   d loss / d logits                                 */
+  float* dPl;               /* [N,P,J]                                                   */
+  float* dZ;                /* [N*P]   gradient at the attention logits (rank-1 factor)  */
+  void* dX;                 /* [N,P,C] dtype                                             */
+  float *dW1, *db1, *dW2, *db2, *dWa, *dba, *dWt, *dbt;
+  /* scratch */
+  void* ws_pool;  size_t ws_pool_bytes;   /* apa_attn_pool_workspace_bytes(N,P,C,Cp,K,1,flags) */
+  void* ws_pose;  size_t ws_pose_bytes;   /* apa_pose_head_workspace_bytes(N,P,C,Cp,J,dtype)   */
+} apa_pose_attn_step_io;
+int apa_pose_attn_train_step(const apa_pose_attn_step_io* io, int N, int P, int C, int Cp, int J, int K,
+                             unsigned flags, float keep_prob, uint64_t seed, uint64_t offset, int dtype,
+                             void* stream);
+
 /* Pose loss: src/loss.py:29-70 ('l2', LOSS_FN_POSE_SAMPLED off) fused with its gradient.
  *   loss[0] = wt * sum_j mean_n( valid[n,j] ? 0.5*sum_p (Pl-lbl)^2 / (N*P) : 0 )
  *   dPl = grad_scale * wt * valid[n,j] * (Pl - lbl) / (N*N*P)
@@ -419,6 +473,14 @@ int apa_attn_pool_bwd_cat(const apa_concat_feat* cat, const apa_hooks* hooks, co
 int apa_momentum_sgd_step(int nseg, float* const* weights, const size_t* sizes,
                           const float* weight_decay, const float* grad_flat, float* acc_flat,
                           float lr, float momentum, float grad_scale, void* stream);
+/* The same update; bf16_shadow[i] (HOST array of nseg device pointers, entries may be NULL) additionally receives
+ * the UPDATED weights of segment i rounded to bf16 (round-to-nearest-even) -- the operand copy the bf16 MFMA
+ * products read (apa_pose_attn_step_io.W1_bf16), kept current by the optimizer's own launch instead of a
+ * conversion kernel in every step. */
+int apa_momentum_sgd_step_shadow(int nseg, float* const* weights, const size_t* sizes,
+                                 const float* weight_decay, const float* grad_flat, float* acc_flat,
+                                 float lr, float momentum, float grad_scale, void* const* bf16_shadow,
+                                 void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * TRAIN.ITER_SIZE accumulation (src/train.py:529-566: `ref = grad` on the first micro-step, `ref += grad` on the

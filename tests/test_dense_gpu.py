@@ -170,6 +170,82 @@ def test_cfg003_one_call_attention_step_equals_the_separate_calls(gpu, dtype):
         cof.HeadTrainStep(Xd, Xd, Wtd[:, :1].contiguous(), bad, Wtd, btd, lab, grads, dxatt_rank1=True)
 
 
+@pytest.mark.parametrize('dtype,N,H,softmax,relu', [(torch.bfloat16, 4, 7, False, False),
+                                                     (torch.bfloat16, 32, 14, False, False),
+                                                     (torch.bfloat16, 3, 5, True, False),
+                                                     (torch.bfloat16, 2, 15, False, True),
+                                                     (torch.float32, 3, 7, False, False)])
+def test_cfg003_whole_step_in_one_call_matches_the_per_op_sequence(gpu, dtype, N, H, softmax, relu):
+    """apa_pose_attn_train_step (cof.PoseAttnTrainStep): the cfg 003 head step of one sess.run -- PoseLogits head ->
+    attention from pose_pre_logits -> dropout + pooling -> pose L2 + softmax cross-entropy -> all gradients
+    (nets_factory.py:147-160,247-328, loss.py:11-80) -- as ONE host call, against the per-op sequence.
+    bf16 features take the fused kernels (Pl product + attention logits + pose-loss gradient in one launch; dWa / dba
+    on the pose head's backward rows pass; pose loss and dropout counter finished by its column-sum launch): what is
+    computed by the same kernel on the same operands must be BIT-identical (Ppre, Pl, dPl), the attention logits are
+    summed in a different order (1e-6), everything downstream of them follows at fp32 / bf16-storage round-off.
+    fp32 features run the four calls inside the entry point: bit-identical throughout."""
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    C, Cp, J, K = 2048, 768, 16, 393
+    P = H * H
+    X, W1, b1, W2, b2, g = _pose_problem(N, H, C, Cp, J, seed=100 * N + H, dtype=dtype)
+    Wa = torch.randn(Cp, 1, generator=g) / Cp ** 0.5
+    ba = torch.randn(1, generator=g) * 0.1
+    Wt = torch.randn(C, K, generator=g) / C ** 0.5
+    bt = torch.randn(K, generator=g) * 0.1
+    labels = torch.randint(0, K, (N,), generator=g)
+    pose_lbl = torch.rand(N, P, J, generator=g)
+    valid = torch.rand(N, J, generator=g) > 0.3
+    d = lambda t: t.to(gpu).contiguous()
+    Xd, W1d, b1d, W2d, b2d, Wad, bad, Wtd, btd, lab = map(d, (X.view(N, P, C), W1, b1, W2, b2, Wa, ba, Wt, bt, labels))
+    lbl_d, valid_d = d(pose_lbl), d(valid)
+    flags = cof.attn_flags(softmax, relu, True)
+    ctr_a = torch.full((1,), 7, dtype=torch.int64, device=gpu)
+    ctr_b = ctr_a.clone()
+    wts = dict(action_wt=1.3, pose_wt=0.7, grad_scale=0.5)
+
+    # ---- per-op sequence (device-side dropout counter, like the one-call form)
+    kw = dict(flags=flags, keep_prob=0.5, seed=9, offset=ctr_a)
+    Ppre, Pl, pws = cof.pose_head_fwd(Xd, W1d, b1d, W2d, b2d)
+    lossp, dPl = cof.pose_l2_loss_fwd_bwd(Pl, lbl_d, valid_d, wt=wts['pose_wt'], grad_scale=wts['grad_scale'])
+    logits, att, zs, ab, _, ws = cof.attn_pool_fwd(Xd, Ppre, Wad, bad, Wtd, btd, **kw)
+    lossx, G, _, _ = cof.softmax_xent_fwd_bwd(logits, lab, wt=wts['action_wt'], grad_scale=wts['grad_scale'])
+    dX, dZ, dWa, dba, dWt, dbt = cof.attn_pool_bwd(Xd, Ppre, Wad, bad, Wtd, btd, att, zs, ab, G, workspace=ws,
+                                                   dxatt_rank1=True, **kw)
+    dXf, dW1, db1, dW2, db2 = cof.pose_head_bwd(Xd, W1d, W2d, Ppre, dPl, None, dX=dX, accumulate_dX=True,
+                                                workspace=pws, ext_rank1=(dZ, Wad.view(-1)))
+    torch.cuda.synchronize()
+    assert int(ctr_a) == 8
+
+    # ---- one call (with and without the caller-maintained bf16 copy of W1)
+    for shadow in ((None, W1d.to(torch.bfloat16)) if dtype == torch.bfloat16 else (None,)):
+        ctr_b.fill_(7)
+        e = lambda t: torch.full_like(t, float('nan'))
+        grads = (e(Xd), e(W1d), e(b1d), e(W2d), e(b2d), e(Wad), e(bad), e(Wtd), e(btd))
+        st = cof.PoseAttnTrainStep(Xd, (W1d, b1d, W2d, b2d, Wad, bad, Wtd, btd), lab, lbl_d, valid_d, grads,
+                                   flags=flags, keep_prob=0.5, seed=9, offset=ctr_b, w1_bf16=shadow, **wts)
+        st.run()
+        torch.cuda.synchronize()
+        assert int(ctr_b) == 8                                  # the dropout counter advanced exactly once
+        exact = dtype == torch.float32
+        assert torch.equal(st.Ppre, Ppre) and torch.equal(st.Pl, Pl) and torch.equal(st.dPl.view_as(dPl), dPl)
+        tol = 0.0 if exact else 2e-6
+        assert _rel(st.att, att) <= tol and _rel(st.loss_pose, lossp) <= (0.0 if exact else 1e-6)
+        got = dict(logits=st.logits, loss=st.loss_action, G=st.G, dZ=st.dZ, dWa=grads[5], dba=grads[6],
+                   dWt=grads[7], dbt=grads[8], dW1=grads[1], db1=grads[2], dW2=grads[3], db2=grads[4])
+        want = dict(logits=logits, loss=lossx, G=G, dZ=dZ, dWa=dWa, dba=dba, dWt=dWt, dbt=dbt, dW1=dW1, db1=db1,
+                    dW2=dW2, db2=db2)
+        for k_ in got:
+            if exact:
+                assert torch.equal(got[k_].view_as(want[k_]), want[k_]), k_
+            else:
+                assert _rel(got[k_], want[k_]) < 2e-4, (k_, _rel(got[k_], want[k_]))
+        if exact:
+            assert torch.equal(grads[0], dXf)
+        else:                                                   # bf16 storage: an ulp of the output format
+            assert _rel(grads[0].float(), dXf.float()) < 1.0 / 128
+            assert not torch.isnan(grads[0].float()).any()
+
+
 @pytest.mark.parametrize('K,dtype', [(130, torch.bfloat16), (51, torch.bfloat16), (70, torch.float32)])
 def test_per_class_one_call_train_step_equals_the_separate_calls(gpu, K, dtype):
     """Per-class maps through apa_attn_head_train_step: the backward half reuses what the forward half left in

@@ -34,7 +34,7 @@ def _features(N, P, C, dtype, dev, seed=42):
     return torch.relu(torch.randn(N, P, C, generator=g, device=dev)).to(dtype)
 
 
-def build_cfg003(cof, dev, N=32, H=14, K=393, dtype='bf16', rank1=True):
+def build_cfg003(cof, dev, N=32, H=14, K=393, dtype='bf16', rank1=True, one_call=True):
     C, Cp, J, P = 2048, 768, 16, H * H
     td = torch.bfloat16 if dtype == 'bf16' else torch.float32
     g = torch.Generator().manual_seed(42)
@@ -59,6 +59,21 @@ def build_cfg003(cof, dev, N=32, H=14, K=393, dtype='bf16', rank1=True):
     dX = torch.empty_like(X)
     dZ = torch.empty((N * P,), dtype=torch.float32, device=dev)
     grads = (dX, dZ, torch.empty_like(Wa), torch.empty_like(ba), torch.empty_like(Wt), torch.empty_like(bt))
+    if one_call and rank1:
+        # the whole step as ONE host call (apa_pose_attn_train_step): neighbouring ops share launches, and the bf16
+        # operand copy of W1 is the caller's -- in a training loop the optimizer's own launch keeps it current
+        # (apa_momentum_sgd_step_shadow), here the weights do not change between steps
+        w1_bf16 = W1.to(torch.bfloat16).contiguous()
+        new = lambda t: torch.empty_like(t)
+        st = cof.PoseAttnTrainStep(X, (W1, b1, W2, b2, Wa, ba, Wt, bt), labels, lbl, valid,
+                                   (dX, new(W1), new(b1), new(W2), new(b2), new(Wa), new(ba), new(Wt), new(bt)),
+                                   flags=flags, keep_prob=0.2, seed=42, offset=ctr, w1_bf16=w1_bf16)
+        info = {'workload': 'cfg003 pose-regularised attention head fwd+bwd (pose head 2048->768->16 + M=1 '
+                            'pooling + pose L2 + softmax-xent), one host call; per-GPU batch {} x {}x{}x{} {}, K={}, '
+                            'dropout keep=0.2'.format(N, H, H, C, dtype, K),
+                'bound': 'mfma', 'dtype': dtype, 'N': N,
+                'flops_per_image': 3 * (2.0 * P * C * Cp + 2.0 * P * Cp * J)}
+        return st.run, info
     if rank1:
         head = cof.HeadTrainStep(X, Ppre, Wa, ba, Wt, bt, labels, grads, flags=flags, keep_prob=0.2, seed=42,
                                  offset=ctr, dxatt_rank1=True)
@@ -194,6 +209,9 @@ def main():
     ap.add_argument('--hw', type=int, default=14)
     ap.add_argument('--classes', type=int, default=None)
     ap.add_argument('--dtype', default=None, choices=['bf16', 'f32'])
+    ap.add_argument('--per-op', action='store_true',
+                    help='cfg003: drive the step as separate calls (pose head fwd, pose loss, attention train step, '
+                         'pose head bwd) instead of the one-call apa_pose_attn_train_step')
     ap.add_argument('--no-rank1', action='store_true',
                     help='cfg003: materialise the [N,P,768] attention-branch gradient between the two backward calls')
     ap.add_argument('--steps', type=int, default=50)
@@ -203,7 +221,7 @@ def main():
     dev = torch.device('cuda:0')
     if args.workload == 'cfg003':
         step, info = build_cfg003(cof, dev, args.batch, args.hw, args.classes or 393, args.dtype or 'bf16',
-                                  rank1=not args.no_rank1)
+                                  rank1=not args.no_rank1, one_call=not args.per_op)
     elif args.workload == 'rank1':
         step, info = build_rank1(cof, dev, args.batch, args.hw, args.classes or 51, args.dtype or 'bf16')
     elif args.workload == 'eval002':
