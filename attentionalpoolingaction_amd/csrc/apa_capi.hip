@@ -207,7 +207,7 @@ static int attn_pool_fwd_impl(const Hooks& hk, const apa_concat_feat* catp, M1Xe
   }
   if (hk.td_ready) APA_HIP_CHECK(hipStreamWaitEvent(st, hk.td_ready, 0));
   return pc_forward(X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, topdown, ws, N, P, C, Ca, K, flags,
-                    keep_prob, seed, offset, dtype, st);
+                    keep_prob, seed, offset, dtype, st, topdown ? nullptr : xf);
 }
 
 extern "C" int apa_attn_pool_fwd(const void* X, const void* Xatt, const float* Wa, const float* ba,
@@ -296,7 +296,7 @@ static int attn_pool_bwd_impl(const Hooks& hk, const apa_concat_feat* catp, cons
     return APA_ERR_WORKSPACE;
   }
   rc = pc_backward(X, Xatt, Wa, Wt, att, zsave, G, dX, dXatt, dWa, dba, dWt, dbt, ws, N, P, C, Ca, K,
-                   flags, keep_prob, seed, offset, dtype, st);
+                   flags, keep_prob, seed, offset, dtype, st, xf);
   if (rc == APA_OK && hk.grad_ready) APA_HIP_CHECK(hipEventRecord(hk.grad_ready, st));
   return rc;
 }
@@ -371,7 +371,7 @@ extern "C" int apa_attn_head_train_step_ex(const apa_hooks* hooks, const void* X
   xf.lscale = N > 0 ? loss_wt / (float)N : 0.f;
   xf.gscale = N > 0 ? loss_wt * grad_scale / (float)N : 0.f;
   xf.done = false;
-  int rc = attn_pool_fwd_impl(hk, nullptr, M == 1 ? &xf : nullptr, X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar,
+  int rc = attn_pool_fwd_impl(hk, nullptr, &xf, X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, abar,
                               nullptr, ws, ws_bytes, N, P, C, Ca, K, M, flags, keep_prob, seed, offset,
                               dtype, stream);
   if (rc != APA_OK) return rc;

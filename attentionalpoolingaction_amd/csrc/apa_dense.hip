@@ -995,13 +995,17 @@ __device__ __forceinline__ float pc_colmax(const float (&red)[PC_PG][64], int kk
 // groups (16 waves per block: these passes are short dependent-load chains, 4 groups measured 27 us
 // at K = 51 where 32 blocks of 4 waves cannot hide any latency)
 //   A[n,p,k] = f(Z[n,p,k]);  logits[n,k] = (1/P) sum_p A * T;  optional TopDownAttention copy
+// xe (one-call train step, K <= 64 so that one block holds the whole row): the row's softmax cross-entropy on the
+// logits it has just reduced -- G[n,:] = gscale (softmax - onehot), loss[1 + n] = xent_n (src/loss.py:74-80); the batch
+// mean is finished by the tail of the dW reduce launch.  One launch (4.7 us at the latency floor) less per step.
+struct PcXent { const int64_t* labels; float* loss; float* G; float gscale; };
 template <typename T>
 __global__ __launch_bounds__(1024) void pc_fwd_act_kernel(const float* __restrict__ Z, int ldz,
                                                          const float* __restrict__ Tm,
                                                          float* __restrict__ att,
                                                          float* __restrict__ logits,
                                                          T* __restrict__ topdown, int P, int K,
-                                                         int act) {
+                                                         int act, PcXent xe) {
   __shared__ float red[PC_PG][64];
   const int n = blockIdx.x;
   const int kk = threadIdx.x & 63, pg = threadIdx.x >> 6;
@@ -1053,8 +1057,20 @@ __global__ __launch_bounds__(1024) void pc_fwd_act_kernel(const float* __restric
   }
   red[pg][kk] = acc;
   __syncthreads();
-  if (pg == 0 && ok)
-    logits[(size_t)n * K + k] = pc_colsum(red, kk) / (float)P;
+  if (pg == 0) {                       // wave 0: lane kk owns class k
+    const float lg = ok ? pc_colsum(red, kk) / (float)P : -INFINITY;
+    if (ok) logits[(size_t)n * K + k] = lg;
+    if (xe.labels) {                   // (gridDim.y == 1: the wave holds the whole row)
+      const int lab = (int)xe.labels[n];
+      const bool lab_ok = lab >= 0 && lab < K;
+      const float mw = wave_max(lg);
+      const float e = ok ? exp_fast(lg - mw) : 0.f;
+      const float l = wave_sum(e);
+      const float xl = __shfl(lg, lab_ok ? lab : 0);
+      if (ok) xe.G[(size_t)n * K + k] = fmaf(e * (1.0f / l), xe.gscale, k == lab ? -xe.gscale : 0.f);
+      if (kk == 0) xe.loss[1 + n] = lab_ok ? -(xl - mw - logf(l)) : 0.f;
+    }
+  }
 }
 
 // backward of the same: dT = G*A/P, dA = G*T/P, dZ = act'(dA); column partials for dbt / dba.
@@ -1209,7 +1225,7 @@ static void set_dropout(GemmDesc& g, bool on_a, bool on_c, float keep_prob, uint
 int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba, const float* Wt,
                const float* bt, float* logits, float* att, float* Tsave, void* topdown, void* ws,
                int N, int P, int C, int Ca, int K, unsigned flags, float keep_prob, uint64_t seed,
-               uint64_t offset, int dtype, hipStream_t st) {
+               uint64_t offset, int dtype, hipStream_t st, M1Xent* xf) {
   const PcPlan pl = pc_plan(N, P, C, Ca, K, dtype);
   char* w = static_cast<char*>(ws);
   void* WaP = w + pl.off_wap;
@@ -1223,15 +1239,26 @@ int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
   if (pc_fused_supported(N, P, C, Ca, K, dtype, X, Xatt) && !rng_external(flags)) {
     // K <= 64 (HMDB-51): Z | T in ONE pass over X, dropout applied on the way into LDS (apa_pc_fused.hip)
     const PcFusedWs f = pc_fused_carve(w + pl.off_fused, N, P, C);
-    int rc = pc_fused_prep(f, Wa, Wt, ba, bt, C, K, st);
-    if (rc != APA_OK) return rc;
     const bool devctr = flags & APA_FLAG_RNG_DEVICE;
-    rc = pc_fused_forward(f, X, Z, Tsave, R, C, K, train, keep_prob, seed, devctr ? 0 : offset,
-                          devctr ? reinterpret_cast<const uint64_t*>(static_cast<uintptr_t>(offset)) : nullptr, st);
+    const uint64_t* offd = devctr ? reinterpret_cast<const uint64_t*>(static_cast<uintptr_t>(offset)) : nullptr;
+    // training: the weight-preparation launch also writes the step's keep bits (its 128 weight blocks leave half
+    // the chip idle), and the product kernel DMAs them instead of hashing on its critical chain
+    static const int prebits_knob = knob("APA_PC_PREBITS", 1);
+    const bool prebits = train && prebits_knob;
+    const PcPrepBits pb = {(size_t)R * C, keep_prob, seed, devctr ? 0 : offset, offd};
+    int rc = pc_fused_prep(f, Wa, Wt, ba, bt, C, K, st, prebits ? &pb : nullptr);
+    if (rc != APA_OK) return rc;
+    rc = pc_fused_forward(f, X, Z, Tsave, R, C, K, train, keep_prob, seed, devctr ? 0 : offset, offd, st, prebits);
     if (rc != APA_OK) return rc;
     dim3 grid(N, (K + 63) / 64);
+    PcXent xe = {nullptr, nullptr, nullptr, 0.f};
+    static const int fold_xent = knob("APA_PC_XENT_FOLD", 1);
+    if (fold_xent && xf && xf->labels && xf->G && xf->loss && !xf->probs && K <= 64) {
+      xe.labels = xf->labels; xe.loss = xf->loss; xe.G = xf->G; xe.gscale = xf->gscale;
+      xf->done = true;
+    }
     hipLaunchKernelGGL(pc_fwd_act_kernel<bf16_t>, grid, dim3(64 * PC_PG), 0, st, Z, Kp, Tsave, att, logits,
-                       static_cast<bf16_t*>(topdown), P, K, act_code(flags));
+                       static_cast<bf16_t*>(topdown), P, K, act_code(flags), xe);
     APA_LAUNCH_CHECK("pc_fwd_act_kernel");
     return APA_OK;
   }
@@ -1275,10 +1302,10 @@ int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
   dim3 grid(N, (K + 63) / 64);
   if (dtype == APA_DTYPE_F32)
     hipLaunchKernelGGL(pc_fwd_act_kernel<float>, grid, dim3(64 * PC_PG), 0, st, Z, Kp, Tsave, att, logits,
-                       static_cast<float*>(topdown), P, K, act_code(flags));
+                       static_cast<float*>(topdown), P, K, act_code(flags), PcXent{nullptr, nullptr, nullptr, 0.f});
   else
     hipLaunchKernelGGL(pc_fwd_act_kernel<bf16_t>, grid, dim3(64 * PC_PG), 0, st, Z, Kp, Tsave, att, logits,
-                       static_cast<bf16_t*>(topdown), P, K, act_code(flags));
+                       static_cast<bf16_t*>(topdown), P, K, act_code(flags), PcXent{nullptr, nullptr, nullptr, 0.f});
   APA_LAUNCH_CHECK("pc_fwd_act_kernel");
   return APA_OK;
 }
@@ -1287,7 +1314,7 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
                 const float* Tsave, const float* G, void* dX, void* dXatt, float* dWa, float* dba,
                 float* dWt, float* dbt, void* ws, int N, int P, int C, int Ca, int K,
                 unsigned flags, float keep_prob, uint64_t seed, uint64_t offset, int dtype,
-                hipStream_t st) {
+                hipStream_t st, const M1Xent* xf) {
   const PcPlan pl = pc_plan(N, P, C, Ca, K, dtype);
   char* w = static_cast<char*>(ws);
   void* WaP = w + pl.off_wap;
@@ -1308,13 +1335,13 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
     const bool devctr = flags & APA_FLAG_RNG_DEVICE;
     const uint64_t off = devctr ? 0 : offset;
     const uint64_t* offd = devctr ? reinterpret_cast<const uint64_t*>(static_cast<uintptr_t>(offset)) : nullptr;
+    // APA_FLAG_RNG_DEVICE: this call advances the dropout counter when it is done (include/apa.h) -- in the launch
+    // after the last reader of the counter (the mask bits are regenerated at most here, right below)
+    uint64_t* bump = (train && devctr) ? reinterpret_cast<uint64_t*>(static_cast<uintptr_t>(offset)) : nullptr;
     if (!(flags & APA_FLAG_WS_FROM_FWD)) {   // else the forward call left the operands and the mask bits in place
-      rc = pc_fused_prep(f, Wa, Wt, nullptr, nullptr, C, K, st);
+      const PcPrepBits pb = {(size_t)R * C, keep_prob, seed, off, offd};
+      rc = pc_fused_prep(f, Wa, Wt, nullptr, nullptr, C, K, st, train ? &pb : nullptr);
       if (rc != APA_OK) return rc;
-      if (train) {
-        rc = pc_fused_maskbits(f, (size_t)R * C, keep_prob, seed, off, offd, st);
-        if (rc != APA_OK) return rc;
-      }
     }
     bf16_t* dTc = static_cast<bf16_t*>(f.dTdZ);              // [R][dT (64) | dZ (64)]
     const int ps = pc_bwd_act_psplit(N, (Kp + 63) / 64, P, act_code(flags));
@@ -1322,9 +1349,11 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
     hipLaunchKernelGGL(pc_bwd_act_kernel<bf16_t>, grid, dim3(64 * PC_PG), 0, st, G, att, Tsave, dTc, dTc + 64,
                        pdbt, pdba, P, K, Kp, act_code(flags), 128);
     APA_LAUNCH_CHECK("pc_bwd_act_kernel");
-    rc = m1_colsum(pdbt, nullptr, dbt, nullptr, N * ps, 2 * K, 2 * K, nullptr, st, dba, K);
-    if (rc != APA_OK) return rc;
-    rc = pc_fused_dw(f, X, dWt, dWa, R, C, K, train, keep_prob, st);
+    // dbt | dba (column sums of the activation pass's block partials), the batch mean of a folded cross-entropy
+    // and the dropout counter ride on the tail blocks of the dW reduce launch
+    PcDwTail tail = {pdbt, dbt, dba, N * ps, bump, nullptr, 0, 0.f, nullptr};
+    if (xf && xf->done) { tail.aux_src = xf->loss + 1; tail.aux_n = N; tail.aux_scale = xf->lscale; tail.aux_dst = xf->loss; }
+    rc = pc_fused_dw(f, X, dWt, dWa, R, C, K, train, keep_prob, st, &tail);
     if (rc != APA_OK) return rc;
     // dX = (dT . Wt^T) * mask/keep + dZ . Wa^T: one launch over the concatenated k = 128
     static const int exp_mask = knob("APA_PC_EXP", 0);
@@ -1360,8 +1389,7 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
                        static_cast<bf16_t*>(dT), static_cast<bf16_t*>(dZ), pdbt, pdba, P, K, Kp,
                        act_code(flags), Kp);
   APA_LAUNCH_CHECK("pc_bwd_act_kernel");
-  int rc = m1_colsum(pdbt, nullptr, dbt, nullptr, N * ps, 2 * K, 2 * K, nullptr, st, dba, K);
-  if (rc != APA_OK) return rc;
+  int rc = APA_OK;
   {  // dWt[c,k] = sum_r Xt[r,c] dT[r,k]
     GemmDesc g;
     g.A = X; g.lda = C; g.ta = tdt; g.a_kc = false;
@@ -1412,8 +1440,13 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
     g.C = fused ? dX : dXatt; g.ldc = fused ? C : Ca; g.tc = tdt;
     g.M = R; g.N = fused ? C : Ca; g.K = Kp; g.beta = fused ? 1.f : 0.f;
     rc = gemm_launch(g, st);
+    if (rc != APA_OK) return rc;
   }
-  return rc;
+  // dbt | dba: the LAST launch, so that it can also advance a device-side dropout counter (APA_FLAG_RNG_DEVICE)
+  // after every kernel that keys its mask with it has run
+  uint64_t* bump = (train && (flags & APA_FLAG_RNG_DEVICE))
+                       ? reinterpret_cast<uint64_t*>(static_cast<uintptr_t>(offset)) : nullptr;
+  return m1_colsum(pdbt, nullptr, dbt, nullptr, N * ps, 2 * K, 2 * K, bump, st, dba, K);
 }
 
 }  // namespace apa

@@ -246,4 +246,93 @@ __device__ __forceinline__ int half_min_first(int v, int lane) {
   return lane < 32 ? s0 : s1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fixed-order column sums of a matrix of per-block partial rows (apa_m1_small.hip: m1_colsum_kernel)
+// ---------------------------------------------------------------------------------------------
+struct ColsumExtra {
+  float* dwa4 = nullptr; int C3 = 0;
+  float* dwa5 = nullptr; int C4 = 0;
+  const float* aux_src = nullptr; int aux_n = 0; float aux_scale = 0.f; float* aux_dst = nullptr;
+};
+// One 1024-thread block of the fixed-order column sum (the body of m1_colsum_kernel; also run by the tail blocks of
+// pc_dw_reduce_kernel, so that both give bit-identical sums): block `bid` of `nbid` owns columns 32 bid .. 32 bid + 31.
+__device__ __forceinline__ void colsum_block(int bid, int nbid, const float* __restrict__ pdwa,
+                                             const float* __restrict__ pdba, float* __restrict__ dwa,
+                                             float* __restrict__ dba, int nblk, int C, int ld,
+                                             uint64_t* __restrict__ rng_bump, float* __restrict__ dwa2, int C1,
+                                             float* __restrict__ dwa3, int C2, int perm_nthr, int perm_cp,
+                                             const ColsumExtra& x) {
+  // perm_nthr > 0: the first section holds the pose head's dW2 partials in the permuted order of
+  // pose_bwd_rows_kernel (float4 v of thread t at float4 index v * nthr + t; v = 4 (column & 1) + q / 4)
+  __shared__ float red[32][33];
+  const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = bid * 32 + col;
+  float acc = 0.f;
+  if (c < C) {
+    int b = rg;
+    for (; b + 480 < nblk; b += 512) {  // 16 independent loads in flight (one round trip at 512 rows)
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = pdwa[(size_t)(b + 32 * u) * ld + c];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc += v[u];
+    }
+    for (; b + 224 < nblk; b += 256) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = pdwa[(size_t)(b + 32 * u) * ld + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; b < nblk; b += 32) acc += pdwa[(size_t)b * ld + c];
+  }
+  red[rg][col] = acc;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 32; ++g) s += red[g][col];
+    if (c < C1) {
+      if (perm_nthr > 0) {
+        const int v = c / (4 * perm_nthr), rem = c - v * 4 * perm_nthr;
+        const int col = 2 * (rem >> 2) + (v >> 2);
+        if (col < perm_cp) dwa[col * 16 + (v & 3) * 4 + (rem & 3)] = s;
+      } else {
+        dwa[c] = s;
+      }
+    } else if (c < C2) dwa2[c - C1] = s;
+    else if (c < x.C3) dwa3[c - C2] = s;
+    else if (c < x.C4) x.dwa4[c - x.C3] = s;
+    else x.dwa5[c - x.C4] = s;
+  }
+  if (bid == 0 && pdba) {
+    __syncthreads();
+    float a = 0.f;
+    for (int b = threadIdx.x; b < nblk; b += 1024) a += pdba[b];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float s = 0.f;
+      for (int w = 0; w < 16; ++w) s += red[0][w];
+      dba[0] = s;
+    }
+  }
+  if (bid == 0 && threadIdx.x == 0 && rng_bump) *rng_bump += 1;
+  if (x.aux_src && bid == nbid - 1) {
+    __syncthreads();
+    float a = 0.f;
+    for (int b = threadIdx.x; b < x.aux_n; b += 1024) a += x.aux_src[b];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) red[1][threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float s = 0.f;
+      for (int w = 0; w < 16; ++w) s += red[1][w];
+      x.aux_dst[0] = s * x.aux_scale;
+    }
+  }
+}
+
+
 }  // namespace apa

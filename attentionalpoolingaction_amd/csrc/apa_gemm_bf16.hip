@@ -122,9 +122,11 @@ struct FastParams {
 
 // 8 consecutive output columns of one row: split-K partial, or bias / relu / output dropout /
 // + beta*C / pack and one 16-byte store
+// `cprev` (bf16 outputs, beta != 0): the 8 old values of C, fetched by the caller ahead of time
 template <typename TC>
 __device__ __forceinline__ void store8(const FastParams& p, TC* C, int grow, int gcol, float4 x0, float4 x1,
-                                       uint32_t h0, uint32_t h1) {
+                                       uint32_t h0, uint32_t h1, bool has_prev = false,
+                                       uint4 cprev = uint4{0u, 0u, 0u, 0u}) {
   float o[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
   if (p.partial) {
     float* dst = p.partial + ((size_t)blockIdx.z * p.M + grow) * p.Nout + gcol;
@@ -155,7 +157,7 @@ __device__ __forceinline__ void store8(const FastParams& p, TC* C, int grow, int
   if constexpr (sizeof(TC) == 2) {
     if (p.beta != 0.f) {
       float c[8];
-      Vec<bf16_t>::unpack(ld16(dst), c);
+      Vec<bf16_t>::unpack(has_prev ? cprev : ld16(dst), c);
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] += c[e];
     }
@@ -1038,6 +1040,22 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_wide_kernel(FastParams p) {
   if (p.drop_c) rng_key_dev_x(p.seed, p.offset_dev ? *p.offset_dev : p.offset, p.thresh, h0, h1);
   float* stage = reinterpret_cast<float*>(smem);
   constexpr int LDS_C = TN + 4;
+  // accumulate form (dX += ...): the old values of this thread's 2 x MT row segments are requested NOW, all at
+  // once, and arrive while the tile is staged -- read one by one inside the store loop they were 2 MT dependent
+  // round trips per thread (the epilogue of the first version cost as much as the 12-tile loop)
+  constexpr int NSEG = (W::TMR * 16 + 511) / 512;             // row segments per thread and half: MT
+  const bool pre = sizeof(TC) == 2 && p.vec_epi && p.beta != 0.f && !p.partial;
+  uint4 cold[2][NSEG];
+  if (pre) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int u = 0; u < NSEG; ++u) {
+        const int v = tid + u * 512, row = v >> 4, c8 = (v & 15) * 8;
+        const int grow = min(m0 + row, p.M - 1), gcol = min(n0 + half * 128 + c8, p.Nout - 8);
+        cold[half][u] = ld16(reinterpret_cast<const bf16_t*>(C) + (long)grow * p.ldc + gcol);
+      }
+  }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // everyone is done with the LDS contents
@@ -1052,13 +1070,15 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_wide_kernel(FastParams p) {
     }
     __syncthreads();
     if (p.vec_epi) {
-      for (int v = tid; v < W::TMR * 16; v += 512) {
+#pragma unroll
+      for (int u = 0; u < NSEG; ++u) {
+        const int v = tid + u * 512;
         const int row = v >> 4, c8 = (v & 15) * 8;
         const int grow = m0 + row, gcol = n0 + half * 128 + c8;
-        if (grow >= p.M || gcol >= p.Nout) continue;
+        if (v >= W::TMR * 16 || grow >= p.M || gcol >= p.Nout) continue;
         const float4 x0 = *reinterpret_cast<const float4*>(stage + row * LDS_C + c8);
         const float4 x1 = *reinterpret_cast<const float4*>(stage + row * LDS_C + c8 + 4);
-        store8<TC>(p, C, grow, gcol, x0, x1, h0, h1);
+        store8<TC>(p, C, grow, gcol, x0, x1, h0, h1, pre, cold[half][u]);
       }
     } else {
       for (int v = tid; v < W::TMR * 128; v += 512) {

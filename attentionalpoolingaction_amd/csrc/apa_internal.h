@@ -329,25 +329,34 @@ struct PcFusedWs {
 bool pc_fused_supported(int N, int P, int C, int Ca, int K, int dtype, const void* X, const void* Xatt);
 size_t pc_fused_ws_bytes(int N, int P, int C);
 PcFusedWs pc_fused_carve(void* base, int N, int P, int C);
+struct PcPrepBits {   // the step's keep bits, written by the weight-preparation launch's extra blocks
+  size_t n_elems; float keep_prob; uint64_t seed, offset; const uint64_t* offset_dev;
+};
+struct PcDwTail {     // what the dW reduce launch's tail blocks also do (see pc_dw_reduce_kernel)
+  const float* pdbt; float* dbt; float* dba; int nrows;         // dbt | dba from [nrows][2K] block partials
+  uint64_t* rng_bump;                                            // device-side dropout counter to advance
+  const float* aux_src; int aux_n; float aux_scale; float* aux_dst;   // aux_dst[0] = aux_scale * sum(aux_src)
+};
 int pc_fused_prep(const PcFusedWs& f, const float* Wa, const float* Wt, const float* ba, const float* bt, int C,
-                  int K, hipStream_t st);
+                  int K, hipStream_t st, const PcPrepBits* bits = nullptr);
 int pc_fused_forward(const PcFusedWs& f, const void* X, float* Z, float* T, int R, int C, int K, bool train,
-                     float keep_prob, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, hipStream_t st);
+                     float keep_prob, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, hipStream_t st,
+                     bool prebits = false);
 int pc_fused_maskbits(const PcFusedWs& f, size_t n_elems, float keep_prob, uint64_t seed, uint64_t offset,
                       const uint64_t* offset_dev, hipStream_t st);
 int pc_fused_dw(const PcFusedWs& f, const void* X, float* dWt, float* dWa, int R, int C, int K, bool train,
-                float keep_prob, hipStream_t st);
+                float keep_prob, hipStream_t st, const PcDwTail* tail = nullptr);
 
 // apa_dense.hip: per-class bottom-up maps (M == K); Tsave = fp32 [N,P,K] top-down map saved for bwd
 size_t pc_workspace_bytes(int N, int P, int C, int Ca, int K, int dtype);
 int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba, const float* Wt,
                const float* bt, float* logits, float* att, float* Tsave, void* topdown, void* ws,
                int N, int P, int C, int Ca, int K, unsigned flags, float keep_prob, uint64_t seed,
-               uint64_t offset, int dtype, hipStream_t st);
+               uint64_t offset, int dtype, hipStream_t st, M1Xent* xf = nullptr);
 int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* Wt, const float* att,
                 const float* Tsave, const float* G, void* dX, void* dXatt, float* dWa, float* dba,
                 float* dWt, float* dbt, void* ws, int N, int P, int C, int Ca, int K,
                 unsigned flags, float keep_prob, uint64_t seed, uint64_t offset, int dtype,
-                hipStream_t st);
+                hipStream_t st, const M1Xent* xf = nullptr);
 
 }  // namespace apa

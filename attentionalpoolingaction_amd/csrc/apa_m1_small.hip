@@ -955,11 +955,6 @@ __global__ __launch_bounds__(256) void m1_bwd_head_tiles_kernel(
 // pose head); C1 == ... == C for a single output.
 // aux (optional): aux_dst[0] = aux_scale * sum(aux_src[0 .. aux_n)) in a fixed order, by the LAST block -- a
 // scalar reduction that would otherwise be a launch of its own (the pose loss of the fused cfg 003 step).
-struct ColsumExtra {
-  float* dwa4 = nullptr; int C3 = 0;
-  float* dwa5 = nullptr; int C4 = 0;
-  const float* aux_src = nullptr; int aux_n = 0; float aux_scale = 0.f; float* aux_dst = nullptr;
-};
 __global__ __launch_bounds__(1024) void m1_colsum_kernel(const float* __restrict__ pdwa,
                                                          const float* __restrict__ pdba,
                                                          float* __restrict__ dwa,
@@ -968,76 +963,8 @@ __global__ __launch_bounds__(1024) void m1_colsum_kernel(const float* __restrict
                                                          float* __restrict__ dwa2, int C1,
                                                          float* __restrict__ dwa3, int C2, int perm_nthr,
                                                          int perm_cp, ColsumExtra x) {
-  // perm_nthr > 0: the first section holds the pose head's dW2 partials in the permuted order of
-  // pose_bwd_rows_kernel (float4 v of thread t at float4 index v * nthr + t; v = 4 (column & 1) + q / 4)
-  __shared__ float red[32][33];
-  const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + col;
-  float acc = 0.f;
-  if (c < C) {
-    int b = rg;
-    for (; b + 480 < nblk; b += 512) {  // 16 independent loads in flight (one round trip at 512 rows)
-      float v[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = pdwa[(size_t)(b + 32 * u) * ld + c];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) acc += v[u];
-    }
-    for (; b + 224 < nblk; b += 256) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = pdwa[(size_t)(b + 32 * u) * ld + c];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc += v[u];
-    }
-    for (; b < nblk; b += 32) acc += pdwa[(size_t)b * ld + c];
-  }
-  red[rg][col] = acc;
-  __syncthreads();
-  if (rg == 0 && c < C) {
-    float s = 0.f;
-#pragma unroll
-    for (int g = 0; g < 32; ++g) s += red[g][col];
-    if (c < C1) {
-      if (perm_nthr > 0) {
-        const int v = c / (4 * perm_nthr), rem = c - v * 4 * perm_nthr;
-        const int col = 2 * (rem >> 2) + (v >> 2);
-        if (col < perm_cp) dwa[col * 16 + (v & 3) * 4 + (rem & 3)] = s;
-      } else {
-        dwa[c] = s;
-      }
-    } else if (c < C2) dwa2[c - C1] = s;
-    else if (c < x.C3) dwa3[c - C2] = s;
-    else if (c < x.C4) x.dwa4[c - x.C3] = s;
-    else x.dwa5[c - x.C4] = s;
-  }
-  if (blockIdx.x == 0 && pdba) {
-    __syncthreads();
-    float a = 0.f;
-    for (int b = threadIdx.x; b < nblk; b += 1024) a += pdba[b];
-    a = wave_sum(a);
-    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = a;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float s = 0.f;
-      for (int w = 0; w < 16; ++w) s += red[0][w];
-      dba[0] = s;
-    }
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0 && rng_bump) *rng_bump += 1;
-  if (x.aux_src && blockIdx.x == gridDim.x - 1) {
-    __syncthreads();
-    float a = 0.f;
-    for (int b = threadIdx.x; b < x.aux_n; b += 1024) a += x.aux_src[b];
-    a = wave_sum(a);
-    if ((threadIdx.x & 63) == 0) red[1][threadIdx.x >> 6] = a;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float s = 0.f;
-      for (int w = 0; w < 16; ++w) s += red[1][w];
-      x.aux_dst[0] = s * x.aux_scale;
-    }
-  }
+  colsum_block(blockIdx.x, gridDim.x, pdwa, pdba, dwa, dba, nblk, C, ld, rng_bump, dwa2, C1, dwa3, C2, perm_nthr,
+               perm_cp, x);
 }
 
 // ============================================================================================

@@ -76,10 +76,25 @@ __global__ __launch_bounds__(256) void pc_maskbits_kernel(uint8_t* __restrict__ 
 //   Wcat2 [C][128]   cols 0..63: Wt[c, :] ; cols 64..127: Wa[c, :]                     -- dX B operand
 //   bcat  [128] f32  ba | bt (zero padded)
 // ---------------------------------------------------------------------------------------------
+// Round 4: the same launch also produces the step's keep bits (blocks >= C/16, when `bits` is given).  The weight
+// part is 128 blocks at the launch-latency floor -- half the chip idle for 5 us -- and the forward product used to
+// hash the mask itself, on the barrier-to-barrier chain of every stage (3.9 us of hashing + 1 us of bit stores by
+// its own ablation); now it DMAs 512 bytes of bits per stage next to its operands.
+struct PcBitsArgs {
+  uint8_t* bits; size_t n8; uint32_t thresh; uint64_t seed, offset; const uint64_t* offset_dev;
+};
 __global__ __launch_bounds__(256) void pc_prep_kernel(const float* __restrict__ Wa, const float* __restrict__ Wt,
                                                       const float* __restrict__ ba, const float* __restrict__ bt,
                                                       bf16_t* __restrict__ WcatT, bf16_t* __restrict__ Wcat2,
-                                                      float* __restrict__ bcat, int C, int K) {
+                                                      float* __restrict__ bcat, int C, int K, PcBitsArgs mb) {
+  if ((int)blockIdx.x >= C / 16) {     // keep-bit blocks: 8 elements (one byte) per thread and round
+    uint32_t k0, k1;
+    rng_key_dev(mb.seed, mb.offset_dev ? *mb.offset_dev : mb.offset, k0, k1);
+    const size_t nb = gridDim.x - C / 16, b = blockIdx.x - C / 16;
+    for (size_t v = b * 256 + threadIdx.x; v < mb.n8; v += nb * 256)
+      mb.bits[v] = (uint8_t)keep_bits8(v * 8, k0, k1, mb.thresh);
+    return;
+  }
   // one block per 16 channels: rows of Wa / Wt are read as they lie (thread -> 8 (c, column) pairs, all loads
   // in flight, consecutive threads consecutive columns), the [16 c][128 col] slab is turned in LDS and both
   // images leave as one 16-byte vector per thread (the element-per-thread form wrote WcatT two bytes at a
@@ -154,7 +169,7 @@ constexpr int ZB_A_EL = 32 * ZB_KT;                      // 4096 shorts (8 KB): 
 constexpr int ZB_B_EL = 128 * ZB_KT;                     // 16384 shorts (32 KB): two [128][64] tiles
 constexpr int ZB_STAGE_EL = ZB_A_EL + ZB_B_EL;           // 40 KB
 constexpr int ZB_NST = 3;
-constexpr size_t ZB_LDS_BYTES = (size_t)ZB_NST * ZB_STAGE_EL * 2 + 2 * 512;
+constexpr size_t ZB_LDS_BYTES = (size_t)ZB_NST * ZB_STAGE_EL * 2 + ZB_NST * 512;
 
 __device__ __forceinline__ void glds16_asm(const void* gsrc, uint32_t lds_dst) {
   unsigned keep;
@@ -167,7 +182,11 @@ __device__ __forceinline__ bf16x8 frag_sw64(const short* img, int rbase, int ks,
   return *reinterpret_cast<const bf16x8*>(img + row * 64 + chunk * 8);
 }
 
-template <bool TRAIN>
+// PREBITS (round 4): the keep bits of the step already lie in `maskbits` (written by pc_prep_kernel's extra blocks):
+// a stage's 32 rows x 16 bytes of bits arrive by ONE more LDS-DMA instruction (wave 0, lanes 0-31: 16 bytes per
+// row) into a ring of three 512-byte slots, in natural [row][chunk] order; a T wave reads its row's 16 bytes once
+// per stage and picks the four bytes of its lane group.  No hashing, no bit stores, no DPP shuffles in this kernel.
+template <bool TRAIN, bool PREBITS = false>
 __global__ __launch_bounds__(512) void pc_fwd_zt_dma_kernel(
     const bf16_t* __restrict__ X, const bf16_t* __restrict__ WcatT, const float* __restrict__ bcat,
     float* __restrict__ Z, float* __restrict__ T, uint8_t* __restrict__ maskbits, int R, int C, int K,
@@ -199,12 +218,17 @@ __global__ __launch_bounds__(512) void pc_fwd_zt_dma_kernel(
     }
   }
   const uint32_t lds0 = (uint32_t)(size_t)(lptr)smem;
+  const uint8_t* msrc = nullptr;     // PREBITS: this lane's row of bits (lanes 0-31 of wave 0)
+  if (TRAIN && PREBITS) msrc = maskbits + (((size_t)min(m0 + (lane & 31), R - 1) * C) >> 3);
+  const uint32_t lds_bits = lds0 + (uint32_t)(ZB_NST * ZB_STAGE_EL * 2);
   auto issue = [&](int t) {
     const uint32_t st = lds0 + (uint32_t)((t % ZB_NST) * ZB_STAGE_EL * 2);
     glds16_asm(asrc + (size_t)t * ZB_KT, st + (uint32_t)wave * 1024u);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       glds16_asm(bsrc[j] + (size_t)t * (2 * 128 * 64), st + (uint32_t)(ZB_A_EL * 2) + (uint32_t)(4 * wave + j) * 1024u);
+    if (TRAIN && PREBITS && wave == 0 && lane < 32)       // 16 bytes per row: chunks 0..15 of stage t
+      glds16_asm(msrc + (size_t)t * (ZB_KT / 8), lds_bits + (uint32_t)((t % ZB_NST) * 512));
   };
   // keep decisions of stage t: thread -> (row = tid >> 4, 8-channel chunk c = tid & 15 of the stage)
   auto make_bits = [&](int t) {
@@ -223,18 +247,29 @@ __global__ __launch_bounds__(512) void pc_fwd_zt_dma_kernel(
   f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   issue(0);
   if (nkt > 1) issue(1);
-  if (TRAIN) make_bits(0);
+  if (TRAIN && !PREBITS) make_bits(0);
   for (int t = 0; t < nkt; ++t) {
-    // tile t has landed once at most the five pieces of tile t+1 are outstanding; the barrier publishes
-    // everybody's pieces and the bits, and says that stage (t+2) % 3 (read in iteration t-1) is free
-    if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // tile t has landed once at most the five pieces of tile t+1 are outstanding (six for the wave that also
+    // moves the bits); the barrier publishes everybody's pieces and the bits, and says that stage (t+2) % 3 (read
+    // in iteration t-1) is free
+    if (t + 1 >= nkt) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (TRAIN && PREBITS && wave == 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (t + 2 < nkt) issue(t + 2);
-    if (TRAIN && t + 1 < nkt) make_bits(t + 1);
+    if (TRAIN && !PREBITS && t + 1 < nkt) make_bits(t + 1);
     const short* a_img = smem + (t % ZB_NST) * ZB_STAGE_EL;
     const short* b_img = a_img + ZB_A_EL;
     uint32_t mb = 0;
-    if (TRAIN && half) mb = *reinterpret_cast<const uint32_t*>(s_bits + (t & 1) * 512 + (mt * 16 + l16) * 16 + kb * 4);
+    if (TRAIN && half) {
+      if (PREBITS) {   // natural order: byte c = 4 sk + kb of the row -> byte kb of word sk
+        const uint4 rb = *reinterpret_cast<const uint4*>(s_bits + (t % ZB_NST) * 512 + (mt * 16 + l16) * 16);
+        const int sh = 8 * kb;
+        mb = ((rb.x >> sh) & 0xffu) | (((rb.y >> sh) & 0xffu) << 8) | (((rb.z >> sh) & 0xffu) << 16) |
+             (((rb.w >> sh) & 0xffu) << 24);
+      } else {
+        mb = *reinterpret_cast<const uint32_t*>(s_bits + (t & 1) * 512 + (mt * 16 + l16) * 16 + kb * 4);
+      }
+    }
 #pragma unroll
     for (int sk = 0; sk < 4; ++sk) {   // sk = 2 s + ks
       bf16x8 af = frag_sw64(a_img + (sk >> 1) * (32 * 64), mt * 16, sk & 1, lane);
@@ -282,12 +317,31 @@ __device__ __forceinline__ bf16x8 frag_km(const short* img, int rbase, int ks, i
   return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <bool TRAIN>
+// SWZ (round 4): unpadded 256-byte rows with the XOR swizzle of apa_gemm_bf16.hip's [k][row] image (16-byte chunk
+// c of row k lives at chunk c ^ 2 (k & 3) ^ 8 ((k >> 3) & 1)) instead of 272-byte padded rows: with padding alone the
+// transposing reads of rows k and k + 8 -- lane groups kb and kb + 1 of one ds_read_b64_tr_b16 -- share banks whatever
+// the pad (2-way at best: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.29 in profiles/r03_perclass_pmc.md); the
+// swizzled image measured conflict-free in the GEMM kernels.
+__device__ __forceinline__ bf16x8 frag_km_sw(const short* img, int rbase, int ks, int lane) {
+  typedef bf16x4 __attribute__((address_space(3))) * lds_v4;
+  const int l16 = lane & 15, kb = lane >> 4;
+  const int k = ks * 32 + kb * 8 + (l16 >> 2);
+  const int r = rbase + 4 * (l16 & 3);
+  const int sw = 8 * (kb & 1);
+  const short* s0 = img + k * 128 + (((r >> 3) ^ (2 * (k & 3)) ^ sw) * 8) + (r & 7);
+  const short* s1 = img + (k + 4) * 128 + (((r >> 3) ^ (2 * ((k + 4) & 3)) ^ sw) * 8) + (r & 7);
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(s0));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(s1));
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <bool TRAIN, bool SWZ = true>
 __global__ __launch_bounds__(256) void pc_bwd_dw_kernel(
     const bf16_t* __restrict__ X, const bf16_t* __restrict__ dTdZ, const uint8_t* __restrict__ maskbits,
     float* __restrict__ partial, int R, int C, int rows_per_split) {
   extern __shared__ __attribute__((aligned(16))) short smem[];
-  constexpr int IMG = FK * LDM;
+  constexpr int LDI = SWZ ? 128 : LDM;
+  constexpr int IMG = FK * LDI;
   constexpr int STAGE = (TRAIN ? 3 : 2) * IMG;     // A plain | [A masked] | B
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int half = wave >> 1, wm = wave & 1;
@@ -331,9 +385,10 @@ __global__ __launch_bounds__(256) void pc_bwd_dw_kernel(
       const bool ok = rbeg + t * FK + kk < rend;                  // rows past the split: zero operands
       const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
       const uint4 a = ok ? q.av[i] : z4, bb = ok ? q.bv[i] : z4;
-      *reinterpret_cast<uint4*>(a0 + kk * LDM + m) = a;
-      if (TRAIN) *reinterpret_cast<uint4*>(a1 + kk * LDM + m) = apply_bits8(a, q.mb[i]);
-      *reinterpret_cast<uint4*>(b + kk * LDM + m) = bb;
+      const int mo = SWZ ? (((vi & 15) ^ (2 * (kk & 3)) ^ (8 * ((kk >> 3) & 1))) * 8) : m;
+      *reinterpret_cast<uint4*>(a0 + kk * LDI + mo) = a;
+      if (TRAIN) *reinterpret_cast<uint4*>(a1 + kk * LDI + mo) = apply_bits8(a, q.mb[i]);
+      *reinterpret_cast<uint4*>(b + kk * LDI + mo) = bb;
     }
   };
   auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
@@ -353,8 +408,8 @@ __global__ __launch_bounds__(256) void pc_bwd_dw_kernel(
       bf16x8 af[4], bf[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        af[i] = frag_km(a_img, wm * 64 + i * 16, ks, lane);
-        bf[i] = frag_km(b_img, half * 64 + i * 16, ks, lane);
+        af[i] = SWZ ? frag_km_sw(a_img, wm * 64 + i * 16, ks, lane) : frag_km(a_img, wm * 64 + i * 16, ks, lane);
+        bf[i] = SWZ ? frag_km_sw(b_img, half * 64 + i * 16, ks, lane) : frag_km(b_img, half * 64 + i * 16, ks, lane);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -395,10 +450,23 @@ __global__ __launch_bounds__(256) void pc_bwd_dw_kernel(
 }
 
 // dWt[c,k] = inv_keep * sum_s partial[s][c][k];  dWa[c,k] = sum_s partial[s][c][64 + k]   (fixed order)
-__global__ __launch_bounds__(256) void pc_dw_reduce_kernel(const float* __restrict__ partial,
-                                                           float* __restrict__ dWt, float* __restrict__ dWa,
-                                                           int C, int K, int S, float inv_keep) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+// Round 4: the launch's TAIL blocks (blockIdx >= nmain) are the column-sum launch that used to follow -- dbt | dba
+// from the activation pass's block partials, literally m1_colsum_kernel's body (same sums bit for bit) -- and, in the
+// one-call train step, the batch mean of the per-example losses and the dropout counter's increment.
+struct PcTail {
+  const float* pdbt; float* dbt; float* dba; int nrows, K;      // pdbt [nrows][2K]: dbt | dba partials
+  uint64_t* rng_bump; ColsumExtra x;
+};
+__global__ __launch_bounds__(1024) void pc_dw_reduce_kernel(const float* __restrict__ partial,
+                                                            float* __restrict__ dWt, float* __restrict__ dWa,
+                                                            int C, int K, int S, float inv_keep, int nmain,
+                                                            PcTail tl) {
+  if ((int)blockIdx.x >= nmain) {
+    colsum_block((int)blockIdx.x - nmain, (int)gridDim.x - nmain, tl.pdbt, nullptr, tl.dbt, nullptr, tl.nrows,
+                 2 * tl.K, 2 * tl.K, tl.rng_bump, tl.dba, tl.K, nullptr, 2 * tl.K, 0, 0, tl.x);
+    return;
+  }
+  const long idx = (long)blockIdx.x * 1024 + threadIdx.x;
   if (idx >= (long)C * 128) return;
   const int c = (int)(idx >> 7), col = (int)(idx & 127), k = col & 63;
   if (k >= K) return;
@@ -441,16 +509,28 @@ PcFusedWs pc_fused_carve(void* base, int N, int P, int C) {
   return f;
 }
 
+// `bits` (training): the same launch also writes the step's keep bits (f.maskbits, n_elems / 8 bytes)
 int pc_fused_prep(const PcFusedWs& f, const float* Wa, const float* Wt, const float* ba, const float* bt, int C,
-                  int K, hipStream_t st) {
-  hipLaunchKernelGGL(pc_prep_kernel, dim3((unsigned)(C / 16)), dim3(256), 0, st, Wa, Wt, ba,
-                     bt, static_cast<bf16_t*>(f.WcatT), static_cast<bf16_t*>(f.Wcat2), f.bcat, C, K);
+                  int K, hipStream_t st, const PcPrepBits* bits) {
+  PcBitsArgs mb = {nullptr, 0, 0, 0, 0, nullptr};
+  unsigned extra = 0;
+  if (bits) {
+    mb.bits = f.maskbits; mb.n8 = bits->n_elems / 8; mb.thresh = keep_thresh(bits->keep_prob);
+    mb.seed = bits->seed; mb.offset = bits->offset; mb.offset_dev = bits->offset_dev;
+    // 8 bytes of bits per thread: the rest of the chip, but not more blocks than there is work for
+    size_t nb = (mb.n8 + 256 * 8 - 1) / (256 * 8);
+    if (nb > 1024) nb = 1024;
+    extra = (unsigned)(nb < 1 ? 1 : nb);
+  }
+  hipLaunchKernelGGL(pc_prep_kernel, dim3((unsigned)(C / 16) + extra), dim3(256), 0, st, Wa, Wt, ba,
+                     bt, static_cast<bf16_t*>(f.WcatT), static_cast<bf16_t*>(f.Wcat2), f.bcat, C, K, mb);
   APA_LAUNCH_CHECK("pc_prep_kernel");
   return APA_OK;
 }
 
 int pc_fused_forward(const PcFusedWs& f, const void* X, float* Z, float* T, int R, int C, int K, bool train,
-                     float keep_prob, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, hipStream_t st) {
+                     float keep_prob, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, hipStream_t st,
+                     bool prebits) {
   if (C % ZB_KT != 0) {     // pc_fused_supported() admits multiples of 256 only
     set_error("pc_fused_forward: C=%d is not a multiple of %d", C, ZB_KT);
     return APA_ERR_UNSUPPORTED;
@@ -464,9 +544,14 @@ int pc_fused_forward(const PcFusedWs& f, const void* X, float* Z, float* T, int 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_BYTES));
     APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_fwd_zt_dma_kernel<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_BYTES));
+    APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_fwd_zt_dma_kernel<true, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_BYTES));
     attr_set = true;
   }
-  if (train)
+  if (train && prebits)
+    hipLaunchKernelGGL((pc_fwd_zt_dma_kernel<true, true>), dim3((R + 31) / 32), dim3(512), ZB_LDS_BYTES, st, xx, ww,
+                       f.bcat, Z, T, f.maskbits, R, C, K, ik, keep_thresh(keep_prob), seed, offset, offset_dev);
+  else if (train)
     hipLaunchKernelGGL(pc_fwd_zt_dma_kernel<true>, dim3((R + 31) / 32), dim3(512), ZB_LDS_BYTES, st, xx, ww,
                        f.bcat, Z, T, f.maskbits, R, C, K, ik, keep_thresh(keep_prob), seed, offset, offset_dev);
   else
@@ -488,7 +573,7 @@ int pc_fused_maskbits(const PcFusedWs& f, size_t n_elems, float keep_prob, uint6
 }
 
 int pc_fused_dw(const PcFusedWs& f, const void* X, float* dWt, float* dWa, int R, int C, int K, bool train,
-                float keep_prob, hipStream_t st) {
+                float keep_prob, hipStream_t st, const PcDwTail* tail) {
   static const int s_env = knob("APA_PC_DW_SPLITS", 0);
   const int ctiles = C / 128;
   int S = s_env ? s_env : (256 + ctiles - 1) / ctiles;            // one block per CU
@@ -499,31 +584,46 @@ int pc_fused_dw(const PcFusedWs& f, const void* X, float* dWt, float* dWa, int R
   S = (R + rows_per_split - 1) / rows_per_split;
   static const int exp_mask = knob("APA_PC_EXP", 0);
   if (exp_mask & 4) train = false;    // timing experiments only (wrong results)
-  const size_t shm = (size_t)2 * (train ? 3 : 2) * FK * LDM * sizeof(short);
+  static const int swz = knob("APA_PC_DW_SWZ", 1);
+  const size_t shm = (size_t)2 * (train ? 3 : 2) * FK * (swz ? 128 : LDM) * sizeof(short);
   const bf16_t* x = static_cast<const bf16_t*>(X);
   const bf16_t* g = static_cast<const bf16_t*>(f.dTdZ);
+#define APA_DW(TR, SW)                                                                                          \
+  do {                                                                                                          \
+    static thread_local PerDevice<bool> attr_dev; bool& attr_set = attr_dev.here();                             \
+    if (!attr_set) {                                                                                            \
+      APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_bwd_dw_kernel<TR, SW>),                \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));                 \
+      attr_set = true;                                                                                          \
+    }                                                                                                           \
+    hipLaunchKernelGGL((pc_bwd_dw_kernel<TR, SW>), dim3(ctiles, S), dim3(256), shm, st, x, g, f.maskbits,        \
+                       f.partial, R, C, rows_per_split);                                                        \
+  } while (0)
   if (train) {
-    static thread_local PerDevice<bool> attr_dev; bool& attr_set = attr_dev.here();
-    if (!attr_set) {
-      APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_bwd_dw_kernel<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(pc_bwd_dw_kernel<true>, dim3(ctiles, S), dim3(256), shm, st, x, g, f.maskbits, f.partial,
-                       R, C, rows_per_split);
+#ifdef APA_ABLATION
+    if (!swz) APA_DW(true, false); else
+#endif
+    APA_DW(true, true);
   } else {
-    static thread_local PerDevice<bool> attr_dev; bool& attr_set = attr_dev.here();
-    if (!attr_set) {
-      APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_bwd_dw_kernel<false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(pc_bwd_dw_kernel<false>, dim3(ctiles, S), dim3(256), shm, st, x, g, f.maskbits, f.partial,
-                       R, C, rows_per_split);
+#ifdef APA_ABLATION
+    if (!swz) APA_DW(false, false); else
+#endif
+    APA_DW(false, true);
   }
+#undef APA_DW
   APA_LAUNCH_CHECK("pc_bwd_dw_kernel");
-  hipLaunchKernelGGL(pc_dw_reduce_kernel, dim3((unsigned)(((long)C * 128 + 255) / 256)), dim3(256), 0, st,
-                     f.partial, dWt, dWa, C, K, S, train ? 1.0f / keep_prob : 1.0f);
+  const int nmain = (int)(((long)C * 128 + 1023) / 1024);
+  PcTail tl;
+  tl.pdbt = nullptr; tl.dbt = nullptr; tl.dba = nullptr; tl.nrows = 0; tl.K = K; tl.rng_bump = nullptr;
+  int ntail = 0;
+  if (tail) {
+    tl.pdbt = tail->pdbt; tl.dbt = tail->dbt; tl.dba = tail->dba; tl.nrows = tail->nrows; tl.rng_bump = tail->rng_bump;
+    tl.x.aux_src = tail->aux_src; tl.x.aux_n = tail->aux_n; tl.x.aux_scale = tail->aux_scale; tl.x.aux_dst = tail->aux_dst;
+    tl.x.C3 = 2 * K; tl.x.C4 = 2 * K;
+    ntail = (2 * K + 31) / 32;
+  }
+  hipLaunchKernelGGL(pc_dw_reduce_kernel, dim3((unsigned)(nmain + ntail)), dim3(1024), 0, st, f.partial, dWt, dWa,
+                     C, K, S, train ? 1.0f / keep_prob : 1.0f, nmain, tl);
   APA_LAUNCH_CHECK("pc_dw_reduce_kernel");
   return APA_OK;
 }

@@ -237,6 +237,8 @@ def test_cfg003_whole_step_in_one_call_matches_the_per_op_sequence(gpu, dtype, N
         for k_ in got:
             if exact:
                 assert torch.equal(got[k_].view_as(want[k_]), want[k_]), k_
+            elif k_ == 'dba' and softmax:      # a spatial softmax is shift invariant: exactly 0, round-off on both sides
+                assert float(got[k_].abs().max()) < 1e-5 * float(want['dZ'].abs().sum())
             else:
                 assert _rel(got[k_], want[k_]) < 2e-4, (k_, _rel(got[k_], want[k_]))
         if exact:
@@ -271,11 +273,56 @@ def test_per_class_one_call_train_step_equals_the_separate_calls(gpu, K, dtype):
     loss, G, _, _ = cof.softmax_xent_fwd_bwd(logits, labels)
     cof.attn_pool_bwd(X, X, Wa, ba, Wt, bt, att, Ts, None, G, workspace=ws, out=gb, **kw)
     torch.cuda.synchronize()
+    # K <= 64 (the fused HMDB-51 path): inside the one call the row's cross-entropy is computed by the activation
+    # pass itself (one launch less) with a wave-wide instead of a half-wave reduction -- loss and G agree to fp32
+    # round-off, and since dT / dZ are STORED in bf16 a last-bit difference in G can flip a rounding downstream
+    folded = K <= 64 and dtype == torch.bfloat16
     for a, b, name in ((st.logits, logits, 'logits'), (st.att, att, 'att'), (st.loss, loss, 'loss'), (st.G, G, 'G'),
                        (ga[0], gb[0], 'dX'), (ga[2], gb[2], 'dWa'), (ga[3], gb[3], 'dba'), (ga[4], gb[4], 'dWt'),
                        (ga[5], gb[5], 'dbt')):
-        assert torch.equal(a, b), name
+        if not folded or name in ('logits', 'att'):
+            assert torch.equal(a, b), name
+        elif name in ('loss', 'G'):
+            assert _rel(a, b) < 2e-6, (name, _rel(a, b))
+        else:
+            assert _rel(a.float(), b.float()) < 1.0 / 128, (name, _rel(a.float(), b.float()))
     assert bool(torch.isfinite(ga[0].float()).all()) and float(ga[4].abs().max()) > 0
+
+
+@pytest.mark.parametrize('K', [51, 130])
+def test_per_class_device_side_dropout_counter_is_advanced_by_the_backward_call(gpu, K):
+    """APA_FLAG_RNG_DEVICE (include/apa.h): `offset` is the address of a step counter in HBM that apa_attn_pool_bwd
+    advances when it is done -- also on the per-class paths (fused K <= 64 and generic), per-op and one-call: every
+    step draws a fresh mask, and the counter never moves before the last kernel that keys its mask with it."""
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    N, P, C = 3, 49, 512
+    g = torch.Generator().manual_seed(K + 1)
+    X = torch.relu(torch.randn(N, P, C, generator=g)).to(torch.bfloat16).to(gpu)
+    Wa = (torch.randn(C, K, generator=g) / C ** 0.5).to(gpu); ba = (torch.randn(K, generator=g) * 0.1).to(gpu)
+    Wt = (torch.randn(C, K, generator=g) / C ** 0.5).to(gpu); bt = (torch.randn(K, generator=g) * 0.1).to(gpu)
+    labels = torch.randint(0, K, (N,), generator=g).to(gpu)
+    flags = cof.attn_flags(False, False, True)
+    ctr = torch.full((1,), 5, dtype=torch.int64, device=gpu)
+    kw = dict(flags=flags, keep_prob=0.5, seed=3, offset=ctr)
+    logits, att, Ts, _, _, ws = cof.attn_pool_fwd(X, X, Wa, ba, Wt, bt, **kw)
+    _, G, _, _ = cof.softmax_xent_fwd_bwd(logits, labels)
+    dX1 = cof.attn_pool_bwd(X, X, Wa, ba, Wt, bt, att, Ts, None, G, workspace=ws, **kw)[0].clone()
+    torch.cuda.synchronize()
+    assert int(ctr) == 6
+    # the same step keyed by value with offset 5 gives the same gradient: the counter was read as 5 throughout
+    kv = dict(flags=flags, keep_prob=0.5, seed=3, offset=5)
+    l2, a2, T2, _, _, ws2 = cof.attn_pool_fwd(X, X, Wa, ba, Wt, bt, **kv)
+    _, G2, _, _ = cof.softmax_xent_fwd_bwd(l2, labels)
+    dX2 = cof.attn_pool_bwd(X, X, Wa, ba, Wt, bt, a2, T2, None, G2, workspace=ws2, **kv)[0]
+    assert torch.equal(dX1, dX2)
+    # one-call steps: +1 each, and a different mask each
+    grads = (torch.empty_like(X), None, torch.empty_like(Wa), torch.empty_like(ba), torch.empty_like(Wt),
+             torch.empty_like(bt))
+    st = cof.HeadTrainStep(X, X, Wa, ba, Wt, bt, labels, grads, **kw)
+    st.run(); torch.cuda.synchronize()
+    first = grads[0].clone()
+    st.run(); torch.cuda.synchronize()
+    assert int(ctr) == 8 and not torch.equal(first, grads[0])
 
 
 def _pc_problem(N, H, C, K, seed, Ca=None, dtype=torch.float32):

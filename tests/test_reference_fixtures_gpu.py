@@ -126,7 +126,7 @@ def test_hip_head_matches_reference_at_the_benchmark_shape(gpu, path, dtype):
     inputs and variables are bf16-representable, so what is measured is the kernels' own rounding (bf16 stores of
     pose_pre_logits / dX, bf16 MFMA operands): logits within 3e-3 (tests/test_bf16_parity_gpu.py's
     LOGIT_TOL_BF16), argmax exact on rows whose top-2 margin exceeds twice that, gradients within
-    KAPPA * 2^-8 = 1.2e-2 of max|reference| elementwise and 2e-3 of the l2 norm on the projections."""
+    KAPPA * 2^-8 = 1.2e-2 of max|reference| elementwise and 8e-3 of the l2 norm on the projections."""
     fx = _big(path)
     assert fx.quant == 'bf16'
     bf = dtype == 'bf16'
@@ -148,7 +148,8 @@ def test_hip_head_matches_reference_at_the_benchmark_shape(gpu, path, dtype):
     else:
         assert err <= 1e-3 and _rel(got_logits, exp_logits) < 2e-5
         assert np.array_equal(got_logits.argmax(1), exp_logits.argmax(1))
-    tol, tolp = (1.2e-2, 2e-3) if bf else (5e-5, 5e-5)
+    # bf16 storage of a tensor: element errors ~ U(+-2^-9 |x|), i.e. 1.1e-3 |x|_2 on a random projection (1 sigma)
+    tol, tolp = (1.2e-2, 8e-3) if bf else (5e-5, 5e-5)
     for key in fx.meta['end_points']:
         name = key[len('out/ep/'):]
         if name == 'TopDownAttention':
