@@ -1057,18 +1057,50 @@ __global__ __launch_bounds__(1024) void pc_fwd_act_kernel(const float* __restric
   }
   red[pg][kk] = acc;
   __syncthreads();
+  __shared__ float lrow[64];
   if (pg == 0) {                       // wave 0: lane kk owns class k
     const float lg = ok ? pc_colsum(red, kk) / (float)P : -INFINITY;
     if (ok) logits[(size_t)n * K + k] = lg;
-    if (xe.labels) {                   // (gridDim.y == 1: the wave holds the whole row)
+    lrow[kk] = lg;
+  }
+  if (xe.labels) {                     // (block-uniform; gridDim.y == 1 and 4 <= K <= 64: lrow holds the whole row)
+    __syncthreads();
+    if (pg == 0) {
+      // softmax_xent_kernel<1>'s arithmetic to the letter (apa_loss.hip), so that the folded loss and its gradient
+      // are BIT-identical to the separate launch: half a wave owns the row (both halves run the same row here),
+      // lane hl holds the 4 columns colc .. colc + 3, the ragged last vector is shifted back and its
+      // already-covered columns masked out; half-wave max / sum trees, exp_fast, fmaf(p, gscale, -gscale)
+      const int lane = threadIdx.x & 63, hl = lane & 31;
       const int lab = (int)xe.labels[n];
       const bool lab_ok = lab >= 0 && lab < K;
-      const float mw = wave_max(lg);
-      const float e = ok ? exp_fast(lg - mw) : 0.f;
-      const float l = wave_sum(e);
-      const float xl = __shfl(lg, lab_ok ? lab : 0);
-      if (ok) xe.G[(size_t)n * K + k] = fmaf(e * (1.0f / l), xe.gscale, k == lab ? -xe.gscale : 0.f);
-      if (kk == 0) xe.loss[1 + n] = lab_ok ? -(xl - mw - logf(l)) : 0.f;
+      const int col0 = 4 * hl, colc = min(col0, K - 4);
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = colc + e >= col0 ? lrow[colc + e] : -INFINITY;
+      const float xl = lrow[lab_ok ? lab : 0];
+      float m = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (v[e] > m) m = v[e];
+      const float mw = half_max(m, lane);
+      float l = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = exp_fast(v[e] - mw);
+        l += v[e];
+      }
+      l = half_sum(l, lane);
+      const float inv = 1.0f / l;
+      const float lv = lab_ok ? -(xl - mw - logf(l)) : 0.f;
+      if (lane < 32) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = colc + e;
+          if (c >= col0 && c < K)
+            xe.G[(size_t)n * K + c] = fmaf(v[e] * inv, xe.gscale, c == lab ? -xe.gscale : 0.f);
+        }
+        if (hl == 0) xe.loss[1 + n] = lv;
+      }
     }
   }
 }
@@ -1253,7 +1285,7 @@ int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
     dim3 grid(N, (K + 63) / 64);
     PcXent xe = {nullptr, nullptr, nullptr, 0.f};
     static const int fold_xent = knob("APA_PC_XENT_FOLD", 1);
-    if (fold_xent && xf && xf->labels && xf->G && xf->loss && !xf->probs && K <= 64) {
+    if (fold_xent && xf && xf->labels && xf->G && xf->loss && !xf->probs && K >= 4 && K <= 64) {
       xe.labels = xf->labels; xe.loss = xf->loss; xe.G = xf->G; xe.gscale = xf->gscale;
       xf->done = true;
     }
@@ -1352,7 +1384,8 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
     // dbt | dba (column sums of the activation pass's block partials), the batch mean of a folded cross-entropy
     // and the dropout counter ride on the tail blocks of the dW reduce launch
     PcDwTail tail = {pdbt, dbt, dba, N * ps, bump, nullptr, 0, 0.f, nullptr};
-    if (xf && xf->done) { tail.aux_src = xf->loss + 1; tail.aux_n = N; tail.aux_scale = xf->lscale; tail.aux_dst = xf->loss; }
+    // (aux_n < 0: the batch mean in apa_softmax_xent_fwd_bwd's own summation order -- bit-identical loss[0])
+    if (xf && xf->done) { tail.aux_src = xf->loss + 1; tail.aux_n = -N; tail.aux_scale = xf->lscale; tail.aux_dst = xf->loss; }
     rc = pc_fused_dw(f, X, dWt, dWa, R, C, K, train, keep_prob, st, &tail);
     if (rc != APA_OK) return rc;
     // dX = (dT . Wt^T) * mask/keep + dZ . Wa^T: one launch over the concatenated k = 128

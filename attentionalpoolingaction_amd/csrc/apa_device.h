@@ -321,15 +321,43 @@ __device__ __forceinline__ void colsum_block(int bid, int nbid, const float* __r
   if (bid == 0 && threadIdx.x == 0 && rng_bump) *rng_bump += 1;
   if (x.aux_src && bid == nbid - 1) {
     __syncthreads();
-    float a = 0.f;
-    for (int b = threadIdx.x; b < x.aux_n; b += 1024) a += x.aux_src[b];
-    a = wave_sum(a);
-    if ((threadIdx.x & 63) == 0) red[1][threadIdx.x >> 6] = a;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float s = 0.f;
-      for (int w = 0; w < 16; ++w) s += red[1][w];
-      x.aux_dst[0] = s * x.aux_scale;
+    if (x.aux_n < 0) {
+      // the batch mean of per-example losses in apa_softmax_xent_fwd_bwd's own summation order, so that a
+      // cross-entropy folded into another kernel leaves a bit-identical loss[0]:
+      //   N <= 64 (softmax_xent_kernel modes 1 / 2): slot w = n mod 32 adds its rows in increasing n, the slots
+      //   are added in order;  N > 64 (sum_scale_kernel): 256 strided threads, wave sums, (r0 + r1) + (r2 + r3)
+      const int N = -x.aux_n;
+      if (N <= 64) {
+        if (threadIdx.x == 0) {
+          float t = 0.f;
+          for (int w = 0; w < 32; ++w) {
+            float sl = 0.f;
+            if (w < N) sl += x.aux_src[w];
+            if (w + 32 < N) sl += x.aux_src[w + 32];
+            t += sl;
+          }
+          x.aux_dst[0] = t * x.aux_scale;
+        }
+      } else {
+        float a = 0.f;
+        if (threadIdx.x < 256)
+          for (int i = threadIdx.x; i < N; i += 256) a += x.aux_src[i];
+        a = wave_sum(a);
+        if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) red[1][threadIdx.x >> 6] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) x.aux_dst[0] = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) * x.aux_scale;
+      }
+    } else {
+      float a = 0.f;
+      for (int b2 = threadIdx.x; b2 < x.aux_n; b2 += 1024) a += x.aux_src[b2];
+      a = wave_sum(a);
+      if ((threadIdx.x & 63) == 0) red[1][threadIdx.x >> 6] = a;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int w = 0; w < 16; ++w) s += red[1][w];
+        x.aux_dst[0] = s * x.aux_scale;
+      }
     }
   }
 }
