@@ -917,16 +917,24 @@ constexpr int TNW = 256;
 template <int MT> struct WideCfg {
   static constexpr int TMR = 32 * MT;
   static constexpr int A_EL = TMR * TK, B_EL = TNW * TK;       // shorts per image
-  static constexpr int STAGE_EL = A_EL + B_EL;
-  static constexpr int NBLK = TMR / 8 + TNW / 8;               // KiB-blocks (DMA wave-instructions) per stage
-  static constexpr int C_LO = NBLK / 8, N_HI = NBLK % 8;
-  static constexpr size_t LDS_BYTES = (size_t)2 * STAGE_EL * 2;
-  static_assert((size_t)TMR * (TN + 4) * 4 <= LDS_BYTES, "half-tile epilogue staging fits in the two stages");
+  // A ring of TWO stages, B ring of THREE (152 KB at MT = 7): with two whole stages only one K tile is in flight
+  // while the other is multiplied, and a tile's DMA takes ~2 us from issue to landed when the whole chip pulls --
+  // the first version ran 12 tiles x 2 us + epilogue = 29 us whatever the MFMA loop did.  The third B stage lets
+  // B(t + 2) fly a whole iteration early; A(t + 1) (less than half the bytes) keeps one iteration.
+  static constexpr int NA = TMR / 8, NB = TNW / 8;             // KiB-blocks (DMA wave-instructions) per A / B stage
+  static constexpr int A_LO = NA / 8, A_HI = NA % 8;           // waves < A_HI issue A_LO + 1 A blocks
+  static constexpr int B_PER_WAVE = NB / 8;                    // 4
+  static constexpr size_t LDS_BYTES = ((size_t)2 * A_EL + (size_t)3 * B_EL) * 2;
+  static_assert((size_t)TMR * (TN + 4) * 4 <= LDS_BYTES, "half-tile epilogue staging fits in the rings");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <typename TC, int MT, bool PIPE>
+// MID (the per-class dX product of apa_pc_fused.hip, K = 128): after K tile `drop_mid` the accumulators are
+// multiplied by the dropout mask / keep of their output element, read as bits (one 8-byte word per row and 64
+// columns, fetched before the first DMA so that their latency hides under tile 0).
+template <typename TC, int MT, bool PIPE, bool MID = false>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_wide_kernel(FastParams p) {
+  static_assert(!(PIPE && MID), "the masked form uses the plain loop");
   typedef WideCfg<MT> W;
   extern __shared__ __attribute__((aligned(16))) short smem[];
   typedef __attribute__((address_space(3))) void* lptr;
@@ -938,29 +946,35 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_wide_kernel(FastParams p) {
   const int m0 = (tile / ntn) * W::TMR, n0 = (tile % ntn) * TNW;
   const int nk = p.K / TK;
 
-  // this wave's KiB-blocks of a stage: b = wave, wave + 8, ...  (b < TMR/8: A rows 8b..; else B rows 8(b - TMR/8)..)
-  constexpr int NMINE = W::C_LO + (W::N_HI ? 1 : 0);
-  const bf16_t* src[NMINE];
-  uint32_t dst[NMINE];
+  // this wave's KiB-blocks: A blocks wave, wave + 8, ... (< NA: rows 8b..), B blocks wave, wave + 8, ... (rows 8g..)
+  constexpr int NAM = W::A_LO + (W::A_HI ? 1 : 0);
+  const bf16_t* asrc[NAM];
+  const bf16_t* bsrc[W::B_PER_WAVE];
 #pragma unroll
-  for (int j = 0; j < NMINE; ++j) {
-    const int b = wave + 8 * j;
-    if (b < W::TMR / 8) {
-      src[j] = static_cast<const bf16_t*>(p.A) + glds_src_offset<false>(b, lane, p.lda, m0, p.M);
-      dst[j] = (uint32_t)b * 1024u;
-    } else {
-      const int g = min(b - W::TMR / 8, TNW / 8 - 1);
-      src[j] = static_cast<const bf16_t*>(p.B) + glds_src_offset<false>(g, lane, p.ldb, n0, p.N);
-      dst[j] = (uint32_t)(W::A_EL * 2) + (uint32_t)g * 1024u;
-    }
-  }
-  const bool extra = wave < W::N_HI;              // wave-uniform: issues slot C_LO as well
+  for (int j = 0; j < NAM; ++j)
+    asrc[j] = static_cast<const bf16_t*>(p.A) + glds_src_offset<false>(min(wave + 8 * j, W::NA - 1), lane, p.lda, m0, p.M);
+#pragma unroll
+  for (int j = 0; j < W::B_PER_WAVE; ++j)
+    bsrc[j] = static_cast<const bf16_t*>(p.B) + glds_src_offset<false>(wave + 8 * j, lane, p.ldb, n0, p.N);
+  const bool a_extra = wave < W::A_HI;            // wave-uniform: issues A slot A_LO as well
   const uint32_t lds0 = (uint32_t)(size_t)(lptr)smem;
-  auto issue = [&](int t) {
-    const uint32_t st = lds0 + (uint32_t)((t & 1) * W::STAGE_EL * 2);
+  const uint32_t ldsB = lds0 + (uint32_t)(2 * W::A_EL * 2);
+  auto issueA = [&](int t) {
+    const uint32_t st = lds0 + (uint32_t)((t & 1) * W::A_EL * 2);
 #pragma unroll
-    for (int j = 0; j < W::C_LO; ++j) glds16_ring(src[j] + (long)t * TK, st + dst[j]);
-    if (W::N_HI && extra) glds16_ring(src[NMINE - 1] + (long)t * TK, st + dst[NMINE - 1]);
+    for (int j = 0; j < W::A_LO; ++j) glds16_ring(asrc[j] + (long)t * TK, st + (uint32_t)(wave + 8 * j) * 1024u);
+    if (W::A_HI && a_extra) glds16_ring(asrc[NAM - 1] + (long)t * TK, st + (uint32_t)(wave + 8 * W::A_LO) * 1024u);
+  };
+  auto issueB = [&](int t) {
+    const uint32_t st = ldsB + (uint32_t)((t % 3) * W::B_EL * 2);
+#pragma unroll
+    for (int j = 0; j < W::B_PER_WAVE; ++j) glds16_ring(bsrc[j] + (long)t * TK, st + (uint32_t)(wave + 8 * j) * 1024u);
+  };
+  // tile `want` = A(want) + B(want) has landed once at most the B blocks issued AFTER A(want) are outstanding (vmcnt
+  // counts in issue order; every wave issues B_PER_WAVE B blocks per stage); the barrier publishes everybody's blocks
+  auto hand_over = [&](bool b_after) {
+    if (b_after) ring_wait_barrier<W::B_PER_WAVE>();
+    else ring_wait_barrier<0>();
   };
 
   f32x4 acc[MT][4];
@@ -970,8 +984,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_wide_kernel(FastParams p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto load_frags = [&](int t, int ks, bf16x8 (&af)[MT], bf16x8 (&bf)[4]) {
-    const short* a_img = smem + (t & 1) * W::STAGE_EL;
-    const short* b_img = a_img + W::A_EL;
+    const short* a_img = smem + (t & 1) * W::A_EL;
+    const short* b_img = smem + 2 * W::A_EL + (t % 3) * W::B_EL;
 #pragma unroll
     for (int j = 0; j < 4; ++j) bf[j] = fragment_sw<false>(b_img, wn * 64 + j * 16, ks, lane);
 #pragma unroll
@@ -984,24 +998,53 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_wide_kernel(FastParams p) {
       for (int j = 0; j < 4; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
   };
+  uint64_t mbits[MID ? MT * 4 : 1];
+  if (MID) {
+    const int kbm = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = min(m0 + (wm * MT + i) * 16 + 4 * kbm + r, p.M - 1);
+        mbits[i * 4 + r] = *reinterpret_cast<const uint64_t*>(
+            p.maskbits + (((size_t)row * p.Nout + min(n0 + wn * 64, p.Nout - 64)) >> 3));
+      }
+  }
+  // issue order: A0 B0 B1 | A1 B2 | A2 B3 | ...   (one group per hand-over)
+  if (nk > 0) { issueA(0); issueB(0); }
+  if (nk > 1) issueB(1);
   if (!PIPE) {
-    if (nk > 0) issue(0);
     for (int t = 0; t < nk; ++t) {
-      // my pieces of tile t are home; the barrier publishes everybody's and tells me that every wave is done with
-      // tile t - 1, whose stage the next DMA overwrites
-      ring_wait_barrier<0>();
-      if (t + 1 < nk) issue(t + 1);
+      hand_over(t + 1 < nk);                        // tile t is in (B(t + 1) may still fly); tile t - 1's stages are free
+      if (MID && t == 0) {                          // the bit words are older than every DMA: home by now
+#pragma unroll
+        for (int u = 0; u < MT * 4; ++u) asm volatile("" : "+v"(mbits[u]));
+      }
+      if (t + 1 < nk) issueA(t + 1);
+      if (t + 2 < nk) issueB(t + 2);
 #pragma unroll
       for (int ks = 0; ks < TK / 32; ++ks) {
         bf16x8 bf[4], af[MT];
         load_frags(t, ks, af, bf);
         mma(af, bf);
       }
+      if (MID && t == p.drop_mid) {                 // D layout: row = 4 * (lane >> 4) + reg, col = lane & 15
+        const int l16m = lane & 15;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const uint64_t bits = mbits[i * 4 + r];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[i][j][r] *= ((bits >> (j * 16 + l16m)) & 1ull) ? p.inv_keep : 0.f;
+          }
+      }
     }
   } else {
-    // the ring kernel's two-step software pipeline (see there) on two stages: the fragments of k step 1 are read
-    // under the MFMAs of step 0, the hand-over (wait + barrier + next DMA) sits between the two MFMA groups, step 0
-    // of the next tile is read under the MFMAs of step 1
+    // the ring kernel's two-step software pipeline (see there): the fragments of k step 1 are read under the MFMAs of
+    // step 0, the hand-over (wait + barrier + next DMA) sits between the two MFMA groups, step 0 of the next tile is
+    // read under the MFMAs of step 1
     static_assert(TK / 32 == 2, "two k steps per tile");
     bf16x8 af0[MT], bf0[4], af1[MT], bf1[4];
     auto settle = [&](bf16x8 (&af)[MT], bf16x8 (&bf)[4]) {
@@ -1010,9 +1053,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_wide_kernel(FastParams p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bf[j]));
     };
-    if (nk > 0) issue(0);
-    ring_wait_barrier<0>();
-    if (1 < nk) issue(1);
+    hand_over(1 < nk);                              // tile 0 is in
+    if (1 < nk) issueA(1);
+    if (2 < nk) issueB(2);
     load_frags(0, 0, af0, bf0);
     for (int t = 0; t + 1 < nk; ++t) {
       settle(af0, bf0);
@@ -1020,8 +1063,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_wide_kernel(FastParams p) {
       __builtin_amdgcn_sched_barrier(0);
       mma(af0, bf0);
       __builtin_amdgcn_sched_barrier(0);
-      ring_wait_barrier<0>();                       // tile t + 1 is in; every wave's reads of tile t are home
-      if (t + 2 < nk) issue(t + 2);
+      hand_over(t + 2 < nk);                        // tile t + 1 is in; every wave's reads of tile t are home
+      if (t + 2 < nk) issueA(t + 2);
+      if (t + 3 < nk) issueB(t + 3);
       load_frags(t + 1, 0, af0, bf0);
       __builtin_amdgcn_sched_barrier(0);
       mma(af1, bf1);
@@ -1105,6 +1149,21 @@ int launch_wide_p(const FastParams& p, hipStream_t st) {
   APA_LAUNCH_CHECK("gemm_bf16_wide_kernel");
   return APA_OK;
 }
+template <int MT>
+int launch_wide_mid(const FastParams& p, hipStream_t st) {
+  typedef WideCfg<MT> W;
+  static thread_local PerDevice<bool> attr_dev; bool& attr_set = attr_dev.here();
+  if (!attr_set) {
+    APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_wide_kernel<bf16_t, MT, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS_BYTES));
+    attr_set = true;
+  }
+  const int tiles = ((p.M + W::TMR - 1) / W::TMR) * ((p.N + TNW - 1) / TNW);
+  hipLaunchKernelGGL((gemm_bf16_wide_kernel<bf16_t, MT, false, true>), dim3(tiles), dim3(512), W::LDS_BYTES, st, p);
+  APA_LAUNCH_CHECK("gemm_bf16_wide_kernel<mid>");
+  return APA_OK;
+}
+
 template <typename TC, int MT>
 int launch_wide(const FastParams& p, hipStream_t st) {
   static const int pipe = knob("APA_GEMM_WIDE_PIPE", 1);
@@ -1241,6 +1300,19 @@ int gemm_bf16_mid_dropout(const void* A, long lda, const void* B, long ldb, void
   p.vec_epi = N % 8 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && (ldc * 2) % 16 == 0;
   p.drop_mid = 0;
   p.maskbits = maskbits;
+  static const int use_wide = knob("APA_GEMM_WIDE_MID", 1);
+  if (use_wide && N % 64 == 0 && N >= 1024 && p.vec_epi) {   // one resident round of (32 MT) x 256 tiles
+    const int cus = gemm_cu_count();
+    const int mt = wide_pick_mt(M, N, cus);
+    if (mt && (long)((M + 32 * mt - 1) / (32 * mt)) * ((N + TNW - 1) / TNW) * 4 >= (long)cus * 3) {
+      switch (mt) {
+        case 4: return launch_wide_mid<4>(p, st);
+        case 5: return launch_wide_mid<5>(p, st);
+        case 6: return launch_wide_mid<6>(p, st);
+        default: return launch_wide_mid<7>(p, st);
+      }
+    }
+  }
   const size_t shm = (size_t)2 * 2 * OP_ELEMS * sizeof(short);
   static thread_local PerDevice<bool> attr_dev; bool& attr_set = attr_dev.here();
   if (!attr_set) {
