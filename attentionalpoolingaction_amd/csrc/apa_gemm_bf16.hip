@@ -903,8 +903,13 @@ int launch_ring(const FastParams& p, hipStream_t st) {
 // Wide variant (round 4) for the products whose OUTPUT is wide and whose contraction is short: the pose head's
 // dX (+)= dPpre . W1^T, [6272 x 768] . [768 x 2048] -- only 12 K tiles, so a tile's prologue and its
 // epilogue (read + write of its share of a 25.7 MB bf16 map) weigh as much as its loop, and with 784 tiles of
-// 128 x 128 the second round of the two-stage kernel is half empty (34.3 us against hipBLASLt's 24.0 us,
-// profiles/r03_*).  Here ONE resident round covers the product with (32 MT) x 256 tiles (MT = 7: 28 x 8 = 224
+// 128 x 128 the second round of the two-stage kernel is half empty (34.3 us, profiles/r03_*).
+// Measured (rocprofv3, N = 32): 33.6 -> 28.8 us for the accumulate form (beta = 1: 25.7 MB of C read + 25.7 MB
+// written -- 9 us of HBM traffic by itself at the streaming kernels' 5.5 TB/s); the same kernel on the two K tiles of
+// the per-class dX product takes 16 us, i.e. launch + prologue + epilogue are ~13 us of the 28.8 and a K tile
+// costs 1.3 us.  Tried on top and measured equal within 2 %: requesting the old C values before the tile is staged
+// (28.8 vs 29.1), two whole LDS stages vs an A ring of two + B ring of three (29.4 vs 28.8), the plain loop vs the
+// two-step software pipeline (29.9 vs 28.8) -- the epilogue's 228 KB per CU, not the loop, is what is left.  Here ONE resident round covers the product with (32 MT) x 256 tiles (MT = 7: 28 x 8 = 224
 // tiles for 256 CUs): one block of 8 waves per CU as 2 x 4, wave tile (16 MT) x 64 = MT x 4 MFMA tiles -- MT + 4
 // fragment reads per 4 MT MFMAs (0.39 reads per MFMA against 0.70 in the ring kernel's MT x 2 layout and 0.5 in the
 // 4 x 4 layout: the LDS port was what bounded those loops) and half the operand bytes per flop of a 128-wide
@@ -929,12 +934,8 @@ template <int MT> struct WideCfg {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-// MID (the per-class dX product of apa_pc_fused.hip, K = 128): after K tile `drop_mid` the accumulators are
-// multiplied by the dropout mask / keep of their output element, read as bits (one 8-byte word per row and 64
-// columns, fetched before the first DMA so that their latency hides under tile 0).
-template <typename TC, int MT, bool PIPE, bool MID = false>
+template <typename TC, int MT, bool PIPE>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_wide_kernel(FastParams p) {
-  static_assert(!(PIPE && MID), "the masked form uses the plain loop");
   typedef WideCfg<MT> W;
   extern __shared__ __attribute__((aligned(16))) short smem[];
   typedef __attribute__((address_space(3))) void* lptr;
@@ -998,28 +999,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_wide_kernel(FastParams p) {
       for (int j = 0; j < 4; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
   };
-  uint64_t mbits[MID ? MT * 4 : 1];
-  if (MID) {
-    const int kbm = lane >> 4;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = min(m0 + (wm * MT + i) * 16 + 4 * kbm + r, p.M - 1);
-        mbits[i * 4 + r] = *reinterpret_cast<const uint64_t*>(
-            p.maskbits + (((size_t)row * p.Nout + min(n0 + wn * 64, p.Nout - 64)) >> 3));
-      }
-  }
   // issue order: A0 B0 B1 | A1 B2 | A2 B3 | ...   (one group per hand-over)
   if (nk > 0) { issueA(0); issueB(0); }
   if (nk > 1) issueB(1);
   if (!PIPE) {
     for (int t = 0; t < nk; ++t) {
       hand_over(t + 1 < nk);                        // tile t is in (B(t + 1) may still fly); tile t - 1's stages are free
-      if (MID && t == 0) {                          // the bit words are older than every DMA: home by now
-#pragma unroll
-        for (int u = 0; u < MT * 4; ++u) asm volatile("" : "+v"(mbits[u]));
-      }
       if (t + 1 < nk) issueA(t + 1);
       if (t + 2 < nk) issueB(t + 2);
 #pragma unroll
@@ -1027,18 +1012,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_wide_kernel(FastParams p) {
         bf16x8 bf[4], af[MT];
         load_frags(t, ks, af, bf);
         mma(af, bf);
-      }
-      if (MID && t == p.drop_mid) {                 // D layout: row = 4 * (lane >> 4) + reg, col = lane & 15
-        const int l16m = lane & 15;
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const uint64_t bits = mbits[i * 4 + r];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              acc[i][j][r] *= ((bits >> (j * 16 + l16m)) & 1ull) ? p.inv_keep : 0.f;
-          }
       }
     }
   } else {
@@ -1149,21 +1122,6 @@ int launch_wide_p(const FastParams& p, hipStream_t st) {
   APA_LAUNCH_CHECK("gemm_bf16_wide_kernel");
   return APA_OK;
 }
-template <int MT>
-int launch_wide_mid(const FastParams& p, hipStream_t st) {
-  typedef WideCfg<MT> W;
-  static thread_local PerDevice<bool> attr_dev; bool& attr_set = attr_dev.here();
-  if (!attr_set) {
-    APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_wide_kernel<bf16_t, MT, false, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS_BYTES));
-    attr_set = true;
-  }
-  const int tiles = ((p.M + W::TMR - 1) / W::TMR) * ((p.N + TNW - 1) / TNW);
-  hipLaunchKernelGGL((gemm_bf16_wide_kernel<bf16_t, MT, false, true>), dim3(tiles), dim3(512), W::LDS_BYTES, st, p);
-  APA_LAUNCH_CHECK("gemm_bf16_wide_kernel<mid>");
-  return APA_OK;
-}
-
 template <typename TC, int MT>
 int launch_wide(const FastParams& p, hipStream_t st) {
   static const int pipe = knob("APA_GEMM_WIDE_PIPE", 1);
@@ -1300,19 +1258,6 @@ int gemm_bf16_mid_dropout(const void* A, long lda, const void* B, long ldb, void
   p.vec_epi = N % 8 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && (ldc * 2) % 16 == 0;
   p.drop_mid = 0;
   p.maskbits = maskbits;
-  static const int use_wide = knob("APA_GEMM_WIDE_MID", 1);
-  if (use_wide && N % 64 == 0 && N >= 1024 && p.vec_epi) {   // one resident round of (32 MT) x 256 tiles
-    const int cus = gemm_cu_count();
-    const int mt = wide_pick_mt(M, N, cus);
-    if (mt && (long)((M + 32 * mt - 1) / (32 * mt)) * ((N + TNW - 1) / TNW) * 4 >= (long)cus * 3) {
-      switch (mt) {
-        case 4: return launch_wide_mid<4>(p, st);
-        case 5: return launch_wide_mid<5>(p, st);
-        case 6: return launch_wide_mid<6>(p, st);
-        default: return launch_wide_mid<7>(p, st);
-      }
-    }
-  }
   const size_t shm = (size_t)2 * 2 * OP_ELEMS * sizeof(short);
   static thread_local PerDevice<bool> attr_dev; bool& attr_set = attr_dev.here();
   if (!attr_set) {
