@@ -103,6 +103,28 @@ def build_cfg003(cof, dev, N=32, H=14, K=393, dtype='bf16', rank1=True, one_call
     return step, info
 
 
+def build_posebwd(cof, dev, N=32, H=14, dtype='bf16', accumulate=False):
+    """the pose head's backward call alone (dPpre rows pass, column sums, dW1 split-K + reduce, dX product) --
+    with accumulate=False the dX product runs with beta = 0, the form a plain library GEMM is timed in
+    (tools/hipblaslt_ref.py): for kernel-by-kernel comparisons under rocprofv3."""
+    C, Cp, J, P = 2048, 768, 16, H * H
+    td = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    g = torch.Generator().manual_seed(42)
+    X = _features(N, P, C, td, dev)
+    W1 = (torch.randn(C, Cp, generator=g) / C ** 0.5).to(dev); b1 = torch.zeros(Cp, device=dev)
+    W2 = (torch.randn(Cp, J, generator=g) / Cp ** 0.5).to(dev); b2 = torch.zeros(J, device=dev)
+    dPl = torch.randn(N, P, J, generator=g).to(dev)
+    Ppre, Pl, ws = cof.pose_head_fwd(X, W1, b1, W2, b2)
+    dX = torch.zeros_like(X)
+
+    def step():
+        cof.pose_head_bwd(X, W1, W2, Ppre, dPl, None, dX=dX, accumulate_dX=accumulate, workspace=ws)
+    info = {'workload': 'pose head backward call alone (beta = {}); per-GPU batch {} x {}x{}x{} {}'.format(
+                int(accumulate), N, H, H, C, dtype),
+            'bound': 'mfma', 'dtype': dtype, 'N': N, 'flops_per_image': 2 * (2.0 * P * C * Cp)}
+    return step, info
+
+
 def build_perclass(cof, dev, N=32, H=14, K=51, dtype='bf16'):
     C, P = 2048, H * H
     td = torch.bfloat16 if dtype == 'bf16' else torch.float32
@@ -204,7 +226,7 @@ def report(info, sec, repeats):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--workload', default='cfg003', choices=['cfg003', 'perclass', 'eval002', 'rank1'])
+    ap.add_argument('--workload', default='cfg003', choices=['cfg003', 'perclass', 'eval002', 'rank1', 'posebwd', 'posebwd_acc'])
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--hw', type=int, default=14)
     ap.add_argument('--classes', type=int, default=None)
@@ -222,6 +244,9 @@ def main():
     if args.workload == 'cfg003':
         step, info = build_cfg003(cof, dev, args.batch, args.hw, args.classes or 393, args.dtype or 'bf16',
                                   rank1=not args.no_rank1, one_call=not args.per_op)
+    elif args.workload in ('posebwd', 'posebwd_acc'):
+        step, info = build_posebwd(cof, dev, args.batch, args.hw, args.dtype or 'bf16',
+                                   accumulate=args.workload == 'posebwd_acc')
     elif args.workload == 'rank1':
         step, info = build_rank1(cof, dev, args.batch, args.hw, args.classes or 51, args.dtype or 'bf16')
     elif args.workload == 'eval002':
