@@ -452,138 +452,6 @@ __global__ __launch_bounds__(256) void pc_bwd_dw_kernel(
         out[(size_t)(wm * 64 + i * 16 + 4 * kb + r) * 128 + half * 64 + j * 16 + l16] = acc[i][j][r];
 }
 
-// 64-CHANNEL form of the same kernel (round 4): block = 64 channels x 128 columns, so that one block per CU means
-// 32 channel tiles x 8 row splits instead of 16 x 16 -- HALF the fp32 partials (8.4 MB instead of 16.8 MB written
-// here and read back by the reduce launch; they were a third of this kernel's HBM traffic).  4 waves: column half
-// (dT with the masked image | dZ with the plain one) x 32 channels; A images [64 k][64 ch] with the 8-chunk swizzle of
-// apa_gemm_bf16.hip's 64-wide [k][n] image (chunk ^ 2 ((k >> 1) & 1) ^ 4 ((k >> 3) & 1)), B image as above.
-__device__ __forceinline__ bf16x8 frag_km64(const short* img, int rbase, int ks, int lane) {
-  typedef bf16x4 __attribute__((address_space(3))) * lds_v4;
-  const int l16 = lane & 15, kb = lane >> 4;
-  const int k = ks * 32 + kb * 8 + (l16 >> 2);
-  const int r = rbase + 4 * (l16 & 3);
-  const int chunk = (r >> 3) ^ (2 * ((k >> 1) & 1)) ^ (4 * (kb & 1));
-  const short* s0 = img + k * 64 + chunk * 8 + (r & 7);
-  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(s0));
-  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(s0 + 4 * 64));   // k + 4: same swizzle
-  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-}
-
-template <bool TRAIN>
-__global__ __launch_bounds__(256) void pc_bwd_dw64_kernel(
-    const bf16_t* __restrict__ X, const bf16_t* __restrict__ dTdZ, const uint8_t* __restrict__ maskbits,
-    float* __restrict__ partial, int R, int C, int rows_per_split) {
-  extern __shared__ __attribute__((aligned(16))) short smem[];
-  constexpr int IMGA = FK * 64, IMGB = FK * 128;
-  constexpr int STAGE = (TRAIN ? 2 : 1) * IMGA + IMGB;     // A plain | [A masked] | B
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int half = wave >> 1, wm = wave & 1;
-  const int l16 = lane & 15, kb = lane >> 4;
-  const int c0 = blockIdx.x * 64;
-  const int rbeg = blockIdx.y * rows_per_split, rend = min(R, rbeg + rows_per_split);
-  const int nk = (rend - rbeg + FK - 1) / FK;
-  // two tiles ahead through registers, LDS-only hand-over barrier (see pc_bwd_dw_kernel)
-  struct Stage { uint4 av[2], bv[4]; uint32_t mb[TRAIN ? 2 : 1]; };
-  auto load = [&](int t, Stage& q) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int vi = tid + i * 256;
-      const int rc = min(rbeg + t * FK + (vi >> 3), rend - 1), m = (vi & 7) * 8;
-      q.av[i] = ld16(X + (size_t)rc * C + c0 + m);
-      if (TRAIN) q.mb[i] = maskbits[((size_t)rc * C + c0 + m) >> 3];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int vi = tid + i * 256;
-      const int rc = min(rbeg + t * FK + (vi >> 4), rend - 1);
-      q.bv[i] = ld16(dTdZ + (size_t)rc * 128 + (vi & 15) * 8);
-    }
-  };
-  auto settle = [&](Stage& q) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      asm volatile("" : "+v"(q.av[i].x), "+v"(q.av[i].y), "+v"(q.av[i].z), "+v"(q.av[i].w));
-      if (TRAIN) asm volatile("" : "+v"(q.mb[i]));
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(q.bv[i].x), "+v"(q.bv[i].y), "+v"(q.bv[i].z), "+v"(q.bv[i].w));
-  };
-  auto store = [&](int buf, int t, const Stage& q) {
-    short* a0 = smem + buf * STAGE;
-    short* a1 = a0 + IMGA;
-    short* b = a0 + (TRAIN ? 2 : 1) * IMGA;
-    const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int vi = tid + i * 256;
-      const int kk = vi >> 3;
-      const bool ok = rbeg + t * FK + kk < rend;                  // rows past the split: zero operands
-      const uint4 a = ok ? q.av[i] : z4;
-      const int mo = ((vi & 7) ^ (2 * ((kk >> 1) & 1)) ^ (4 * ((kk >> 3) & 1))) * 8;
-      *reinterpret_cast<uint4*>(a0 + kk * 64 + mo) = a;
-      if (TRAIN) *reinterpret_cast<uint4*>(a1 + kk * 64 + mo) = apply_bits8(a, q.mb[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int vi = tid + i * 256;
-      const int kk = vi >> 4;
-      const bool ok = rbeg + t * FK + kk < rend;
-      const int mo = ((vi & 15) ^ (2 * (kk & 3)) ^ (8 * ((kk >> 3) & 1))) * 8;
-      *reinterpret_cast<uint4*>(b + kk * 128 + mo) = ok ? q.bv[i] : z4;
-    }
-  };
-  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-  f32x4 acc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto compute = [&](int t) {
-    const short* a_img = smem + (t & 1) * STAGE + ((TRAIN && half == 0) ? IMGA : 0);
-    const short* b_img = smem + (t & 1) * STAGE + (TRAIN ? 2 : 1) * IMGA;
-#pragma unroll
-    for (int ks = 0; ks < FK / 32; ++ks) {
-      bf16x8 af[2], bf[4];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = frag_km64(a_img, wm * 32 + i * 16, ks, lane);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bf[j] = frag_km_sw(b_img, half * 64 + j * 16, ks, lane);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-    }
-  };
-  Stage SA, SB;
-  if (nk > 0) {
-    load(0, SA);
-    if (nk > 1) load(1, SB);
-    settle(SA);
-    store(0, 0, SA);
-  }
-  lds_barrier();
-  auto iteration = [&](int t, Stage& nx, Stage& fr) {
-    if (t + 1 < nk) settle(nx);
-    if (t + 2 < nk) load(t + 2, fr);
-    compute(t);
-    if (t + 1 < nk) store((t + 1) & 1, t + 1, nx);
-    lds_barrier();
-  };
-  for (int t = 0; t < nk; t += 2) {
-    iteration(t, SB, SA);
-    if (t + 1 < nk) iteration(t + 1, SA, SB);
-  }
-  float* out = partial + ((size_t)blockIdx.y * C + c0) * 128;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        out[(size_t)(wm * 32 + i * 16 + 4 * kb + r) * 128 + half * 64 + j * 16 + l16] = acc[i][j][r];
-}
-
 // dWt[c,k] = inv_keep * sum_s partial[s][c][k];  dWa[c,k] = sum_s partial[s][c][64 + k]   (fixed order)
 // Round 4: the launch's TAIL blocks (blockIdx >= nmain) are the column-sum launch that used to follow -- dbt | dba
 // from the activation pass's block partials, literally m1_colsum_kernel's body (same sums bit for bit) -- and, in the
@@ -710,8 +578,9 @@ int pc_fused_maskbits(const PcFusedWs& f, size_t n_elems, float keep_prob, uint6
 int pc_fused_dw(const PcFusedWs& f, const void* X, float* dWt, float* dWa, int R, int C, int K, bool train,
                 float keep_prob, hipStream_t st, const PcDwTail* tail) {
   static const int s_env = knob("APA_PC_DW_SPLITS", 0);
-  static const int ct = knob("APA_PC_DW_CT", 64);      // channels per block: 64 (half the partials) | 128
-  const int ctiles = C / (ct == 64 ? 64 : 128);
+  // (a 64-channel form -- 32 channel tiles x 8 row splits, half the fp32 partials -- was built and measured in round
+  // 4: 51.9 us against 15.5 us: every block then reads 128-byte pieces of X rows 4 KB apart)
+  const int ctiles = C / 128;
   int S = s_env ? s_env : (256 + ctiles - 1) / ctiles;            // one block per CU
   if (S > PC_DW_MAX_SPLITS) S = PC_DW_MAX_SPLITS;
   int ktiles = (R + FK - 1) / FK;
@@ -723,22 +592,6 @@ int pc_fused_dw(const PcFusedWs& f, const void* X, float* dWt, float* dWa, int R
   static const int swz = knob("APA_PC_DW_SWZ", 1);
   const bf16_t* x = static_cast<const bf16_t*>(X);
   const bf16_t* g = static_cast<const bf16_t*>(f.dTdZ);
-  if (ct == 64) {
-    const size_t shm64 = (size_t)2 * ((train ? 2 : 1) * FK * 64 + FK * 128) * sizeof(short);   // 64 KB / 48 KB
-#define APA_DW64(TR)                                                                                            \
-  do {                                                                                                          \
-    static thread_local PerDevice<bool> attr_dev; bool& attr_set = attr_dev.here();                             \
-    if (!attr_set) {                                                                                            \
-      APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_bwd_dw64_kernel<TR>),                  \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm64));               \
-      attr_set = true;                                                                                          \
-    }                                                                                                           \
-    hipLaunchKernelGGL((pc_bwd_dw64_kernel<TR>), dim3(ctiles, S), dim3(256), shm64, st, x, g, f.maskbits,        \
-                       f.partial, R, C, rows_per_split);                                                        \
-  } while (0)
-    if (train) APA_DW64(true); else APA_DW64(false);
-#undef APA_DW64
-  } else {
   const size_t shm = (size_t)2 * (train ? 3 : 2) * FK * (swz ? 128 : LDM) * sizeof(short);
 #define APA_DW(TR, SW)                                                                                          \
   do {                                                                                                          \
@@ -763,7 +616,6 @@ int pc_fused_dw(const PcFusedWs& f, const void* X, float* dWt, float* dWa, int R
     APA_DW(false, true);
   }
 #undef APA_DW
-  }
   APA_LAUNCH_CHECK("pc_bwd_dw_kernel");
   const int nmain = (int)(((long)C * 128 + 1023) / 1024);
   PcTail tl;
