@@ -9,7 +9,7 @@ timeout 600 bash tools/profile_dense.sh $tag > gpurun_out/final_dense.log 2>&1; 
 timeout 600 bash tools/profile_dense_pmc.sh $tag > gpurun_out/final_dense_pmc.log 2>&1; echo "profile_dense_pmc rc=$?"
 timeout 300 bash tools/profile_hot_pmc.sh $tag > gpurun_out/final_hot_pmc.log 2>&1; echo "profile_hot_pmc rc=$?"
 python tools/hipblaslt_ref.py > gpurun_out/${tag}_hipblaslt_ref.log 2>&1; cat gpurun_out/${tag}_hipblaslt_ref.log
-APA_LIB_PATH= bash tools/prof_variant.sh posebwd_beta0 "--workload posebwd" | tee gpurun_out/${tag}_posebwd_beta0.log
+bash tools/prof_variant.sh posebwd_beta0 "--workload posebwd" | tee gpurun_out/${tag}_posebwd_beta0.log
 bash tools/prof_variant.sh posebwd_beta1 "--workload posebwd_acc" | tee gpurun_out/${tag}_posebwd_beta1.log
 timeout 900 python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; echo "bench rc=$?"
 python - <<'PY'
