@@ -1287,8 +1287,7 @@ int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
     const uint64_t* offd = devctr ? reinterpret_cast<const uint64_t*>(static_cast<uintptr_t>(offset)) : nullptr;
     // training: the weight-preparation launch also writes the step's keep bits (its 128 weight blocks leave half
     // the chip idle), and the product kernel DMAs them instead of hashing on its critical chain
-    static const int prebits_knob = knob("APA_PC_PREBITS", 1);
-    const bool prebits = train && prebits_knob;
+    const bool prebits = train;
     const PcPrepBits pb = {(size_t)R * C, keep_prob, seed, devctr ? 0 : offset, offd};
     int rc = pc_fused_prep(f, Wa, Wt, ba, bt, C, K, st, prebits ? &pb : nullptr);
     if (rc != APA_OK) return rc;

@@ -934,7 +934,7 @@ template <int MT> struct WideCfg {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <typename TC, int MT, bool PIPE>
+template <typename TC, int MT>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_wide_kernel(FastParams p) {
   typedef WideCfg<MT> W;
   extern __shared__ __attribute__((aligned(16))) short smem[];
@@ -1002,19 +1002,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_wide_kernel(FastParams p) {
   // issue order: A0 B0 B1 | A1 B2 | A2 B3 | ...   (one group per hand-over)
   if (nk > 0) { issueA(0); issueB(0); }
   if (nk > 1) issueB(1);
-  if (!PIPE) {
-    for (int t = 0; t < nk; ++t) {
-      hand_over(t + 1 < nk);                        // tile t is in (B(t + 1) may still fly); tile t - 1's stages are free
-      if (t + 1 < nk) issueA(t + 1);
-      if (t + 2 < nk) issueB(t + 2);
-#pragma unroll
-      for (int ks = 0; ks < TK / 32; ++ks) {
-        bf16x8 bf[4], af[MT];
-        load_frags(t, ks, af, bf);
-        mma(af, bf);
-      }
-    }
-  } else {
+  {
     // the ring kernel's two-step software pipeline (see there): the fragments of k step 1 are read under the MFMAs of
     // step 0, the hand-over (wait + barrier + next DMA) sits between the two MFMA groups, step 0 of the next tile is
     // read under the MFMAs of step 1
@@ -1108,27 +1096,19 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_wide_kernel(FastParams p) {
   }
 }
 
-template <typename TC, int MT, bool PIPE>
-int launch_wide_p(const FastParams& p, hipStream_t st) {
+template <typename TC, int MT>
+int launch_wide(const FastParams& p, hipStream_t st) {
   typedef WideCfg<MT> W;
   static thread_local PerDevice<bool> attr_dev; bool& attr_set = attr_dev.here();
   if (!attr_set) {
-    APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_wide_kernel<TC, MT, PIPE>),
+    APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_wide_kernel<TC, MT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS_BYTES));
     attr_set = true;
   }
   const int tiles = ((p.M + W::TMR - 1) / W::TMR) * ((p.N + TNW - 1) / TNW);
-  hipLaunchKernelGGL((gemm_bf16_wide_kernel<TC, MT, PIPE>), dim3(tiles), dim3(512), W::LDS_BYTES, st, p);
+  hipLaunchKernelGGL((gemm_bf16_wide_kernel<TC, MT>), dim3(tiles), dim3(512), W::LDS_BYTES, st, p);
   APA_LAUNCH_CHECK("gemm_bf16_wide_kernel");
   return APA_OK;
-}
-template <typename TC, int MT>
-int launch_wide(const FastParams& p, hipStream_t st) {
-  static const int pipe = knob("APA_GEMM_WIDE_PIPE", 1);
-#ifdef APA_ABLATION
-  if (!pipe) return launch_wide_p<TC, MT, false>(p, st);
-#endif
-  return launch_wide_p<TC, MT, true>(p, st);
 }
 
 // tile height of the wide kernel: the smallest (32 MT) x 256 tiling that fits one resident round; 0 = none

@@ -342,8 +342,6 @@ int pc_fused_prep(const PcFusedWs& f, const float* Wa, const float* Wt, const fl
 int pc_fused_forward(const PcFusedWs& f, const void* X, float* Z, float* T, int R, int C, int K, bool train,
                      float keep_prob, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, hipStream_t st,
                      bool prebits = false);
-int pc_fused_maskbits(const PcFusedWs& f, size_t n_elems, float keep_prob, uint64_t seed, uint64_t offset,
-                      const uint64_t* offset_dev, hipStream_t st);
 int pc_fused_dw(const PcFusedWs& f, const void* X, float* dWt, float* dWa, int R, int C, int K, bool train,
                 float keep_prob, hipStream_t st, const PcDwTail* tail = nullptr);
 

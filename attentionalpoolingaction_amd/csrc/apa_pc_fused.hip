@@ -32,7 +32,6 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int FK = 64;          // k tile
-constexpr int LDM = 128 + 8;    // [k][row] image: 272-byte rows (transposing reads)
 
 // keep decisions of 8 consecutive elements (flat element index e, a multiple of 8) as bits 0..7
 __device__ __forceinline__ uint32_t keep_bits8(uint64_t e, uint32_t k0, uint32_t k1, uint32_t thresh) {
@@ -55,19 +54,10 @@ __device__ __forceinline__ uint4 apply_bits8(uint4 v, uint32_t bits) {
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// The keep-mask of the whole map as bits ([R*C/8] bytes, 1/16 of the bf16 map): the forward pass writes it
-// while it masks its A tiles; the backward kernels read it instead of hashing again (the mask-in-registers
-// step of the dX product cost as much as the product itself with 64 hashes per lane).  A backward call
-// that cannot rely on the forward call's workspace regenerates it with this kernel.
-__global__ __launch_bounds__(256) void pc_maskbits_kernel(uint8_t* __restrict__ bits, size_t n8, uint32_t thresh,
-                                                          uint64_t seed, uint64_t offset,
-                                                          const uint64_t* __restrict__ offset_dev) {
-  uint32_t k0, k1;
-  rng_key_dev(seed, offset_dev ? *offset_dev : offset, k0, k1);
-  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n8; v += (size_t)gridDim.x * 256)
-    bits[v] = (uint8_t)keep_bits8(v * 8, k0, k1, thresh);
-}
-
+// The keep-mask of the whole map as bits ([R*C/8] bytes, 1/16 of the bf16 map; bit (e & 7) of byte e >> 3 for flat
+// element e): written once per step by the extra blocks of pc_prep_kernel, read by the forward product (one LDS-DMA
+// instruction per stage) and by the two backward kernels (the mask-in-registers step of the dX product cost as much
+// as the product itself with 64 hashes per lane).
 // ---------------------------------------------------------------------------------------------
 // Weight preparation: the padded, concatenated bf16 operands of the three products (one launch).
 //   WcatT [C/64][128][64]  k-tile-major: tile t holds rows n < 64: Wa[64t.., n], rows 64 + n: Wt[64t.., n]
@@ -185,11 +175,11 @@ __device__ __forceinline__ bf16x8 frag_sw64(const short* img, int rbase, int ks,
   return *reinterpret_cast<const bf16x8*>(img + row * 64 + chunk * 8);
 }
 
-// PREBITS (round 4): the keep bits of the step already lie in `maskbits` (written by pc_prep_kernel's extra blocks):
+// Dropout (round 4): the keep bits of the step already lie in `maskbits` (written by pc_prep_kernel's extra blocks):
 // a stage's 32 rows x 16 bytes of bits arrive by ONE more LDS-DMA instruction (wave 0, lanes 0-31: 16 bytes per
 // row) into a ring of three 512-byte slots, in natural [row][chunk] order; a T wave reads its row's 16 bytes once
 // per stage and picks the four bytes of its lane group.  No hashing, no bit stores, no DPP shuffles in this kernel.
-template <bool TRAIN, bool PREBITS = false>
+template <bool TRAIN>
 __global__ __launch_bounds__(512) void pc_fwd_zt_dma_kernel(
     const bf16_t* __restrict__ X, const bf16_t* __restrict__ WcatT, const float* __restrict__ bcat,
     float* __restrict__ Z, float* __restrict__ T, uint8_t* __restrict__ maskbits, int R, int C, int K,
@@ -203,8 +193,7 @@ __global__ __launch_bounds__(512) void pc_fwd_zt_dma_kernel(
   const int l16 = lane & 15, kb = lane >> 4;
   const int m0 = blockIdx.x * 32;
   const int nkt = C / ZB_KT;
-  uint32_t k0 = 0, k1 = 0;
-  if (TRAIN) rng_key_dev(seed, offset_dev ? *offset_dev : offset, k0, k1);
+  (void)thresh; (void)seed; (void)offset; (void)offset_dev;   // the mask arrives as bits
 
   // per-lane DMA sources of this wave's five 1 KiB blocks of a stage: A block `wave` (sub-image wave >> 2,
   // rows 8 (wave & 3) ..), slab blocks 4 wave .. 4 wave + 3 (tile (4 wave + j) >> 4, rows 8 ((4 wave + j) & 15) ..)
@@ -222,7 +211,7 @@ __global__ __launch_bounds__(512) void pc_fwd_zt_dma_kernel(
   }
   const uint32_t lds0 = (uint32_t)(size_t)(lptr)smem;
   const uint8_t* msrc = nullptr;     // PREBITS: this lane's row of bits (lanes 0-31 of wave 0)
-  if (TRAIN && PREBITS) msrc = maskbits + (((size_t)min(m0 + (lane & 31), R - 1) * C) >> 3);
+  if (TRAIN) msrc = maskbits + (((size_t)min(m0 + (lane & 31), R - 1) * C) >> 3);
   const uint32_t lds_bits = lds0 + (uint32_t)(ZB_NST * ZB_STAGE_EL * 2);
   auto issue = [&](int t) {
     const uint32_t st = lds0 + (uint32_t)((t % ZB_NST) * ZB_STAGE_EL * 2);
@@ -230,48 +219,28 @@ __global__ __launch_bounds__(512) void pc_fwd_zt_dma_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       glds16_asm(bsrc[j] + (size_t)t * (2 * 128 * 64), st + (uint32_t)(ZB_A_EL * 2) + (uint32_t)(4 * wave + j) * 1024u);
-    if (TRAIN && PREBITS && wave == 0 && lane < 32)       // 16 bytes per row: chunks 0..15 of stage t
+    if (TRAIN && wave == 0 && lane < 32)                  // 16 bytes per row: chunks 0..15 of stage t
       glds16_asm(msrc + (size_t)t * (ZB_KT / 8), lds_bits + (uint32_t)((t % ZB_NST) * 512));
   };
-  // keep decisions of stage t: thread -> (row = tid >> 4, 8-channel chunk c = tid & 15 of the stage)
-  auto make_bits = [&](int t) {
-    const int row = tid >> 4, c = tid & 15;
-    const uint64_t e = (uint64_t)min(m0 + row, R - 1) * C + (uint64_t)t * ZB_KT + c * 8;
-    const uint32_t kb8 = keep_bits8(e, k0, k1, thresh);
-    // fragment (sub-image s, k step ks, lane group kb) holds chunk c = 8 s + 4 ks + kb: byte [row][kb][2 s + ks]
-    s_bits[(t & 1) * 512 + row * 16 + (c & 3) * 4 + (c >> 2)] = (uint8_t)kb8;
-    const uint32_t b1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)kb8, 0x39, 0xf, 0xf, true);   // lane + 1
-    const uint32_t b2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)kb8, 0x4E, 0xf, 0xf, true);   // lane + 2
-    const uint32_t b3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)kb8, 0x93, 0xf, 0xf, true);   // lane + 3
-    if ((c & 3) == 0 && m0 + row < R)
-      *reinterpret_cast<uint32_t*>(maskbits + (e >> 3)) = kb8 | (b1 << 8) | (b2 << 16) | (b3 << 24);
-  };
-
   f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   issue(0);
   if (nkt > 1) issue(1);
-  if (TRAIN && !PREBITS) make_bits(0);
   for (int t = 0; t < nkt; ++t) {
     // tile t has landed once at most the five pieces of tile t+1 are outstanding (six for the wave that also
     // moves the bits); the barrier publishes everybody's pieces and the bits, and says that stage (t+2) % 3 (read
     // in iteration t-1) is free
     if (t + 1 >= nkt) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else if (TRAIN && PREBITS && wave == 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (TRAIN && wave == 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (t + 2 < nkt) issue(t + 2);
-    if (TRAIN && !PREBITS && t + 1 < nkt) make_bits(t + 1);
     const short* a_img = smem + (t % ZB_NST) * ZB_STAGE_EL;
     const short* b_img = a_img + ZB_A_EL;
     uint32_t mb = 0;
-    if (TRAIN && half) {
-      if (PREBITS) {   // natural order: byte c = 4 sk + kb of the row -> byte kb of word sk
-        const uint4 rb = *reinterpret_cast<const uint4*>(s_bits + (t % ZB_NST) * 512 + (mt * 16 + l16) * 16);
-        const int sh = 8 * kb;
-        mb = ((rb.x >> sh) & 0xffu) | (((rb.y >> sh) & 0xffu) << 8) | (((rb.z >> sh) & 0xffu) << 16) |
-             (((rb.w >> sh) & 0xffu) << 24);
-      } else {
-        mb = *reinterpret_cast<const uint32_t*>(s_bits + (t & 1) * 512 + (mt * 16 + l16) * 16 + kb * 4);
-      }
+    if (TRAIN && half) {   // natural order: byte c = 4 sk + kb of the row -> byte kb of word sk
+      const uint4 rb = *reinterpret_cast<const uint4*>(s_bits + (t % ZB_NST) * 512 + (mt * 16 + l16) * 16);
+      const int sh = 8 * kb;
+      mb = ((rb.x >> sh) & 0xffu) | (((rb.y >> sh) & 0xffu) << 8) | (((rb.z >> sh) & 0xffu) << 16) |
+           (((rb.w >> sh) & 0xffu) << 24);
     }
 #pragma unroll
     for (int sk = 0; sk < 4; ++sk) {   // sk = 2 s + ks
@@ -311,16 +280,7 @@ __global__ __launch_bounds__(512) void pc_fwd_zt_dma_kernel(
 // [k][row] LDS images read with ds_read_b64_tr_b16 (see apa_gemm_bf16.hip for the lane mapping).
 // 4 waves: column half (w >> 1: 0 = dT with the masked image, 1 = dZ with the plain one) x 64 channels.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bf16x8 frag_km(const short* img, int rbase, int ks, int lane) {
-  typedef bf16x4 __attribute__((address_space(3))) * lds_v4;
-  const int l16 = lane & 15, kb = lane >> 4;
-  const short* s0 = img + (ks * 32 + kb * 8 + (l16 >> 2)) * LDM + rbase + 4 * (l16 & 3);
-  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(s0));
-  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(s0 + 4 * LDM));
-  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-}
-
-// SWZ (round 4): unpadded 256-byte rows with the XOR swizzle of apa_gemm_bf16.hip's [k][row] image (16-byte chunk
+// Images (round 4): unpadded 256-byte rows with the XOR swizzle of apa_gemm_bf16.hip's [k][row] image (16-byte chunk
 // c of row k lives at chunk c ^ 2 (k & 3) ^ 8 ((k >> 3) & 1)) instead of 272-byte padded rows: with padding alone the
 // transposing reads of rows k and k + 8 -- lane groups kb and kb + 1 of one ds_read_b64_tr_b16 -- share banks whatever
 // the pad (2-way at best: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.29 in profiles/r03_perclass_pmc.md); the
@@ -338,12 +298,12 @@ __device__ __forceinline__ bf16x8 frag_km_sw(const short* img, int rbase, int ks
   return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <bool TRAIN, bool SWZ = true>
+template <bool TRAIN>
 __global__ __launch_bounds__(256) void pc_bwd_dw_kernel(
     const bf16_t* __restrict__ X, const bf16_t* __restrict__ dTdZ, const uint8_t* __restrict__ maskbits,
     float* __restrict__ partial, int R, int C, int rows_per_split) {
   extern __shared__ __attribute__((aligned(16))) short smem[];
-  constexpr int LDI = SWZ ? 128 : LDM;
+  constexpr int LDI = 128;
   constexpr int IMG = FK * LDI;
   constexpr int STAGE = (TRAIN ? 3 : 2) * IMG;     // A plain | [A masked] | B
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -384,11 +344,11 @@ __global__ __launch_bounds__(256) void pc_bwd_dw_kernel(
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int vi = tid + i * 256;
-      const int kk = vi >> 4, m = (vi & 15) * 8;
+      const int kk = vi >> 4;
       const bool ok = rbeg + t * FK + kk < rend;                  // rows past the split: zero operands
       const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
       const uint4 a = ok ? q.av[i] : z4, bb = ok ? q.bv[i] : z4;
-      const int mo = SWZ ? (((vi & 15) ^ (2 * (kk & 3)) ^ (8 * ((kk >> 3) & 1))) * 8) : m;
+      const int mo = ((vi & 15) ^ (2 * (kk & 3)) ^ (8 * ((kk >> 3) & 1))) * 8;
       *reinterpret_cast<uint4*>(a0 + kk * LDI + mo) = a;
       if (TRAIN) *reinterpret_cast<uint4*>(a1 + kk * LDI + mo) = apply_bits8(a, q.mb[i]);
       *reinterpret_cast<uint4*>(b + kk * LDI + mo) = bb;
@@ -411,8 +371,8 @@ __global__ __launch_bounds__(256) void pc_bwd_dw_kernel(
       bf16x8 af[4], bf[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        af[i] = SWZ ? frag_km_sw(a_img, wm * 64 + i * 16, ks, lane) : frag_km(a_img, wm * 64 + i * 16, ks, lane);
-        bf[i] = SWZ ? frag_km_sw(b_img, half * 64 + i * 16, ks, lane) : frag_km(b_img, half * 64 + i * 16, ks, lane);
+        af[i] = frag_km_sw(a_img, wm * 64 + i * 16, ks, lane);
+        bf[i] = frag_km_sw(b_img, half * 64 + i * 16, ks, lane);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -547,31 +507,19 @@ int pc_fused_forward(const PcFusedWs& f, const void* X, float* Z, float* T, int 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_BYTES));
     APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_fwd_zt_dma_kernel<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_BYTES));
-    APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_fwd_zt_dma_kernel<true, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_BYTES));
     attr_set = true;
   }
-  if (train && prebits)
-    hipLaunchKernelGGL((pc_fwd_zt_dma_kernel<true, true>), dim3((R + 31) / 32), dim3(512), ZB_LDS_BYTES, st, xx, ww,
-                       f.bcat, Z, T, f.maskbits, R, C, K, ik, keep_thresh(keep_prob), seed, offset, offset_dev);
-  else if (train)
+  if (train && !prebits) {
+    set_error("pc_fused_forward: training mode needs the keep bits of pc_fused_prep (internal)");
+    return APA_ERR_INVALID_ARG;
+  }
+  if (train)
     hipLaunchKernelGGL(pc_fwd_zt_dma_kernel<true>, dim3((R + 31) / 32), dim3(512), ZB_LDS_BYTES, st, xx, ww,
                        f.bcat, Z, T, f.maskbits, R, C, K, ik, keep_thresh(keep_prob), seed, offset, offset_dev);
   else
     hipLaunchKernelGGL(pc_fwd_zt_dma_kernel<false>, dim3((R + 31) / 32), dim3(512), ZB_LDS_BYTES, st, xx, ww,
                        f.bcat, Z, T, f.maskbits, R, C, K, ik, keep_thresh(keep_prob), seed, offset, offset_dev);
   APA_LAUNCH_CHECK("pc_fwd_zt_dma_kernel");
-  return APA_OK;
-}
-
-int pc_fused_maskbits(const PcFusedWs& f, size_t n_elems, float keep_prob, uint64_t seed, uint64_t offset,
-                      const uint64_t* offset_dev, hipStream_t st) {
-  const size_t n8 = n_elems / 8;
-  size_t nb = (n8 + 255) / 256;
-  if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(pc_maskbits_kernel, dim3((unsigned)nb), dim3(256), 0, st, f.maskbits, n8,
-                     keep_thresh(keep_prob), seed, offset, offset_dev);
-  APA_LAUNCH_CHECK("pc_maskbits_kernel");
   return APA_OK;
 }
 
@@ -589,32 +537,21 @@ int pc_fused_dw(const PcFusedWs& f, const void* X, float* dWt, float* dWa, int R
   S = (R + rows_per_split - 1) / rows_per_split;
   static const int exp_mask = knob("APA_PC_EXP", 0);
   if (exp_mask & 4) train = false;    // timing experiments only (wrong results)
-  static const int swz = knob("APA_PC_DW_SWZ", 1);
   const bf16_t* x = static_cast<const bf16_t*>(X);
   const bf16_t* g = static_cast<const bf16_t*>(f.dTdZ);
-  const size_t shm = (size_t)2 * (train ? 3 : 2) * FK * (swz ? 128 : LDM) * sizeof(short);
-#define APA_DW(TR, SW)                                                                                          \
+  const size_t shm = (size_t)2 * (train ? 3 : 2) * FK * 128 * sizeof(short);
+#define APA_DW(TR)                                                                                              \
   do {                                                                                                          \
     static thread_local PerDevice<bool> attr_dev; bool& attr_set = attr_dev.here();                             \
     if (!attr_set) {                                                                                            \
-      APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_bwd_dw_kernel<TR, SW>),                \
+      APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_bwd_dw_kernel<TR>),                    \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));                 \
       attr_set = true;                                                                                          \
     }                                                                                                           \
-    hipLaunchKernelGGL((pc_bwd_dw_kernel<TR, SW>), dim3(ctiles, S), dim3(256), shm, st, x, g, f.maskbits,        \
-                       f.partial, R, C, rows_per_split);                                                        \
+    hipLaunchKernelGGL((pc_bwd_dw_kernel<TR>), dim3(ctiles, S), dim3(256), shm, st, x, g, f.maskbits, f.partial, \
+                       R, C, rows_per_split);                                                                   \
   } while (0)
-  if (train) {
-#ifdef APA_ABLATION
-    if (!swz) APA_DW(true, false); else
-#endif
-    APA_DW(true, true);
-  } else {
-#ifdef APA_ABLATION
-    if (!swz) APA_DW(false, false); else
-#endif
-    APA_DW(false, true);
-  }
+  if (train) APA_DW(true); else APA_DW(false);
 #undef APA_DW
   APA_LAUNCH_CHECK("pc_bwd_dw_kernel");
   const int nmain = (int)(((long)C * 128 + 1023) / 1024);

@@ -16,6 +16,8 @@ m1 APA_M1_LOGITS_XENT=0
 m1 APA_M1_GEMV_BWD2=0 APA_M1_KEEP_BITS=0
 dense APA_PC_FUSED=0
 dense APA_GEMM_RING=0
+dense APA_GEMM_WIDE=0
+dense APA_POSE_STEP_FUSED=0 APA_PC_XENT_FOLD=0
 dense APA_GEMM_GLDS=0
 dense APA_GEMM_FAST=0
 dense APA_POSE_BWD_ROWS=0 APA_POSE_PL_FAST=0
