@@ -170,12 +170,15 @@ def test_cfg003_one_call_attention_step_equals_the_separate_calls(gpu, dtype):
         cof.HeadTrainStep(Xd, Xd, Wtd[:, :1].contiguous(), bad, Wtd, btd, lab, grads, dxatt_rank1=True)
 
 
-@pytest.mark.parametrize('dtype,N,H,softmax,relu', [(torch.bfloat16, 4, 7, False, False),
-                                                     (torch.bfloat16, 32, 14, False, False),
-                                                     (torch.bfloat16, 3, 5, True, False),
-                                                     (torch.bfloat16, 2, 15, False, True),
-                                                     (torch.float32, 3, 7, False, False)])
-def test_cfg003_whole_step_in_one_call_matches_the_per_op_sequence(gpu, dtype, N, H, softmax, relu):
+@pytest.mark.parametrize('dtype,N,H,softmax,relu,Cp,K', [(torch.bfloat16, 4, 7, False, False, 768, 393),
+                                                          (torch.bfloat16, 32, 14, False, False, 768, 393),
+                                                          (torch.bfloat16, 3, 5, True, False, 768, 393),
+                                                          (torch.bfloat16, 2, 15, False, True, 768, 393),
+                                                          (torch.bfloat16, 5, 9, False, False, 256, 51),
+                                                          (torch.bfloat16, 1, 13, False, False, 1024, 10),
+                                                          (torch.bfloat16, 7, 6, True, False, 512, 500),
+                                                          (torch.float32, 3, 7, False, False, 768, 393)])
+def test_cfg003_whole_step_in_one_call_matches_the_per_op_sequence(gpu, dtype, N, H, softmax, relu, Cp, K):
     """apa_pose_attn_train_step (cof.PoseAttnTrainStep): the cfg 003 head step of one sess.run -- PoseLogits head ->
     attention from pose_pre_logits -> dropout + pooling -> pose L2 + softmax cross-entropy -> all gradients
     (nets_factory.py:147-160,247-328, loss.py:11-80) -- as ONE host call, against the per-op sequence.
@@ -185,7 +188,7 @@ def test_cfg003_whole_step_in_one_call_matches_the_per_op_sequence(gpu, dtype, N
     summed in a different order (1e-6), everything downstream of them follows at fp32 / bf16-storage round-off.
     fp32 features run the four calls inside the entry point: bit-identical throughout."""
     from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
-    C, Cp, J, K = 2048, 768, 16, 393
+    C, J = 2048, 16
     P = H * H
     X, W1, b1, W2, b2, g = _pose_problem(N, H, C, Cp, J, seed=100 * N + H, dtype=dtype)
     Wa = torch.randn(Cp, 1, generator=g) / Cp ** 0.5
