@@ -478,8 +478,9 @@ extern "C" int apa_pose_attn_train_step(const apa_pose_attn_step_io* io, int N, 
   if (rc != APA_OK) return rc;
   uint64_t* bump = (train && (flags & APA_FLAG_RNG_DEVICE))
                        ? reinterpret_cast<uint64_t*>(static_cast<uintptr_t>(offset)) : nullptr;
-  return pose_bwd_fused(s.X, s.W1, s.W2, s.Ppre, s.dPl, s.dZ, s.Wa, s.dX, 1, s.dW1, s.db1, s.dW2, s.db2, s.dWa,
-                        s.dba, s.loss_pose, bump, s.ws_pose, s.ws_pose_bytes, N, P, C, Cp, J, dtype, a, st);
+  // (same workspace, same call: the bf16 copy of W1 the forward half built there -- when the caller keeps none -- is reused)
+  return pose_bwd_fused(s.X, s.W1, s.W2, s.Ppre, s.dPl, s.dZ, s.Wa, s.dX, 1 | APA_POSE_WS_FROM_FWD, s.dW1, s.db1, s.dW2,
+                        s.db2, s.dWa, s.dba, s.loss_pose, bump, s.ws_pose, s.ws_pose_bytes, N, P, C, Cp, J, dtype, a, st);
 }
 
 extern "C" int apa_attn_head_eval_step(const void* X, const void* Xatt, const float* Wa, const float* ba,
