@@ -471,11 +471,27 @@ extern "C" int apa_pose_attn_train_step(const apa_pose_attn_step_io* io, int N, 
                                   s.grad_scale, stream);
     if (rc != APA_OK) return rc;
   }
+  // The pooling pass's own dX share (A/P . dz . mask/keep) is not written and read back: the streaming backward
+  // kernel becomes read-only (APA_IFLAG_NO_DX) and the pose head's dX product adds the term in its epilogue from att,
+  // dz and the forward half's keep bits -- one 25.7 MB write and one 25.7 MB read less at the benchmark shape.
+  static const int nodx_knob = knob("APA_POSE_STEP_NODX", 1);
+  const int wide_rows = gemm_bf16_wide_tile_rows(N * P, C, Cp);   // (its rank-1 epilogue wants <= 3 images per tile)
+  const bool nodx = nodx_knob && m1_no_dx_supported(C, dtype, train) && wide_rows > 0 && wide_rows <= 2 * P &&
+                    (reinterpret_cast<uintptr_t>(s.dX) & 15) == 0;
   rc = attn_pool_bwd_impl(hk, nullptr, xf.done ? &xf : nullptr, s.X, s.Ppre, s.Wa, s.ba, s.Wt, s.bt, s.att, s.zsave,
                           s.abar, s.G, s.dX, s.dZ, s.dWa, s.dba, s.dWt, s.dbt, s.ws_pool, s.ws_pool_bytes, N, P, C,
-                          Cp, K, 1, flags | APA_FLAG_DXATT_RANK1 | APA_FLAG_WS_FROM_FWD | APA_IFLAG_NO_ATT_WGRAD,
+                          Cp, K, 1, flags | APA_FLAG_DXATT_RANK1 | APA_FLAG_WS_FROM_FWD | APA_IFLAG_NO_ATT_WGRAD |
+                              (nodx ? APA_IFLAG_NO_DX : 0u),
                           keep_prob, seed, offset, dtype, stream);
   if (rc != APA_OK) return rc;
+  if (nodx) {
+    const M1Plan mp = m1_plan(N, P, C, Cp, K);
+    char* wp = static_cast<char*>(s.ws_pool);
+    a.pool_att = s.att;
+    a.pool_dz = reinterpret_cast<const float*>(wp + mp.off_dz);
+    a.pool_bits = reinterpret_cast<const uint8_t*>(wp + mp.off_maskbits);
+    a.pool_inv_keep = 1.0f / keep_prob;
+  }
   uint64_t* bump = (train && (flags & APA_FLAG_RNG_DEVICE))
                        ? reinterpret_cast<uint64_t*>(static_cast<uintptr_t>(offset)) : nullptr;
   // (same workspace, same call: the bf16 copy of W1 the forward half built there -- when the caller keeps none -- is reused)

@@ -672,11 +672,16 @@ struct PoseBwdFuse {
   const float* aux_src = nullptr; int aux_n = 0; float aux_scale = 0.f; float* aux_dst = nullptr;   // pose loss
   uint64_t* rng_bump = nullptr;                               // device-side dropout counter to advance
   const void* W1_bf16 = nullptr;                              // caller-maintained bf16 copy of W1
+  // the attentional pooling's own dX share, formed in the dX product's epilogue (APA_IFLAG_NO_DX on the pooling side):
+  // dX = dPpre . W1^T + att/P . dz . mask/keep  -- att [R], dz [N, C], keep bits [R * C / 8] (nullptr: all kept)
+  const float* pool_att = nullptr; const float* pool_dz = nullptr; const uint8_t* pool_bits = nullptr;
+  int pool_P = 0; float pool_inv_keep = 1.f;
 };
 
 static int pose_head_bwd_big(const void* X, const float* W1, const void* dPpre, void* dX, int accumulate_dX,
                              float* dW1, char* w, const PosePlan& pl, float* gws, int R, int C, int Cp,
-                             int dtype, hipStream_t st, const void* W1_shadow = nullptr) {
+                             int dtype, hipStream_t st, const void* W1_shadow = nullptr,
+                             const PoseBwdFuse* fuse = nullptr) {
   const int tdt = dt_code(dtype);
   int rc;
   {  // dW1[c,j] = sum_r X[r,c] dPpre[r,j]
@@ -700,6 +705,11 @@ static int pose_head_bwd_big(const void* X, const float* W1, const void* dPpre, 
     g.B = W1op; g.ldb = Cp; g.tb = w1_tb; g.b_kc = true;   // W1 [C][Cp]: n = c rows, k contiguous
     g.C = dX; g.ldc = C; g.tc = tdt;
     g.M = R; g.N = C; g.K = Cp; g.beta = (accumulate_dX & 1) ? 1.f : 0.f;
+    if (fuse && fuse->pool_att) {   // nothing was written to dX: its pooling share is formed in this epilogue
+      g.beta = 0.f;
+      g.r1_row = fuse->pool_att; g.r1_col = fuse->pool_dz; g.r1_bits = fuse->pool_bits; g.r1_P = fuse->pool_P;
+      g.r1_invP = 1.0f / (float)fuse->pool_P; g.r1_inv_keep = fuse->pool_inv_keep;
+    }
     rc = gemm_launch(g, st);
   }
   return rc;
@@ -788,7 +798,7 @@ static int pose_head_bwd_impl(const void* X, const float* W1, const float* W2, c
                        db2, c1 + Cp, J == 16 ? nthr2 : 0, Cp, fuse ? &more : nullptr);
     if (rc != APA_OK) return rc;
     return pose_head_bwd_big(X, W1, dPpre, dX, accumulate_dX, dW1, w, pl, gws, R, C, Cp, dtype, st,
-                             fuse ? fuse->W1_bf16 : nullptr);
+                             fuse ? fuse->W1_bf16 : nullptr, fuse);
   }
   if (fuse) {
     set_error("apa_pose_head_bwd: the fused step needs the one-pass rows kernel (J <= 16, Cp <= 1024; internal)");
@@ -898,6 +908,8 @@ int pose_bwd_fused(const void* X, const float* W1, const float* W2, const void* 
   f.aux_dst = loss_pose;
   f.rng_bump = rng_bump;
   f.W1_bf16 = a.W1_bf16;
+  f.pool_att = a.pool_att; f.pool_dz = a.pool_dz; f.pool_bits = a.pool_bits; f.pool_P = P;
+  f.pool_inv_keep = a.pool_inv_keep;
   return pose_head_bwd_impl(X, W1, W2, Ppre, dPl, nullptr, dZ, wa, dX, accumulate_dX, dW1, db1, dW2, db2, ws,
                             ws_bytes, N, P, C, Cp, J, dtype, st, &f);
 }

@@ -381,6 +381,10 @@ static int gemm_launch_t(const GemmDesc& d, hipStream_t st) {
     const int rc = gemm_bf16_launch(d, splits, kps64, st);
     if (rc != APA_OK) return rc;
   } else {
+  if (d.r1_row) {
+    set_error("gemm: the rank-1 epilogue exists in the wide bf16 kernel only (internal)");
+    return APA_ERR_UNSUPPORTED;
+  }
   hipLaunchKernelGGL((gemm128_kernel<TA, TB, TC, A_KC, B_KC, BF16>), dim3(tiles, 1, splits), dim3(256),
                      0, st, p);
   APA_LAUNCH_CHECK("gemm128_kernel");

@@ -118,6 +118,8 @@ struct FastParams {
                  // multiplied by the dropout mask / keep of their output element (flat index row*Nout+col):
                  // C = (A[:, :k1] . B[:, :k1]^T) * mask/keep + A[:, k1:] . B[:, k1:]^T in one launch
   const uint8_t* maskbits;   // the keep decisions as bits ([M*Nout/8] bytes); Nout % 64 == 0
+  // rank-1 addend of the epilogue (GemmDesc::r1_*; the wide kernel's own epilogue branch)
+  const float* r1_row; const float* r1_col; const uint8_t* r1_bits; int r1_P; float r1_invP, r1_inv_keep;
 };
 
 // 8 consecutive output columns of one row: split-K partial, or bias / relu / output dropout /
@@ -1049,6 +1051,66 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_wide_kernel(FastParams p) {
   // once, and arrive while the tile is staged -- read one by one inside the store loop they were 2 MT dependent
   // round trips per thread (the epilogue of the first version cost as much as the 12-tile loop)
   constexpr int NSEG = (W::TMR * 16 + 511) / 512;             // row segments per thread and half: MT
+  if constexpr (sizeof(TC) == 2) {
+    if (p.r1_row) {
+      // Rank-1 epilogue (the fused cfg 003 step): out = acc + (att[m] / P / keep) * bit(m, n) * dz[image(m), n].  A
+      // thread's column group is the same for all its row segments and a tile spans at most three images, so the
+      // three dz vectors, the MT att values and the MT bit bytes of a half are requested BEFORE the tile is staged
+      // (fetched one by one inside the store loop this epilogue was 2 us slower than the read-modify-write it replaces).
+      const int c8 = (tid & 15) * 8, row0 = tid >> 4;
+      const int img0 = m0 / p.r1_P, img_last = (p.M - 1) / p.r1_P;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int gcol = n0 + half * 128 + c8;
+        const bool col_ok = gcol < p.Nout;
+        const int gcc = col_ok ? gcol : 0;
+        float dzv[3][8];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float* dzp = p.r1_col + (size_t)min(img0 + k, img_last) * p.Nout + gcc;
+          const float4 d0 = *reinterpret_cast<const float4*>(dzp), d1 = *reinterpret_cast<const float4*>(dzp + 4);
+          dzv[k][0] = d0.x; dzv[k][1] = d0.y; dzv[k][2] = d0.z; dzv[k][3] = d0.w;
+          dzv[k][4] = d1.x; dzv[k][5] = d1.y; dzv[k][6] = d1.z; dzv[k][7] = d1.w;
+        }
+        float apk[NSEG];
+        uint32_t bitv[NSEG];
+#pragma unroll
+        for (int u = 0; u < NSEG; ++u) {
+          const int grow = min(m0 + row0 + 32 * u, p.M - 1);
+          apk[u] = p.r1_row[grow] * p.r1_invP * p.r1_inv_keep;
+          bitv[u] = p.r1_bits ? p.r1_bits[((size_t)grow * p.Nout + gcc) >> 3] : 0xffu;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // everyone is done with the LDS contents
+        if ((wn >> 1) == half) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                stage[((wm * MT + i) * 16 + 4 * kb + r) * LDS_C + (wn & 1) * 64 + j * 16 + l16] = acc[i][j][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NSEG; ++u) {
+          const int row = row0 + 32 * u, grow = m0 + row;
+          if (row >= W::TMR || grow >= p.M || !col_ok) continue;
+          const float4 x0 = *reinterpret_cast<const float4*>(stage + row * LDS_C + c8);
+          const float4 x1 = *reinterpret_cast<const float4*>(stage + row * LDS_C + c8 + 4);
+          float o[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+          const int rel = grow - img0 * p.r1_P;
+          const int k = (rel >= p.r1_P ? 1 : 0) + (rel >= 2 * p.r1_P ? 1 : 0);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float dz = k == 0 ? dzv[0][e] : (k == 1 ? dzv[1][e] : dzv[2][e]);
+            o[e] = fmaf(((bitv[u] >> e) & 1u) ? apk[u] : 0.f, dz, o[e]);
+          }
+          st16(reinterpret_cast<bf16_t*>(C) + (long)grow * p.ldc + gcol, Vec<bf16_t>::pack(o));
+        }
+      }
+      return;
+    }
+  }
   const bool pre = sizeof(TC) == 2 && p.vec_epi && p.beta != 0.f && !p.partial;
   uint4 cold[2][NSEG];
   if (pre) {
@@ -1238,6 +1300,7 @@ int gemm_bf16_mid_dropout(const void* A, long lda, const void* B, long ldb, void
   p.vec_epi = N % 8 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && (ldc * 2) % 16 == 0;
   p.drop_mid = 0;
   p.maskbits = maskbits;
+  p.r1_row = nullptr; p.r1_col = nullptr; p.r1_bits = nullptr; p.r1_P = 1; p.r1_invP = 0.f; p.r1_inv_keep = 1.f;
   const size_t shm = (size_t)2 * 2 * OP_ELEMS * sizeof(short);
   static thread_local PerDevice<bool> attr_dev; bool& attr_set = attr_dev.here();
   if (!attr_set) {
@@ -1250,6 +1313,18 @@ int gemm_bf16_mid_dropout(const void* A, long lda, const void* B, long ldb, void
   APA_LAUNCH_CHECK("gemm_bf16_glds_kernel<mid>");
   return APA_OK;
 }
+
+// wide output, short contraction (both operands k-contiguous bf16, no split-K): one resident round of 256-wide tiles,
+// worth it only when that round is reasonably full (else the 128-wide kernels' second block per CU wins)
+int gemm_bf16_wide_tile_rows(int M, int N, int K) {   // rows of the tile the wide kernel would use; 0 = not served
+  static const int use_wide = knob("APA_GEMM_WIDE", 1);
+  if (!use_wide || N < 1024 || K % TK != 0 || K / TK > 16 || K / TK < 2) return 0;
+  const int cus = gemm_cu_count();
+  const int mt = wide_pick_mt(M, N, cus);
+  if (!mt || (long)((M + 32 * mt - 1) / (32 * mt)) * ((N + TNW - 1) / TNW) * 4 < (long)cus * 3) return 0;
+  return 32 * mt;
+}
+bool gemm_bf16_wide_serves(int M, int N, int K) { return gemm_bf16_wide_tile_rows(M, N, K) > 0; }
 
 // Eligibility: bf16 A, bf16 or fp32 B, no fused dropout, 16-byte addressable rows, K a multiple of 8,
 // at least one full vector of rows for k-major operands.
@@ -1279,6 +1354,7 @@ int gemm_bf16_launch(const GemmDesc& d, int splits, int k_per_split, hipStream_t
   p.offset_dev = d.offset_dev;
   p.drop_mid = -1;
   p.maskbits = nullptr;
+  p.r1_row = nullptr; p.r1_col = nullptr; p.r1_bits = nullptr; p.r1_P = 1; p.r1_invP = 0.f; p.r1_inv_keep = 1.f;
   const int ec = d.tc == 1 ? 2 : 4;
   p.vec_epi = p.Nout % 8 == 0 && (!d.drop_c || p.Nout % 2 == 0) && (reinterpret_cast<uintptr_t>(d.C) & 15) == 0 && (d.ldc * ec) % 16 == 0 &&
               (!d.bias || (reinterpret_cast<uintptr_t>(d.bias) & 15) == 0) &&
@@ -1290,15 +1366,23 @@ int gemm_bf16_launch(const GemmDesc& d, int splits, int k_per_split, hipStream_t
     // 294 tiles 38.2 -> 32.6 us, 96 x 3 splits 40.0 -> 35.2 us, but 784 tiles 34.4 -> 37.4 us
     // few tiles, A k-contiguous, no split-K: the ring kernel (one resident round, 3-4 K tiles in flight)
     // wide output, short contraction, both operands k-contiguous, no split-K: one resident round of 256-wide tiles
-    static const int use_wide = knob("APA_GEMM_WIDE", 1);
-    if (use_wide && d.a_kc && d.b_kc && splits == 1 && d.N >= 1024 && d.K / TK <= 16 && d.K / TK >= 2) {
-      const int cus = gemm_cu_count();
-      const int mt = wide_pick_mt(d.M, d.N, cus);
-      // worth it only when the one round is reasonably full (else the 128-wide kernels' second block per CU wins)
-      if (mt && (long)((d.M + 32 * mt - 1) / (32 * mt)) * ((d.N + TNW - 1) / TNW) * 4 >= (long)cus * 3) {
-        if (d.tc == 1) return launch_wide_mt<bf16_t>(p, mt, st);
-        return launch_wide_mt<float>(p, mt, st);
+    if (splits == 1 && d.a_kc && d.b_kc && gemm_bf16_wide_serves(d.M, d.N, d.K)) {
+      const int mt = wide_pick_mt(d.M, d.N, gemm_cu_count());
+      if (d.r1_row) {   // the rank-1 addend lives in the vector epilogue
+        if (!p.vec_epi || d.n_valid > 0 || d.tc != 1 || d.bias || d.act || d.drop_c || d.beta != 0.f ||
+            d.r1_P * 2 < 32 * mt) {   // (a tile must not span more than three images)
+          set_error("gemm_bf16: rank-1 epilogue: plain bf16 product with 16-byte addressable rows only");
+          return APA_ERR_UNSUPPORTED;
+        }
+        p.r1_row = d.r1_row; p.r1_col = d.r1_col; p.r1_bits = d.r1_bits; p.r1_P = d.r1_P;
+        p.r1_invP = d.r1_invP; p.r1_inv_keep = d.r1_inv_keep;
       }
+      if (d.tc == 1) return launch_wide_mt<bf16_t>(p, mt, st);
+      return launch_wide_mt<float>(p, mt, st);
+    }
+    if (d.r1_row) {
+      set_error("gemm_bf16: rank-1 epilogue requested for a product the wide kernel does not serve (internal)");
+      return APA_ERR_UNSUPPORTED;
     }
     static const int use_ring = knob("APA_GEMM_RING", 1);
     if (use_ring && d.a_kc && splits == 1 && d.K / TK >= 4) {

@@ -161,7 +161,14 @@ struct GemmDesc {
   int drop_a = 0, drop_c = 0;
   float inv_keep = 1.f; uint32_t thresh = 0; uint64_t seed = 0, offset = 0;
   const uint64_t* offset_dev = nullptr;
+  // rank-1 addend of the epilogue (the fused cfg 003 step): C[m,n] += (r1_row[m] * r1_invP * r1_inv_keep) *
+  // r1_col[(m / r1_P) * N + n] * bit(m, n) -- the attentional pooling's own dX share A/P . dz . mask/keep, formed here
+  // instead of being written by the streaming kernel and read back (beta = 1).  Wide kernel only.
+  const float* r1_row = nullptr; const float* r1_col = nullptr; const uint8_t* r1_bits = nullptr;
+  int r1_P = 0; float r1_invP = 0.f, r1_inv_keep = 1.f;
 };
+bool gemm_bf16_wide_serves(int M, int N, int K);   // would this all-bf16, k-contiguous, unsplit product take the wide kernel?
+int gemm_bf16_wide_tile_rows(int M, int N, int K);  // ... and with how many rows per tile (0 = not served)
 size_t gemm_ws_bytes(int M, int N, int splits);
 int gemm_pick_splits(int M, int N, int K);
 int gemm_launch(const GemmDesc& d, hipStream_t st);
@@ -178,6 +185,8 @@ int gemm_bf16_launch(const GemmDesc& d, int splits, int k_per_split, hipStream_t
 constexpr unsigned APA_PUBLIC_FLAGS = 0xFFu;
 constexpr unsigned APA_IFLAG_ATT_READY = 1u << 24;      // M == 1, Xatt != X: `att` already holds Z (id / relu applied)
 constexpr unsigned APA_IFLAG_NO_ATT_WGRAD = 1u << 25;   // M == 1 + DXATT_RANK1: dWa / dba / RNG bump done by the caller
+constexpr unsigned APA_IFLAG_NO_DX = 1u << 26;          // M == 1, Xatt != X: dX is NOT written -- the caller forms the
+                                                        // pooling share A/P . dz . mask/keep in its own product's epilogue
 
 struct M1Xent {
   const int64_t* labels;
@@ -220,6 +229,7 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
                 float keep_prob, uint64_t seed, uint64_t offset, int dtype, hipStream_t stream,
                 const M1Xent* xf = nullptr, const Hooks& hk = Hooks(), const CatFeat* cat = nullptr);
 bool m1_supported(int C, int Ca, int dtype, bool fused);
+bool m1_no_dx_supported(int C, int dtype, bool train);   // can m1_backward honour APA_IFLAG_NO_DX for this shape?
 
 // apa_m1_stream.hip: "pixel tile x channel split" streaming passes for wide maps
 struct M1Rng {
@@ -231,6 +241,7 @@ struct M1Rng {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // apa_hooks prof_*: dispatch begin / end timestamps
   uint8_t* maskbits_out = nullptr;           // forward (training): where the keep-bits go
   const uint8_t* maskbits_in = nullptr;      // backward: the forward call's keep-bits, or nullptr (hash again)
+  bool no_dx = false;                        // backward, Xatt != X, keep-bits form: skip the dX stores (APA_IFLAG_NO_DX)
 };
 // apa_m1_cat.hip
 bool m1_cat_supported(int J);
@@ -288,6 +299,9 @@ struct PoseStepArgs {
   const float* wa = nullptr; const float* ba = nullptr; float* att = nullptr; bool relu_att = false;
   const float* pose_labels = nullptr; const uint8_t* pose_valid = nullptr; float* dPl = nullptr;
   float pose_wt = 1.f, grad_scale = 1.f;
+  // backward half: the pooling's dX share formed in the pose head's dX product (nullptr: dX already holds it)
+  const float* pool_att = nullptr; const float* pool_dz = nullptr; const uint8_t* pool_bits = nullptr;
+  float pool_inv_keep = 1.f;
 };
 bool pose_step_fast_ok(int N, int P, int C, int Cp, int J, int dtype, const void* Ppre, const float* W2,
                        const float* wa);

@@ -719,6 +719,14 @@ static bool use_stream_kernels(int C, int dtype) {
   return enabled && m1s_supported(C, dtype);
 }
 
+// APA_IFLAG_NO_DX is served by the keep-bits form of the streaming backward kernel: bf16 features in training mode
+// inside a one-call step (the forward half left the bits in the workspace)
+bool m1_no_dx_supported(int C, int dtype, bool train) {
+  static const int use_bits = knob("APA_M1_KEEP_BITS", 1);
+  static const int pix = knob("APA_M1S_PIX", 2);
+  return train && dtype == APA_DTYPE_BF16 && use_bits && pix == 2 && use_stream_kernels(C, dtype);
+}
+
 template <typename T, int VEC>
 static int launch_pool_fwd(bool fused, bool train, int nblk, hipStream_t st, const void* X,
                            const float* Wa, const float* ba, float* att, float* pacc, float* pstat,
@@ -918,6 +926,14 @@ int m1_backward(const void* X, const void* Xatt, const float* Wa, const float* b
   static const int use_bits = knob("APA_M1_KEEP_BITS", 1);
   if ((flags & APA_FLAG_WS_FROM_FWD) && use_bits)   // same workspace, untouched since the forward call
     r.maskbits_in = reinterpret_cast<const uint8_t*>(w + pl.off_maskbits);
+  if (flags & APA_IFLAG_NO_DX) {
+    if (fused || !(flags & APA_FLAG_WS_FROM_FWD) || !m1_no_dx_supported(C, dtype, train) || rng_external(flags) || cat) {
+      set_error("attn_pool M=1: NO_DX needs a separate attention input, the forward half's keep bits and the bf16 "
+                "streaming kernels (internal)");
+      return APA_ERR_UNSUPPORTED;
+    }
+    r.no_dx = true;
+  }
   if (r.relu_input && !(fused && use_stream_kernels(C, dtype))) {
     set_error("attn_pool M=1: APA_FLAG_RELU_INPUT needs Xatt == X and C in {1024,2048,4096} (f32) / 2048 (bf16)");
     return APA_ERR_UNSUPPORTED;

@@ -331,7 +331,7 @@ struct BwdState {
   float dba_acc, sn, corr;
 };
 
-template <typename T, int VW, int PIX, bool FUSED, bool TRAIN, bool RIN, bool BITS>
+template <typename T, int VW, int PIX, bool FUSED, bool TRAIN, bool RIN, bool BITS, bool NODX = false>
 __device__ __forceinline__ void bwd_chunk(BwdState<T, VW, PIX, FUSED, TRAIN>& st,
                                           const uint4 (&xr)[PIX][VW], float a_l, float e_l,
                                           const uint32_t (&kbits)[PIX],
@@ -386,6 +386,9 @@ __device__ __forceinline__ void bwd_chunk(BwdState<T, VW, PIX, FUSED, TRAIN>& st
   else if (act == S_ACT_RELU) dZl = a_l > 0.f ? dA : 0.f;
   else dZl = dA;
   if (!FUSED && wave == 0 && lane < np) dZout_im[q0 + lane] = dZl;
+  // NODX (separate attention input, fused cfg 003 step): the dX share A/P . dz . mask/keep is formed by the pose
+  // head's dX product in its epilogue; with Xatt != X the loop below does nothing else, so the pass is read-only
+  if constexpr (NODX) return;
 
 #pragma unroll
   for (int i = 0; i < PIX; ++i) {
@@ -431,7 +434,7 @@ template <int BPL> __device__ __forceinline__ uint32_t ld_keep_bits(const uint8_
   return *reinterpret_cast<const uint16_t*>(p);
 }
 
-template <typename T, int VW, int PIX, bool FUSED, bool TRAIN, bool RIN = false, bool BITS = false>
+template <typename T, int VW, int PIX, bool FUSED, bool TRAIN, bool RIN = false, bool BITS = false, bool NODX = false>
 __global__ __launch_bounds__(256, 2) void m1s_bwd_main_kernel(
     const T* __restrict__ X, const float* __restrict__ Wa, const float* __restrict__ att,
     const float* __restrict__ dz, const float* __restrict__ zsave, const float* __restrict__ abar,
@@ -532,7 +535,7 @@ __global__ __launch_bounds__(256, 2) void m1s_bwd_main_kernel(
       for (int i = 0; i < PIX; ++i)
         kb_b[i] = ld_keep_bits<BPL>(kb_im + (size_t)min(p_begin + (ch + 1) * PIX + i, p_last) * BPP);
     }
-    bwd_chunk<T, VW, PIX, FUSED, TRAIN, RIN, BITS>(st, xa, a_a, e_a, kb_a, chunk_range<PIX>(p_begin, p_end, ch), sm_x[0],
+    bwd_chunk<T, VW, PIX, FUSED, TRAIN, RIN, BITS, NODX>(st, xa, a_a, e_a, kb_a, chunk_range<PIX>(p_begin, p_end, ch), sm_x[0],
                                         dxim, dZout_im, n, P, C, cbase, wave, lane, act, invP,
                                         inv_keep, thresh, k0, k1);
     if (ch + 1 >= nchunk) break;
@@ -544,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void m1s_bwd_main_kernel(
       for (int i = 0; i < PIX; ++i)
         kb_a[i] = ld_keep_bits<BPL>(kb_im + (size_t)min(p_begin + (ch + 2) * PIX + i, p_last) * BPP);
     }
-    bwd_chunk<T, VW, PIX, FUSED, TRAIN, RIN, BITS>(st, xb, a_b, e_b, kb_b, chunk_range<PIX>(p_begin, p_end, ch + 1),
+    bwd_chunk<T, VW, PIX, FUSED, TRAIN, RIN, BITS, NODX>(st, xb, a_b, e_b, kb_b, chunk_range<PIX>(p_begin, p_end, ch + 1),
                                         sm_x[1], dxim, dZout_im, n, P, C, cbase, wave, lane, act,
                                         invP, inv_keep, thresh, k0, k1);
   }
@@ -647,10 +650,19 @@ static int launch_bwd_t(bool fused, bool train, int nblk, hipStream_t st, const 
             r.thresh, r.seed, r.offset, r.offset_dev, ex, exs, mbits)
   bool bits_done = false;
   if constexpr (PIX == 2 && KeepBits<T>::ON) {   // the keep-bits variant: default chunk width, bf16 features
-    if (train && mbits) {
+    if (train && mbits && !fused && r.no_dx) {   // ... without the dX stores (APA_IFLAG_NO_DX)
+      launch_ev(m1s_bwd_main_kernel<T, VW, PIX, false, true, false, true, true>, dim3(nblk), dim3(256), 0, st, r.ev0,
+                r.ev1, x, Wa, att, dz, zsave, abar, G, bt, sn_pre, dx, dZout, pdwa, pdba, P, S, K, act, r.inv_keep,
+                r.thresh, r.seed, r.offset, r.offset_dev, ex, exs, mbits);
+      bits_done = true;
+    } else if (train && mbits) {
       if (fused) APA_GO(true, true, true); else APA_GO(false, true, true);
       bits_done = true;
     }
+  }
+  if (r.no_dx && !bits_done) {
+    set_error("m1 stream kernels: APA_IFLAG_NO_DX without the keep-bits backward form (internal)");
+    return APA_ERR_UNSUPPORTED;
   }
   if (!bits_done) {
     if (fused) { if (train) APA_GO(true, true, false); else APA_GO(true, false, false); }
