@@ -422,7 +422,12 @@ extern "C" int apa_pose_attn_train_step(const apa_pose_attn_step_io* io, int N, 
     set_error("apa_pose_attn_train_step: J=%d", J);
     return APA_ERR_INVALID_ARG;
   }
-  flags &= APA_PUBLIC_FLAGS & ~(APA_FLAG_WS_FROM_FWD | APA_FLAG_DXATT_RANK1 | APA_FLAG_RELU_INPUT | APA_FLAG_RNG_EXTERNAL);
+  if (flags & (APA_FLAG_RELU_INPUT | APA_FLAG_RNG_EXTERNAL)) {
+    set_error("apa_pose_attn_train_step: APA_FLAG_RELU_INPUT / APA_FLAG_RNG_EXTERNAL are served by the per-op entry "
+              "points (the attention input of cfg 003 is pose_pre_logits; a replayed mask takes the generic kernels)");
+    return APA_ERR_UNSUPPORTED;
+  }
+  flags &= APA_PUBLIC_FLAGS & ~(APA_FLAG_WS_FROM_FWD | APA_FLAG_DXATT_RANK1);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool train = (flags & APA_FLAG_TRAIN) && keep_prob < 1.0f;
   const bool fast = pose_step_fast_ok(N, P, C, Cp, J, dtype, s.Ppre, s.W2, s.Wa) && m1_small_supported(C, K) &&

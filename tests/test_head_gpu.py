@@ -896,6 +896,56 @@ def test_fused_momentum_sgd_matches_torch_sgd(gpu):
         assert _rel(params[k].cpu().numpy(), ref[k].detach().numpy()) < 1e-6, k
 
 
+def test_momentum_sgd_keeps_a_bf16_shadow_of_the_pose_head_weights_current(gpu):
+    """apa_momentum_sgd_step_shadow (deploy.MomentumSGD(bf16_shadows=...)): the optimizer's own launch rewrites the bf16
+    operand copy of chosen segments from the UPDATED weights -- bit-identical to rounding the updated fp32 weights, at odd
+    sizes (vector body + scalar tail), with the other segments and the update itself untouched; and the one-call cfg 003
+    step fed that shadow gives exactly the results of the call that converts W1 itself."""
+    from attentionalpoolingaction_amd import deploy
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    g = torch.Generator().manual_seed(9)
+    shapes = {'pose_w1': (2048, 768), 'pose_b1': (768,), 'odd': (1031,), 'td_weights': (2048, 51)}
+    params = {k: torch.randn(s, generator=g).to(gpu) for k, s in shapes.items()}
+    twin = {k: v.clone() for k, v in params.items()}
+    bucket, bucket2 = deploy.GradientBucket(shapes, gpu), deploy.GradientBucket(shapes, gpu)
+    shadows = {'pose_w1': torch.zeros(2048, 768, dtype=torch.bfloat16, device=gpu),
+               'odd': torch.zeros(1031, dtype=torch.bfloat16, device=gpu)}
+    opt = deploy.MomentumSGD(params, bucket, lr=1e-2, momentum=0.9, weight_decay=5e-4, regularized=['pose_w1'],
+                             bf16_shadows=shadows)
+    ref = deploy.MomentumSGD(twin, bucket2, lr=1e-2, momentum=0.9, weight_decay=5e-4, regularized=['pose_w1'])
+    for step in range(2):
+        grad = torch.randn(bucket.flat.numel(), generator=g).to(gpu)
+        bucket.flat.copy_(grad)
+        bucket2.flat.copy_(grad)
+        opt.step()
+        ref.step()
+        torch.cuda.synchronize()
+        for k in shapes:
+            assert torch.equal(params[k], twin[k]), k                          # the update is the same launch body
+        for k, sh in shadows.items():
+            assert torch.equal(sh, params[k].to(torch.bfloat16)), k            # round-to-nearest-even of the new weights
+    # the shadow as the one-call step's W1 operand == the in-call conversion
+    N, P, C, Cp, J, K = 2, 25, 2048, 768, 16, 51
+    X = torch.relu(torch.randn(N, P, C, generator=g)).to(torch.bfloat16).to(gpu)
+    mk = lambda *s_: (torch.randn(*s_, generator=g) / 30).to(gpu)
+    W2, b2, Wa, ba, bt = mk(Cp, J), mk(J), mk(Cp, 1), mk(1), mk(K)
+    labels = torch.randint(0, K, (N,), generator=g).to(gpu)
+    lbl = torch.rand(N, P, J, generator=g).to(gpu)
+    valid = (torch.rand(N, J, generator=g) > 0.3).to(gpu)
+    outs = []
+    for shadow in (None, shadows['pose_w1']):
+        e = lambda t: torch.zeros_like(t)
+        prm = (params['pose_w1'], params['pose_b1'], W2, b2, Wa, ba, params['td_weights'], bt)
+        grads = (e(X),) + tuple(e(t) for t in prm)
+        st = cof.PoseAttnTrainStep(X, prm, labels, lbl, valid, grads, flags=cof.attn_flags(False, False, True),
+                                   keep_prob=0.5, seed=5, offset=1, w1_bf16=shadow)
+        st.run()
+        torch.cuda.synchronize()
+        outs.append((st.logits.clone(), st.Pl.clone(), grads[0].clone(), grads[1].clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_direct_rccl_allreduce_single_rank(gpu):
     """rccl.RcclCommunicator: ctypes ncclCommInitRank / ncclAllReduce on the compute stream.  One GPU
     per box here, so a 1-rank communicator: the sum over ranks is the identity; the N > 1 arithmetic
@@ -1338,6 +1388,10 @@ def test_bench_prints_one_json_line_with_the_contract_fields(gpu):
                       'cfg002_train_n512'):
                 assert 'error' not in d['extra'][k], d['extra'][k]
                 assert d['extra'][k]['ms_per_step'] > 0 and 0.0 < d['extra'][k]['roofline']['frac'] < 1.0
+            # ... and BASELINE configs[1] / [2] end to end, with the torch-ROCm ResNet-101 in front of the HIP head
+            for k in ('cfg002_eval_e2e', 'cfg003_train_e2e'):
+                assert 'error' not in d['extra'][k], d['extra'][k]
+                assert d['extra'][k]['images_per_sec'] > 100 and 0.0 < d['extra'][k]['head_share']['fraction_of_step'] < 0.2
             it = d['extra']['cfg002_train_iter_size']
             assert 'error' not in it, it
             assert it['iter_size'] == 2 and 0.2 < it['overlapped']['step_roofline_frac'] < 1.0
