@@ -1022,7 +1022,6 @@ __device__ __forceinline__ float pc_colmax(const float (&red)[PC_PG][64], int kk
 // xe (one-call train step, K <= 64 so that one block holds the whole row): the row's softmax cross-entropy on the
 // logits it has just reduced -- G[n,:] = gscale (softmax - onehot), loss[1 + n] = xent_n (src/loss.py:74-80); the batch
 // mean is finished by the tail of the dW reduce launch.  One launch (4.7 us at the latency floor) less per step.
-struct PcXent { const int64_t* labels; float* loss; float* G; float gscale; };
 template <typename T>
 __global__ __launch_bounds__(1024) void pc_fwd_act_kernel(const float* __restrict__ Z, int ldz,
                                                          const float* __restrict__ Tm,
@@ -1090,45 +1089,12 @@ __global__ __launch_bounds__(1024) void pc_fwd_act_kernel(const float* __restric
   if (xe.labels) {                     // (block-uniform; gridDim.y == 1 and 4 <= K <= 64: lrow holds the whole row)
     __syncthreads();
     if (pg == 0) {
-      // softmax_xent_kernel<1>'s arithmetic to the letter (apa_loss.hip), so that the folded loss and its gradient
-      // are BIT-identical to the separate launch: half a wave owns the row (both halves run the same row here),
-      // lane hl holds the 4 columns colc .. colc + 3, the ragged last vector is shifted back and its
-      // already-covered columns masked out; half-wave max / sum trees, exp_fast, fmaf(p, gscale, -gscale)
-      const int lane = threadIdx.x & 63, hl = lane & 31;
-      const int lab = (int)xe.labels[n];
-      const bool lab_ok = lab >= 0 && lab < K;
-      const int col0 = 4 * hl, colc = min(col0, K - 4);
-      float v[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = colc + e >= col0 ? lrow[colc + e] : -INFINITY;
-      const float xl = lrow[lab_ok ? lab : 0];
-      float m = -INFINITY;
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (v[e] > m) m = v[e];
-      const float mw = half_max(m, lane);
-      float l = 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] = exp_fast(v[e] - mw);
-        l += v[e];
-      }
-      l = half_sum(l, lane);
-      const float inv = 1.0f / l;
-      const float lv = lab_ok ? -(xl - mw - logf(l)) : 0.f;
-      if (lane < 32) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int c = colc + e;
-          if (c >= col0 && c < K)
-            xe.G[(size_t)n * K + c] = fmaf(v[e] * inv, xe.gscale, c == lab ? -xe.gscale : 0.f);
-        }
-        if (hl == 0) xe.loss[1 + n] = lv;
-      }
+      pc_row_xent(lrow, n, K, xe, true, nullptr);
     }
   }
 }
 
+struct PcDefer { const float* lpart; float* logits; PcXent xe; };   // (lpart == nullptr: G is read from memory)
 // backward of the same: dT = G*A/P, dA = G*T/P, dZ = act'(dA); column partials for dbt / dba.
 // dT/dZ are written with leading dimension Kp (pad columns zeroed) in the intermediate dtype.
 template <typename T>
@@ -1138,7 +1104,7 @@ __global__ __launch_bounds__(1024) void pc_bwd_act_kernel(const float* __restric
                                                          T* __restrict__ dT, T* __restrict__ dZ,
                                                          float* __restrict__ pdbt,
                                                          float* __restrict__ pdba, int P, int K,
-                                                         int Kp, int act, int ldg) {
+                                                         int Kp, int act, int ldg, PcDefer df) {
   // dT / dZ: [R][ldg] with Kp written columns each (ldg = Kp, or 2*Kp when the two are interleaved as
   // one [R][dT | dZ] operand for apa_pc_fused.hip)
   __shared__ float red[PC_PG][64];
@@ -1150,7 +1116,27 @@ __global__ __launch_bounds__(1024) void pc_bwd_act_kernel(const float* __restric
   const bool pad = !ok && k < Kp;
   const size_t rbase = (size_t)n * P;
   const float invP = 1.0f / (float)P;
-  const float g = ok ? G[(size_t)n * K + k] * invP : 0.f;
+  float g;
+  if (df.lpart) {
+    // one-call step after a folded forward product: this launch finishes the logits row from the product's block
+    // partials and takes the row's cross-entropy itself (every pixel split recomputes the same 64 numbers; split 0
+    // writes logits / G / loss[1 + n]) -- G never makes a round trip through memory before its first use
+    float* lrow = &red[0][0];
+    float* grow = &red2[0][0];
+    if (pg == 0) {
+      const float lg = ok ? pc_logit_from_partials(df.lpart, n, k, P) : -INFINITY;
+      if (ok && blockIdx.z == 0) df.logits[(size_t)n * K + k] = lg;
+      lrow[kk] = lg;
+      __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the row is in LDS before this wave reads it back
+      __builtin_amdgcn_wave_barrier();
+      pc_row_xent(lrow, n, K, df.xe, blockIdx.z == 0, grow);
+    }
+    __syncthreads();
+    g = ok ? grow[kk] * invP : 0.f;
+    __syncthreads();                         // red / red2 are reused below
+  } else {
+    g = ok ? G[(size_t)n * K + k] * invP : 0.f;
+  }
   // grid.z > 1 (identity / relu only: no sum over the image's pixels is needed): block z owns a contiguous
   // share of the pixels and its own partial row -- N x 1 blocks of 16 waves were 32 CUs' worth of latency chains
   const int pchunk = (P + gridDim.z - 1) / gridDim.z;
@@ -1210,7 +1196,8 @@ static PcPlan pc_plan(int N, int P, int C, int Ca, int K, int dtype) {
   pl.off_z = off;    off += align_up((size_t)pl.R * pl.Kp * 4, 256);
   pl.off_dt = off;   off += align_up((size_t)pl.R * pl.Kp * dt_size(dtype), 256);
   pl.off_dz = off;   off += align_up((size_t)pl.R * pl.Kp * dt_size(dtype), 256);
-  pl.off_pdbt = off; off += align_up((size_t)N * PC_MAX_PSPLIT * 2 * K * 4, 256);   // [N * splits][2K]: dbt | dba partials
+  // [N * splits][2K]: dbt | dba partials ([ceil(R / 128)][2K] from pc_bwd_dx_kernel)
+  pl.off_pdbt = off; off += align_up(((size_t)N * PC_MAX_PSPLIT + (size_t)pl.R / 128 + 1) * 2 * K * 4, 256);
   pl.off_pdba = pl.off_pdbt + (size_t)K * 4;
   const int cm = C > Ca ? C : Ca;
   {
@@ -1303,12 +1290,29 @@ int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
     const PcPrepBits pb = {(size_t)R * C, keep_prob, seed, devctr ? 0 : offset, offd};
     int rc = pc_fused_prep(f, Wa, Wt, ba, bt, C, K, st, prebits ? &pb : nullptr);
     if (rc != APA_OK) return rc;
-    rc = pc_fused_forward(f, X, Z, Tsave, R, C, K, train, keep_prob, seed, devctr ? 0 : offset, offd, st, prebits);
+    static const int fold_xent = knob("APA_PC_XENT_FOLD", 1);
+    static const int fold_act = knob("APA_PC_ACT_FOLD", 1);
+    const bool xent_here = fold_xent && xf && xf->labels && xf->G && xf->loss && !xf->probs && K >= 4 && K <= 64;
+    // identity / relu attention: the activation pass rides on the product's epilogue (a block's 32 rows touch at most
+    // two images when P >= 32); the softmax needs the whole image's Z first and keeps its own launch
+    const int act = act_code(flags);
+    const bool fold = fold_act && act != 2 && !topdown && P >= 32;
+    const PcFwdFold ff = {att, act, P};
+    rc = pc_fused_forward(f, X, Z, Tsave, R, C, K, train, keep_prob, seed, devctr ? 0 : offset, offd, st, prebits,
+                          fold ? &ff : nullptr);
     if (rc != APA_OK) return rc;
+    if (fold) {
+      if (xent_here) {   // one-call train step: pc_backward's first launch finishes logits + cross-entropy
+        xf->done = true;
+        xf->deferred = true;
+        xf->logits = logits;
+        return APA_OK;
+      }
+      return pc_fused_logits_finish(f, logits, N, P, K, st);
+    }
     dim3 grid(N, (K + 63) / 64);
     PcXent xe = {nullptr, nullptr, nullptr, 0.f};
-    static const int fold_xent = knob("APA_PC_XENT_FOLD", 1);
-    if (fold_xent && xf && xf->labels && xf->G && xf->loss && !xf->probs && K >= 4 && K <= 64) {
+    if (xent_here) {
       xe.labels = xf->labels; xe.loss = xf->loss; xe.G = xf->G; xe.gscale = xf->gscale;
       xf->done = true;
     }
@@ -1398,11 +1402,27 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
       rc = pc_fused_prep(f, Wa, Wt, nullptr, nullptr, C, K, st, train ? &pb : nullptr);
       if (rc != APA_OK) return rc;
     }
+    if (pc_fused_dx_supported(P, act_code(flags))) {
+      // identity / relu attention: ONE write-bound kernel forms [dT | dZ] from att / T / G in registers, writes dX,
+      // leaves [dT | dZ] and the dbt | dba block partials behind for the dW launch and its reduce tail
+      const int rbs = pc_fused_dx_rows(R);
+      rc = pc_fused_dx(f, G, att, Tsave, dX, pdbt, R, C, K, P, act_code(flags), train, keep_prob,
+                       (xf && xf->deferred) ? xf : nullptr, st);
+      if (rc != APA_OK) return rc;
+      PcDwTail tail = {pdbt, dbt, dba, rbs, bump, nullptr, 0, 0.f, nullptr};
+      if (xf && xf->done) { tail.aux_src = xf->loss + 1; tail.aux_n = -N; tail.aux_scale = xf->lscale; tail.aux_dst = xf->loss; }
+      return pc_fused_dw(f, X, dWt, dWa, R, C, K, train, keep_prob, st, &tail);
+    }
     bf16_t* dTc = static_cast<bf16_t*>(f.dTdZ);              // [R][dT (64) | dZ (64)]
     const int ps = pc_bwd_act_psplit(N, (Kp + 63) / 64, P, act_code(flags));
     dim3 grid(N, (Kp + 63) / 64, ps);
+    PcDefer df = {nullptr, nullptr, {nullptr, nullptr, nullptr, 0.f}};
+    if (xf && xf->deferred) {
+      df.lpart = f.lpart; df.logits = xf->logits;
+      df.xe.labels = xf->labels; df.xe.loss = xf->loss; df.xe.G = xf->G; df.xe.gscale = xf->gscale;
+    }
     hipLaunchKernelGGL(pc_bwd_act_kernel<bf16_t>, grid, dim3(64 * PC_PG), 0, st, G, att, Tsave, dTc, dTc + 64,
-                       pdbt, pdba, P, K, Kp, act_code(flags), 128);
+                       pdbt, pdba, P, K, Kp, act_code(flags), 128, df);
     APA_LAUNCH_CHECK("pc_bwd_act_kernel");
     // dbt | dba (column sums of the activation pass's block partials), the batch mean of a folded cross-entropy
     // and the dropout counter ride on the tail blocks of the dW reduce launch
@@ -1439,11 +1459,11 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
   if (dtype == APA_DTYPE_F32)
     hipLaunchKernelGGL(pc_bwd_act_kernel<float>, grid, dim3(64 * PC_PG), 0, st, G, att, Tsave,
                        static_cast<float*>(dT), static_cast<float*>(dZ), pdbt, pdba, P, K, Kp,
-                       act_code(flags), Kp);
+                       act_code(flags), Kp, PcDefer{nullptr, nullptr, {nullptr, nullptr, nullptr, 0.f}});
   else
     hipLaunchKernelGGL(pc_bwd_act_kernel<bf16_t>, grid, dim3(64 * PC_PG), 0, st, G, att, Tsave,
                        static_cast<bf16_t*>(dT), static_cast<bf16_t*>(dZ), pdbt, pdba, P, K, Kp,
-                       act_code(flags), Kp);
+                       act_code(flags), Kp, PcDefer{nullptr, nullptr, {nullptr, nullptr, nullptr, 0.f}});
   APA_LAUNCH_CHECK("pc_bwd_act_kernel");
   int rc = APA_OK;
   {  // dWt[c,k] = sum_r Xt[r,c] dT[r,k]

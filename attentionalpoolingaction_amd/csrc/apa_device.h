@@ -363,4 +363,69 @@ __device__ __forceinline__ void colsum_block(int bid, int nbid, const float* __r
 }
 
 
+// per-class fused path, folded activation pass (apa_pc_fused.hip: pc_fwd_zt_dma_kernel<.., FOLD>): logits[n, k] from
+// the per-block partial rows lpart[row block][2 segments][64], summed in block order -- ONE definition, shared by the
+// forward-only finish kernel and the backward activation pass of the one-call step, so that both give the same bits
+__device__ __forceinline__ float pc_logit_from_partials(const float* __restrict__ lpart, int n, int k, int P) {
+  const int b_lo = (n * P) / 32, b_hi = ((n + 1) * P - 1) / 32;
+  float s = 0.f;
+  // eight partial rows in flight per round (a plain loop is one dependent round trip per block: 2.7 us at P = 196);
+  // segment 0 = the image of the block's first row, 1 = the next one -- only block b_lo can hold image n as segment 1
+  for (int b = b_lo; b <= b_hi; b += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int bb = b + j;
+      v[j] = bb <= b_hi ? lpart[((size_t)bb * 2 + (bb * 32 < n * P ? 1 : 0)) * 64 + k] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+  }
+  return s / (float)P;
+}
+
+// softmax_xent_kernel<1>'s arithmetic to the letter (apa_loss.hip), so that a folded loss and its gradient are
+// BIT-identical to the separate launch: half a wave owns the row (both halves run the same row here), lane hl holds
+// the 4 columns colc .. colc + 3, the ragged last vector is shifted back and its already-covered columns masked out;
+// half-wave max / sum trees, exp_fast, fmaf(p, gscale, -gscale).  Called by ONE whole wave; lrow = the logits row in
+// LDS (4 <= K <= 64).  write: G[n, :] and loss[1 + n] go to memory; grow (optional, LDS): the gradient row for the
+// caller's own use.
+struct PcXent { const int64_t* labels; float* loss; float* G; float gscale; };
+__device__ __forceinline__ void pc_row_xent(const float* lrow, int n, int K, const PcXent& xe, bool write, float* grow) {
+  const int lane = threadIdx.x & 63, hl = lane & 31;
+  const int lab = (int)xe.labels[n];
+  const bool lab_ok = lab >= 0 && lab < K;
+  const int col0 = 4 * hl, colc = min(col0, K - 4);
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = colc + e >= col0 ? lrow[colc + e] : -INFINITY;
+  const float xl = lrow[lab_ok ? lab : 0];
+  float m = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (v[e] > m) m = v[e];
+  const float mw = half_max(m, lane);
+  float l = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    v[e] = exp_fast(v[e] - mw);
+    l += v[e];
+  }
+  l = half_sum(l, lane);
+  const float inv = 1.0f / l;
+  const float lv = lab_ok ? -(xl - mw - logf(l)) : 0.f;
+  if (lane < 32) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = colc + e;
+      if (c >= col0 && c < K) {
+        const float gv = fmaf(v[e] * inv, xe.gscale, c == lab ? -xe.gscale : 0.f);
+        if (write) xe.G[(size_t)n * K + c] = gv;
+        if (grow) grow[c] = gv;
+      }
+    }
+    if (hl == 0 && write) xe.loss[1 + n] = lv;
+  }
+}
+
 }  // namespace apa

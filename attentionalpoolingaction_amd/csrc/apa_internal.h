@@ -194,6 +194,8 @@ struct M1Xent {
   float* G;      // [N,K]
   float gscale, lscale;
   bool done;
+  bool deferred = false;   // per-class fused path: logits + cross-entropy are finished by the backward activation pass
+  float* logits = nullptr; // (deferred: where that pass writes the logits)
   // evaluation form (apa_attn_head_eval_step without ground truth): probabilities + argmax instead
   float* probs = nullptr;     // [N,K]
   int64_t* pred = nullptr;    // [N]
@@ -339,6 +341,7 @@ struct PcFusedWs {
   void* dTdZ;       // bf16 [R][128]: dT | dZ
   float* partial;   // f32 [splits][C][128]
   uint8_t* maskbits;  // [R*C/8]: keep decisions of the dropout mask, bit (e & 7) of byte e >> 3
+  float* lpart;       // f32 [ceil(R/32)][2][64]: per-block partial rows of sum_p A * T (folded activation pass)
 };
 bool pc_fused_supported(int N, int P, int C, int Ca, int K, int dtype, const void* X, const void* Xatt);
 size_t pc_fused_ws_bytes(int N, int P, int C);
@@ -353,9 +356,15 @@ struct PcDwTail {     // what the dW reduce launch's tail blocks also do (see pc
 };
 int pc_fused_prep(const PcFusedWs& f, const float* Wa, const float* Wt, const float* ba, const float* bt, int C,
                   int K, hipStream_t st, const PcPrepBits* bits = nullptr);
+struct PcFwdFold { float* att; int act; int P; };   // identity (0) / relu (1) attention folded into the product's epilogue
 int pc_fused_forward(const PcFusedWs& f, const void* X, float* Z, float* T, int R, int C, int K, bool train,
                      float keep_prob, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, hipStream_t st,
-                     bool prebits = false);
+                     bool prebits = false, const PcFwdFold* fold = nullptr);
+bool pc_fused_dx_supported(int P, int act);
+int pc_fused_dx_rows(int R);
+int pc_fused_dx(const PcFusedWs& f, const float* G, const float* att, const float* Tm, void* dX, float* pd, int R,
+                int C, int K, int P, int act, bool train, float keep_prob, const M1Xent* defer, hipStream_t st);
+int pc_fused_logits_finish(const PcFusedWs& f, float* logits, int N, int P, int K, hipStream_t st);
 int pc_fused_dw(const PcFusedWs& f, const void* X, float* dWt, float* dWa, int R, int C, int K, bool train,
                 float keep_prob, hipStream_t st, const PcDwTail* tail = nullptr);
 

@@ -179,11 +179,25 @@ __device__ __forceinline__ bf16x8 frag_sw64(const short* img, int rbase, int ks,
 // a stage's 32 rows x 16 bytes of bits arrive by ONE more LDS-DMA instruction (wave 0, lanes 0-31: 16 bytes per
 // row) into a ring of three 512-byte slots, in natural [row][chunk] order; a T wave reads its row's 16 bytes once
 // per stage and picks the four bytes of its lane group.  No hashing, no bit stores, no DPP shuffles in this kernel.
-template <bool TRAIN>
+// FOLD (round 4, identity / relu attention): the activation pass that used to follow is folded into this epilogue.  The
+// T waves hand their tile to the Z waves through LDS; a Z wave applies the activation, writes the attention map A = f(Z)
+// itself and sums A * T over its 16 rows -- split at the image boundary, a block's 32 rows may straddle two images --;
+// the block leaves two partial rows [segment][64 classes] behind (lpart[blk][2][64]).  logits[n, k] = (1 / P) * the sum
+// of the partial rows of image n in block order (pc_logit_from_partials): computed by pc_logits_finish_kernel in a
+// forward-only call, by pc_bwd_act_kernel itself in the one-call train step (one launch less: 5.7 us at the floor).
+struct PcFoldArgs { float* att; float* lpart; int act; int P; };
+__global__ __launch_bounds__(64) void pc_logits_finish_kernel(const float* __restrict__ lpart,
+                                                              float* __restrict__ logits, int P, int K) {
+  const int n = blockIdx.x, k = threadIdx.x;
+  if (k < K) logits[(size_t)n * K + k] = pc_logit_from_partials(lpart, n, k, P);
+}
+
+template <bool TRAIN, bool FOLD = false>
 __global__ __launch_bounds__(512) void pc_fwd_zt_dma_kernel(
     const bf16_t* __restrict__ X, const bf16_t* __restrict__ WcatT, const float* __restrict__ bcat,
     float* __restrict__ Z, float* __restrict__ T, uint8_t* __restrict__ maskbits, int R, int C, int K,
-    float inv_keep, uint32_t thresh, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev) {
+    float inv_keep, uint32_t thresh, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev,
+    PcFoldArgs fo) {
   extern __shared__ __attribute__((aligned(16))) short smem[];
   typedef __attribute__((address_space(3))) void* lptr;
   uint8_t* const s_bits = reinterpret_cast<uint8_t*>(smem + ZB_NST * ZB_STAGE_EL);   // [2][32 rows][4 kb][4]
@@ -258,6 +272,59 @@ __global__ __launch_bounds__(512) void pc_fwd_zt_dma_kernel(
   }
   // D layout of the 16x16 MFMA: row = 4 * (lane >> 4) + reg, col = lane & 15
   const float scale = (TRAIN && half) ? inv_keep : 1.0f;
+  if constexpr (FOLD) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with the last stage
+    constexpr int LDX = 65;
+    float* exch = reinterpret_cast<float*>(smem);                    // [32 rows][64 classes] of T
+    float* psum = exch + 32 * LDX;                                   // [2 row tiles][2 segments][64]
+    if (half == 1) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = wn * 32 + j * 16 + l16;
+        const float bias = bcat[64 + col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rr = mt * 16 + 4 * kb + r, row = m0 + rr;
+          const float v = fmaf(acc[j][r], scale, bias);
+          exch[rr * LDX + col] = v;
+          if (row < R && col < K) T[(size_t)row * K + col] = v;
+        }
+      }
+    }
+    __syncthreads();
+    if (half == 0) {
+      const int bnd = (m0 / fo.P + 1) * fo.P;                        // first row of the next image
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = wn * 32 + j * 16 + l16;
+        const float bias = bcat[col];
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rr = mt * 16 + 4 * kb + r, row = m0 + rr;
+          const float v = acc[j][r] + bias;                          // (= fmaf(acc, 1, bias) of the plain epilogue)
+          const float a = fo.act == 1 ? fmaxf(v, 0.f) : v;
+          if (row < R) {
+            if (col < K) fo.att[(size_t)row * K + col] = a;
+            const float pr = a * exch[rr * LDX + col];
+            if (row < bnd) s0 += pr; else s1 += pr;
+          }
+        }
+        s0 += __shfl_xor(s0, 16); s0 += __shfl_xor(s0, 32);          // the four row quads of the tile
+        s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+        if (kb == 0) {
+          psum[(mt * 2 + 0) * 64 + col] = s0;
+          psum[(mt * 2 + 1) * 64 + col] = s1;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int seg = tid >> 6, c = tid & 63;
+      fo.lpart[((size_t)blockIdx.x * 2 + seg) * 64 + c] = psum[(0 * 2 + seg) * 64 + c] + psum[(1 * 2 + seg) * 64 + c];
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = wn * 32 + j * 16 + l16;       // within the half
@@ -412,6 +479,241 @@ __global__ __launch_bounds__(256) void pc_bwd_dw_kernel(
         out[(size_t)(wm * 64 + i * 16 + 4 * kb + r) * 128 + half * 64 + j * 16 + l16] = acc[i][j][r];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward, feature gradient (round 4; identity / relu attention):
+//     dX[r, c] = (sum_k dT[r,k] Wt[c,k]) * mask[r,c] / keep + sum_k dZ[r,k] Wa[c,k]
+// with the activation pass that used to precede it folded in:  dT = g A,  dZ = act'(g T),  g = G[n, :] / P.
+// A 128-deep contraction against 25.7 MB of output: a WRITE-bound kernel (the 128 x 128-tile GEMM it replaces spent
+// 15.4 us, nearly all of it in a staged epilogue, after a 6.4 us launch that only produced its 1.6 MB operand).
+//   * block = 128 rows x a channel range of <= 16 units of 32 channels; 4 waves, wave w owns rows 32w .. 32w+31
+//     (two 16-row tiles) for the whole range;
+//   * the MFMA runs TRANSPOSED: the weights are the A operand (M = channels), the rows the B operand (N = rows).  A
+//     lane then holds D[channel 4 kb + reg][row l16]: with the unit's two channel tiles mapped as
+//     channel = c0 + 8 kb + 4 t + reg, a lane's eight accumulators are eight CONSECUTIVE channels of one row --
+//     packed and stored as one 16-byte vector straight from registers, no LDS staging, no barrier;
+//   * the B fragments [dT | dZ] of a wave's 32 rows are computed by its own lanes from att / T (a lane needs 16
+//     classes of its row) and stay in registers for the whole kernel;
+//   * the block's whole weight slab (<= 16 x 8 KB) is DMA'd to LDS up front, rows in MFMA order, 16-byte chunks
+//     XOR-swizzled by (row & 7): ds_read_b128 conflict-free; no ring, one barrier;
+//   * the keep bits of the block's 128 rows x range are staged in LDS once ([row][17] dwords), one byte per lane,
+//     unit and row tile -- exactly its eight channels;
+//   * channel range 0 also writes [dT | dZ] (bf16, the dW kernel's operand) and the block's partial column sums of
+//     dT / dZ (dbt | dba), and, in the one-call step after a folded forward product, finishes logits and
+//     cross-entropy of the images that START in its rows (pc_row_xent: G never comes from memory).
+// ---------------------------------------------------------------------------------------------
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+constexpr int DX_ROWS = 128, DX_MAXU = 16, DX_MAXIMG = 5, DX_MLD = 17, DX_WAVES = 8;
+constexpr size_t DX_LDS_W = (size_t)DX_MAXU * 8192;
+constexpr size_t DX_LDS_BYTES = DX_LDS_W + DX_ROWS * DX_MLD * 4 + DX_MAXIMG * 64 * 4 + DX_WAVES * 2 * 64 * 4;
+struct PcDxArgs {
+  const float* G; const float* att; const float* Tm; const bf16_t* Wcat2; const uint8_t* bits;
+  bf16_t* dX; bf16_t* dTdZ; float* pd;
+  int R, C, K, P, act, upb, exp; float inv_keep;
+  const float* lpart; float* logits; PcXent xe;      // lpart != nullptr: deferred logits + cross-entropy
+};
+// sum over the 16 lanes of a DPP row (= the 16 rows of a wave's tile): four rotate-and-add steps on the VALU, no LDS
+// crossbar; every lane ends with a total, lane 0's association order is what the caller keeps
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));   // row_ror:2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));   // row_ror:1
+  return v;
+}
+template <bool TRAIN>
+__global__ __launch_bounds__(512) void pc_bwd_dx_kernel(PcDxArgs a) {
+  extern __shared__ __attribute__((aligned(16))) short smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l16 = lane & 15, kb = lane >> 4;
+  const int rb = blockIdx.x, sp = blockIdx.y;
+  const int m0 = rb * DX_ROWS;
+  const int u0 = sp * a.upb, nu = min(a.upb, a.C / 32 - u0), cbeg = u0 * 32;
+  const int K = a.K, P = a.P, R = a.R;
+  uint32_t* mlds = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(smem) + DX_LDS_W);   // [128][17] keep bits
+  float* grow = reinterpret_cast<float*>(mlds + DX_ROWS * DX_MLD);                           // [5][64]: G / P
+  float* scr = grow + DX_MAXIMG * 64;                                                       // [8][2][64] scratch
+
+  // 1. the weight slab: unit u = 32 channels x 128 k, image row j = 16 t + m <- channel c0 + 8 (m >> 2) + 4 t + (m & 3);
+  //    one 1 KB DMA instruction per wave and unit
+  {
+    const uint32_t lbase = (uint32_t)(uintptr_t)smem;
+    const int q = wave * 64 + lane, j = q >> 4, m = j & 15, t = j >> 4;
+    const bf16_t* src = a.Wcat2 + (size_t)(cbeg + 8 * (m >> 2) + 4 * t + (m & 3)) * 128 + (((q & 15) ^ (j & 7)) * 8);
+    for (int u = 0; u < nu; ++u)
+      glds16_asm(src + (size_t)u * 32 * 128, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lbase + u * 8192 + wave * 1024)));
+  }
+  // 2. (one-call step after a folded forward product) the logits of the images these rows touch, from the forward
+  //    product's block partials: wave w takes image n_first + w
+  const int n_first = m0 / P, n_last = min(m0 + DX_ROWS - 1, R - 1) / P;
+  const float invP = 1.0f / (float)P;
+  const int n_mine = n_first + wave;
+  const bool has_img = a.lpart && n_mine <= n_last;
+  float lg = -INFINITY;
+  if (has_img && lane < K) lg = pc_logit_from_partials(a.lpart, n_mine, lane, P);
+  // 3. att / T of this lane's row: classes 8 kb + e and 32 + 8 kb + e
+  const int rowg = m0 + wave * 16 + l16;
+  const bool valid = rowg < R;
+  float av[2][8], tv[2][8];
+  {
+    const size_t rbase = (size_t)min(rowg, R - 1) * K;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int e4 = 0; e4 < 8; e4 += 4) {     // rows are K floats: 4-byte aligned 16-byte loads (dword alignment is enough)
+        const int k = 32 * hh + 8 * kb + e4;
+        if (k + 3 < K) {
+          const f4u x = *reinterpret_cast<const f4u*>(a.att + rbase + k), y = *reinterpret_cast<const f4u*>(a.Tm + rbase + k);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { av[hh][e4 + e] = x[e]; tv[hh][e4 + e] = y[e]; }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            av[hh][e4 + e] = k + e < K ? a.att[rbase + k + e] : 0.f;
+            tv[hh][e4 + e] = k + e < K ? a.Tm[rbase + k + e] : 0.f;
+          }
+        }
+      }
+  }
+  // 4. keep bits of the block: [row][unit] dwords
+  uint32_t mreg[4];
+  if (TRAIN) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int i = tid + it * 512, row = i >> 4, d = i & 15;
+      const size_t e = (size_t)min(m0 + row, R - 1) * a.C + cbeg + 32 * min(d, nu - 1);
+      mreg[it] = *reinterpret_cast<const uint32_t*>(a.bits + (e >> 3));
+    }
+  }
+  // 5. g = G / P rows into LDS (cross-entropy of the images that START in this block is also written out)
+  if (a.lpart) {
+    if (has_img) {
+      float* lrow = scr + wave * 64;
+      const bool mine = sp == 0 && n_mine * P >= m0;
+      if (mine && lane < K) a.logits[(size_t)n_mine * K + lane] = lg;
+      lrow[lane] = lg;
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      float* gr = grow + wave * 64;
+      pc_row_xent(lrow, n_mine, K, a.xe, mine, gr);
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      const float gv = lane < K ? gr[lane] * invP : 0.f;
+      __builtin_amdgcn_wave_barrier();
+      gr[lane] = gv;
+    }
+  } else {
+    for (int i = tid; i < (n_last - n_first + 1) * 64; i += 512) {
+      const int k = i & 63;
+      grow[i] = k < K ? a.G[(size_t)(n_first + (i >> 6)) * K + k] * invP : 0.f;
+    }
+  }
+  if (TRAIN) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int i = tid + it * 512;
+      mlds[(i >> 4) * DX_MLD + (i & 15)] = mreg[it];
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // 6. the B fragments: [dT (k 0..63) | dZ (k 64..127)] of row l16
+  bf16x8 bfrag[4];
+  {
+    const float* gr = grow + (min(rowg, R - 1) / P - n_first) * 64;
+    float dt[2][8], dz[2][8];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gr + 32 * hh + 8 * kb);
+      const f32x4 g1 = *reinterpret_cast<const f32x4*>(gr + 32 * hh + 8 * kb + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float g = valid ? (e < 4 ? g0[e & 3] : g1[e & 3]) : 0.f;
+        const float dA = g * tv[hh][e];
+        dt[hh][e] = g * av[hh][e];
+        dz[hh][e] = a.act == 1 ? (av[hh][e] > 0.f ? dA : 0.f) : dA;
+      }
+      const uint4 pt = Vec<bf16_t>::pack(dt[hh]), pz = Vec<bf16_t>::pack(dz[hh]);
+      bfrag[hh] = *reinterpret_cast<const bf16x8*>(&pt);
+      bfrag[2 + hh] = *reinterpret_cast<const bf16x8*>(&pz);
+      if (sp == 0 && valid) {
+        st16(a.dTdZ + (size_t)rowg * 128 + 32 * hh + 8 * kb, pt);
+        st16(a.dTdZ + (size_t)rowg * 128 + 64 + 32 * hh + 8 * kb, pz);
+      }
+    }
+    if (sp == 0) {     // dbt | dba: this wave's 16-row column sums (the block's partial row is finished after the loop)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float s = row16_sum(dt[hh][e]), z = row16_sum(dz[hh][e]);
+          if (l16 == 0) {
+            scr[(wave * 2 + 0) * 64 + 32 * hh + 8 * kb + e] = s;
+            scr[(wave * 2 + 1) * 64 + 32 * hh + 8 * kb + e] = z;
+          }
+        }
+    }
+  }
+
+  // 7. the channel units: two register sets, the next unit's fragments and keep byte in flight under this unit's MFMAs
+  const char* wl = reinterpret_cast<const char*>(smem);
+  const uint8_t* mb8 = reinterpret_cast<const uint8_t*>(mlds) + ((wave * 16 + l16) * DX_MLD) * 4 + kb;
+  const uint32_t ikb = __float_as_uint(a.inv_keep);
+  auto load_u = [&](int u, bf16x8 (&af)[2][4], uint32_t& mb) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int j = 16 * t + l16;
+        af[t][ks] = *reinterpret_cast<const bf16x8*>(wl + u * 8192 + j * 256 + (((4 * ks + kb) ^ (j & 7)) * 16));
+      }
+    mb = TRAIN ? mb8[u * 4] : 0xffu;
+  };
+  auto unit = [&](int u, const bf16x8 (&af)[2][4], uint32_t mb) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    float o[8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x4 aT = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t][0], bfrag[0], zero, 0, 0, 0);
+      f32x4 aZ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t][2], bfrag[2], zero, 0, 0, 0);
+      aT = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t][1], bfrag[1], aT, 0, 0, 0);
+      aZ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t][3], bfrag[3], aZ, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (TRAIN) {   // keep bit -> 0 / -1 -> 0.0f / 1/keep
+          const float mk = __uint_as_float((uint32_t)__builtin_amdgcn_sbfe((int)mb, 4 * t + r, 1) & ikb);
+          o[4 * t + r] = fmaf(aT[r], mk, aZ[r]);
+        } else {
+          o[4 * t + r] = aT[r] + aZ[r];
+        }
+      }
+    }
+    if (valid && !(a.exp & 1)) st16(a.dX + (size_t)rowg * a.C + cbeg + 32 * u + 8 * kb, Vec<bf16_t>::pack(o));
+  };
+  bf16x8 afA[2][4], afB[2][4];
+  uint32_t mbA, mbB;
+  load_u(0, afA, mbA);
+  for (int u = 0; u < ((a.exp & 2) ? 0 : nu); u += 2) {
+    load_u(min(u + 1, nu - 1), afB, mbB);
+    unit(u, afA, mbA);
+    if (u + 1 < nu) {
+      load_u(min(u + 2, nu - 1), afA, mbA);
+      unit(u + 1, afB, mbB);
+    }
+  }
+  if (sp == 0) {     // the block's dbt | dba partial row: waves in fixed order
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6, k = tid & 63;
+      if (k < K) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < DX_WAVES; ++w) s += scr[(w * 2 + which) * 64 + k];
+        a.pd[(size_t)rb * 2 * K + which * K + k] = s;
+      }
+    }
+  }
+}
+
 // dWt[c,k] = inv_keep * sum_s partial[s][c][k];  dWa[c,k] = sum_s partial[s][c][64 + k]   (fixed order)
 // Round 4: the launch's TAIL blocks (blockIdx >= nmain) are the column-sum launch that used to follow -- dbt | dba
 // from the activation pass's block partials, literally m1_colsum_kernel's body (same sums bit for bit) -- and, in the
@@ -456,6 +758,7 @@ size_t pc_fused_ws_bytes(int N, int P, int C) {
   off += align_up(R * 128 * 2, 256);                  // dT | dZ
   off += align_up((size_t)PC_DW_MAX_SPLITS * C * 128 * 4, 256);   // dW partials
   off += align_up(R * C / 8, 256);                    // keep-mask bits
+  off += align_up(((R + 31) / 32) * 2 * 64 * 4, 256); // folded activation pass: [row blocks][2 segments][64] partials
   return off;
 }
 
@@ -468,7 +771,8 @@ PcFusedWs pc_fused_carve(void* base, int N, int P, int C) {
   f.bcat = reinterpret_cast<float*>(w);  w += align_up((size_t)128 * 4, 256);
   f.dTdZ = w;    w += align_up(R * 128 * 2, 256);
   f.partial = reinterpret_cast<float*>(w);  w += align_up((size_t)PC_DW_MAX_SPLITS * C * 128 * 4, 256);
-  f.maskbits = reinterpret_cast<uint8_t*>(w);
+  f.maskbits = reinterpret_cast<uint8_t*>(w);  w += align_up(R * C / 8, 256);
+  f.lpart = reinterpret_cast<float*>(w);
   return f;
 }
 
@@ -491,9 +795,15 @@ int pc_fused_prep(const PcFusedWs& f, const float* Wa, const float* Wt, const fl
   return APA_OK;
 }
 
+int pc_fused_logits_finish(const PcFusedWs& f, float* logits, int N, int P, int K, hipStream_t st) {
+  hipLaunchKernelGGL(pc_logits_finish_kernel, dim3(N), dim3(64), 0, st, f.lpart, logits, P, K);
+  APA_LAUNCH_CHECK("pc_logits_finish_kernel");
+  return APA_OK;
+}
+
 int pc_fused_forward(const PcFusedWs& f, const void* X, float* Z, float* T, int R, int C, int K, bool train,
                      float keep_prob, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, hipStream_t st,
-                     bool prebits) {
+                     bool prebits, const PcFwdFold* fold) {
   if (C % ZB_KT != 0) {     // pc_fused_supported() admits multiples of 256 only
     set_error("pc_fused_forward: C=%d is not a multiple of %d", C, ZB_KT);
     return APA_ERR_UNSUPPORTED;
@@ -507,19 +817,67 @@ int pc_fused_forward(const PcFusedWs& f, const void* X, float* Z, float* T, int 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_BYTES));
     APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_fwd_zt_dma_kernel<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_BYTES));
+    APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_fwd_zt_dma_kernel<true, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_BYTES));
+    APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_fwd_zt_dma_kernel<false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_BYTES));
     attr_set = true;
   }
   if (train && !prebits) {
     set_error("pc_fused_forward: training mode needs the keep bits of pc_fused_prep (internal)");
     return APA_ERR_INVALID_ARG;
   }
-  if (train)
-    hipLaunchKernelGGL(pc_fwd_zt_dma_kernel<true>, dim3((R + 31) / 32), dim3(512), ZB_LDS_BYTES, st, xx, ww,
-                       f.bcat, Z, T, f.maskbits, R, C, K, ik, keep_thresh(keep_prob), seed, offset, offset_dev);
-  else
-    hipLaunchKernelGGL(pc_fwd_zt_dma_kernel<false>, dim3((R + 31) / 32), dim3(512), ZB_LDS_BYTES, st, xx, ww,
-                       f.bcat, Z, T, f.maskbits, R, C, K, ik, keep_thresh(keep_prob), seed, offset, offset_dev);
+  PcFoldArgs fo = {nullptr, nullptr, 0, 1};
+  if (fold) { fo.att = fold->att; fo.lpart = f.lpart; fo.act = fold->act; fo.P = fold->P; }
+#define APA_ZT(TR, FO)                                                                                         \
+  hipLaunchKernelGGL((pc_fwd_zt_dma_kernel<TR, FO>), dim3((R + 31) / 32), dim3(512), ZB_LDS_BYTES, st, xx, ww,  \
+                     f.bcat, Z, T, f.maskbits, R, C, K, ik, keep_thresh(keep_prob), seed, offset, offset_dev, fo)
+  if (fold) { if (train) APA_ZT(true, true); else APA_ZT(false, true); }
+  else      { if (train) APA_ZT(true, false); else APA_ZT(false, false); }
+#undef APA_ZT
   APA_LAUNCH_CHECK("pc_fwd_zt_dma_kernel");
+  return APA_OK;
+}
+
+// dX with the backward activation pass folded in (pc_bwd_dx_kernel); pd: [ceil(R / 128)][2K] partial rows of dbt | dba
+bool pc_fused_dx_supported(int P, int act) {
+  static const int enabled = knob("APA_PC_DX_FUSED", 1);
+  return enabled && act != 2 && P >= 32;
+}
+int pc_fused_dx_rows(int R) { return (R + DX_ROWS - 1) / DX_ROWS; }
+int pc_fused_dx(const PcFusedWs& f, const float* G, const float* att, const float* Tm, void* dX, float* pd, int R,
+                int C, int K, int P, int act, bool train, float keep_prob, const M1Xent* defer, hipStream_t st) {
+  PcDxArgs a;
+  a.G = G; a.att = att; a.Tm = Tm; a.Wcat2 = static_cast<const bf16_t*>(f.Wcat2); a.bits = f.maskbits;
+  a.dX = static_cast<bf16_t*>(dX); a.dTdZ = static_cast<bf16_t*>(f.dTdZ); a.pd = pd;
+  a.R = R; a.C = C; a.K = K; a.P = P; a.act = act; a.inv_keep = train ? 1.0f / keep_prob : 1.0f;
+  static const int dx_exp = knob("APA_PC_DX_EXP", 0);     // timing experiments (development library only)
+  a.exp = dx_exp;
+  a.lpart = nullptr; a.logits = nullptr; a.xe = PcXent{nullptr, nullptr, nullptr, 0.f};
+  if (defer) {
+    a.lpart = f.lpart; a.logits = defer->logits;
+    a.xe.labels = defer->labels; a.xe.loss = defer->loss; a.xe.G = defer->G; a.xe.gscale = defer->gscale;
+  }
+  const int rbs = pc_fused_dx_rows(R), units = C / 32;
+  static const int sp_env = knob("APA_PC_DX_SPLITS", 0);
+  int splits = sp_env > 0 ? sp_env : (256 + rbs / 2) / rbs;      // about one block per CU
+  if (splits < (units + DX_MAXU - 1) / DX_MAXU) splits = (units + DX_MAXU - 1) / DX_MAXU;
+  if (splits > units) splits = units;
+  a.upb = (units + splits - 1) / splits;
+  splits = (units + a.upb - 1) / a.upb;
+#define APA_DX(TR)                                                                                              \
+  do {                                                                                                          \
+    static thread_local PerDevice<bool> attr_dev; bool& attr_set = attr_dev.here();                             \
+    if (!attr_set) {                                                                                            \
+      APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_bwd_dx_kernel<TR>),                    \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)DX_LDS_BYTES));        \
+      attr_set = true;                                                                                          \
+    }                                                                                                           \
+    hipLaunchKernelGGL((pc_bwd_dx_kernel<TR>), dim3(rbs, splits), dim3(512), DX_LDS_BYTES, st, a);              \
+  } while (0)
+  if (train) APA_DX(true); else APA_DX(false);
+#undef APA_DX
+  APA_LAUNCH_CHECK("pc_bwd_dx_kernel");
   return APA_OK;
 }
 
