@@ -313,3 +313,64 @@ def test_per_class_small_k_bf16_training_fused_kernels(gpu, N, K, softmax):
             assert float(got.abs().max()) < 1e-6        # d(ba) == 0 under the spatial softmax
             continue
         assert rel <= (2.0 + KAPPA) * U, name
+
+
+@pytest.mark.parametrize('N,H,C,K,relu,train', [(3, 7, 512, 5, True, True),      # R = 147: ragged row blocks, relu
+                                                (2, 6, 256, 64, False, False),   # K = 64, no dropout (kernel<false>)
+                                                (5, 14, 512, 51, True, True),    # images straddle 32- and 128-row blocks
+                                                (9, 7, 256, 2, True, False),     # K < 4: logits by the finish kernel
+                                                (1, 5, 256, 3, False, True),     # P = 25 < 32: the separate passes
+                                                (40, 6, 256, 17, False, True)])  # 5 images per 128-row block
+def test_per_class_small_k_folded_activation_passes(gpu, N, H, C, K, relu, train):
+    """Round 4: for identity / relu attention the per-class K <= 64 path has no activation launches left -- the
+    forward product's epilogue writes A = f(Z) and per-block partial rows of sum_p A * T, the backward dX kernel forms
+    [dT | dZ] in registers (apa_pc_fused.hip).  Shapes that exercise what the HMDB-51 benchmark shape does not: row
+    counts that are not multiples of the 32 / 128-row blocks, several images per block, relu, evaluation mode, K < 4
+    (no folded cross-entropy) and P < 32 (falls back to the separate passes).  Against the float64 oracle fed the
+    kernel's own mask, in units of u; one-call step bit-identical to the per-op sequence."""
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    g = torch.Generator().manual_seed(1000 * N + 10 * K + H)
+    X = torch.relu(torch.randn(N, H, H, C, generator=g)).bfloat16()
+    Wa = torch.randn(C, K, generator=g) / C ** 0.5
+    ba = torch.randn(K, generator=g) * 0.1
+    Wt = torch.randn(C, K, generator=g) / C ** 0.5
+    bt = torch.randn(K, generator=g) * 0.1
+    labels = torch.randint(0, K, (N,), generator=g)
+    keep, seed, offset = (0.5, 13, 6) if train else (1.0, 0, 0)
+    d = lambda t: t.to(gpu).contiguous()
+    Xd, Wad, bad, Wtd, btd, lab = d(X), d(Wa), d(ba), d(Wt), d(bt), d(labels)
+    flags = cof.attn_flags(False, relu, train)
+    kw = dict(flags=flags, keep_prob=keep, seed=seed, offset=offset)
+    logits, att, Ts, _, _, ws = cof.attn_pool_fwd(Xd, Xd, Wad, bad, Wtd, btd, **kw)
+    loss, G, _, pred = cof.softmax_xent_fwd_bwd(logits, lab, want_pred=True)
+    dX, _, dWa, dba, dWt, dbt = cof.attn_pool_bwd(Xd, Xd, Wad, bad, Wtd, btd, att, Ts, None, G, **kw)
+    grads = (torch.empty_like(Xd), None, torch.empty_like(Wad), torch.empty_like(bad), torch.empty_like(Wtd),
+             torch.empty_like(btd))
+    st = cof.HeadTrainStep(Xd, Xd, Wad, bad, Wtd, btd, lab, grads, **kw)
+    st.run()
+    torch.cuda.synchronize()
+    assert torch.equal(st.logits, logits) and torch.equal(st.G, G) and torch.equal(st.att, att)
+    assert torch.equal(st.loss, loss)
+    for a, b, name in zip(grads, (dX, None, dWa, dba, dWt, dbt), ('dX', '', 'dWa', 'dba', 'dWt', 'dbt')):
+        if a is not None:
+            assert torch.equal(a, b), name
+
+    mask = cof.dropout_mask((N, H, H, C), keep, seed, offset).cpu() if train else None
+    leaf = lambda t: t.double().clone().requires_grad_(True)
+    Xr, War, bar, Wtr, btr = map(leaf, (X, Wa, ba, Wt, bt))
+    oflags = orc.AttnFlags(per_class=True, relu_att=relu)
+    okw = dict(is_training=True, keep_prob=keep, dropout_mask=mask) if train else {}
+    lg, ep = orc.attentional_pooling(Xr, None, None, [War], [bar], [Wtr], [btr], oflags, **okw)
+    orc.action_softmax_xent(lg, labels, K).backward()
+    with torch.no_grad():
+        lg_q, ep_q = orc.attentional_pooling(Xr, None, None, [_bf16(War)], [bar], [_bf16(Wtr)], [btr], oflags, **okw)
+    assert float((logits.cpu().double() - lg_q).abs().max()) < 3e-4
+    assert float((logits.cpu().double() - lg.detach()).abs().max()) < 2 * LOGIT_TOL_BF16
+    a_q = ep_q['PosePrelogitsBasedAttention'].reshape(N, H * H, K)
+    assert float((att.cpu().double().view(N, H * H, K) - a_q).abs().max()) < 3e-4 * max(1.0, float(a_q.abs().max()))
+    assert torch.equal(pred.cpu(), logits.argmax(1).cpu())
+    for name, got, ref in (('dWt', dWt, Wtr.grad), ('dWa', dWa, War.grad), ('dbt', dbt, btr.grad),
+                           ('dba', dba, bar.grad), ('dX', dX.float().view(N, H, H, C), Xr.grad)):
+        scale = max(float(ref.abs().max()), 1e-30)
+        rel = float((got.detach().cpu().double().reshape(ref.shape) - ref).abs().max()) / scale
+        assert rel <= (2.0 + KAPPA) * U, (name, rel / U)
