@@ -953,9 +953,34 @@ struct PcPadSegs {
   int bf16[3];
   int n;
 };
+// Xd = X * mask / keep (bf16), the same counter-based mask as everywhere else (flat index r*C + c); block `bid` of `nb`
+struct PcDropArgs {
+  const bf16_t* X; bf16_t* Xd; size_t n8; float inv_keep; uint32_t thresh; uint64_t seed, offset;
+  const uint64_t* offset_dev; unsigned nblocks;     // nblocks == 0: none
+};
+__device__ __forceinline__ void pc_dropout_block(const PcDropArgs& a, unsigned bid, unsigned nb) {
+  uint32_t k0, k1;
+  rng_key_dev_x(a.seed, a.offset_dev ? *a.offset_dev : a.offset, a.thresh, k0, k1);
+  for (size_t v = (size_t)bid * 256 + threadIdx.x; v < a.n8; v += (size_t)nb * 256) {
+    float x[8];
+    Vec<bf16_t>::unpack(ld16(a.X + v * 8), x);
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      float m0, m1;
+      rng_keep2_x(v * 8 + e, k0, k1, a.thresh, m0, m1);
+      x[e] *= m0 * a.inv_keep;
+      x[e + 1] *= m1 * a.inv_keep;
+    }
+    st16(a.Xd + v * 8, Vec<bf16_t>::pack(x));
+  }
+}
 // One thread per 8 output columns (Kp is a multiple of 8): 16-byte stores and 8x fewer waves -- the
 // one-element-per-thread form was bound by wave dispatch (28 k waves for 1.8 M elements: 8.4 us).
-__global__ __launch_bounds__(256) void pc_pad_kernel(PcPadSegs sg, int K, int Kp) {
+// Round 4: the forward call's dropout(X) materialisation rides on the same launch (blocks past the padding work):
+// two launches at the floor (6.1 + 8.8 us at K = 393) become one.
+__global__ __launch_bounds__(256) void pc_pad_kernel(PcPadSegs sg, int K, int Kp, PcDropArgs dr) {
+  const unsigned npad = gridDim.x - dr.nblocks;
+  if (blockIdx.x >= npad) { pc_dropout_block(dr, blockIdx.x - npad, dr.nblocks); return; }
   const unsigned idx = blockIdx.x * 256u + threadIdx.x;       // vector index: 8 elements each
   if (idx >= (unsigned)(sg.end[sg.n - 1] >> 3)) return;
   int s = 0;
@@ -986,8 +1011,11 @@ struct PcPadList {
     sg.src[i] = W; sg.dst[i] = Wp; sg.bf16[i] = to_bf16 ? 1 : 0;
     sg.end[i] = (i ? sg.end[i - 1] : 0) + (long)rows * Kp;
   }
-  void launch(int K, int Kp, hipStream_t st) const {
-    hipLaunchKernelGGL(pc_pad_kernel, dim3((unsigned)(((sg.end[sg.n - 1] >> 3) + 255) / 256)), dim3(256), 0, st, sg, K, Kp);
+  void launch(int K, int Kp, hipStream_t st, const PcDropArgs* drop = nullptr) const {
+    PcDropArgs dr = {nullptr, nullptr, 0, 1.f, 0, 0, 0, nullptr, 0};
+    if (drop) dr = *drop;
+    hipLaunchKernelGGL(pc_pad_kernel, dim3((unsigned)(((sg.end[sg.n - 1] >> 3) + 255) / 256) + dr.nblocks), dim3(256), 0,
+                       st, sg, K, Kp, dr);
   }
 };
 
@@ -1094,7 +1122,9 @@ __global__ __launch_bounds__(1024) void pc_fwd_act_kernel(const float* __restric
   }
 }
 
-struct PcDefer { const float* lpart; float* logits; PcXent xe; };   // (lpart == nullptr: G is read from memory)
+// one-call step: where the gradient row G[n, :] comes from -- memory (both null), the forward product's block partials
+// (lpart; logits are written), or the logits row the forward activation pass left (row_logits; 4 <= K <= 1024)
+struct PcDefer { const float* lpart; float* logits; PcXent xe; const float* row_logits; };
 // backward of the same: dT = G*A/P, dA = G*T/P, dZ = act'(dA); column partials for dbt / dba.
 // dT/dZ are written with leading dimension Kp (pad columns zeroed) in the intermediate dtype.
 template <typename T>
@@ -1116,6 +1146,20 @@ __global__ __launch_bounds__(1024) void pc_bwd_act_kernel(const float* __restric
   const bool pad = !ok && k < Kp;
   const size_t rbase = (size_t)n * P;
   const float invP = 1.0f / (float)P;
+  // grid.z > 1 (identity / relu only: no sum over the image's pixels is needed): block z owns a contiguous
+  // share of the pixels and its own partial row -- N x 1 blocks of 16 waves were 32 CUs' worth of latency chains
+  const int pchunk = (P + gridDim.z - 1) / gridDim.z;
+  const int p_lo = blockIdx.z * pchunk, p_hi = min(P, p_lo + pchunk);
+  // the first two pixels of every thread are requested before the gradient row is known: with the cross-entropy
+  // taken in this launch (df) the two round trips would otherwise be serial (measured 7.4 -> 14.4 us at K = 393)
+  constexpr int NPRE = 2;
+  float pa[NPRE], pt[NPRE];
+#pragma unroll
+  for (int u = 0; u < NPRE; ++u) {
+    const int p = p_lo + pg + u * PC_PG;
+    pa[u] = pt[u] = 0.f;
+    if (ok && p < p_hi) { pa[u] = att[(rbase + p) * K + k]; pt[u] = Tm[(rbase + p) * K + k]; }
+  }
   float g;
   if (df.lpart) {
     // one-call step after a folded forward product: this launch finishes the logits row from the product's block
@@ -1134,13 +1178,16 @@ __global__ __launch_bounds__(1024) void pc_bwd_act_kernel(const float* __restric
     __syncthreads();
     g = ok ? grow[kk] * invP : 0.f;
     __syncthreads();                         // red / red2 are reused below
+  } else if (df.row_logits) {
+    // K > 64 (generic path), one-call step: every block takes its image's cross-entropy itself from the logits row
+    // (softmax_xent_kernel's arithmetic: bit-identical G); block (y, z) = (0, 0) writes G[n, :] and loss[1 + n]
+    __shared__ float growf[1024];
+    if (pg == 0) pc_row_xent_any(df.row_logits + (size_t)n * K, n, K, df.xe, blockIdx.y == 0 && blockIdx.z == 0, growf);
+    __syncthreads();
+    g = ok ? growf[k] * invP : 0.f;
   } else {
     g = ok ? G[(size_t)n * K + k] * invP : 0.f;
   }
-  // grid.z > 1 (identity / relu only: no sum over the image's pixels is needed): block z owns a contiguous
-  // share of the pixels and its own partial row -- N x 1 blocks of 16 waves were 32 CUs' worth of latency chains
-  const int pchunk = (P + gridDim.z - 1) / gridDim.z;
-  const int p_lo = blockIdx.z * pchunk, p_hi = min(P, p_lo + pchunk);
   float corr = 0.f;
   if (act == 2) {  // sum_p A * dA (host: grid.z == 1)
     float s = 0.f;
@@ -1152,10 +1199,9 @@ __global__ __launch_bounds__(1024) void pc_bwd_act_kernel(const float* __restric
     __syncthreads();
   }
   float sdt = 0.f, sdz = 0.f;
-  for (int p = p_lo + pg; p < p_hi; p += PC_PG) {   // (batching the loads four pixels deep, as in the forward
-    if (ok) {                               //  pass, measured slower here: 8.9 -> 10.7 us)
-      const float a = att[(rbase + p) * K + k];
-      const float dA = g * Tm[(rbase + p) * K + k];
+  auto pixel = [&](int p, float a, float tm) {
+    if (ok) {
+      const float dA = g * tm;
       const float dt = g * a;
       float dz = dA;
       if (act == 2) dz = a * (dA - corr);
@@ -1168,6 +1214,16 @@ __global__ __launch_bounds__(1024) void pc_bwd_act_kernel(const float* __restric
       stf<T>(dT, (rbase + p) * ldg + k, 0.f);
       stf<T>(dZ, (rbase + p) * ldg + k, 0.f);
     }
+  };
+#pragma unroll
+  for (int u = 0; u < NPRE; ++u) {
+    const int p = p_lo + pg + u * PC_PG;
+    if (p < p_hi) pixel(p, pa[u], pt[u]);
+  }
+  for (int p = p_lo + pg + NPRE * PC_PG; p < p_hi; p += PC_PG) {   // (batching the loads four pixels deep, as in
+    float a = 0.f, tm = 0.f;                                        //  the forward pass, measured slower here)
+    if (ok) { a = att[(rbase + p) * K + k]; tm = Tm[(rbase + p) * K + k]; }
+    pixel(p, a, tm);
   }
   red[pg][kk] = sdt;
   red2[pg][kk] = sdz;
@@ -1201,8 +1257,9 @@ static PcPlan pc_plan(int N, int P, int C, int Ca, int K, int dtype) {
   pl.off_pdba = pl.off_pdbt + (size_t)K * 4;
   const int cm = C > Ca ? C : Ca;
   {
-    size_t g = gemm_ws_bytes(cm, K, 32);
-    const size_t g2 = gemm_ws_bytes((int)pl.R, pl.Kp, 8);   // split-K of the skinny forward products
+    // split-K partials cover the padded width; two buffers: the twin products (Z | T, dWt | dWa) share a launch
+    size_t g = 2 * gemm_ws_bytes(cm, pl.Kp, 32);
+    const size_t g2 = 2 * gemm_ws_bytes((int)pl.R, pl.Kp, 8);   // split-K of the skinny forward products
     if (g2 > g) g = g2;
     pl.off_gemm = off; off += align_up(g, 256);
   }
@@ -1215,36 +1272,14 @@ static PcPlan pc_plan(int N, int P, int C, int Ca, int K, int dtype) {
   return pl;
 }
 
-// Xd = X * mask / keep (bf16), the same counter-based mask as everywhere else (flat index r*C + c)
-__global__ __launch_bounds__(256) void pc_dropout_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Xd,
-                                                         size_t n8, float inv_keep, uint32_t thresh,
-                                                         uint64_t seed, uint64_t offset,
-                                                         const uint64_t* __restrict__ offset_dev) {
-  uint32_t k0, k1;
-  rng_key_dev_x(seed, offset_dev ? *offset_dev : offset, thresh, k0, k1);
-  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n8; v += (size_t)gridDim.x * 256) {
-    float x[8];
-    Vec<bf16_t>::unpack(ld16(X + v * 8), x);
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-      float m0, m1;
-      rng_keep2_x(v * 8 + e, k0, k1, thresh, m0, m1);
-      x[e] *= m0 * inv_keep;
-      x[e + 1] *= m1 * inv_keep;
-    }
-    st16(Xd + v * 8, Vec<bf16_t>::pack(x));
-  }
-}
-
-static const void* pc_dropped_features(const void* X, void* Xd, long R, int C, float keep_prob,
-                                       uint64_t seed, uint64_t offset, unsigned flags, hipStream_t st) {
+static PcDropArgs pc_drop_args(const void* X, void* Xd, long R, int C, float keep_prob, uint64_t seed, uint64_t offset,
+                               unsigned flags) {
   const size_t n8 = (size_t)R * C / 8;
   size_t nb = (n8 + 255) / 256;
   if (nb > 4096) nb = 4096;
   const RngKeyArgs k = rng_resolve(flags, keep_prob, seed, offset);
-  hipLaunchKernelGGL(pc_dropout_kernel, dim3((unsigned)nb), dim3(256), 0, st, static_cast<const bf16_t*>(X),
-                     static_cast<bf16_t*>(Xd), n8, 1.0f / keep_prob, k.thresh, k.seed, k.offset, k.offset_dev);
-  return Xd;
+  return PcDropArgs{static_cast<const bf16_t*>(X), static_cast<bf16_t*>(Xd), n8, 1.0f / keep_prob, k.thresh, k.seed,
+                    k.offset, k.offset_dev, (unsigned)nb};
 }
 
 size_t pc_workspace_bytes(int N, int P, int C, int Ca, int K, int dtype) {
@@ -1326,7 +1361,12 @@ int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
     pads.add(Wa, WaP, Ca, Kp, wb16);
     pads.add(ba, baP, 1, Kp, false);
     if (fast) pads.add(Wt, w + pl.off_wtp, C, Kp, true);
-    pads.launch(K, Kp, st);
+    if (fast && train) {   // + the materialised dropout(X) of the DMA-staged T product, same launch
+      const PcDropArgs dr = pc_drop_args(X, w + pl.off_xd, pl.R, C, keep_prob, seed, offset, flags);
+      pads.launch(K, Kp, st, &dr);
+    } else {
+      pads.launch(K, Kp, st);
+    }
     APA_LAUNCH_CHECK("pc_pad_kernel");
   }
   GemmDesc gz;  // Z = Xatt . Wa + ba
@@ -1338,8 +1378,6 @@ int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
   float* gws = reinterpret_cast<float*>(w + pl.off_gemm);
   gz.splits = gemm_pick_splits(R, Kp, Ca); if (gz.splits > 8) gz.splits = 8;
   gz.ws = gws;
-  int rc = gemm_launch(gz, st);
-  if (rc != APA_OK) return rc;
   GemmDesc gt;  // T = dropout(X) . Wt + bt
   gt.A = X; gt.lda = C; gt.ta = tdt; gt.a_kc = true;
   gt.C = Tsave; gt.ldc = K; gt.tc = 0;
@@ -1348,15 +1386,18 @@ int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
     void* WtP = w + pl.off_wtp;
     gt.B = WtP; gt.ldb = Kp; gt.tb = 1; gt.b_kc = false;
     gt.N = Kp; gt.n_valid = K;
-    if (train) gt.A = pc_dropped_features(X, w + pl.off_xd, pl.R, C, keep_prob, seed, offset, flags, st);
+    if (train) gt.A = w + pl.off_xd;     // (written by the padding launch above)
   } else {      // Wt rows are K floats: unaligned -> scalar staging, mask applied while staging
     gt.B = Wt; gt.ldb = K; gt.tb = 0; gt.b_kc = false;
     gt.N = K;
     if (train) set_dropout(gt, true, false, keep_prob, seed, offset, flags);
   }
   gt.splits = gemm_pick_splits(R, Kp, C); if (gt.splits > 8) gt.splits = 8;
-  gt.ws = gws;
-  rc = gemm_launch(gt, st);
+  gt.ws = gws + (size_t)8 * R * Kp;
+  // Z | T: same shape when the attention input has C channels too -- one launch (GemmDesc::twin), else one after
+  // the other (the dispatcher decides)
+  gz.twin = &gt;
+  int rc = gemm_launch(gz, st);
   if (rc != APA_OK) return rc;
   dim3 grid(N, (K + 63) / 64);
   if (dtype == APA_DTYPE_F32)
@@ -1366,6 +1407,14 @@ int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
     hipLaunchKernelGGL(pc_fwd_act_kernel<bf16_t>, grid, dim3(64 * PC_PG), 0, st, Z, Kp, Tsave, att, logits,
                        static_cast<bf16_t*>(topdown), P, K, act_code(flags), PcXent{nullptr, nullptr, nullptr, 0.f});
   APA_LAUNCH_CHECK("pc_fwd_act_kernel");
+  // one-call train step: the cross-entropy of the logits row is taken by the backward activation pass (one launch
+  // less); the batch mean rides on the column-sum launch that ends the backward half
+  static const int fold_xent = knob("APA_PC_XENT_FOLD", 1);
+  if (fold_xent && xf && xf->labels && xf->G && xf->loss && !xf->probs && K >= 4 && K <= 1024) {
+    xf->done = true;
+    xf->deferred = true;
+    xf->logits = logits;
+  }
   return APA_OK;
 }
 
@@ -1416,7 +1465,7 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
     bf16_t* dTc = static_cast<bf16_t*>(f.dTdZ);              // [R][dT (64) | dZ (64)]
     const int ps = pc_bwd_act_psplit(N, (Kp + 63) / 64, P, act_code(flags));
     dim3 grid(N, (Kp + 63) / 64, ps);
-    PcDefer df = {nullptr, nullptr, {nullptr, nullptr, nullptr, 0.f}};
+    PcDefer df = {nullptr, nullptr, {nullptr, nullptr, nullptr, 0.f}, nullptr};
     if (xf && xf->deferred) {
       df.lpart = f.lpart; df.logits = xf->logits;
       df.xe.labels = xf->labels; df.xe.loss = xf->loss; df.xe.G = xf->G; df.xe.gscale = xf->gscale;
@@ -1451,19 +1500,29 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
     PcPadList pads;
     pads.add(Wa, WaP, Ca, Kp, wb16);
     pads.add(Wt, WtP, C, Kp, wb16);
-    pads.launch(K, Kp, st);
+    if (fast_bf16 && train) {   // + dropout(X) for the dWt product, same launch
+      const PcDropArgs dr = pc_drop_args(X, w + pl.off_xd, pl.R, C, keep_prob, seed, offset, flags);
+      pads.launch(K, Kp, st, &dr);
+    } else {
+      pads.launch(K, Kp, st);
+    }
     APA_LAUNCH_CHECK("pc_pad_kernel");
   }
   const int ps = pc_bwd_act_psplit(N, (Kp + 63) / 64, P, act_code(flags));
   dim3 grid(N, (Kp + 63) / 64, ps);
+  PcDefer df = {nullptr, nullptr, {nullptr, nullptr, nullptr, 0.f}, nullptr};
+  if (xf && xf->deferred) {
+    df.row_logits = xf->logits;
+    df.xe.labels = xf->labels; df.xe.loss = xf->loss; df.xe.G = xf->G; df.xe.gscale = xf->gscale;
+  }
   if (dtype == APA_DTYPE_F32)
     hipLaunchKernelGGL(pc_bwd_act_kernel<float>, grid, dim3(64 * PC_PG), 0, st, G, att, Tsave,
                        static_cast<float*>(dT), static_cast<float*>(dZ), pdbt, pdba, P, K, Kp,
-                       act_code(flags), Kp, PcDefer{nullptr, nullptr, {nullptr, nullptr, nullptr, 0.f}});
+                       act_code(flags), Kp, df);
   else
     hipLaunchKernelGGL(pc_bwd_act_kernel<bf16_t>, grid, dim3(64 * PC_PG), 0, st, G, att, Tsave,
                        static_cast<bf16_t*>(dT), static_cast<bf16_t*>(dZ), pdbt, pdba, P, K, Kp,
-                       act_code(flags), Kp, PcDefer{nullptr, nullptr, {nullptr, nullptr, nullptr, 0.f}});
+                       act_code(flags), Kp, df);
   APA_LAUNCH_CHECK("pc_bwd_act_kernel");
   int rc = APA_OK;
   {  // dWt[c,k] = sum_r Xt[r,c] dT[r,k]
@@ -1476,26 +1535,24 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
     const bool fast = dtype == APA_DTYPE_BF16 && C % 8 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
     if (fast) {
       g.N = Kp; g.n_valid = K;   // dT is [R][Kp] with zero pad columns
-      if (train)
-        g.A = reuse_fwd ? static_cast<const void*>(w + pl.off_xd)
-                        : pc_dropped_features(X, w + pl.off_xd, pl.R, C, keep_prob, seed, offset, flags, st);
+      if (train) g.A = w + pl.off_xd;   // (from the forward call, or from the padding launch above)
     } else if (train) {
       set_dropout(g, true, false, keep_prob, seed, offset, flags);
       // dropout index of A(m=c, k=r) is r*C + c: the stager computes row*Ktot + k with row = m, so
       // the transposed operand needs the swapped form -> handled by drop_a == 2
       g.drop_a = 2;
     }
-    rc = gemm_launch(g, st);
-    if (rc != APA_OK) return rc;
-  }
-  {  // dWa[c,k] = sum_r Xatt[r,c] dZ[r,k]
-    GemmDesc g;
-    g.A = Xatt; g.lda = Ca; g.ta = tdt; g.a_kc = false;
-    g.B = dZ; g.ldb = Kp; g.tb = tdt; g.b_kc = false;
-    g.C = dWa; g.ldc = K; g.tc = 0;
-    g.M = Ca; g.N = K; g.K = R;
-    g.splits = gemm_pick_splits(Ca, K, R); g.ws = gws;
-    if (dtype == APA_DTYPE_BF16) { g.N = Kp; g.n_valid = K; }   // dZ is [R][Kp] with zero pad columns
+    // dWa[c,k] = sum_r Xatt[r,c] dZ[r,k]: the twin of the same launch when the shapes agree (Ca == C, bf16)
+    GemmDesc h;
+    h.A = Xatt; h.lda = Ca; h.ta = tdt; h.a_kc = false;
+    h.B = dZ; h.ldb = Kp; h.tb = tdt; h.b_kc = false;
+    h.C = dWa; h.ldc = K; h.tc = 0;
+    h.M = Ca; h.N = K; h.K = R;
+    h.splits = gemm_pick_splits(Ca, K, R);
+    const int cm = C > Ca ? C : Ca;
+    h.ws = gws + (size_t)32 * cm * Kp;
+    if (dtype == APA_DTYPE_BF16) { h.N = Kp; h.n_valid = K; }   // dZ is [R][Kp] with zero pad columns
+    g.twin = &h;
     rc = gemm_launch(g, st);
     if (rc != APA_OK) return rc;
   }
@@ -1522,7 +1579,11 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
   // after every kernel that keys its mask with it has run
   uint64_t* bump = (train && (flags & APA_FLAG_RNG_DEVICE))
                        ? reinterpret_cast<uint64_t*>(static_cast<uintptr_t>(offset)) : nullptr;
-  return m1_colsum(pdbt, nullptr, dbt, nullptr, N * ps, 2 * K, 2 * K, bump, st, dba, K);
+  ColsumMore more;
+  const bool mean = xf && xf->done;     // the batch mean of a cross-entropy taken inside this step (xent's own order)
+  if (mean) { more.aux_src = xf->loss + 1; more.aux_n = -N; more.aux_scale = xf->lscale; more.aux_dst = xf->loss; }
+  return m1_colsum(pdbt, nullptr, dbt, nullptr, N * ps, 2 * K, 2 * K, bump, st, dba, K, nullptr, 0, 0, 0,
+                   mean ? &more : nullptr);
 }
 
 }  // namespace apa

@@ -428,4 +428,68 @@ __device__ __forceinline__ void pc_row_xent(const float* lrow, int n, int K, con
   }
 }
 
+// The same for any 4 <= K <= 1024: softmax_xent_kernel<NV4>'s arithmetic (apa_loss.hip) on one row that lies in global
+// memory -- NV4 = 16-byte vectors per lane of the half wave; ONE whole wave calls it, both halves run the same row.
+// Three passes that re-read the row (cache hits) instead of holding 4 * NV4 values per lane: the caller is a 16-wave
+// block whose occupancy 100+ registers would halve (pc_bwd_act_kernel went 7.4 -> 14.4 us with the register form).
+// The operation order per lane -- vectors in increasing i, elements in increasing e, then the half-wave trees -- is
+// the kernel's, so the results are bit-identical.
+// grow (LDS, >= K floats) receives the gradient row; write: G[n, :] and loss[1 + n] also go to memory.
+__device__ __forceinline__ void pc_row_xent_any(const float* __restrict__ row, int n, int K, const PcXent& xe, bool write,
+                                                float* grow) {
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  const int nv4 = K <= 128 ? 1 : (K <= 256 ? 2 : (K <= 512 ? 4 : 8));
+  const int lane = threadIdx.x & 63, hl = lane & 31;
+  const int lab = (int)xe.labels[n];
+  const bool lab_ok = lab >= 0 && lab < K;
+  const float xl = row[lab_ok ? lab : 0];
+  auto vec = [&](int i, int& colc) {       // this lane's i-th vector, columns the previous lane covers masked out
+    const int col0 = 4 * (hl + 32 * i);
+    colc = min(col0, K - 4);
+    f4u v = *reinterpret_cast<const f4u*>(row + colc);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = colc + e >= col0 ? v[e] : -INFINITY;
+    return v;
+  };
+  float m = -INFINITY;
+#pragma unroll 1
+  for (int i = 0; i < nv4; ++i) {
+    int colc;
+    const f4u v = vec(i, colc);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (v[e] > m) m = v[e];
+  }
+  const float mw = half_max(m, lane);
+  float l = 0.f;
+#pragma unroll 1
+  for (int i = 0; i < nv4; ++i) {
+    int colc;
+    const f4u v = vec(i, colc);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) l += exp_fast(v[e] - mw);
+  }
+  l = half_sum(l, lane);
+  const float inv = 1.0f / l;
+  const float lv = lab_ok ? -(xl - mw - logf(l)) : 0.f;
+  if (lane < 32) {
+#pragma unroll 1
+    for (int i = 0; i < nv4; ++i) {
+      int colc;
+      const f4u v = vec(i, colc);
+      const int col0 = 4 * (hl + 32 * i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = colc + e;
+        if (c >= col0 && c < K) {
+          const float gv = fmaf(exp_fast(v[e] - mw) * inv, xe.gscale, c == lab ? -xe.gscale : 0.f);
+          if (write) xe.G[(size_t)n * K + c] = gv;
+          grow[c] = gv;
+        }
+      }
+    }
+    if (hl == 0 && write) xe.loss[1 + n] = lv;
+  }
+}
+
 }  // namespace apa

@@ -285,20 +285,26 @@ __global__ __launch_bounds__(256) void gemm128_kernel(GemmParams p) {
 
 // C = act(sum_s partial[s] + bias) + beta*C, fixed order over s.  One thread per 4 consecutive
 // elements when rows allow it (VEC): all `splits` 16-byte loads of a thread in flight at once.
+// pN: row length of the partials (>= N: the bf16 kernels write zero-padded columns too, so that their rows stay
+// 16-byte addressable); blockIdx.y == 1: the twin problem of the launch (GemmDesc::twin).
+template <typename TC>
+struct ReduceTwin { const float* partial; TC* C; long ldc; const float* bias; int N; };
 template <typename TC, bool VEC>
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ partial,
                                                                  TC* __restrict__ C, long ldc,
-                                                                 int M, int N, int splits,
+                                                                 int M, int N, int pN, int splits,
                                                                  const float* __restrict__ bias,
-                                                                 float beta, int act) {
+                                                                 float beta, int act, ReduceTwin<TC> tw) {
+  if (blockIdx.y) { partial = tw.partial; C = tw.C; ldc = tw.ldc; bias = tw.bias; N = tw.N; }
   constexpr int W = VEC ? 4 : 1;
   const long idx = ((long)blockIdx.x * 256 + threadIdx.x) * W;
-  if (idx >= (long)M * N) return;
-  const int row = (int)(idx / N), col = (int)(idx % N);
+  if (idx >= (long)M * pN) return;
+  const int row = (int)(idx / pN), col = (int)(idx % pN);
+  if (col >= N) return;
   float v[W];
 #pragma unroll
   for (int e = 0; e < W; ++e) v[e] = 0.f;
-  const size_t stride = (size_t)M * N;
+  const size_t stride = (size_t)M * pN;
   for (int s0 = 0; s0 < splits; s0 += 8) {
     float t[8][W];
 #pragma unroll
@@ -318,6 +324,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
   }
 #pragma unroll
   for (int e = 0; e < W; ++e) {
+    if (col + e >= N) break;
     if (bias) v[e] += bias[col + e];
     if (act == 1) v[e] = fmaxf(v[e], 0.f);
     if (beta != 0.f) v[e] += Elem<TC>::get(C, (long)row * ldc + col + e);
@@ -373,14 +380,28 @@ static int gemm_launch_t(const GemmDesc& d, hipStream_t st) {
     return APA_ERR_UNSUPPORTED;
   }
   const int tiles = ((d.M + GM - 1) / GM) * ((Nst + GN - 1) / GN);
+  int pN = Nst;                 // row length of the split-K partials
+  bool twin = false;
   if (gemm_bf16_eligible(d)) {
     // 64-deep K tiles: re-derive the split so every chunk is a multiple of 64
     int kps64 = (d.K + splits - 1) / splits;
     kps64 = (kps64 + 63) / 64 * 64;
     splits = (d.K + kps64 - 1) / kps64;
+    if (d.twin && !gemm_bf16_twin_ok(d, splits, kps64)) {   // one after the other
+      GemmDesc a = d; a.twin = nullptr;
+      const int rc = gemm_launch_t<TA, TB, TC, A_KC, B_KC>(a, st);
+      return rc != APA_OK ? rc : gemm_launch(*d.twin, st);
+    }
+    twin = d.twin != nullptr;
     const int rc = gemm_bf16_launch(d, splits, kps64, st);
     if (rc != APA_OK) return rc;
+    pN = d.N;
   } else {
+  if (d.twin) {
+    GemmDesc a = d; a.twin = nullptr;
+    const int rc = gemm_launch_t<TA, TB, TC, A_KC, B_KC>(a, st);
+    return rc != APA_OK ? rc : gemm_launch(*d.twin, st);
+  }
   if (d.r1_row) {
     set_error("gemm: the rank-1 epilogue exists in the wide bf16 kernel only (internal)");
     return APA_ERR_UNSUPPORTED;
@@ -390,15 +411,21 @@ static int gemm_launch_t(const GemmDesc& d, hipStream_t st) {
   APA_LAUNCH_CHECK("gemm128_kernel");
   }
   if (splits > 1) {
-    const long tot = (long)d.M * Nst;
-    if (Nst % 4 == 0 && aligned16(d.ws)) {
-      hipLaunchKernelGGL((gemm_splitk_reduce_kernel<TC, true>), dim3((unsigned)((tot / 4 + 255) / 256)),
-                         dim3(256), 0, st, d.ws, static_cast<TC*>(d.C), d.ldc, d.M, Nst, splits, d.bias,
-                         d.beta, d.act);
+    const long tot = (long)d.M * pN;
+    ReduceTwin<TC> tw = {nullptr, nullptr, 0, nullptr, 0};
+    if (twin) {
+      tw.partial = d.twin->ws; tw.C = static_cast<TC*>(d.twin->C); tw.ldc = d.twin->ldc; tw.bias = d.twin->bias;
+      tw.N = d.twin->n_valid > 0 ? d.twin->n_valid : d.twin->N;
+    }
+    const bool vec = pN % 4 == 0 && aligned16(d.ws) && (!twin || aligned16(d.twin->ws));
+    if (vec) {
+      hipLaunchKernelGGL((gemm_splitk_reduce_kernel<TC, true>), dim3((unsigned)((tot / 4 + 255) / 256), twin ? 2 : 1),
+                         dim3(256), 0, st, d.ws, static_cast<TC*>(d.C), d.ldc, d.M, Nst, pN, splits, d.bias,
+                         d.beta, d.act, tw);
     } else {
-      hipLaunchKernelGGL((gemm_splitk_reduce_kernel<TC, false>), dim3((unsigned)((tot + 255) / 256)),
-                         dim3(256), 0, st, d.ws, static_cast<TC*>(d.C), d.ldc, d.M, Nst, splits, d.bias,
-                         d.beta, d.act);
+      hipLaunchKernelGGL((gemm_splitk_reduce_kernel<TC, false>), dim3((unsigned)((tot + 255) / 256), twin ? 2 : 1),
+                         dim3(256), 0, st, d.ws, static_cast<TC*>(d.C), d.ldc, d.M, Nst, pN, splits, d.bias,
+                         d.beta, d.act, tw);
     }
     APA_LAUNCH_CHECK("gemm_splitk_reduce_kernel");
   }

@@ -120,7 +120,15 @@ struct FastParams {
   const uint8_t* maskbits;   // the keep decisions as bits ([M*Nout/8] bytes); Nout % 64 == 0
   // rank-1 addend of the epilogue (GemmDesc::r1_*; the wide kernel's own epilogue branch)
   const float* r1_row; const float* r1_col; const uint8_t* r1_bits; int r1_P; float r1_invP, r1_inv_keep;
+  // GemmDesc::twin: the second problem of the launch (blockIdx.y == 1); A2 == nullptr: none
+  const void* A2; const void* B2; void* C2; long ldc2; const float* bias2; float* partial2; int Nout2, vec_epi2;
 };
+__device__ __forceinline__ void twin_select(FastParams& p) {
+  if (blockIdx.y) {
+    p.A = p.A2; p.B = p.B2; p.C = p.C2; p.ldc = p.ldc2; p.bias = p.bias2; p.partial = p.partial2;
+    p.Nout = p.Nout2; p.vec_epi = p.vec_epi2;
+  }
+}
 
 // 8 consecutive output columns of one row: split-K partial, or bias / relu / output dropout /
 // + beta*C / pack and one 16-byte store
@@ -564,6 +572,7 @@ __device__ __forceinline__ bf16x8 fragment_b64(const short* img, int rbase, int 
 template <typename TC, bool A_KM, bool B_KM>
 __global__ __launch_bounds__(256, 3) void gemm_bf16_glds64_kernel(FastParams p) {
   extern __shared__ __attribute__((aligned(16))) short smem[];   // [2 stages][A 16 KiB | B 8 KiB]
+  twin_select(p);
   constexpr int BN = 64, STAGE = IMG + IMGB64;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
@@ -730,6 +739,7 @@ __device__ __forceinline__ void ring_wait_barrier() {
 template <typename TC, bool B_KM, int MT>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_ring_kernel(FastParams p) {
   typedef RingCfg<MT> R;
+  twin_select(p);
   extern __shared__ __attribute__((aligned(16))) short smem[];
   typedef __attribute__((address_space(3))) void* lptr;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -896,7 +906,7 @@ int launch_ring(const FastParams& p, hipStream_t st) {
     attr_set = true;
   }
   const int tiles = ((p.M + R::TMR - 1) / R::TMR) * ((p.N + TN - 1) / TN);
-  hipLaunchKernelGGL((gemm_bf16_ring_kernel<TC, B_KM, MT>), dim3(tiles), dim3(512), R::LDS_BYTES, st, p);
+  hipLaunchKernelGGL((gemm_bf16_ring_kernel<TC, B_KM, MT>), dim3(tiles, p.A2 ? 2 : 1), dim3(512), R::LDS_BYTES, st, p);
   APA_LAUNCH_CHECK("gemm_bf16_ring_kernel");
   return APA_OK;
 }
@@ -1215,7 +1225,7 @@ template <typename TC, bool A_KM, bool B_KM>
 int launch_glds64(const FastParams& p, int splits, hipStream_t st) {
   const size_t shm = (size_t)2 * (IMG + IMGB64) * sizeof(short);   // 49 152 B
   const int tiles = ((p.M + TM - 1) / TM) * ((p.N + 63) / 64);
-  hipLaunchKernelGGL((gemm_bf16_glds64_kernel<TC, A_KM, B_KM>), dim3(tiles, 1, splits), dim3(256), shm, st, p);
+  hipLaunchKernelGGL((gemm_bf16_glds64_kernel<TC, A_KM, B_KM>), dim3(tiles, p.A2 ? 2 : 1, splits), dim3(256), shm, st, p);
   APA_LAUNCH_CHECK("gemm_bf16_glds64_kernel");
   return APA_OK;
 }
@@ -1295,6 +1305,8 @@ int gemm_bf16_mid_dropout(const void* A, long lda, const void* B, long ldb, void
   p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
   p.M = M; p.N = N; p.K = K; p.bias = nullptr; p.beta = 0.f; p.act = 0;
   p.k_per_split = K; p.partial = nullptr; p.Nout = N;
+  p.A2 = nullptr; p.B2 = nullptr; p.C2 = nullptr; p.ldc2 = 0; p.bias2 = nullptr; p.partial2 = nullptr;
+  p.Nout2 = 0; p.vec_epi2 = 0;
   p.drop_c = 0; p.inv_keep = inv_keep; p.thresh = 0; p.seed = 0; p.offset = 0;
   p.offset_dev = nullptr;
   p.vec_epi = N % 8 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && (ldc * 2) % 16 == 0;
@@ -1342,31 +1354,76 @@ bool gemm_bf16_eligible(const GemmDesc& d) {
   return true;
 }
 
-// splits / k_per_split as chosen by the caller (k_per_split a multiple of 64)
+// which kernel gemm_bf16_launch picks for an eligible product
+enum { KIND_GENERIC = 0, KIND_WIDE, KIND_RING, KIND_GLDS64, KIND_GLDS128 };
+static int bf16_kind(const GemmDesc& d, int splits, int k_per_split) {
+  static const int use_glds = knob("APA_GEMM_GLDS", 1);
+  if (!(use_glds && d.tb == 1 && k_per_split % TK == 0 && d.K % TK == 0)) return KIND_GENERIC;
+  if (splits == 1 && d.a_kc && d.b_kc && gemm_bf16_wide_serves(d.M, d.N, d.K)) return KIND_WIDE;
+  static const int use_ring = knob("APA_GEMM_RING", 1);
+  if (use_ring && d.a_kc && splits == 1 && d.K / TK >= 4 && ring_pick_mt(d.M, d.N, gemm_cu_count())) return KIND_RING;
+  static const int bn_env = knob("APA_GEMM_BN", 0);
+  const long tiles128 = (long)((d.M + TM - 1) / TM) * ((d.N + TN - 1) / TN) * splits;
+  return (bn_env ? bn_env : (tiles128 < 640 ? 64 : 128)) == 64 ? KIND_GLDS64 : KIND_GLDS128;
+}
+bool gemm_bf16_twin_ok(const GemmDesc& d, int splits, int k_per_split) {
+  static const int enabled = knob("APA_GEMM_TWIN", 1);
+  if (!enabled || !d.twin) return false;
+  const GemmDesc& t = *d.twin;
+  if (!gemm_bf16_eligible(d) || !gemm_bf16_eligible(t)) return false;
+  if (t.ta != d.ta || t.tb != d.tb || t.tc != d.tc || t.a_kc != d.a_kc || t.b_kc != d.b_kc || t.M != d.M ||
+      t.N != d.N || t.K != d.K || t.lda != d.lda || t.ldb != d.ldb || t.beta != d.beta || t.act != d.act ||
+      d.drop_c || t.drop_c || d.r1_row || t.r1_row || t.twin)
+    return false;
+  if (splits > 1 && (!d.ws || !t.ws || d.ws == t.ws)) return false;
+  const int kind = bf16_kind(d, splits, k_per_split);
+  return kind == KIND_RING || kind == KIND_GLDS64;
+}
+
+static bool vec_epilogue_ok(const GemmDesc& d, int nout, const float* partial) {
+  const int ec = d.tc == 1 ? 2 : 4;
+  return nout % 8 == 0 && (!d.drop_c || nout % 2 == 0) && (reinterpret_cast<uintptr_t>(d.C) & 15) == 0 &&
+         (d.ldc * ec) % 16 == 0 && (!d.bias || (reinterpret_cast<uintptr_t>(d.bias) & 15) == 0) &&
+         (!partial || (reinterpret_cast<uintptr_t>(partial) & 15) == 0);
+}
+
+// splits / k_per_split as chosen by the caller (k_per_split a multiple of 64).  Split-K partials are [splits][M][N]
+// over ALL N columns, zero-padded ones included (rows of n_valid floats are not 16-byte addressable: the scalar
+// epilogue and reduce cost 25 + 5.3 us per dW product of the K = 393 per-class maps).
 int gemm_bf16_launch(const GemmDesc& d, int splits, int k_per_split, hipStream_t st) {
   FastParams p;
   p.A = d.A; p.lda = d.lda; p.B = d.B; p.ldb = d.ldb; p.C = d.C; p.ldc = d.ldc;
   p.M = d.M; p.N = d.N; p.K = d.K; p.bias = d.bias; p.beta = d.beta; p.act = d.act;
   p.k_per_split = k_per_split;
   p.partial = splits > 1 ? d.ws : nullptr;
-  p.Nout = d.n_valid > 0 ? d.n_valid : d.N;
+  p.Nout = (d.n_valid > 0 && splits == 1) ? d.n_valid : d.N;
+  p.A2 = nullptr; p.B2 = nullptr; p.C2 = nullptr; p.ldc2 = 0; p.bias2 = nullptr; p.partial2 = nullptr;
+  p.Nout2 = 0; p.vec_epi2 = 0;
   p.drop_c = d.drop_c; p.inv_keep = d.inv_keep; p.thresh = d.thresh; p.seed = d.seed; p.offset = d.offset;
   p.offset_dev = d.offset_dev;
   p.drop_mid = -1;
   p.maskbits = nullptr;
   p.r1_row = nullptr; p.r1_col = nullptr; p.r1_bits = nullptr; p.r1_P = 1; p.r1_invP = 0.f; p.r1_inv_keep = 1.f;
-  const int ec = d.tc == 1 ? 2 : 4;
-  p.vec_epi = p.Nout % 8 == 0 && (!d.drop_c || p.Nout % 2 == 0) && (reinterpret_cast<uintptr_t>(d.C) & 15) == 0 && (d.ldc * ec) % 16 == 0 &&
-              (!d.bias || (reinterpret_cast<uintptr_t>(d.bias) & 15) == 0) &&
-              (!p.partial || (reinterpret_cast<uintptr_t>(p.partial) & 15) == 0);
-  static const int use_glds = knob("APA_GEMM_GLDS", 1);
-  if (use_glds && d.tb == 1 && k_per_split % TK == 0 && d.K % TK == 0) {   // all-bf16, whole K tiles: DMA staging
+  p.vec_epi = vec_epilogue_ok(d, p.Nout, p.partial);
+  const int kind = bf16_kind(d, splits, k_per_split);
+  if (d.twin) {
+    if (!gemm_bf16_twin_ok(d, splits, k_per_split)) {
+      set_error("gemm_bf16: twin products reached a kernel that serves one problem per launch (internal)");
+      return APA_ERR_UNSUPPORTED;
+    }
+    const GemmDesc& t = *d.twin;
+    p.A2 = t.A; p.B2 = t.B; p.C2 = t.C; p.ldc2 = t.ldc; p.bias2 = t.bias;
+    p.partial2 = splits > 1 ? t.ws : nullptr;
+    p.Nout2 = (t.n_valid > 0 && splits == 1) ? t.n_valid : t.N;
+    p.vec_epi2 = vec_epilogue_ok(t, p.Nout2, p.partial2);
+  }
+  if (kind != KIND_GENERIC) {   // all-bf16, whole K tiles: DMA staging
     // tile shape: with fewer than ~2.5 tiles of 128 x 128 per CU the ragged last round dominates and
     // the 128 x 64 variant (twice the tiles, three blocks per CU) wins -- measured on the pose head:
     // 294 tiles 38.2 -> 32.6 us, 96 x 3 splits 40.0 -> 35.2 us, but 784 tiles 34.4 -> 37.4 us
     // few tiles, A k-contiguous, no split-K: the ring kernel (one resident round, 3-4 K tiles in flight)
     // wide output, short contraction, both operands k-contiguous, no split-K: one resident round of 256-wide tiles
-    if (splits == 1 && d.a_kc && d.b_kc && gemm_bf16_wide_serves(d.M, d.N, d.K)) {
+    if (kind == KIND_WIDE) {
       const int mt = wide_pick_mt(d.M, d.N, gemm_cu_count());
       if (d.r1_row) {   // the rank-1 addend lives in the vector epilogue
         if (!p.vec_epi || d.n_valid > 0 || d.tc != 1 || d.bias || d.act || d.drop_c || d.beta != 0.f ||
@@ -1384,18 +1441,12 @@ int gemm_bf16_launch(const GemmDesc& d, int splits, int k_per_split, hipStream_t
       set_error("gemm_bf16: rank-1 epilogue requested for a product the wide kernel does not serve (internal)");
       return APA_ERR_UNSUPPORTED;
     }
-    static const int use_ring = knob("APA_GEMM_RING", 1);
-    if (use_ring && d.a_kc && splits == 1 && d.K / TK >= 4) {
+    if (kind == KIND_RING) {
       const int mt = ring_pick_mt(d.M, d.N, gemm_cu_count());
-      if (mt) {
-        if (d.tc == 1) return d.b_kc ? launch_ring_mt<bf16_t, false>(p, mt, st) : launch_ring_mt<bf16_t, true>(p, mt, st);
-        return d.b_kc ? launch_ring_mt<float, false>(p, mt, st) : launch_ring_mt<float, true>(p, mt, st);
-      }
+      if (d.tc == 1) return d.b_kc ? launch_ring_mt<bf16_t, false>(p, mt, st) : launch_ring_mt<bf16_t, true>(p, mt, st);
+      return d.b_kc ? launch_ring_mt<float, false>(p, mt, st) : launch_ring_mt<float, true>(p, mt, st);
     }
-    static const int bn_env = knob("APA_GEMM_BN", 0);
-    const long tiles128 = (long)((d.M + TM - 1) / TM) * ((d.N + TN - 1) / TN) * splits;
-    const int bn = bn_env ? bn_env : (tiles128 < 640 ? 64 : 128);
-    if (bn == 64) {
+    if (kind == KIND_GLDS64) {
       if (d.tc == 1) return launch_glds64_layout<bf16_t>(p, !d.a_kc, !d.b_kc, splits, st);
       return launch_glds64_layout<float>(p, !d.a_kc, !d.b_kc, splits, st);
     }

@@ -166,6 +166,11 @@ struct GemmDesc {
   // instead of being written by the streaming kernel and read back (beta = 1).  Wide kernel only.
   const float* r1_row = nullptr; const float* r1_col = nullptr; const uint8_t* r1_bits = nullptr;
   int r1_P = 0; float r1_invP = 0.f, r1_inv_keep = 1.f;
+  // a second product of the SAME shape, layouts, dtypes, beta, act and split count, served by the same launch
+  // (blockIdx.y selects the problem) when the kernel that takes the first one can (DMA ring / 128 x 64 tiles of the bf16
+  // path, and the split-K reduce); else the two are launched one after the other.  Only A, B, C, ldc, n_valid, bias
+  // and ws differ.  Used by the per-class maps (Z | T, dWt | dWa): bit-identical to two launches.
+  const GemmDesc* twin = nullptr;
 };
 bool gemm_bf16_wide_serves(int M, int N, int K);   // would this all-bf16, k-contiguous, unsplit product take the wide kernel?
 int gemm_bf16_wide_tile_rows(int M, int N, int K);  // ... and with how many rows per tile (0 = not served)
@@ -175,6 +180,7 @@ int gemm_launch(const GemmDesc& d, hipStream_t st);
 // apa_gemm_bf16.hip: the fast bf16 path (128x128x64, transposing LDS reads for k-major operands)
 bool gemm_bf16_eligible(const GemmDesc& d);
 int gemm_bf16_launch(const GemmDesc& d, int splits, int k_per_split, hipStream_t st);
+bool gemm_bf16_twin_ok(const GemmDesc& d, int splits, int k_per_split);   // can d and d.twin share one launch?
 
 // ------------------------------------------------------------------------------------------
 // M == 1 factorised path (apa_m1.hip)
