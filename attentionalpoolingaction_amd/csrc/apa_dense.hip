@@ -705,6 +705,7 @@ static int pose_head_bwd_big(const void* X, const float* W1, const void* dPpre, 
     g.B = W1op; g.ldb = Cp; g.tb = w1_tb; g.b_kc = true;   // W1 [C][Cp]: n = c rows, k contiguous
     g.C = dX; g.ldc = C; g.tc = tdt;
     g.M = R; g.N = C; g.K = Cp; g.beta = (accumulate_dX & 1) ? 1.f : 0.f;
+    g.stream_out = true;      // dX is the step's output: nothing in this call reads it back
     if (fuse && fuse->pool_att) {   // nothing was written to dX: its pooling share is formed in this epilogue
       g.beta = 0.f;
       g.r1_row = fuse->pool_att; g.r1_col = fuse->pool_dz; g.r1_bits = fuse->pool_bits; g.r1_P = fuse->pool_P;
@@ -1572,6 +1573,7 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
     g.B = WaP; g.ldb = Kp; g.tb = wb16 ? 1 : 0; g.b_kc = true;
     g.C = fused ? dX : dXatt; g.ldc = fused ? C : Ca; g.tc = tdt;
     g.M = R; g.N = fused ? C : Ca; g.K = Kp; g.beta = fused ? 1.f : 0.f;
+    g.stream_out = true;
     rc = gemm_launch(g, st);
     if (rc != APA_OK) return rc;
   }

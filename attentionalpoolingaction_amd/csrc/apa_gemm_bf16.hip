@@ -122,6 +122,7 @@ struct FastParams {
   const float* r1_row; const float* r1_col; const uint8_t* r1_bits; int r1_P; float r1_invP, r1_inv_keep;
   // GemmDesc::twin: the second problem of the launch (blockIdx.y == 1); A2 == nullptr: none
   const void* A2; const void* B2; void* C2; long ldc2; const float* bias2; float* partial2; int Nout2, vec_epi2;
+  int nt_out;    // GemmDesc::stream_out: non-temporal bf16 vector stores of C
 };
 __device__ __forceinline__ void twin_select(FastParams& p) {
   if (blockIdx.y) {
@@ -171,7 +172,8 @@ __device__ __forceinline__ void store8(const FastParams& p, TC* C, int grow, int
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] += c[e];
     }
-    st16(dst, Vec<bf16_t>::pack(o));
+    if (p.nt_out) st16_nt(dst, Vec<bf16_t>::pack(o));
+    else st16(dst, Vec<bf16_t>::pack(o));
   } else {
     float* d = reinterpret_cast<float*>(dst);
     if (p.beta != 0.f) {
@@ -271,7 +273,8 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][4], const FastParams& p
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] += c[e];
         }
-        st16(dst, Vec<bf16_t>::pack(o));
+        if (p.nt_out) st16_nt(dst, Vec<bf16_t>::pack(o));
+        else st16(dst, Vec<bf16_t>::pack(o));
       } else {
         float* d = reinterpret_cast<float*>(dst);
         if (p.beta != 0.f) {
@@ -1115,7 +1118,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_wide_kernel(FastParams p) {
             const float dz = k == 0 ? dzv[0][e] : (k == 1 ? dzv[1][e] : dzv[2][e]);
             o[e] = fmaf(((bitv[u] >> e) & 1u) ? apk[u] : 0.f, dz, o[e]);
           }
-          st16(reinterpret_cast<bf16_t*>(C) + (long)grow * p.ldc + gcol, Vec<bf16_t>::pack(o));
+          if (p.nt_out) st16_nt(reinterpret_cast<bf16_t*>(C) + (long)grow * p.ldc + gcol, Vec<bf16_t>::pack(o));
+          else st16(reinterpret_cast<bf16_t*>(C) + (long)grow * p.ldc + gcol, Vec<bf16_t>::pack(o));
         }
       }
       return;
@@ -1306,7 +1310,7 @@ int gemm_bf16_mid_dropout(const void* A, long lda, const void* B, long ldb, void
   p.M = M; p.N = N; p.K = K; p.bias = nullptr; p.beta = 0.f; p.act = 0;
   p.k_per_split = K; p.partial = nullptr; p.Nout = N;
   p.A2 = nullptr; p.B2 = nullptr; p.C2 = nullptr; p.ldc2 = 0; p.bias2 = nullptr; p.partial2 = nullptr;
-  p.Nout2 = 0; p.vec_epi2 = 0;
+  p.Nout2 = 0; p.vec_epi2 = 0; p.nt_out = 0;
   p.drop_c = 0; p.inv_keep = inv_keep; p.thresh = 0; p.seed = 0; p.offset = 0;
   p.offset_dev = nullptr;
   p.vec_epi = N % 8 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && (ldc * 2) % 16 == 0;
@@ -1399,6 +1403,8 @@ int gemm_bf16_launch(const GemmDesc& d, int splits, int k_per_split, hipStream_t
   p.Nout = (d.n_valid > 0 && splits == 1) ? d.n_valid : d.N;
   p.A2 = nullptr; p.B2 = nullptr; p.C2 = nullptr; p.ldc2 = 0; p.bias2 = nullptr; p.partial2 = nullptr;
   p.Nout2 = 0; p.vec_epi2 = 0;
+  static const int use_nt = knob("APA_GEMM_NT", 1);
+  p.nt_out = (use_nt && d.stream_out) ? 1 : 0;
   p.drop_c = d.drop_c; p.inv_keep = d.inv_keep; p.thresh = d.thresh; p.seed = d.seed; p.offset = d.offset;
   p.offset_dev = d.offset_dev;
   p.drop_mid = -1;
