@@ -18,6 +18,9 @@ dense APA_PC_FUSED=0
 dense APA_GEMM_RING=0
 dense APA_GEMM_WIDE=0
 dense APA_POSE_STEP_FUSED=0 APA_PC_XENT_FOLD=0
+dense APA_PC_ACT_FOLD=0
+dense APA_PC_DX_FUSED=0
+dense APA_GEMM_TWIN=0 APA_GEMM_NT=0
 dense APA_GEMM_GLDS=0
 dense APA_GEMM_FAST=0
 dense APA_POSE_BWD_ROWS=0 APA_POSE_PL_FAST=0
