@@ -16,10 +16,14 @@
 //                                                    ahead; the 1/keep scale goes on the fp32 accumulators.
 //   pc_bwd_dw_kernel   dWt | dWa = [Xd | X]^T . [dT | dZ]   one pass over X (k-major operand, transposing
 //                                                    LDS reads), same two-image trick, split over the rows.
-//   dX                 = (dT . Wt^T) * mask/keep + dZ . Wa^T   ONE launch of the DMA-staged GEMM
-//                                                    (apa_gemm_bf16.hip) over the concatenated operands
-//                                                    [dT | dZ] . [Wt | Wa]^T: the accumulators are masked
-//                                                    in registers between the two 64-deep k tiles.
+//   pc_bwd_dx_kernel   dX = (dT . Wt^T) * mask/keep + dZ . Wa^T   (identity / relu attention, round 4) a write-bound
+//                                                    kernel that also IS the backward activation pass: [dT | dZ]
+//                                                    formed in registers from att / T / G, transposed MFMA, 16-byte
+//                                                    stores straight from the accumulators.  Spatial-softmax
+//                                                    attention and P < 32 keep the older form: pc_bwd_act_kernel
+//                                                    (apa_dense.hip) + ONE launch of the DMA-staged GEMM
+//                                                    (apa_gemm_bf16.hip) over [dT | dZ] . [Wt | Wa]^T, accumulators
+//                                                    masked in registers between the two 64-deep k tiles.
 // The dropout mask is the library's counter-based one (flat element index r*C + c); the forward pass leaves
 // its keep decisions behind as a bit map (1/16 of the bf16 map) which the two backward kernels read.
 #include "apa_device.h"
