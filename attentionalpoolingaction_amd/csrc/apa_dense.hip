@@ -952,12 +952,14 @@ struct PcPadSegs {
   void* dst[3];
   long end[3];     // cumulative element counts (rows * Kp)
   int bf16[3];
+  int ld[3];       // row stride of dst in elements (>= Kp: two parameters can share rows as [Wt | Wa], see pc_cat)
   int n;
 };
 // Xd = X * mask / keep (bf16), the same counter-based mask as everywhere else (flat index r*C + c); block `bid` of `nb`
 struct PcDropArgs {
   const bf16_t* X; bf16_t* Xd; size_t n8; float inv_keep; uint32_t thresh; uint64_t seed, offset;
   const uint64_t* offset_dev; unsigned nblocks;     // nblocks == 0: none
+  uint8_t* bits;                                    // optional: the keep decisions, bit (e & 7) of byte e >> 3
 };
 __device__ __forceinline__ void pc_dropout_block(const PcDropArgs& a, unsigned bid, unsigned nb) {
   uint32_t k0, k1;
@@ -965,14 +967,18 @@ __device__ __forceinline__ void pc_dropout_block(const PcDropArgs& a, unsigned b
   for (size_t v = (size_t)bid * 256 + threadIdx.x; v < a.n8; v += (size_t)nb * 256) {
     float x[8];
     Vec<bf16_t>::unpack(ld16(a.X + v * 8), x);
+    uint32_t byte = 0;
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {
       float m0, m1;
       rng_keep2_x(v * 8 + e, k0, k1, a.thresh, m0, m1);
       x[e] *= m0 * a.inv_keep;
       x[e + 1] *= m1 * a.inv_keep;
+      byte |= (m0 != 0.f ? 1u : 0u) << e;
+      byte |= (m1 != 0.f ? 1u : 0u) << (e + 1);
     }
     st16(a.Xd + v * 8, Vec<bf16_t>::pack(x));
+    if (a.bits) a.bits[v] = (uint8_t)byte;
   }
 }
 // One thread per 8 output columns (Kp is a multiple of 8): 16-byte stores and 8x fewer waves -- the
@@ -996,10 +1002,11 @@ __global__ __launch_bounds__(256) void pc_pad_kernel(PcPadSegs sg, int K, int Kp
   float v[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = (k0 + e) < K ? src[k0 + e] : 0.f;
+  const size_t doff = (size_t)r * sg.ld[s] + k0;
   if (sg.bf16[s]) {
-    st16(static_cast<bf16_t*>(sg.dst[s]) + (size_t)j * 8, Vec<bf16_t>::pack(v));
+    st16(static_cast<bf16_t*>(sg.dst[s]) + doff, Vec<bf16_t>::pack(v));
   } else {
-    float4* d = reinterpret_cast<float4*>(static_cast<float*>(sg.dst[s]) + (size_t)j * 8);
+    float4* d = reinterpret_cast<float4*>(static_cast<float*>(sg.dst[s]) + doff);
     d[0] = make_float4(v[0], v[1], v[2], v[3]);
     d[1] = make_float4(v[4], v[5], v[6], v[7]);
   }
@@ -1007,13 +1014,13 @@ __global__ __launch_bounds__(256) void pc_pad_kernel(PcPadSegs sg, int K, int Kp
 struct PcPadList {
   PcPadSegs sg;
   PcPadList() { sg.n = 0; }
-  void add(const float* W, void* Wp, int rows, int Kp, bool to_bf16) {
+  void add(const float* W, void* Wp, int rows, int Kp, bool to_bf16, int ld = 0) {
     const int i = sg.n++;
-    sg.src[i] = W; sg.dst[i] = Wp; sg.bf16[i] = to_bf16 ? 1 : 0;
+    sg.src[i] = W; sg.dst[i] = Wp; sg.bf16[i] = to_bf16 ? 1 : 0; sg.ld[i] = ld > 0 ? ld : Kp;
     sg.end[i] = (i ? sg.end[i - 1] : 0) + (long)rows * Kp;
   }
   void launch(int K, int Kp, hipStream_t st, const PcDropArgs* drop = nullptr) const {
-    PcDropArgs dr = {nullptr, nullptr, 0, 1.f, 0, 0, 0, nullptr, 0};
+    PcDropArgs dr = {nullptr, nullptr, 0, 1.f, 0, 0, 0, nullptr, 0, nullptr};
     if (drop) dr = *drop;
     hipLaunchKernelGGL(pc_pad_kernel, dim3((unsigned)(((sg.end[sg.n - 1] >> 3) + 255) / 256) + dr.nblocks), dim3(256), 0,
                        st, sg, K, Kp, dr);
@@ -1239,7 +1246,7 @@ __global__ __launch_bounds__(1024) void pc_bwd_act_kernel(const float* __restric
 struct PcPlan {
   long R;
   int Kp;
-  size_t off_wap, off_wtp, off_bap, off_z, off_dt, off_dz, off_pdbt, off_pdba, off_gemm, off_xd, off_fused, total;
+  size_t off_wap, off_wtp, off_bap, off_z, off_dt, off_dz, off_pdbt, off_pdba, off_gemm, off_xd, off_bits, off_fused, total;
 };
 static PcPlan pc_plan(int N, int P, int C, int Ca, int K, int dtype) {
   PcPlan pl;
@@ -1267,6 +1274,8 @@ static PcPlan pc_plan(int N, int P, int C, int Ca, int K, int dtype) {
   // bf16 training: dropout(X) materialised once per call, so the MFMA GEMMs that consume it can DMA
   // their operands (the generic kernel applies the mask while staging through registers)
   pl.off_xd = off;   off += dtype == APA_DTYPE_BF16 ? align_up((size_t)pl.R * C * 2, 256) : 0;
+  // ... and its keep decisions as bits: the one-launch dX product masks its accumulators with them (pc_cat)
+  pl.off_bits = off; off += dtype == APA_DTYPE_BF16 ? align_up((size_t)pl.R * C / 8 + 16, 256) : 0;
   // K <= 64, bf16: operands of the HBM-bound fused kernels (apa_pc_fused.hip)
   pl.off_fused = off; off += (dtype == APA_DTYPE_BF16 && K <= 64 && Ca == C) ? pc_fused_ws_bytes(N, P, C) : 0;
   pl.total = off;
@@ -1274,13 +1283,23 @@ static PcPlan pc_plan(int N, int P, int C, int Ca, int K, int dtype) {
 }
 
 static PcDropArgs pc_drop_args(const void* X, void* Xd, long R, int C, float keep_prob, uint64_t seed, uint64_t offset,
-                               unsigned flags) {
+                               unsigned flags, uint8_t* bits) {
   const size_t n8 = (size_t)R * C / 8;
   size_t nb = (n8 + 255) / 256;
   if (nb > 4096) nb = 4096;
   const RngKeyArgs k = rng_resolve(flags, keep_prob, seed, offset);
   return PcDropArgs{static_cast<const bf16_t*>(X), static_cast<bf16_t*>(Xd), n8, 1.0f / keep_prob, k.thresh, k.seed,
-                    k.offset, k.offset_dev, (unsigned)nb};
+                    k.offset, k.offset_dev, (unsigned)nb, bits};
+}
+
+// bf16, attention and top-down weights of the same height (Ca == C), 16-byte addressable features: the padded bf16
+// weights lie as ONE [C][Wt (Kp) | Wa (Kp)] image and [dT | dZ] as one [R][2 Kp] image, so that
+//     dX = (dT . Wt^T) * mask/keep + dZ . Wa^T
+// is ONE product over the concatenated contraction (the wide kernel's mid-contraction mask) instead of a product plus
+// a read-modify-write product over the 25.7 MB result.  The forward / dW products read the halves with ld = 2 Kp.
+static bool pc_cat(const void* X, int C, int Ca, int dtype) {
+  static const int enabled = knob("APA_PC_CAT", 1);
+  return enabled && dtype == APA_DTYPE_BF16 && Ca == C && C % 8 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
 }
 
 size_t pc_workspace_bytes(int N, int P, int C, int Ca, int K, int dtype) {
@@ -1307,10 +1326,13 @@ int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
                uint64_t offset, int dtype, hipStream_t st, M1Xent* xf) {
   const PcPlan pl = pc_plan(N, P, C, Ca, K, dtype);
   char* w = static_cast<char*>(ws);
-  void* WaP = w + pl.off_wap;
+  const int Kp = pl.Kp, R = (int)pl.R;
+  const bool cat = pc_cat(X, C, Ca, dtype);
+  const int ldw = cat ? 2 * Kp : Kp;
+  void* WtP = w + pl.off_wtp;                                                   // (bf16 when it is padded at all)
+  void* WaP = cat ? static_cast<void*>(static_cast<bf16_t*>(WtP) + Kp) : static_cast<void*>(w + pl.off_wap);
   float* baP = reinterpret_cast<float*>(w + pl.off_bap);
   float* Z = reinterpret_cast<float*>(w + pl.off_z);
-  const int Kp = pl.Kp, R = (int)pl.R;
   const bool train = (flags & APA_FLAG_TRAIN) && keep_prob < 1.0f;
   const int tdt = dt_code(dtype);
   const bool wb16 = dtype == APA_DTYPE_BF16;   // padded weights stored as bf16
@@ -1359,11 +1381,12 @@ int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
   }
   {
     PcPadList pads;
-    pads.add(Wa, WaP, Ca, Kp, wb16);
+    pads.add(Wa, WaP, Ca, Kp, wb16, ldw);
     pads.add(ba, baP, 1, Kp, false);
-    if (fast) pads.add(Wt, w + pl.off_wtp, C, Kp, true);
-    if (fast && train) {   // + the materialised dropout(X) of the DMA-staged T product, same launch
-      const PcDropArgs dr = pc_drop_args(X, w + pl.off_xd, pl.R, C, keep_prob, seed, offset, flags);
+    if (fast) pads.add(Wt, WtP, C, Kp, true, ldw);
+    if (fast && train) {   // + the materialised dropout(X) of the DMA-staged T product (and its keep bits), same launch
+      const PcDropArgs dr = pc_drop_args(X, w + pl.off_xd, pl.R, C, keep_prob, seed, offset, flags,
+                                         reinterpret_cast<uint8_t*>(w + pl.off_bits));
       pads.launch(K, Kp, st, &dr);
     } else {
       pads.launch(K, Kp, st);
@@ -1372,7 +1395,7 @@ int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
   }
   GemmDesc gz;  // Z = Xatt . Wa + ba
   gz.A = Xatt; gz.lda = Ca; gz.ta = tdt; gz.a_kc = true;
-  gz.B = WaP; gz.ldb = Kp; gz.tb = wb16 ? 1 : 0; gz.b_kc = false;
+  gz.B = WaP; gz.ldb = ldw; gz.tb = wb16 ? 1 : 0; gz.b_kc = false;
   gz.C = Z; gz.ldc = Kp; gz.tc = 0;
   gz.M = R; gz.N = Kp; gz.K = Ca; gz.bias = baP;
   // N = Kp is one tile column: R/128 blocks cannot fill 256 CUs, so split the contraction
@@ -1384,8 +1407,7 @@ int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
   gt.C = Tsave; gt.ldc = K; gt.tc = 0;
   gt.M = R; gt.K = C; gt.bias = bt;
   if (fast) {   // zero-padded weights (16-byte rows) + materialised dropout: the DMA-staged MFMA GEMM
-    void* WtP = w + pl.off_wtp;
-    gt.B = WtP; gt.ldb = Kp; gt.tb = 1; gt.b_kc = false;
+    gt.B = WtP; gt.ldb = ldw; gt.tb = 1; gt.b_kc = false;
     gt.N = Kp; gt.n_valid = K;
     if (train) gt.A = w + pl.off_xd;     // (written by the padding launch above)
   } else {      // Wt rows are K floats: unaligned -> scalar staging, mask applied while staging
@@ -1426,10 +1448,12 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
                 hipStream_t st, const M1Xent* xf) {
   const PcPlan pl = pc_plan(N, P, C, Ca, K, dtype);
   char* w = static_cast<char*>(ws);
-  void* WaP = w + pl.off_wap;
+  const bool cat = pc_cat(X, C, Ca, dtype);
+  const int ldw = cat ? 2 * pl.Kp : pl.Kp;      // row stride of the padded weights and of [dT | dZ]
   void* WtP = w + pl.off_wtp;
+  void* WaP = cat ? static_cast<void*>(static_cast<bf16_t*>(WtP) + pl.Kp) : static_cast<void*>(w + pl.off_wap);
   void* dT = w + pl.off_dt;
-  void* dZ = w + pl.off_dz;
+  void* dZ = cat ? static_cast<void*>(static_cast<bf16_t*>(dT) + pl.Kp) : static_cast<void*>(w + pl.off_dz);
   float* pdbt = reinterpret_cast<float*>(w + pl.off_pdbt);
   float* pdba = reinterpret_cast<float*>(w + pl.off_pdba);
   float* gws = reinterpret_cast<float*>(w + pl.off_gemm);
@@ -1499,10 +1523,11 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
   const bool reuse_fwd = (flags & APA_FLAG_WS_FROM_FWD) && fast_bf16;
   if (!reuse_fwd) {
     PcPadList pads;
-    pads.add(Wa, WaP, Ca, Kp, wb16);
-    pads.add(Wt, WtP, C, Kp, wb16);
-    if (fast_bf16 && train) {   // + dropout(X) for the dWt product, same launch
-      const PcDropArgs dr = pc_drop_args(X, w + pl.off_xd, pl.R, C, keep_prob, seed, offset, flags);
+    pads.add(Wa, WaP, Ca, Kp, wb16, ldw);
+    pads.add(Wt, WtP, C, Kp, wb16, ldw);
+    if (fast_bf16 && train) {   // + dropout(X) for the dWt product (and its keep bits), same launch
+      const PcDropArgs dr = pc_drop_args(X, w + pl.off_xd, pl.R, C, keep_prob, seed, offset, flags,
+                                         reinterpret_cast<uint8_t*>(w + pl.off_bits));
       pads.launch(K, Kp, st, &dr);
     } else {
       pads.launch(K, Kp, st);
@@ -1523,13 +1548,13 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
   else
     hipLaunchKernelGGL(pc_bwd_act_kernel<bf16_t>, grid, dim3(64 * PC_PG), 0, st, G, att, Tsave,
                        static_cast<bf16_t*>(dT), static_cast<bf16_t*>(dZ), pdbt, pdba, P, K, Kp,
-                       act_code(flags), Kp, df);
+                       act_code(flags), ldw, df);
   APA_LAUNCH_CHECK("pc_bwd_act_kernel");
   int rc = APA_OK;
   {  // dWt[c,k] = sum_r Xt[r,c] dT[r,k]
     GemmDesc g;
     g.A = X; g.lda = C; g.ta = tdt; g.a_kc = false;
-    g.B = dT; g.ldb = Kp; g.tb = tdt; g.b_kc = false;
+    g.B = dT; g.ldb = ldw; g.tb = tdt; g.b_kc = false;
     g.C = dWt; g.ldc = K; g.tc = 0;
     g.M = C; g.N = K; g.K = R;
     g.splits = gemm_pick_splits(C, K, R); g.ws = gws;
@@ -1546,7 +1571,7 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
     // dWa[c,k] = sum_r Xatt[r,c] dZ[r,k]: the twin of the same launch when the shapes agree (Ca == C, bf16)
     GemmDesc h;
     h.A = Xatt; h.lda = Ca; h.ta = tdt; h.a_kc = false;
-    h.B = dZ; h.ldb = Kp; h.tb = tdt; h.b_kc = false;
+    h.B = dZ; h.ldb = ldw; h.tb = tdt; h.b_kc = false;
     h.C = dWa; h.ldc = K; h.tc = 0;
     h.M = Ca; h.N = K; h.K = R;
     h.splits = gemm_pick_splits(Ca, K, R);
@@ -1557,20 +1582,37 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
     rc = gemm_launch(g, st);
     if (rc != APA_OK) return rc;
   }
-  {  // dX = (dT . Wt^T) * mask/keep
+  bool dx_done = false;
+  if (cat && fused && gemm_bf16_wide_serves(R, C, 2 * Kp)) {
+    // dX = (dT . Wt^T) * mask/keep + dZ . Wa^T as ONE product over [dT | dZ] . [Wt | Wa]^T: the accumulators are
+    // masked with the keep bits after the first Kp of the contraction (gemm_bf16_wide_kernel<.., MID>)
     GemmDesc g;
-    g.A = dT; g.lda = Kp; g.ta = tdt; g.a_kc = true;
-    g.B = WtP; g.ldb = Kp; g.tb = wb16 ? 1 : 0; g.b_kc = true;
+    g.A = dT; g.lda = ldw; g.ta = 1; g.a_kc = true;
+    g.B = WtP; g.ldb = ldw; g.tb = 1; g.b_kc = true;
+    g.C = dX; g.ldc = C; g.tc = 1;
+    g.M = R; g.N = C; g.K = 2 * Kp;
+    g.stream_out = true;
+    if (train) {
+      g.mid_bits = reinterpret_cast<const uint8_t*>(w + pl.off_bits); g.mid_k = Kp; g.mid_inv_keep = 1.0f / keep_prob;
+    }
+    rc = gemm_launch(g, st);
+    if (rc != APA_OK) return rc;
+    dx_done = true;
+  }
+  if (!dx_done) {  // dX = (dT . Wt^T) * mask/keep
+    GemmDesc g;
+    g.A = dT; g.lda = ldw; g.ta = tdt; g.a_kc = true;
+    g.B = WtP; g.ldb = ldw; g.tb = wb16 ? 1 : 0; g.b_kc = true;
     g.C = dX; g.ldc = C; g.tc = tdt;
     g.M = R; g.N = C; g.K = Kp;
     if (train) set_dropout(g, false, true, keep_prob, seed, offset, flags);
     rc = gemm_launch(g, st);
     if (rc != APA_OK) return rc;
   }
-  {  // + dZ . Wa^T  (into dX when the attention input is X itself, else into dXatt)
+  if (!dx_done) {  // + dZ . Wa^T  (into dX when the attention input is X itself, else into dXatt)
     GemmDesc g;
-    g.A = dZ; g.lda = Kp; g.ta = tdt; g.a_kc = true;
-    g.B = WaP; g.ldb = Kp; g.tb = wb16 ? 1 : 0; g.b_kc = true;
+    g.A = dZ; g.lda = ldw; g.ta = tdt; g.a_kc = true;
+    g.B = WaP; g.ldb = ldw; g.tb = wb16 ? 1 : 0; g.b_kc = true;
     g.C = fused ? dX : dXatt; g.ldc = fused ? C : Ca; g.tc = tdt;
     g.M = R; g.N = fused ? C : Ca; g.K = Kp; g.beta = fused ? 1.f : 0.f;
     g.stream_out = true;

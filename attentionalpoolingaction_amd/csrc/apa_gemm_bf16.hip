@@ -949,7 +949,14 @@ template <int MT> struct WideCfg {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <typename TC, int MT>
+// MID (p.drop_mid >= 0, p.maskbits; bf16 out): C = (A[:, :k1] . B[:, :k1]^T) * mask/keep + A[:, k1:] . B[:, k1:]^T in ONE
+// launch -- after k tile `drop_mid` the accumulators are multiplied by the keep bit / keep of their output element
+// (bit image in natural [row][N/8] layout).  The tile's (32 MT) x 32 bytes of bits reach LDS by one more LDS-DMA
+// instruction per wave, issued before the first operand tile (the oldest entry of the vmcnt queue: the counted
+// waits of the ring need no change), into the 8 KB the rings leave free; a lane reads one 8-byte word per
+// (row tile, register) -- its wave's 64 columns -- when it needs them.  The per-class maps' dX (K > 64): the two
+// products of 23.6 us each, the second a read-modify-write of the 25.7 MB result, become one.
+template <typename TC, int MT, bool MID = false>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_wide_kernel(FastParams p) {
   typedef WideCfg<MT> W;
   extern __shared__ __attribute__((aligned(16))) short smem[];
@@ -1014,6 +1021,15 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_wide_kernel(FastParams p) {
       for (int j = 0; j < 4; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
   };
+  const uint32_t ldsM = lds0 + (uint32_t)W::LDS_BYTES;     // [TMR][32 bytes] keep bits of the tile (MID)
+  if (MID) {
+    constexpr int NMB = (W::TMR * 32 + 1023) / 1024;         // KiB-blocks of the bit tile: MT
+    if (wave < NMB) {
+      const int row = min(wave * 32 + (lane >> 1), W::TMR - 1);
+      const size_t e = (size_t)min(m0 + row, p.M - 1) * p.Nout + n0;
+      glds16_ring(p.maskbits + (e >> 3) + (lane & 1) * 16, ldsM + (uint32_t)wave * 1024u);
+    }
+  }
   // issue order: A0 B0 B1 | A1 B2 | A2 B3 | ...   (one group per hand-over)
   if (nk > 0) { issueA(0); issueB(0); }
   if (nk > 1) issueB(1);
@@ -1046,6 +1062,19 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_wide_kernel(FastParams p) {
       __builtin_amdgcn_sched_barrier(0);
       mma(af1, bf1);
       __builtin_amdgcn_sched_barrier(0);
+      if (MID && t == p.drop_mid) {   // (block-uniform) what has been accumulated so far is the masked product
+        const char* mb = reinterpret_cast<const char*>(smem) + W::LDS_BYTES;
+        const int l16m = lane & 15, kbm = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const uint64_t bits = *reinterpret_cast<const uint64_t*>(mb + ((wm * MT + i) * 16 + 4 * kbm + r) * 32 + wn * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j][r] *= ((bits >> (j * 16 + l16m)) & 1ull) ? p.inv_keep : 0.f;
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     load_frags(nk - 1, 1, af1, bf1);
     __builtin_amdgcn_sched_barrier(0);
@@ -1175,13 +1204,28 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_wide_kernel(FastParams p) {
 template <typename TC, int MT>
 int launch_wide(const FastParams& p, hipStream_t st) {
   typedef WideCfg<MT> W;
+  const int tiles = ((p.M + W::TMR - 1) / W::TMR) * ((p.N + TNW - 1) / TNW);
+  if constexpr (sizeof(TC) == 2) {
+    if (p.drop_mid >= 0) {
+      constexpr size_t shm = W::LDS_BYTES + (size_t)((W::TMR * 32 + 1023) / 1024) * 1024;
+      static_assert(shm <= 160 * 1024, "LDS (rings + bit tile)");
+      static thread_local PerDevice<bool> attr_dev; bool& attr_set = attr_dev.here();
+      if (!attr_set) {
+        APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_wide_kernel<TC, MT, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((gemm_bf16_wide_kernel<TC, MT, true>), dim3(tiles), dim3(512), shm, st, p);
+      APA_LAUNCH_CHECK("gemm_bf16_wide_kernel<mid>");
+      return APA_OK;
+    }
+  }
   static thread_local PerDevice<bool> attr_dev; bool& attr_set = attr_dev.here();
   if (!attr_set) {
     APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_wide_kernel<TC, MT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS_BYTES));
     attr_set = true;
   }
-  const int tiles = ((p.M + W::TMR - 1) / W::TMR) * ((p.N + TNW - 1) / TNW);
   hipLaunchKernelGGL((gemm_bf16_wide_kernel<TC, MT>), dim3(tiles), dim3(512), W::LDS_BYTES, st, p);
   APA_LAUNCH_CHECK("gemm_bf16_wide_kernel");
   return APA_OK;
@@ -1429,8 +1473,20 @@ int gemm_bf16_launch(const GemmDesc& d, int splits, int k_per_split, hipStream_t
     // 294 tiles 38.2 -> 32.6 us, 96 x 3 splits 40.0 -> 35.2 us, but 784 tiles 34.4 -> 37.4 us
     // few tiles, A k-contiguous, no split-K: the ring kernel (one resident round, 3-4 K tiles in flight)
     // wide output, short contraction, both operands k-contiguous, no split-K: one resident round of 256-wide tiles
+    if (d.mid_bits && kind != KIND_WIDE) {
+      set_error("gemm_bf16: mid-contraction mask requested for a product the wide kernel does not serve (internal)");
+      return APA_ERR_UNSUPPORTED;
+    }
     if (kind == KIND_WIDE) {
       const int mt = wide_pick_mt(d.M, d.N, gemm_cu_count());
+      if (d.mid_bits) {
+        if (!p.vec_epi || d.n_valid > 0 || d.tc != 1 || d.drop_c || d.r1_row || d.mid_k <= 0 || d.mid_k % TK != 0 ||
+            d.mid_k >= d.K || (d.N % 8) != 0) {
+          set_error("gemm_bf16: mid-contraction mask: plain bf16 product, whole k tiles on both sides");
+          return APA_ERR_UNSUPPORTED;
+        }
+        p.drop_mid = d.mid_k / TK - 1; p.maskbits = d.mid_bits; p.inv_keep = d.mid_inv_keep;
+      }
       if (d.r1_row) {   // the rank-1 addend lives in the vector epilogue
         if (!p.vec_epi || d.n_valid > 0 || d.tc != 1 || d.bias || d.act || d.drop_c || d.beta != 0.f ||
             d.r1_P * 2 < 32 * mt) {   // (a tile must not span more than three images)

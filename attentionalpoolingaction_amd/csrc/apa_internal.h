@@ -174,6 +174,9 @@ struct GemmDesc {
   // C is a final output of the step that no later launch reads (a 25.7 MB dX): bf16 vector stores carry the
   // non-temporal hint (measured on the HMDB-51 dX kernel: 15.0 -> 13.8 us)
   bool stream_out = false;
+  // mid-contraction mask (wide kernel only, bf16 C): C = (A[:, :mid_k] . B[:, :mid_k]^T) * keepbit / keep + the rest of
+  // the contraction; mid_bits = keep bits of C's elements, natural layout (bit (e & 7) of byte e >> 3, e = m * N + n)
+  const uint8_t* mid_bits = nullptr; int mid_k = 0; float mid_inv_keep = 1.f;
 };
 bool gemm_bf16_wide_serves(int M, int N, int K);   // would this all-bf16, k-contiguous, unsplit product take the wide kernel?
 int gemm_bf16_wide_tile_rows(int M, int N, int K);  // ... and with how many rows per tile (0 = not served)

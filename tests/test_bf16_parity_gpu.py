@@ -374,3 +374,60 @@ def test_per_class_small_k_folded_activation_passes(gpu, N, H, C, K, relu, train
         scale = max(float(ref.abs().max()), 1e-30)
         rel = float((got.detach().cpu().double().reshape(ref.shape) - ref).abs().max()) / scale
         assert rel <= (2.0 + KAPPA) * U, (name, rel / U)
+
+
+@pytest.mark.parametrize('K,relu,train', [(130, False, True), (393, True, True), (70, False, False)])
+def test_per_class_large_k_one_launch_dx_at_the_benchmark_batch(gpu, K, relu, train):
+    """Per-class maps with K > 64 at the benchmark batch (32 x 14x14x2048, bf16): the shape at which the generic
+    path's dX = (dT.Wt^T)*mask/keep + dZ.Wa^T is ONE product over the concatenated contraction with the accumulators
+    masked in between (gemm_bf16_wide_kernel<.., MID>, apa_gemm_bf16.hip), Z | T and dWt | dWa are twin products of one
+    launch each and the cross-entropy is taken by the backward activation pass -- smaller batches fall back to the
+    two-product form.  Against the float64 oracle fed the kernel's own mask, in units of u; one-call == per-op."""
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    N, H, C = 32, 14, 2048
+    g = torch.Generator().manual_seed(31 * K)
+    X = torch.relu(torch.randn(N, H, H, C, generator=g)).bfloat16()
+    Wa = torch.randn(C, K, generator=g) / C ** 0.5
+    ba = torch.randn(K, generator=g) * 0.1
+    Wt = torch.randn(C, K, generator=g) / C ** 0.5
+    bt = torch.randn(K, generator=g) * 0.1
+    labels = torch.randint(0, K, (N,), generator=g)
+    keep, seed, offset = (0.5, 17, 2) if train else (1.0, 0, 0)
+    d = lambda t: t.to(gpu).contiguous()
+    Xd, Wad, bad, Wtd, btd, lab = d(X), d(Wa), d(ba), d(Wt), d(bt), d(labels)
+    kw = dict(flags=cof.attn_flags(False, relu, train), keep_prob=keep, seed=seed, offset=offset)
+    logits, att, Ts, _, _, ws = cof.attn_pool_fwd(Xd, Xd, Wad, bad, Wtd, btd, **kw)
+    loss, G, _, pred = cof.softmax_xent_fwd_bwd(logits, lab, want_pred=True)
+    dX, _, dWa, dba, dWt, dbt = cof.attn_pool_bwd(Xd, Xd, Wad, bad, Wtd, btd, att, Ts, None, G, **kw)
+    grads = (torch.empty_like(Xd), None, torch.empty_like(Wad), torch.empty_like(bad), torch.empty_like(Wtd),
+             torch.empty_like(btd))
+    st = cof.HeadTrainStep(Xd, Xd, Wad, bad, Wtd, btd, lab, grads, **kw)
+    st.run()
+    torch.cuda.synchronize()
+    assert torch.equal(st.logits, logits) and torch.equal(st.G, G) and torch.equal(st.loss, loss)
+    for a, b, name in zip(grads, (dX, None, dWa, dba, dWt, dbt), ('dX', '', 'dWa', 'dba', 'dWt', 'dbt')):
+        if a is not None:
+            assert torch.equal(a, b), name
+    mask = cof.dropout_mask((N, H, H, C), keep, seed, offset).cpu() if train else None
+    leaf = lambda t: t.double().clone().requires_grad_(True)
+    Xr, War, bar, Wtr, btr = map(leaf, (X, Wa, ba, Wt, bt))
+    oflags = orc.AttnFlags(per_class=True, relu_att=relu)
+    okw = dict(is_training=True, keep_prob=keep, dropout_mask=mask) if train else {}
+    lg, ep = orc.attentional_pooling(Xr, None, None, [War], [bar], [Wtr], [btr], oflags, **okw)
+    orc.action_softmax_xent(lg, labels, K).backward()
+    assert float((logits.cpu().double() - lg.detach()).abs().max()) < 2 * LOGIT_TOL_BF16
+    # relu attention: a gate within rounding of 0 flips with the bf16 rounding of the weights (tools/fuzz_all.py skips
+    # such cases; among 2.5 M map elements ~ 1 200 always do).  A flipped gate moves its whole row of dX by one of the
+    # row's K terms -- those rows are compared apart, the weight gradients (sums over all rows) get a wider band.
+    a_ref = ep['PosePrelogitsBasedAttention'].detach().reshape(N * H * H, K)
+    flip_rows = ((att.cpu().double().view(N * H * H, K) > 0) != (a_ref > 0)).any(1) if relu else torch.zeros(N * H * H, dtype=torch.bool)
+    assert int(flip_rows.sum()) < 0.25 * N * H * H
+    for name, got, ref in (('dWt', dWt, Wtr.grad), ('dWa', dWa, War.grad), ('dbt', dbt, btr.grad),
+                           ('dba', dba, bar.grad), ('dX', dX.float().view(N, H, H, C), Xr.grad)):
+        scale = max(float(ref.abs().max()), 1e-30)
+        err = (got.detach().cpu().double().reshape(ref.shape) - ref).abs()
+        if name == 'dX':
+            err = err.view(N * H * H, C)[~flip_rows]
+        rel = float(err.max()) / scale
+        print('   K={} {} rel err {:.2e} (= {:.2f} u)'.format(K, name, rel, rel / U))
+        assert rel <= (2.0 + KAPPA) * U * (3.0 if (relu and name != 'dX') else 1.0), (name, rel / U)

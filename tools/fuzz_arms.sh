@@ -21,6 +21,7 @@ dense APA_POSE_STEP_FUSED=0 APA_PC_XENT_FOLD=0
 dense APA_PC_ACT_FOLD=0
 dense APA_PC_DX_FUSED=0
 dense APA_GEMM_TWIN=0 APA_GEMM_NT=0
+dense APA_PC_CAT=0
 dense APA_GEMM_GLDS=0
 dense APA_GEMM_FAST=0
 dense APA_POSE_BWD_ROWS=0 APA_POSE_PL_FAST=0
