@@ -1246,7 +1246,7 @@ __global__ __launch_bounds__(1024) void pc_bwd_act_kernel(const float* __restric
 struct PcPlan {
   long R;
   int Kp;
-  size_t off_wap, off_wtp, off_bap, off_z, off_dt, off_dz, off_pdbt, off_pdba, off_gemm, off_xd, off_bits, off_fused, total;
+  size_t off_wap, off_wtp, off_bap, off_z, off_dt, off_dz, off_pdbt, off_pdba, off_gemm, gemm_half, off_xd, off_bits, off_fused, total;
 };
 static PcPlan pc_plan(int N, int P, int C, int Ca, int K, int dtype) {
   PcPlan pl;
@@ -1265,11 +1265,20 @@ static PcPlan pc_plan(int N, int P, int C, int Ca, int K, int dtype) {
   pl.off_pdba = pl.off_pdbt + (size_t)K * 4;
   const int cm = C > Ca ? C : Ca;
   {
-    // split-K partials cover the padded width; two buffers: the twin products (Z | T, dWt | dWa) share a launch
-    size_t g = 2 * gemm_ws_bytes(cm, pl.Kp, 32);
-    const size_t g2 = 2 * gemm_ws_bytes((int)pl.R, pl.Kp, 8);   // split-K of the skinny forward products
+    // split-K partials cover the padded width; two buffers: the twin products (Z | T, dWt | dWa) share a launch.
+    // Sized by the splits the launches will pick (the same calls as in pc_forward / pc_backward)
+    int sdw = gemm_pick_splits(C, K, (int)pl.R);
+    const int sdw2 = gemm_pick_splits(Ca, K, (int)pl.R);
+    if (sdw2 > sdw) sdw = sdw2;
+    int sfw = gemm_pick_splits((int)pl.R, pl.Kp, C);
+    const int sfw2 = gemm_pick_splits((int)pl.R, pl.Kp, Ca);
+    if (sfw2 > sfw) sfw = sfw2;
+    if (sfw > 8) sfw = 8;
+    size_t g = gemm_ws_bytes(cm, pl.Kp, sdw);
+    const size_t g2 = gemm_ws_bytes((int)pl.R, pl.Kp, sfw);   // split-K of the skinny forward products
     if (g2 > g) g = g2;
-    pl.off_gemm = off; off += align_up(g, 256);
+    pl.gemm_half = align_up(g, 256);
+    pl.off_gemm = off; off += 2 * pl.gemm_half + 256;
   }
   // bf16 training: dropout(X) materialised once per call, so the MFMA GEMMs that consume it can DMA
   // their operands (the generic kernel applies the mask while staging through registers)
@@ -1416,7 +1425,7 @@ int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
     if (train) set_dropout(gt, true, false, keep_prob, seed, offset, flags);
   }
   gt.splits = gemm_pick_splits(R, Kp, C); if (gt.splits > 8) gt.splits = 8;
-  gt.ws = gws + (size_t)8 * R * Kp;
+  gt.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(gws) + pl.gemm_half);
   // Z | T: same shape when the attention input has C channels too -- one launch (GemmDesc::twin), else one after
   // the other (the dispatcher decides)
   gz.twin = &gt;
@@ -1575,8 +1584,7 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
     h.C = dWa; h.ldc = K; h.tc = 0;
     h.M = Ca; h.N = K; h.K = R;
     h.splits = gemm_pick_splits(Ca, K, R);
-    const int cm = C > Ca ? C : Ca;
-    h.ws = gws + (size_t)32 * cm * Kp;
+    h.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(gws) + pl.gemm_half);
     if (dtype == APA_DTYPE_BF16) { h.N = Kp; h.n_valid = K; }   // dZ is [R][Kp] with zero pad columns
     g.twin = &h;
     rc = gemm_launch(g, st);
