@@ -376,16 +376,17 @@ def test_per_class_small_k_folded_activation_passes(gpu, N, H, C, K, relu, train
         assert rel <= (2.0 + KAPPA) * U, (name, rel / U)
 
 
-@pytest.mark.parametrize('K,relu,train', [(130, False, True), (393, True, True), (70, False, False)])
-def test_per_class_large_k_one_launch_dx_at_the_benchmark_batch(gpu, K, relu, train):
+@pytest.mark.parametrize('N,K,relu,train', [(32, 130, False, True), (32, 393, False, True), (32, 70, True, False),
+                                            (33, 70, False, True)])     # 33: the last row tile is ragged
+def test_per_class_large_k_one_launch_dx_at_the_benchmark_batch(gpu, N, K, relu, train):
     """Per-class maps with K > 64 at the benchmark batch (32 x 14x14x2048, bf16): the shape at which the generic
     path's dX = (dT.Wt^T)*mask/keep + dZ.Wa^T is ONE product over the concatenated contraction with the accumulators
     masked in between (gemm_bf16_wide_kernel<.., MID>, apa_gemm_bf16.hip), Z | T and dWt | dWa are twin products of one
     launch each and the cross-entropy is taken by the backward activation pass -- smaller batches fall back to the
     two-product form.  Against the float64 oracle fed the kernel's own mask, in units of u; one-call == per-op."""
     from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
-    N, H, C = 32, 14, 2048
-    g = torch.Generator().manual_seed(31 * K)
+    H, C = 14, 2048
+    g = torch.Generator().manual_seed(31 * K + N)
     X = torch.relu(torch.randn(N, H, H, C, generator=g)).bfloat16()
     Wa = torch.randn(C, K, generator=g) / C ** 0.5
     ba = torch.randn(K, generator=g) * 0.1
