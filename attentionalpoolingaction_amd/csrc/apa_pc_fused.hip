@@ -31,6 +31,14 @@
 
 namespace apa {
 
+// timing-experiment switches of the development build (make ABLATE=1: pieces of a kernel switched off to price them --
+// wrong results by design).  In the product build the tests are the constant 0 and the code they guard is not compiled.
+#ifdef APA_ABLATION
+#define APA_EXPBIT(v, b) ((v) & (b))
+#else
+#define APA_EXPBIT(v, b) 0
+#endif
+
 namespace {
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
@@ -384,7 +392,7 @@ __global__ __launch_bounds__(512) void pc_bwd_dw_kernel(
   const int l16 = lane & 15, kb = lane >> 4;
   const int c0 = blockIdx.x * 128;
   const int rbeg = blockIdx.y * rows_per_split, rend = min(R, rbeg + rows_per_split);
-  const int nk = (exp & 16) ? 0 : ((exp & 32) ? 1 : (rend - rbeg + FK - 1) / FK);
+  const int nk = APA_EXPBIT(exp, 16) ? 0 : (APA_EXPBIT(exp, 32) ? 1 : (rend - rbeg + FK - 1) / FK);
 
   // Two tiles ahead through registers: a tile's 5 loads per thread are requested two iterations before they are
   // parked in LDS (one iteration of MFMAs does not cover a round trip to HBM with 256 blocks streaming X).  The wait
@@ -399,9 +407,9 @@ __global__ __launch_bounds__(512) void pc_bwd_dw_kernel(
       const int rc = min(r, rend - 1);
       // (plain loads: with the non-temporal hint this kernel is no faster and the NEXT step's forward product loses
       //  1 us -- the map is no longer served from the Infinity Cache)
-      q.av[i] = (exp & 4) ? make_uint4(1u, 2u, 3u, 4u) : ld16(X + (size_t)rc * C + c0 + m);
-      q.bv[i] = (exp & 8) ? make_uint4(1u, 2u, 3u, 4u) : ld16(dTdZ + (size_t)rc * 128 + m);
-      if (TRAIN) q.mb[i] = (exp & 64) ? 0x55u : maskbits[((size_t)rc * C + c0 + m) >> 3];
+      q.av[i] = APA_EXPBIT(exp, 4) ? make_uint4(1u, 2u, 3u, 4u) : ld16(X + (size_t)rc * C + c0 + m);
+      q.bv[i] = APA_EXPBIT(exp, 8) ? make_uint4(1u, 2u, 3u, 4u) : ld16(dTdZ + (size_t)rc * 128 + m);
+      if (TRAIN) q.mb[i] = APA_EXPBIT(exp, 64) ? 0x55u : maskbits[((size_t)rc * C + c0 + m) >> 3];
     }
   };
   auto settle = [&](Stage& q) {
@@ -438,7 +446,7 @@ __global__ __launch_bounds__(512) void pc_bwd_dw_kernel(
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto compute = [&](int t) {
-    if (exp & 2) return;
+    if (APA_EXPBIT(exp, 2)) return;
     // half 0 (dT columns) contracts against the MASKED features, half 1 (dZ) against the plain ones
     const short* a_img = smem + (t & 1) * STAGE + ((TRAIN && half == 0) ? IMG : 0);
     const short* b_img = smem + (t & 1) * STAGE + (TRAIN ? 2 : 1) * IMG;
@@ -479,7 +487,7 @@ __global__ __launch_bounds__(512) void pc_bwd_dw_kernel(
     if (t + 1 < nk) iteration(t + 1, SA, SB);
   }
   float* out = partial + ((size_t)blockIdx.y * C + c0) * 128;
-  if (exp & 1) return;
+  if (APA_EXPBIT(exp, 1)) return;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -554,7 +562,7 @@ __global__ __launch_bounds__(512) void pc_bwd_dx_kernel(PcDxArgs a) {
     const uint32_t lbase = (uint32_t)(uintptr_t)smem;
     const int q = wave * 64 + lane, j = q >> 4, m = j & 15, t = j >> 4;
     const bf16_t* src = a.Wcat2 + (size_t)(cbeg + 8 * (m >> 2) + 4 * t + (m & 3)) * 128 + (((q & 15) ^ dx_swz(m)) * 8);
-    for (int u = 0; u < ((a.exp & 8) ? 0 : nu); ++u)
+    for (int u = 0; u < (APA_EXPBIT(a.exp, 8) ? 0 : nu); ++u)
       glds16_asm(src + (size_t)u * 32 * 128, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lbase + u * 8192 + wave * 1024)));
   }
   // 2. (one-call step after a folded forward product) the logits of the images these rows touch, from the forward
@@ -562,7 +570,7 @@ __global__ __launch_bounds__(512) void pc_bwd_dx_kernel(PcDxArgs a) {
   const int n_first = m0 / P, n_last = min(m0 + DX_ROWS - 1, R - 1) / P;
   const float invP = 1.0f / (float)P;
   const int n_mine = n_first + wave;
-  const bool has_img = a.lpart && n_mine <= n_last && !(a.exp & 128);
+  const bool has_img = a.lpart && n_mine <= n_last && !APA_EXPBIT(a.exp, 128);
   float lg = -INFINITY;
   if (has_img && lane < K) lg = pc_logit_from_partials(a.lpart, n_mine, lane, P);
   // 3. att / T of this lane's row: classes 8 kb + e and 32 + 8 kb + e
@@ -576,7 +584,7 @@ __global__ __launch_bounds__(512) void pc_bwd_dx_kernel(PcDxArgs a) {
 #pragma unroll
       for (int e4 = 0; e4 < 8; e4 += 4) {     // rows are K floats: 4-byte aligned 16-byte loads (dword alignment is enough)
         const int k = 32 * hh + 8 * kb + e4;
-        if (a.exp & 16) {
+        if (APA_EXPBIT(a.exp, 16)) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) { av[hh][e4 + e] = 1.f; tv[hh][e4 + e] = 1.f; }
         } else if (k + 3 < K) {
@@ -659,7 +667,7 @@ __global__ __launch_bounds__(512) void pc_bwd_dx_kernel(PcDxArgs a) {
         st16(a.dTdZ + (size_t)rowg * 128 + 64 + 32 * hh + 8 * kb, pz);
       }
     }
-    if (sp == 0 && !(a.exp & 64)) {     // dbt | dba: this wave's 16-row column sums (the block's partial row is finished after the loop)
+    if (sp == 0 && !APA_EXPBIT(a.exp, 64)) {     // dbt | dba: this wave's 16-row column sums (the block's partial row is finished after the loop)
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
@@ -707,12 +715,12 @@ __global__ __launch_bounds__(512) void pc_bwd_dx_kernel(PcDxArgs a) {
       }
     }
     // (non-temporal: dX is the step's output, nothing in this call reads it back -- 15.0 -> 13.8 us)
-    if (valid && !(a.exp & 1)) st16_nt(a.dX + (size_t)rowg * a.C + cbeg + 32 * u + 8 * kb, Vec<bf16_t>::pack(o));
+    if (valid && !APA_EXPBIT(a.exp, 1)) st16_nt(a.dX + (size_t)rowg * a.C + cbeg + 32 * u + 8 * kb, Vec<bf16_t>::pack(o));
   };
   bf16x8 afA[2][4], afB[2][4];
   uint32_t mbA, mbB;
   load_u(0, afA, mbA);
-  for (int u = 0; u < ((a.exp & 2) ? 0 : nu); u += 2) {
+  for (int u = 0; u < (APA_EXPBIT(a.exp, 2) ? 0 : nu); u += 2) {
     load_u(min(u + 1, nu - 1), afB, mbB);
     unit(u, afA, mbA);
     if (u + 1 < nu) {
