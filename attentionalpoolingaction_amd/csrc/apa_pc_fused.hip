@@ -95,6 +95,28 @@ __global__ __launch_bounds__(256) void pc_prep_kernel(const float* __restrict__ 
   if ((int)blockIdx.x < nbits) {       // 8 elements (one byte) per thread and round
     uint32_t k0, k1;
     rng_key_dev(mb.seed, mb.offset_dev ? *mb.offset_dev : mb.offset, k0, k1);
+    if (mb.n8 <= (1ull << 30) && (mb.n8 & 3) == 0) {
+      // fewer than 2^33 elements: the pair index fits 32 bits and the key's high-word term is zero -- the same
+      // hashes on 32-bit arithmetic (5 of ~21 VALU operations per hash less), four bytes per thread and store
+      uint32_t* bits4 = reinterpret_cast<uint32_t*>(mb.bits);
+      const uint32_t n4 = (uint32_t)(mb.n8 >> 2);
+      for (uint32_t v = blockIdx.x * 256u + threadIdx.x; v < n4; v += (uint32_t)nbits * 256u) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          uint32_t bits = 0;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const uint32_t h = rng_hash((v * 4 + b) * 4 + i, k0, k1);     // pair index q = e / 2, e = 8 (4 v + b) + 2 i
+            bits |= ((h & 0xffffu) < mb.thresh ? 1u : 0u) << (2 * i);
+            bits |= ((h >> 16) < mb.thresh ? 1u : 0u) << (2 * i + 1);
+          }
+          word |= bits << (8 * b);
+        }
+        bits4[v] = word;
+      }
+      return;
+    }
     for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < mb.n8; v += (size_t)nbits * 256)
       mb.bits[v] = (uint8_t)keep_bits8(v * 8, k0, k1, mb.thresh);
     return;
@@ -812,9 +834,9 @@ int pc_fused_prep(const PcFusedWs& f, const float* Wa, const float* Wt, const fl
   if (bits) {
     mb.bits = f.maskbits; mb.n8 = bits->n_elems / 8; mb.thresh = keep_thresh(bits->keep_prob);
     mb.seed = bits->seed; mb.offset = bits->offset; mb.offset_dev = bits->offset_dev;
-    // 8 bytes of bits per thread: the rest of the chip, but not more blocks than there is work for
-    size_t nb = (mb.n8 + 256 * 8 - 1) / (256 * 8);
-    if (nb > 1024) nb = 1024;
+    // 4 bytes of bits (16 hashes) per thread: the rest of the chip, but not more blocks than there is work for
+    size_t nb = (mb.n8 + 256 * 4 - 1) / (256 * 4);
+    if (nb > 2048) nb = 2048;
     extra = (unsigned)(nb < 1 ? 1 : nb);
   }
   hipLaunchKernelGGL(pc_prep_kernel, dim3((unsigned)(C / 16) + extra), dim3(256), 0, st, Wa, Wt, ba,
