@@ -436,6 +436,10 @@ __global__ __launch_bounds__(256) void pose_pl_kernel(const bf16_t* __restrict__
     constexpr int NT = Cp * 2 / 256;             // Cp/2 pairs x 4 quads over 256 threads
     float4 w0[NT], w1[NT];
 #pragma unroll
+    // (the four lanes of a quad write rows n = 0, 4, 8, 12 of one k pair: 4 rows x 1568 B is a multiple of the 128-byte
+    //  bank row, a 4-way conflict on 24 ds_write_b32 per thread -- SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.29.  With
+    //  kp fastest instead the ratio is 0.00 and the kernel SLOWER, 8.5 -> 9.2 us, cfg 003 step +1 us: every lane then
+    //  reads 16 bytes of a different 64-byte row of W2.  Measured in round 4, the coalesced form kept.)
     for (int u = 0; u < NT; ++u) {
       const int t = tid + u * 256, kp = t >> 2, nq = t & 3;
       w0[u] = *reinterpret_cast<const float4*>(W2 + (size_t)(2 * kp) * 16 + nq * 4);
