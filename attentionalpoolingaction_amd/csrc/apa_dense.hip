@@ -1134,9 +1134,10 @@ __global__ __launch_bounds__(1024) void pc_fwd_act_kernel(const float* __restric
   }
 }
 
-// one-call step: where the gradient row G[n, :] comes from -- memory (both null), the forward product's block partials
-// (lpart; logits are written), or the logits row the forward activation pass left (row_logits; 4 <= K <= 1024)
-struct PcDefer { const float* lpart; float* logits; PcXent xe; const float* row_logits; };
+// one-call step, generic K > 64 path: where the gradient row G[n, :] comes from -- memory (row_logits == nullptr) or the
+// logits row the forward activation pass left (4 <= K <= 1024).  (The K <= 64 path takes its cross-entropy in
+// pc_bwd_dx_kernel, apa_pc_fused.hip.)
+struct PcDefer { PcXent xe; const float* row_logits; };
 // backward of the same: dT = G*A/P, dA = G*T/P, dZ = act'(dA); column partials for dbt / dba.
 // dT/dZ are written with leading dimension Kp (pad columns zeroed) in the intermediate dtype.
 template <typename T>
@@ -1173,24 +1174,7 @@ __global__ __launch_bounds__(1024) void pc_bwd_act_kernel(const float* __restric
     if (ok && p < p_hi) { pa[u] = att[(rbase + p) * K + k]; pt[u] = Tm[(rbase + p) * K + k]; }
   }
   float g;
-  if (df.lpart) {
-    // one-call step after a folded forward product: this launch finishes the logits row from the product's block
-    // partials and takes the row's cross-entropy itself (every pixel split recomputes the same 64 numbers; split 0
-    // writes logits / G / loss[1 + n]) -- G never makes a round trip through memory before its first use
-    float* lrow = &red[0][0];
-    float* grow = &red2[0][0];
-    if (pg == 0) {
-      const float lg = ok ? pc_logit_from_partials(df.lpart, n, k, P) : -INFINITY;
-      if (ok && blockIdx.z == 0) df.logits[(size_t)n * K + k] = lg;
-      lrow[kk] = lg;
-      __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the row is in LDS before this wave reads it back
-      __builtin_amdgcn_wave_barrier();
-      pc_row_xent(lrow, n, K, df.xe, blockIdx.z == 0, grow);
-    }
-    __syncthreads();
-    g = ok ? grow[kk] * invP : 0.f;
-    __syncthreads();                         // red / red2 are reused below
-  } else if (df.row_logits) {
+  if (df.row_logits) {
     // K > 64 (generic path), one-call step: every block takes its image's cross-entropy itself from the logits row
     // (softmax_xent_kernel's arithmetic: bit-identical G); block (y, z) = (0, 0) writes G[n, :] and loss[1 + n]
     __shared__ float growf[1024];
@@ -1373,7 +1357,8 @@ int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
                           fold ? &ff : nullptr);
     if (rc != APA_OK) return rc;
     if (fold) {
-      if (xent_here) {   // one-call train step: pc_backward's first launch finishes logits + cross-entropy
+      // one-call train step: pc_backward's first launch (pc_bwd_dx_kernel) finishes logits + cross-entropy
+      if (xent_here && pc_fused_dx_supported(P, act)) {
         xf->done = true;
         xf->deferred = true;
         xf->logits = logits;
@@ -1503,11 +1488,7 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
     bf16_t* dTc = static_cast<bf16_t*>(f.dTdZ);              // [R][dT (64) | dZ (64)]
     const int ps = pc_bwd_act_psplit(N, (Kp + 63) / 64, P, act_code(flags));
     dim3 grid(N, (Kp + 63) / 64, ps);
-    PcDefer df = {nullptr, nullptr, {nullptr, nullptr, nullptr, 0.f}, nullptr};
-    if (xf && xf->deferred) {
-      df.lpart = f.lpart; df.logits = xf->logits;
-      df.xe.labels = xf->labels; df.xe.loss = xf->loss; df.xe.G = xf->G; df.xe.gscale = xf->gscale;
-    }
+    const PcDefer df = {{nullptr, nullptr, nullptr, 0.f}, nullptr};   // (a deferred cross-entropy only goes with the dX kernel above)
     hipLaunchKernelGGL(pc_bwd_act_kernel<bf16_t>, grid, dim3(64 * PC_PG), 0, st, G, att, Tsave, dTc, dTc + 64,
                        pdbt, pdba, P, K, Kp, act_code(flags), 128, df);
     APA_LAUNCH_CHECK("pc_bwd_act_kernel");
@@ -1549,7 +1530,7 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
   }
   const int ps = pc_bwd_act_psplit(N, (Kp + 63) / 64, P, act_code(flags));
   dim3 grid(N, (Kp + 63) / 64, ps);
-  PcDefer df = {nullptr, nullptr, {nullptr, nullptr, nullptr, 0.f}, nullptr};
+  PcDefer df = {{nullptr, nullptr, nullptr, 0.f}, nullptr};
   if (xf && xf->deferred) {
     df.row_logits = xf->logits;
     df.xe.labels = xf->labels; df.xe.loss = xf->loss; df.xe.G = xf->G; df.xe.gscale = xf->gscale;
