@@ -453,7 +453,10 @@ extern "C" int apa_pose_attn_train_step(const apa_pose_attn_step_io* io, int N, 
                                       stream);
   }
   PoseStepArgs a;
-  a.W1_bf16 = s.W1_bf16;
+  // a caller-kept bf16 copy of W1 is an OPTIMISATION: apa_momentum_sgd_step_shadow accepts any 4-byte aligned
+  // shadow (e.g. one carved out of a flat bf16 buffer), the DMA-staged products want 16-byte addressable rows -- an
+  // operand they cannot read is ignored and W1 is converted inside the call, as if none had been given
+  a.W1_bf16 = (reinterpret_cast<uintptr_t>(s.W1_bf16) & 15) == 0 ? s.W1_bf16 : nullptr;
   a.wa = s.Wa; a.ba = s.ba; a.att = s.att;
   a.relu_att = (flags & APA_FLAG_RELU_ATT) && !(flags & APA_FLAG_SOFTMAX_ATT);
   a.pose_labels = s.pose_labels; a.pose_valid = s.pose_valid; a.dPl = s.dPl;
@@ -481,8 +484,12 @@ extern "C" int apa_pose_attn_train_step(const apa_pose_attn_step_io* io, int N, 
   // dz and the forward half's keep bits -- one 25.7 MB write and one 25.7 MB read less at the benchmark shape.
   static const int nodx_knob = knob("APA_POSE_STEP_NODX", 1);
   const int wide_rows = gemm_bf16_wide_tile_rows(N * P, C, Cp);   // (its rank-1 epilogue wants <= 3 images per tile)
+  // ... and only if the dX product is certain to take the wide bf16 kernel (the one with the rank-1 epilogue): all-bf16
+  // operands with 16-byte addressable rows -- dPpre and the W1 operand are the workspace's (aligned) or the shadow
+  // checked above, dX is the caller's
   const bool nodx = nodx_knob && m1_no_dx_supported(C, dtype, train) && wide_rows > 0 && wide_rows <= 2 * P &&
-                    (reinterpret_cast<uintptr_t>(s.dX) & 15) == 0;
+                    (reinterpret_cast<uintptr_t>(s.dX) & 15) == 0 && C % 8 == 0 && Cp % 8 == 0 &&
+                    dtype == APA_DTYPE_BF16;
   rc = attn_pool_bwd_impl(hk, nullptr, xf.done ? &xf : nullptr, s.X, s.Ppre, s.Wa, s.ba, s.Wt, s.bt, s.att, s.zsave,
                           s.abar, s.G, s.dX, s.dZ, s.dWa, s.dba, s.dWt, s.dbt, s.ws_pool, s.ws_pool_bytes, N, P, C,
                           Cp, K, 1, flags | APA_FLAG_DXATT_RANK1 | APA_FLAG_WS_FROM_FWD | APA_IFLAG_NO_ATT_WGRAD |

@@ -1576,7 +1576,8 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
     if (rc != APA_OK) return rc;
   }
   bool dx_done = false;
-  if (cat && fused && gemm_bf16_wide_serves(R, C, 2 * Kp)) {
+  // (the wide kernel's vector epilogue stores 16 bytes at a time: an odd dX address keeps the two-product form)
+  if (cat && fused && gemm_bf16_wide_serves(R, C, 2 * Kp) && (reinterpret_cast<uintptr_t>(dX) & 15) == 0) {
     // dX = (dT . Wt^T) * mask/keep + dZ . Wa^T as ONE product over [dT | dZ] . [Wt | Wa]^T: the accumulators are
     // masked with the keep bits after the first Kp of the contraction (gemm_bf16_wide_kernel<.., MID>)
     GemmDesc g;

@@ -70,8 +70,9 @@ struct AccParts {
 // DIV: out = sum / scale (the reference's own arithmetic, `ref_grad / float(ITER_SIZE)`, IEEE division: differs
 // from sum * (1 / ITER_SIZE) by an ulp when ITER_SIZE is not a power of two); otherwise out = sum * scale.
 template <bool DIV>
-__global__ __launch_bounds__(256) void accumulate_kernel(AccParts parts, float* __restrict__ out, size_t n,
-                                                         float scale) {
+// (`out` is NOT __restrict__: with more than APA_ACC_MAX_PARTS parts the running sum in `out` leads the next launch
+// as parts.p[0]; every thread reads its elements of all parts before it writes the same elements of `out`.)
+__global__ __launch_bounds__(256) void accumulate_kernel(AccParts parts, float* out, size_t n, float scale) {
   typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
   const size_t nv = n / 4;
   for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < nv; v += (size_t)gridDim.x * 256) {

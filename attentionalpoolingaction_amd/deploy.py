@@ -263,12 +263,23 @@ class MomentumSGD:
         `cof.PoseAttnTrainStep(w1_bf16=...)`), rewritten from the updated weights by the update's own launch."""
         self.shadows = dict(bf16_shadows or {})
         self.params = params
+        for name, t in self.shadows.items():
+            if name not in params or t.dtype != torch.bfloat16 or t.numel() != params[name].numel():
+                raise ValueError('bf16 shadow %r: a bfloat16 tensor with the element count of that parameter' % name)
+        self.refresh_shadows()          # a shadow is current from the start, not only after the first update
         self.bucket = bucket
         self.lr = lr
         self.momentum = momentum
         self.acc = torch.zeros_like(bucket.flat)
         reg = set(regularized)
         self.wd = [weight_decay if n in reg else 0.0 for n in bucket.names]
+
+    def refresh_shadows(self) -> None:
+        """Rewrite every bf16 operand copy from its parameter: at construction, and after the weights were
+        changed behind the optimiser's back (load_state_dict, a checkpoint restore)."""
+        with torch.no_grad():
+            for name, t in self.shadows.items():
+                t.copy_(self.params[name].data.reshape(t.shape))
 
     def step(self, lr: Optional[float] = None, grad_scale: float = 1.0) -> None:
         lr = self.lr if lr is None else lr

@@ -192,6 +192,10 @@ int apa_softmax_xent_fwd_bwd(const float* logits, const int64_t* labels, float* 
  * MI355X three separately marshalled foreign calls would make the HOST the bottleneck, so the
  * native sequence is part of the boundary.  All buffers are caller-owned (see the three functions
  * for shapes); loss f32 [1+N], G f32 [N,K].
+ * Every output -- logits, loss and G included -- is valid only when the WHOLE call returns APA_OK: inside the
+ * call launches are shared between the three ops (for the per-class maps with K <= 64 the cross-entropy is taken
+ * by the first backward kernel, which is what writes logits / loss / G), so an error return from the second half
+ * (e.g. APA_ERR_WORKSPACE) leaves them undefined.
  */
 int apa_attn_head_train_step(const void* X, const void* Xatt, const float* Wa, const float* ba,
                              const float* Wt, const float* bt, const int64_t* labels, float loss_wt,

@@ -316,6 +316,10 @@ BIG_CASES = [
          shape=(32, 14, 14, 2048), K=393, libmask=(42, 9), big=True, quant='bf16', full_limit=1 << 17),
     dict(name='cfg002_eval_baseline', yaml='002_MPII_ResNet_withAttention.yaml', train=False,
          shape=(32, 14, 14, 2048), K=393, big=True, quant='bf16', full_limit=1 << 16),
+    # BASELINE configs[4]: HMDB-51, one bottom-up map PER CLASS (nets_factory.py:257 num_classes maps, :298-328), at
+    # the per-GPU batch bench.py's `hmdb51_perclass_bf16_train` line times
+    dict(name='perclass_k51_train_baseline_libmask', train=True, shape=(32, 14, 14, 2048), K=51, train_cfg=NOPOSE,
+         net=dict(SL, **{P + '_PER_CLASS': True}), libmask=(42, 13), big=True, quant='bf16', full_limit=1 << 19),
 ]
 BIG_FULL = 1 << 20       # big cases: tensors up to this many elements are stored in full (float32)
 

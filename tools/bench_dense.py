@@ -29,15 +29,44 @@ PEAK = {'bf16': 2500.0, 'f32': 157.3}  # TFLOP/s, dense (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 
 
+L3_BYTES = 256 << 20    # Infinity Cache (MI355X_MICROARCH.md)
+
+
 def _features(N, P, C, dtype, dev, seed=42):
     g = torch.Generator(device=dev).manual_seed(seed)
     return torch.relu(torch.randn(N, P, C, generator=g, device=dev)).to(dtype)
 
 
-def build_cfg003(cof, dev, N=32, H=14, K=393, dtype='bf16', rank1=True, one_call=True):
+def _n_sets(per_set_bytes, rotate):
+    """how many (X, dX) buffer sets a workload cycles through: enough that 1.5 x the 256 MiB Infinity Cache lies
+    between two uses of the same set (bench.py's headline rule), so that no step finds its feature map cached from
+    the previous one.  rotate = 1: one set (kernel-by-kernel profiling of a variant)."""
+    if rotate and rotate > 0:
+        return int(rotate)
+    return max(3, -(-int(1.5 * L3_BYTES) // int(per_set_bytes)))
+
+
+def _round_robin(runs):
+    state = {'i': 0}
+    n = len(runs)
+
+    def step():
+        runs[state['i'] % n]()
+        state['i'] += 1
+    return step
+
+
+def _rot_note(R, per_set_bytes):
+    return '; X/dX rotated over {} sets ({:.0f} MB live)'.format(R, R * per_set_bytes / 1e6) if R > 1 else \
+        '; ONE buffer set (features stay in the Infinity Cache between steps)'
+
+
+def build_cfg003(cof, dev, N=32, H=14, K=393, dtype='bf16', rank1=True, one_call=True, rotate=0):
     C, Cp, J, P = 2048, 768, 16, H * H
     td = torch.bfloat16 if dtype == 'bf16' else torch.float32
     g = torch.Generator().manual_seed(42)
+    per_set = 2 * N * P * C * (2 if dtype == 'bf16' else 4)
+    R = _n_sets(per_set, rotate) if (one_call and rank1) else 1
     X = _features(N, P, C, td, dev)
     W1 = (torch.randn(C, Cp, generator=g) / C ** 0.5).to(dev); b1 = torch.zeros(Cp, device=dev)
     W2 = (torch.randn(Cp, J, generator=g) / Cp ** 0.5).to(dev); b2 = torch.zeros(J, device=dev)
@@ -65,15 +94,19 @@ def build_cfg003(cof, dev, N=32, H=14, K=393, dtype='bf16', rank1=True, one_call
         # (apa_momentum_sgd_step_shadow), here the weights do not change between steps
         w1_bf16 = W1.to(torch.bfloat16).contiguous()
         new = lambda t: torch.empty_like(t)
-        st = cof.PoseAttnTrainStep(X, (W1, b1, W2, b2, Wa, ba, Wt, bt), labels, lbl, valid,
-                                   (dX, new(W1), new(b1), new(W2), new(b2), new(Wa), new(ba), new(Wt), new(bt)),
-                                   flags=flags, keep_prob=0.2, seed=42, offset=ctr, w1_bf16=w1_bf16)
+        pgrads = (new(W1), new(b1), new(W2), new(b2), new(Wa), new(ba), new(Wt), new(bt))
+        sts = []
+        for r in range(R):        # one bound step per (X, dX) set; weights, parameter gradients, counter shared
+            Xr = X if r == 0 else _features(N, P, C, td, dev, seed=42 + r)
+            sts.append(cof.PoseAttnTrainStep(Xr, (W1, b1, W2, b2, Wa, ba, Wt, bt), labels, lbl, valid,
+                                             (dX if r == 0 else new(Xr),) + pgrads,
+                                             flags=flags, keep_prob=0.2, seed=42, offset=ctr, w1_bf16=w1_bf16))
         info = {'workload': 'cfg003 pose-regularised attention head fwd+bwd (pose head 2048->768->16 + M=1 '
                             'pooling + pose L2 + softmax-xent), one host call; per-GPU batch {} x {}x{}x{} {}, K={}, '
-                            'dropout keep=0.2'.format(N, H, H, C, dtype, K),
-                'bound': 'mfma', 'dtype': dtype, 'N': N,
+                            'dropout keep=0.2'.format(N, H, H, C, dtype, K) + _rot_note(R, per_set),
+                'bound': 'mfma', 'dtype': dtype, 'N': N, 'rotate': R,
                 'flops_per_image': 3 * (2.0 * P * C * Cp + 2.0 * P * Cp * J)}
-        return st.run, info
+        return _round_robin([st.run for st in sts]), info
     if rank1:
         head = cof.HeadTrainStep(X, Ppre, Wa, ba, Wt, bt, labels, grads, flags=flags, keep_prob=0.2, seed=42,
                                  offset=ctr, dxatt_rank1=True)
@@ -125,31 +158,36 @@ def build_posebwd(cof, dev, N=32, H=14, dtype='bf16', accumulate=False):
     return step, info
 
 
-def build_perclass(cof, dev, N=32, H=14, K=51, dtype='bf16'):
+def build_perclass(cof, dev, N=32, H=14, K=51, dtype='bf16', rotate=0):
     C, P = 2048, H * H
     td = torch.bfloat16 if dtype == 'bf16' else torch.float32
     g = torch.Generator().manual_seed(42)
+    per_set = 2 * N * P * C * (2 if dtype == 'bf16' else 4)
+    R = _n_sets(per_set, rotate)
     X = _features(N, P, C, td, dev)
     Wa = (torch.randn(C, K, generator=g) / C ** 0.5).to(dev); ba = torch.zeros(K, device=dev)
     Wt = (torch.randn(C, K, generator=g) / C ** 0.5).to(dev); bt = torch.zeros(K, device=dev)
     labels = torch.randint(0, K, (N,), generator=g).to(dev)
     flags = cof.attn_flags(False, False, True)
     ctr = torch.zeros(1, dtype=torch.int64, device=dev)
-    grads = (torch.empty_like(X), None, torch.empty_like(Wa), torch.empty_like(ba), torch.empty_like(Wt),
-             torch.empty_like(bt))
-    st = cof.HeadTrainStep(X, X, Wa, ba, Wt, bt, labels, grads, flags=flags, keep_prob=0.2, seed=42,
-                           offset=ctr)                       # one host call per step
+    pg = (torch.empty_like(Wa), torch.empty_like(ba), torch.empty_like(Wt), torch.empty_like(bt))
+    sts = []
+    for r in range(R):            # one host call per step, one bound step per (X, dX) set
+        Xr = X if r == 0 else _features(N, P, C, td, dev, seed=42 + r)
+        sts.append(cof.HeadTrainStep(Xr, Xr, Wa, ba, Wt, bt, labels, (torch.empty_like(Xr), None) + pg, flags=flags,
+                                     keep_prob=0.2, seed=42, offset=ctr))
     esz = X.element_size()
     info = {'workload': 'per-class bottom-up maps (M=K, HMDB-51 shape when K=51) attention head fwd+bwd; '
-                        'per-GPU batch {} x {}x{}x{} {}, K={}, dropout keep=0.2'.format(N, H, H, C, dtype, K),
+                        'per-GPU batch {} x {}x{}x{} {}, K={}, dropout keep=0.2'.format(N, H, H, C, dtype, K) +
+                        _rot_note(R, per_set),
             # K = 51: 0.25 GFLOP/img against 3*P*C*s bytes -> HBM-bound; K = 393: MFMA-bound
-            'bound': 'hbm' if K <= 128 else 'mfma', 'dtype': dtype, 'N': N,
+            'bound': 'hbm' if K <= 128 else 'mfma', 'dtype': dtype, 'N': N, 'rotate': R,
             'flops_per_image': 3 * (2 * 2.0 * P * C * K),              # Z and T products, fwd + 2x bwd
             'bytes_per_image': 3.0 * P * C * esz}
-    return st.run, info
+    return _round_robin([st.run for st in sts]), info
 
 
-def build_rank1(cof, dev, N=32, H=14, K=51, dtype='bf16'):
+def build_rank1(cof, dev, N=32, H=14, K=51, dtype='bf16', rotate=0):
     """class-agnostic bottom-up map (M = 1, the shipped HMDB / MPII attention configs) on bf16 features:
     the headline op, one host call per step."""
     C, P = 2048, H * H
@@ -161,28 +199,38 @@ def build_rank1(cof, dev, N=32, H=14, K=51, dtype='bf16'):
     labels = torch.randint(0, K, (N,), generator=g).to(dev)
     flags = cof.attn_flags(False, False, True)
     ctr = torch.zeros(1, dtype=torch.int64, device=dev)
-    grads = (torch.empty_like(X), None, torch.empty_like(Wa), torch.empty_like(ba), torch.empty_like(Wt),
-             torch.empty_like(bt))
-    st = cof.HeadTrainStep(X, X, Wa, ba, Wt, bt, labels, grads, flags=flags, keep_prob=0.2, seed=42, offset=ctr)
+    per_set = 2 * N * P * C * X.element_size()
+    R = _n_sets(per_set, rotate)
+    pg = (torch.empty_like(Wa), torch.empty_like(ba), torch.empty_like(Wt), torch.empty_like(bt))
+    sts = []
+    for r in range(R):
+        Xr = X if r == 0 else _features(N, P, C, td, dev, seed=42 + r)
+        sts.append(cof.HeadTrainStep(Xr, Xr, Wa, ba, Wt, bt, labels, (torch.empty_like(Xr), None) + pg, flags=flags,
+                                     keep_prob=0.2, seed=42, offset=ctr))
     info = {'workload': 'class-agnostic map (M=1) attention head fwd + softmax-xent + bwd; per-GPU batch {} x {}x{}x{} '
-                        '{}, K={}, dropout keep=0.2'.format(N, H, H, C, dtype, K),
-            'bound': 'hbm', 'dtype': dtype, 'N': N, 'flops_per_image': 0.0,
+                        '{}, K={}, dropout keep=0.2'.format(N, H, H, C, dtype, K) + _rot_note(R, per_set),
+            'bound': 'hbm', 'dtype': dtype, 'N': N, 'rotate': R, 'flops_per_image': 0.0,
             'bytes_per_image': 3.0 * P * C * X.element_size()}
-    return st.run, info
+    return _round_robin([st.run for st in sts]), info
 
 
-def build_eval002(cof, dev, N=32, H=14, K=393, dtype='f32'):
+def build_eval002(cof, dev, N=32, H=14, K=393, dtype='f32', rotate=0):
     C, P = 2048, H * H
     td = torch.bfloat16 if dtype == 'bf16' else torch.float32
     g = torch.Generator().manual_seed(42)
     X = _features(N, P, C, td, dev)
     Wa = (torch.randn(C, 1, generator=g) / C ** 0.5).to(dev); ba = torch.zeros(1, device=dev)
     Wt = (torch.randn(C, K, generator=g) / C ** 0.5).to(dev); bt = torch.zeros(K, device=dev)
-    ev = cof.HeadEvalStep(X, X, Wa, ba, Wt, bt)
+    per_set = N * P * C * X.element_size()              # forward only: X is all that streams
+    R = _n_sets(per_set, rotate)
+    evs = []
+    for r in range(R):
+        Xr = X if r == 0 else _features(N, P, C, td, dev, seed=42 + r)
+        evs.append(cof.HeadEvalStep(Xr, Xr, Wa, ba, Wt, bt))
     info = {'workload': 'cfg002 eval step (attn-pool forward + softmax + argmax, one call); per-GPU batch '
-                        '{} x {}x{}x{} {}, K={}'.format(N, H, H, C, dtype, K),
-            'bound': 'hbm', 'dtype': dtype, 'N': N, 'bytes_per_image': 1.0 * P * C * X.element_size()}
-    return ev.run, info
+                        '{} x {}x{}x{} {}, K={}'.format(N, H, H, C, dtype, K) + _rot_note(R, per_set).replace('X/dX', 'X'),
+            'bound': 'hbm', 'dtype': dtype, 'N': N, 'rotate': R, 'bytes_per_image': 1.0 * P * C * X.element_size()}
+    return _round_robin([ev.run for ev in evs]), info
 
 
 def timed(fn, steps, warmup, min_ms=50.0, repeats=5):
@@ -208,7 +256,7 @@ def timed(fn, steps, warmup, min_ms=50.0, repeats=5):
 def report(info, sec, repeats):
     N = info['N']
     out = {'workload': info['workload'], 'images_per_sec': round(N / sec, 1), 'ms_per_step': round(sec * 1e3, 5),
-           'repeats': repeats, 'dtype': info['dtype']}
+           'repeats': repeats, 'dtype': info['dtype'], 'rotate': info.get('rotate', 1)}
     if info['bound'] == 'mfma':
         tflops = N * info['flops_per_image'] / sec / 1e12
         out['roofline'] = {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': PEAK[info['dtype']],
@@ -236,6 +284,8 @@ def main():
                          'pose head bwd) instead of the one-call apa_pose_attn_train_step')
     ap.add_argument('--no-rank1', action='store_true',
                     help='cfg003: materialise the [N,P,768] attention-branch gradient between the two backward calls')
+    ap.add_argument('--rotate', type=int, default=0,
+                    help='number of (X, dX) buffer sets cycled through; 0 = enough for 1.5 x the Infinity Cache')
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
     args = ap.parse_args()
@@ -243,16 +293,19 @@ def main():
     dev = torch.device('cuda:0')
     if args.workload == 'cfg003':
         step, info = build_cfg003(cof, dev, args.batch, args.hw, args.classes or 393, args.dtype or 'bf16',
-                                  rank1=not args.no_rank1, one_call=not args.per_op)
+                                  rank1=not args.no_rank1, one_call=not args.per_op, rotate=args.rotate)
     elif args.workload in ('posebwd', 'posebwd_acc'):
         step, info = build_posebwd(cof, dev, args.batch, args.hw, args.dtype or 'bf16',
                                    accumulate=args.workload == 'posebwd_acc')
     elif args.workload == 'rank1':
-        step, info = build_rank1(cof, dev, args.batch, args.hw, args.classes or 51, args.dtype or 'bf16')
+        step, info = build_rank1(cof, dev, args.batch, args.hw, args.classes or 51, args.dtype or 'bf16',
+                                 rotate=args.rotate)
     elif args.workload == 'eval002':
-        step, info = build_eval002(cof, dev, args.batch, args.hw, args.classes or 393, args.dtype or 'f32')
+        step, info = build_eval002(cof, dev, args.batch, args.hw, args.classes or 393, args.dtype or 'f32',
+                                   rotate=args.rotate)
     else:
-        step, info = build_perclass(cof, dev, args.batch, args.hw, args.classes or 51, args.dtype or 'bf16')
+        step, info = build_perclass(cof, dev, args.batch, args.hw, args.classes or 51, args.dtype or 'bf16',
+                                    rotate=args.rotate)
     sec, reps = timed(step, args.steps, args.warmup)
     print(json.dumps(report(info, sec, reps)))
 
