@@ -61,6 +61,43 @@ __global__ __launch_bounds__(256) void momentum_sgd_kernel(SgdSegs s, const floa
   }
 }
 
+// tf.train.AdamOptimizer / tf.train.RMSPropOptimizer (src/train.py:84-89, :95-100) on the same flat layout, two
+// slot buffers per parameter instead of one.  TensorFlow 1.1's update rules (training/adam.py `_apply_dense` ->
+// ApplyAdam, training/rmsprop.py -> ApplyRMSProp, core/kernels/training_ops.cc):
+//   ADAM     m <- m + (g - m)(1 - b1);  v <- v + (g^2 - v)(1 - b2);  w <- w - lr_t m / (sqrt(v) + eps)
+//            with lr_t = lr sqrt(1 - b2^t) / (1 - b1^t) formed by the HOST (t = number of this update, from 1)
+//   RMSPROP  ms <- ms + (g^2 - ms)(1 - rho);  mom <- momentum mom + lr g / sqrt(ms + eps);  w <- w - mom
+//            (`ms` starts at ONE, `mom` at zero: rmsprop.py `_create_slots`; not the centered form)
+// g includes the slim L2 term wd * w like the momentum update above.
+template <int MODE>   // 0 adam, 1 rmsprop
+__global__ __launch_bounds__(256) void adaptive_step_kernel(SgdSegs s, const float* __restrict__ grad,
+                                                            float* __restrict__ slot1, float* __restrict__ slot2,
+                                                            float lr, float p1, float p2, float eps, float gscale) {
+  const int sg = blockIdx.y;
+  const size_t o = s.off[sg], n = s.off[sg + 1] - o;
+  float* __restrict__ w = s.w[sg];
+  const float wd = s.wd[sg];
+  bf16_t* __restrict__ sh = s.shadow[sg];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float wv = w[i];
+    const float g = fmaf(wd, wv, grad[o + i] * gscale);
+    float a = slot1[o + i], b = slot2[o + i], wn;
+    if (MODE == 0) {
+      a += (g - a) * (1.0f - p1);
+      b += (g * g - b) * (1.0f - p2);
+      wn = wv - (a * lr) / (sqrtf(b) + eps);
+    } else {
+      a += (g * g - a) * (1.0f - p1);
+      b = b * p2 + (g * lr) / sqrtf(a + eps);     // IEEE sqrt / division (no fast-math in this build)
+      wn = wv - b;
+    }
+    slot1[o + i] = a;
+    slot2[o + i] = b;
+    w[i] = wn;
+    if (sh) sh[i].v = (uint16_t)f32_to_bf16_bits(wn);
+  }
+}
+
 // out[i] = ((p0[i] + p1[i]) + p2[i] ...) * scale: TRAIN.ITER_SIZE accumulation (src/train.py:529-566:
 // ref = g0; ref += g1; ...; apply(ref / ITER_SIZE)) of micro-batch gradients that were produced side by side.
 struct AccParts {
@@ -175,6 +212,60 @@ static int sgd_launch(const char* who, int nseg, float* const* weights, const si
                      static_cast<hipStream_t>(stream), s, grad_flat, acc_flat, lr, momentum, grad_scale);
   APA_LAUNCH_CHECK("momentum_sgd_kernel");
   return APA_OK;
+}
+
+static int adaptive_launch(const char* who, int mode, int nseg, float* const* weights, const size_t* sizes,
+                           const float* weight_decay, const float* grad_flat, float* slot1, float* slot2, float lr,
+                           float p1, float p2, float eps, float grad_scale, void* const* bf16_shadow, void* stream) {
+  if (nseg <= 0 || nseg > APA_SGD_MAX_SEGMENTS || !weights || !sizes || !weight_decay || !grad_flat || !slot1 ||
+      !slot2 || slot1 == slot2) {
+    set_error("%s: bad arguments (nseg=%d, max %d; two distinct slot buffers)", who, nseg, APA_SGD_MAX_SEGMENTS);
+    return APA_ERR_INVALID_ARG;
+  }
+  SgdSegs s;
+  s.nseg = nseg;
+  size_t o = 0, biggest = 0;
+  for (int i = 0; i < nseg; ++i) {
+    if (!weights[i]) {
+      set_error("%s: weights[%d] is NULL", who, i);
+      return APA_ERR_INVALID_ARG;
+    }
+    s.w[i] = weights[i];
+    s.shadow[i] = bf16_shadow ? static_cast<bf16_t*>(bf16_shadow[i]) : nullptr;
+    s.off[i] = o;
+    s.wd[i] = weight_decay[i];
+    o += sizes[i];
+    if (sizes[i] > biggest) biggest = sizes[i];
+  }
+  s.off[nseg] = o;
+  if (o == 0) return APA_OK;
+  size_t nbx = (biggest + 255) / 256;
+  if (nbx > 2048) nbx = 2048;
+  const dim3 grid((unsigned)nbx, (unsigned)nseg);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (mode == 0)
+    hipLaunchKernelGGL(adaptive_step_kernel<0>, grid, dim3(256), 0, st, s, grad_flat, slot1, slot2, lr, p1, p2, eps,
+                       grad_scale);
+  else
+    hipLaunchKernelGGL(adaptive_step_kernel<1>, grid, dim3(256), 0, st, s, grad_flat, slot1, slot2, lr, p1, p2, eps,
+                       grad_scale);
+  APA_LAUNCH_CHECK("adaptive_step_kernel");
+  return APA_OK;
+}
+
+extern "C" int apa_adam_step(int nseg, float* const* weights, const size_t* sizes, const float* weight_decay,
+                             const float* grad_flat, float* m_flat, float* v_flat, float lr_t, float beta1,
+                             float beta2, float epsilon, float grad_scale, void* const* bf16_shadow, void* stream) {
+  return adaptive_launch("apa_adam_step", 0, nseg, weights, sizes, weight_decay, grad_flat, m_flat, v_flat, lr_t,
+                         beta1, beta2, epsilon, grad_scale, bf16_shadow, stream);
+}
+
+extern "C" int apa_rmsprop_step(int nseg, float* const* weights, const size_t* sizes, const float* weight_decay,
+                                const float* grad_flat, float* ms_flat, float* mom_flat, float lr, float decay,
+                                float momentum, float epsilon, float grad_scale, void* const* bf16_shadow,
+                                void* stream) {
+  return adaptive_launch("apa_rmsprop_step", 1, nseg, weights, sizes, weight_decay, grad_flat, ms_flat, mom_flat, lr,
+                         decay, momentum, epsilon, grad_scale, bf16_shadow, stream);
 }
 
 extern "C" int apa_momentum_sgd_step(int nseg, float* const* weights, const size_t* sizes,

@@ -91,6 +91,10 @@ _SIGNATURES = {
     'apa_momentum_sgd_step_shadow': (c_int, [c_int, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_float),
                                              c_void_p, c_void_p, c_float, c_float, c_float, POINTER(c_void_p),
                                              c_void_p]),
+    'apa_adam_step': (c_int, [c_int, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_float), c_void_p, c_void_p,
+                              c_void_p, c_float, c_float, c_float, c_float, c_float, POINTER(c_void_p), c_void_p]),
+    'apa_rmsprop_step': (c_int, [c_int, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_float), c_void_p, c_void_p,
+                                 c_void_p, c_float, c_float, c_float, c_float, c_float, POINTER(c_void_p), c_void_p]),
     'apa_pose_attn_train_step': (c_int, [c_void_p] + [c_int] * 6 + [c_uint, c_float, ctypes.c_uint64,
                                                                     ctypes.c_uint64, c_int, c_void_p]),
     'apa_accumulate_gradients': (c_int, [c_void_p, POINTER(c_void_p), c_int, c_size_t, c_float, c_void_p]),
@@ -807,6 +811,28 @@ class HeadTrainStep:
             flags, float(keep_prob), int(seed), off, _feat_dtype(X)]
         self._fn = self.lib.apa_attn_head_train_step_ex
 
+    def rebind(self, X=None, labels=None, offset=None) -> None:
+        """Point the bound step at another feature map / label tensor of the SAME shape and dtype (a training loop
+        whose backbone hands over a fresh conv5 tensor every step) and / or at another dropout offset (int), without
+        re-allocating outputs or workspace.  Fused attention input only (Xatt is X)."""
+        keep = list(self._keep)
+        if X is not None:
+            if self._args[0] != self._args[1]:
+                raise ApaError('HeadTrainStep.rebind: a separate attention input is bound')
+            if X.shape != keep[0].shape or X.dtype != keep[0].dtype:
+                raise ApaError('HeadTrainStep.rebind: same shape and dtype expected')
+            self._args[0] = self._args[1] = _dev_ptr(X, 'X')
+            keep[0] = keep[1] = X
+        if labels is not None:
+            self._args[6] = _dev_ptr(labels, 'labels', torch.int64)
+            keep[6] = labels
+        if offset is not None:
+            if isinstance(keep[8], torch.Tensor):
+                raise ApaError('HeadTrainStep.rebind: the step was bound to a device-side dropout counter')
+            self._args[-2] = int(offset)
+            keep[8] = int(offset)
+        self._keep = tuple(keep)
+
     def run(self, stream: Optional[int] = None, hooks=None) -> None:
         """Enqueue one step on `stream` (a raw hipStream_t) or torch's current stream; `hooks`
         (an ApaHooks) overrides the instance's for this call."""
@@ -886,6 +912,36 @@ class PoseAttnTrainStep:
         self._io = io
         self._args = [ctypes.addressof(io), N, P, C, Cp, J, K, flags, float(keep_prob), int(seed), off, dt]
 
+    def rebind(self, X=None, labels=None, pose_labels=None, pose_valid=None, offset=None) -> None:
+        """Point the bound step at other inputs of the same shapes / dtypes and / or another dropout offset (int)
+        without re-allocating outputs or workspaces (see HeadTrainStep.rebind)."""
+        keep = list(self._keep)
+        io = self._io
+        if X is not None:
+            if X.shape != keep[0].shape or X.dtype != keep[0].dtype:
+                raise ApaError('PoseAttnTrainStep.rebind: same shape and dtype expected')
+            io.X = _dev_ptr(X, 'X')
+            keep[0] = X
+        if labels is not None:
+            io.labels = _dev_ptr(labels, 'labels', torch.int64)
+            keep[2] = labels
+        if pose_labels is not None:
+            if pose_labels.numel() != keep[3].numel():
+                raise ApaError('PoseAttnTrainStep.rebind: pose_labels [N,P,J] expected')
+            io.pose_labels = _dev_ptr(pose_labels, 'pose_labels', torch.float32)
+            keep[3] = pose_labels
+        if pose_valid is not None:
+            if pose_valid.dtype == torch.bool:
+                pose_valid = pose_valid.to(torch.uint8)
+            io.pose_valid = _dev_ptr(pose_valid, 'pose_valid', torch.uint8)
+            keep[4] = pose_valid
+        if offset is not None:
+            if isinstance(keep[6], torch.Tensor):
+                raise ApaError('PoseAttnTrainStep.rebind: the step was bound to a device-side dropout counter')
+            self._args[10] = int(offset)
+            keep[6] = int(offset)
+        self._keep = tuple(keep)
+
     def run(self, stream: Optional[int] = None) -> None:
         rc = self.lib.apa_pose_attn_train_step(*self._args, _stream_ptr() if stream is None else stream)
         if rc != 0:
@@ -959,6 +1015,48 @@ def momentum_sgd_step(weights, weight_decay, grad_flat, acc_flat, lr, momentum=0
     _check(lib.apa_momentum_sgd_step(n, ptrs, sizes, wds, _dev_ptr(grad_flat, 'grad_flat', torch.float32),
                                      _dev_ptr(acc_flat, 'acc_flat', torch.float32), lr, momentum,
                                      grad_scale, _stream_ptr()), 'apa_momentum_sgd_step')
+
+
+def _optim_segments(weights, weight_decay, flats, shadows, who):
+    n = len(weights)
+    ptrs = (c_void_p * n)(*[_dev_ptr(w, 'weights[%d]' % i, torch.float32) for i, w in enumerate(weights)])
+    sizes = (c_size_t * n)(*[w.numel() for w in weights])
+    wds = (c_float * n)(*[float(x) for x in weight_decay])
+    total = sum(w.numel() for w in weights)
+    for f in flats:
+        if f.numel() != total:
+            raise ValueError('%s: a flat buffer holds %d elements, the parameters %d' % (who, f.numel(), total))
+    sh = None
+    if shadows is not None and any(t is not None for t in shadows):
+        for w_, t in zip(weights, shadows):
+            if t is not None and (t.dtype != torch.bfloat16 or t.numel() != w_.numel() or not t.is_contiguous()):
+                raise ApaError('%s: a shadow must be a contiguous bf16 tensor of its weight\'s size' % who)
+        sh = (c_void_p * n)(*[None if t is None else _dev_ptr(t, 'shadow', torch.bfloat16) for t in shadows])
+    return n, ptrs, sizes, wds, sh
+
+
+def adam_step(weights, weight_decay, grad_flat, m_flat, v_flat, lr, t, beta1=0.9, beta2=0.999, epsilon=1e-8,
+              grad_scale=1.0, shadows=None):
+    """tf.train.AdamOptimizer (src/train.py:84-89) as one fused launch; `t` = number of this update (1, 2, ...):
+    lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) is formed here, in double precision, like TF's python side."""
+    lib = load_library()
+    n, ptrs, sizes, wds, sh = _optim_segments(weights, weight_decay, (grad_flat, m_flat, v_flat), shadows, 'adam_step')
+    lr_t = float(lr) * (1.0 - float(beta2) ** int(t)) ** 0.5 / (1.0 - float(beta1) ** int(t))
+    _check(lib.apa_adam_step(n, ptrs, sizes, wds, _dev_ptr(grad_flat, 'grad_flat', torch.float32),
+                             _dev_ptr(m_flat, 'm_flat', torch.float32), _dev_ptr(v_flat, 'v_flat', torch.float32),
+                             lr_t, beta1, beta2, epsilon, grad_scale, sh, _stream_ptr()), 'apa_adam_step')
+
+
+def rmsprop_step(weights, weight_decay, grad_flat, ms_flat, mom_flat, lr, decay=0.9, momentum=0.0, epsilon=1e-10,
+                 grad_scale=1.0, shadows=None):
+    """tf.train.RMSPropOptimizer (src/train.py:95-100) as one fused launch; `ms_flat` starts at ONE."""
+    lib = load_library()
+    n, ptrs, sizes, wds, sh = _optim_segments(weights, weight_decay, (grad_flat, ms_flat, mom_flat), shadows,
+                                              'rmsprop_step')
+    _check(lib.apa_rmsprop_step(n, ptrs, sizes, wds, _dev_ptr(grad_flat, 'grad_flat', torch.float32),
+                                _dev_ptr(ms_flat, 'ms_flat', torch.float32),
+                                _dev_ptr(mom_flat, 'mom_flat', torch.float32), lr, decay, momentum, epsilon,
+                                grad_scale, sh, _stream_ptr()), 'apa_rmsprop_step')
 
 
 # --------------------------------------------------------------------------------------------

@@ -301,6 +301,79 @@ class MomentumSGD:
             t.copy_(self.params[name].data.reshape(t.shape))
 
 
+class _AdaptiveOptimizer(MomentumSGD):
+    """shared plumbing of Adam / RMSProp below: two slot buffers in the bucket's layout, the L2 term folded in"""
+
+    def __init__(self, params, bucket, lr, weight_decay=0.0, regularized=(), bf16_shadows=None):
+        super().__init__(params, bucket, lr, 0.0, weight_decay, regularized, bf16_shadows)
+        self.slot2 = torch.zeros_like(bucket.flat)          # self.acc is the first slot
+
+    def _segments(self, grad_scale):
+        o = 0
+        for name, wd in zip(self.bucket.names, self.wd):
+            w = self.params[name].data
+            n = w.numel()
+            g = self.bucket.flat[o:o + n].view_as(w) * grad_scale + wd * w
+            yield w, g, self.acc[o:o + n].view_as(w), self.slot2[o:o + n].view_as(w)
+            o += n
+
+
+class Adam(_AdaptiveOptimizer):
+    """tf.train.AdamOptimizer(lr, beta1, beta2, epsilon) (src/train.py:84-89; TF 1.1 training/adam.py):
+    lr_t = lr sqrt(1 - b2^t)/(1 - b1^t);  m += (g - m)(1 - b1);  v += (g^2 - v)(1 - b2);  w -= lr_t m/(sqrt(v) + eps).
+    Note the reference's epsilon: cfg.TRAIN.OPT_EPSILON defaults to 1.0 (src/config.py:94).  One fused HIP launch
+    (`apa_adam_step`) on a GPU; the torch expressions on CPU tensors."""
+
+    def __init__(self, params, bucket, lr, beta1=0.9, beta2=0.999, epsilon=1e-8, weight_decay=0.0, regularized=(),
+                 bf16_shadows=None):
+        super().__init__(params, bucket, lr, weight_decay, regularized, bf16_shadows)
+        self.beta1, self.beta2, self.epsilon, self.t = float(beta1), float(beta2), float(epsilon), 0
+
+    def step(self, lr: Optional[float] = None, grad_scale: float = 1.0) -> None:
+        lr = self.lr if lr is None else lr
+        self.t += 1
+        if self.bucket.flat.is_cuda:
+            from .custom_ops import custom_ops_factory as cof
+            ws = [self.params[n].data for n in self.bucket.names]
+            sh = [self.shadows.get(n) for n in self.bucket.names] if self.shadows else None
+            cof.adam_step(ws, self.wd, self.bucket.flat, self.acc, self.slot2, lr, self.t, self.beta1, self.beta2,
+                          self.epsilon, grad_scale, shadows=sh)
+            return
+        lr_t = lr * (1.0 - self.beta2 ** self.t) ** 0.5 / (1.0 - self.beta1 ** self.t)
+        for w, g, m, v in self._segments(grad_scale):
+            m.add_((g - m) * (1.0 - self.beta1))
+            v.add_((g * g - v) * (1.0 - self.beta2))
+            w.sub_(m * lr_t / (v.sqrt() + self.epsilon))
+        self.refresh_shadows()
+
+
+class RMSProp(_AdaptiveOptimizer):
+    """tf.train.RMSPropOptimizer(lr, decay, momentum, epsilon) (src/train.py:95-100; TF 1.1 training/rmsprop.py, not
+    centered):  ms += (g^2 - ms)(1 - decay);  mom = momentum mom + lr g / sqrt(ms + eps);  w -= mom;  `ms` starts at
+    ONE.  One fused HIP launch (`apa_rmsprop_step`) on a GPU."""
+
+    def __init__(self, params, bucket, lr, decay=0.9, momentum=0.0, epsilon=1e-10, weight_decay=0.0, regularized=(),
+                 bf16_shadows=None):
+        super().__init__(params, bucket, lr, weight_decay, regularized, bf16_shadows)
+        self.decay, self.momentum, self.epsilon = float(decay), float(momentum), float(epsilon)
+        self.acc.fill_(1.0)                                  # rmsprop.py _create_slots: init_rms = ones
+
+    def step(self, lr: Optional[float] = None, grad_scale: float = 1.0) -> None:
+        lr = self.lr if lr is None else lr
+        if self.bucket.flat.is_cuda:
+            from .custom_ops import custom_ops_factory as cof
+            ws = [self.params[n].data for n in self.bucket.names]
+            sh = [self.shadows.get(n) for n in self.bucket.names] if self.shadows else None
+            cof.rmsprop_step(ws, self.wd, self.bucket.flat, self.acc, self.slot2, lr, self.decay, self.momentum,
+                             self.epsilon, grad_scale, shadows=sh)
+            return
+        for w, g, ms, mom in self._segments(grad_scale):
+            ms.add_((g * g - ms) * (1.0 - self.decay))
+            mom.mul_(self.momentum).add_(g * lr / (ms + self.epsilon).sqrt())
+            w.sub_(mom)
+        self.refresh_shadows()
+
+
 def exponential_decay_lr(base_lr: float, global_step: int, decay_steps: int, decay_rate: float,
                          staircase: bool = True) -> float:
     """tf.train.exponential_decay (src/train.py:50-56): lr * rate^floor(step/decay_steps)."""
@@ -339,18 +412,214 @@ def configure_learning_rate(cfg, num_samples_per_epoch: int, num_clones: int, gl
 
 
 def configure_optimizer(cfg, params: Dict[str, torch.Tensor], bucket: GradientBucket, learning_rate: float,
-                        regularized: Sequence[str] = ()):
-    """_configure_optimizer (src/train.py:72-105) for the optimisers this library implements as one fused
-    launch: 'momentum' (cfgs 001-003: MomentumOptimizer(lr, TRAIN.MOMENTUM)) and 'sgd' (momentum 0).  The L2
-    regulariser's gradient (TRAIN.WEIGHT_DECAY on `regularized`) is folded into the same launch."""
+                        regularized: Sequence[str] = (), bf16_shadows: Optional[Dict[str, torch.Tensor]] = None):
+    """_configure_optimizer (src/train.py:72-105): every optimiser the reference can select, each as ONE fused
+    launch -- 'momentum' (cfgs 001-003: MomentumOptimizer(lr, TRAIN.MOMENTUM)), 'sgd' (momentum 0), 'adam'
+    (TRAIN.ADAM_BETA1 / ADAM_BETA2 / OPT_EPSILON) and 'rmsprop' (TRAIN.RMSPROP_DECAY / MOMENTUM / OPT_EPSILON).  The
+    L2 regulariser's gradient (TRAIN.WEIGHT_DECAY on `regularized`) is folded into the same launch.  As in the
+    reference, 'rmsprop' reads cfg.TRAIN.RMSPROP_DECAY, a key src/config.py does not define: without it in the
+    YAML the reference fails with an AttributeError at this point, and so does this function."""
     kind = cfg.TRAIN.OPTIMIZER
+    wd = float(cfg.TRAIN.WEIGHT_DECAY)
+    if kind == 'adam':
+        return Adam(params, bucket, lr=learning_rate, beta1=float(cfg.TRAIN.ADAM_BETA1),
+                    beta2=float(cfg.TRAIN.ADAM_BETA2), epsilon=float(cfg.TRAIN.OPT_EPSILON), weight_decay=wd,
+                    regularized=regularized, bf16_shadows=bf16_shadows)
+    if kind == 'rmsprop':
+        if 'RMSPROP_DECAY' not in cfg.TRAIN:
+            raise AttributeError('RMSPROP_DECAY')            # src/train.py:98 on the reference's own config table
+        return RMSProp(params, bucket, lr=learning_rate, decay=float(cfg.TRAIN.RMSPROP_DECAY),
+                       momentum=float(cfg.TRAIN.MOMENTUM), epsilon=float(cfg.TRAIN.OPT_EPSILON), weight_decay=wd,
+                       regularized=regularized, bf16_shadows=bf16_shadows)
     if kind == 'momentum':
         momentum = float(cfg.TRAIN.MOMENTUM)
     elif kind == 'sgd':
         momentum = 0.0
-    elif kind in ('adam', 'rmsprop'):
-        raise NotImplementedError('TRAIN.OPTIMIZER %r: only momentum / sgd have a fused update here' % kind)
     else:
         raise ValueError('Optimizer [%s] was not recognized' % kind)
     return MomentumSGD(params, bucket, lr=learning_rate, momentum=momentum,
-                       weight_decay=float(cfg.TRAIN.WEIGHT_DECAY), regularized=regularized)
+                       weight_decay=float(cfg.TRAIN.WEIGHT_DECAY), regularized=regularized, bf16_shadows=bf16_shadows)
+
+
+class _FusedHeadFunction(torch.autograd.Function):
+    """autograd node of FusedHeadStep: the forward IS the whole head step (forward + losses + backward, one host
+    call); the backward hands the stored conv5 gradient on to the backbone."""
+
+    @staticmethod
+    def forward(ctx, last_conv, owner, labels_action, labels_pose, pose_valid):
+        total = owner._run(last_conv, labels_action, labels_pose, pose_valid)
+        ctx.owner = owner
+        ctx.xshape = last_conv.shape
+        return total
+
+    @staticmethod
+    def backward(ctx, g_total):
+        o = ctx.owner
+        dX = o._dX.view(ctx.xshape)
+        if not o.assume_unit_upstream:        # total entered the differentiated scalar with some coefficient
+            dX = dX * g_total.to(dX.dtype)
+            for n in o._written:
+                o.bucket.views[n].mul_(g_total)
+        return dX, None, None, None, None
+
+
+class FusedHeadStep:
+    """The reference's per-clone training graph for the head -- `clone_fn` (network_fn -> gen_losses,
+    src/train.py:393-422) plus `optimizer.compute_gradients` on the clone loss (model_deploy.py:263) -- as ONE host
+    call on the conv5 map: `apa_pose_attn_train_step` for the cfg 003 form (attention from pose_pre_logits, pose L2 +
+    softmax cross-entropy), `apa_attn_head_train_step` for the cfg 002 / per-class (HMDB-51) forms (attention from
+    the map itself, softmax cross-entropy).  The YAML-driven surface stays the reference's: `get_network_fn(...)`
+    builds backbone + head, this object drives them.
+
+        fused = deploy.FusedHeadStep(network_fn, cfg)                 # raises ValueError if the configuration
+        opt = fused.make_optimizer(lr)                                #   needs the per-op module path
+        total, end_points = fused(images, labels_action, labels_pose, pose_valid)
+        total.backward()              # conv5's gradient enters the backbone's autograd graph; the head's gradients
+        opt.step()                    # already lie in fused.bucket (the flat all-reduce payload)
+
+    * `total` = sum of the clone's tf.losses entries (each scaled by `loss_scale` = 1 / num_clones,
+      model_deploy.py:223-225); the L2 regulariser is the optimiser's (`weight_decay * w` folded into its launch).
+      end_points: 'Logits', 'PosePrelogitsBasedAttention', 'PoseLogits' (cfg 003), 'Losses' (the individual values
+      in tf.GraphKeys.LOSSES order, detached).
+    * the head's gradients are written straight into `bucket` views, in the step's own launches; the bf16 operand
+      copy of the pose head's W1 is owned by the optimiser (`make_optimizer`: `bf16_shadows`) and rewritten by its
+      update launch, so no conversion kernel runs in the step.
+    * `assume_unit_upstream=True`: the caller promises `total` enters the differentiated scalar with coefficient 1
+      (`(total + other).backward()`), which saves one pass over the [N,H,W,C] gradient; the default multiplies by
+      whatever arrives."""
+
+    def __init__(self, network_fn, cfg, loss_scale: float = 1.0, assume_unit_upstream: bool = False):
+        from . import nets_factory
+        head = network_fn.head
+        if not isinstance(head, nets_factory.AttentionalPoolingHead):
+            raise ValueError('FusedHeadStep: the attentional-pooling head only (cfg 001 has no attention op)')
+        why = self.unsupported_reason(head, cfg, network_fn)
+        if why:
+            raise ValueError('FusedHeadStep: ' + why)
+        self.network_fn, self.head, self.cfg = network_fn, head, cfg
+        self.loss_scale = float(loss_scale)
+        self.assume_unit_upstream = bool(assume_unit_upstream)
+        self.pose_form = not head.single_layer
+        names = ['pose_w1', 'pose_b1', 'pose_w2', 'pose_b2', 'att_weights', 'att_biases', 'td_weights', 'td_biases']
+        self.params = {n: getattr(head, n) for n in names}
+        self.bucket = GradientBucket.for_parameters(self.params.items())
+        # cfg 002 forms: the PoseLogits convs are pruned from the data path -- no gradient, but their weights are
+        # regularised and decay (the optimiser's L2 term on a zero gradient), as in the reference (tf.gradients
+        # reaches them through REGULARIZATION_LOSSES only)
+        self._written = names if self.pose_form else names[4:]
+        reg = {id(w) for w in head.regularized_weights()}
+        self.regularized = [n for n in names if id(self.params[n]) in reg]
+        self._step_obj = None
+        self._key = None
+        self._dX = None
+        self.w1_shadow = None
+        self.probe_events = None
+
+    @staticmethod
+    def unsupported_reason(head, cfg, network_fn=None) -> str:
+        tr = cfg.TRAIN
+        if not head.is_training:
+            return 'a training-mode head is required'
+        if head.rank != 1 or head.with_pose_feat or head.want_topdown:
+            return 'rank > 1, ..._WITH_POSE_FEAT and the TopDownAttention dump run through the per-op module'
+        if tr.LOSS_FN_ACTION != 'softmax-xentropy':
+            return 'LOSS_FN_ACTION %r (the one-call steps take the softmax cross-entropy)' % tr.LOSS_FN_ACTION
+        if network_fn is not None and network_fn.temporal is not None:
+            return 'temporal attention / frame pooling sit between the head and the loss'
+        if head.single_layer:
+            if tr.LOSS_FN_POSE and head.with_pose_logits:
+                return 'a pose loss on a head whose attention does not come from the pose head'
+        else:
+            if head.per_class:
+                return 'per-class maps from pose_pre_logits'
+            if tr.LOSS_FN_POSE != 'l2' or tr.LOSS_FN_POSE_SAMPLED:
+                return 'LOSS_FN_POSE %r / sampled (the cfg 003 step takes the plain pose L2 loss)' % tr.LOSS_FN_POSE
+        return ''
+
+    def make_optimizer(self, learning_rate: float):
+        """deploy.configure_optimizer on the head's parameters and this object's bucket, with the bf16 copy of the
+        pose head's W1 as a shadow of the update launch when the cfg 003 step will read one (bf16 features)."""
+        shadows = None
+        if self.pose_form:
+            w1 = self.params['pose_w1']
+            self.w1_shadow = torch.empty(w1.shape, dtype=torch.bfloat16, device=w1.device)
+            shadows = {'pose_w1': self.w1_shadow}
+        self._step_obj = None                        # re-bind with the shadow
+        return configure_optimizer(self.cfg, {n: p.data for n, p in self.params.items()}, self.bucket,
+                                   learning_rate, regularized=self.regularized, bf16_shadows=shadows)
+
+    def _bind(self, X, labels_action, labels_pose, pose_valid):
+        from .custom_ops import custom_ops_factory as cof
+        head, tr, v = self.head, self.cfg.TRAIN, self.bucket.views
+        flags = cof.attn_flags(head.softmax_att, head.relu_att, True, self._preact)
+        self._dX = torch.empty_like(X)
+        p = {n: t.data for n, t in self.params.items()}
+        if self.pose_form:
+            shadow = self.w1_shadow if X.dtype == torch.bfloat16 else None
+            return cof.PoseAttnTrainStep(
+                X, (p['pose_w1'], p['pose_b1'], p['pose_w2'], p['pose_b2'], p['att_weights'], p['att_biases'],
+                    p['td_weights'], p['td_biases']), labels_action, labels_pose, pose_valid,
+                (self._dX, v['pose_w1'], v['pose_b1'], v['pose_w2'], v['pose_b2'], v['att_weights'], v['att_biases'],
+                 v['td_weights'], v['td_biases']), flags=flags, keep_prob=head.keep_prob, seed=head.seed,
+                offset=head._step, action_wt=float(tr.LOSS_FN_ACTION_WT), pose_wt=float(tr.LOSS_FN_POSE_WT),
+                grad_scale=self.loss_scale, w1_bf16=shadow)
+        return cof.HeadTrainStep(
+            X, X, p['att_weights'], p['att_biases'], p['td_weights'], p['td_biases'], labels_action,
+            (self._dX, None, v['att_weights'], v['att_biases'], v['td_weights'], v['td_biases']), flags=flags,
+            keep_prob=head.keep_prob, seed=head.seed, offset=head._step, loss_wt=float(tr.LOSS_FN_ACTION_WT),
+            grad_scale=self.loss_scale, hooks=head.hooks)
+
+    def _run(self, last_conv, labels_action, labels_pose, pose_valid):
+        head = self.head
+        n, c = last_conv.shape[0], last_conv.shape[-1]
+        X = last_conv.detach().contiguous().view(n, -1, c)
+        if self.pose_form:
+            J = self.params['pose_w2'].shape[1]
+            labels_pose = labels_pose.contiguous().float().view(n, -1, J)
+            if pose_valid.dtype == torch.bool:
+                pose_valid = pose_valid.to(torch.uint8)
+            pose_valid = pose_valid.contiguous()
+        key = (tuple(X.shape), X.dtype, self._preact)
+        if self._step_obj is None or key != self._key:
+            self._step_obj, self._key = self._bind(X, labels_action, labels_pose, pose_valid), key
+        elif self.pose_form:
+            self._step_obj.rebind(X=X, labels=labels_action, pose_labels=labels_pose, pose_valid=pose_valid,
+                                  offset=head._step)
+        else:
+            self._step_obj.rebind(X=X, labels=labels_action, offset=head._step)
+        st = self._step_obj
+        if self.probe_events is not None:                # measurement aid (tools/bench_e2e.py): the call's device time
+            self.probe_events[0].record()
+        st.run()
+        if self.probe_events is not None:
+            self.probe_events[1].record()
+        head._step += 1                                  # a fresh dropout mask per step
+        if self.pose_form:                               # loss.py:70 then :75 -- tf.GraphKeys.LOSSES order
+            self._losses = [st.loss_pose[0], st.loss_action[0]]
+            total = st.loss_pose[0] + st.loss_action[0]
+        else:
+            self._losses = [st.loss[0]]
+            total = st.loss[0].clone()
+        if self.loss_scale != 1.0:       # the entry points scale the GRADIENT (grad_scale); the value follows here
+            total = total * self.loss_scale
+        return total
+
+    def __call__(self, images, labels_action, labels_pose=None, pose_valid=None):
+        last_conv, self._preact = self.network_fn.features(images)
+        if last_conv.dim() != 4:
+            raise ValueError('FusedHeadStep: [N,H,W,C] feature maps (video input takes the module path)')
+        if self._preact and not self.head.can_fuse_input_relu(last_conv.dtype):
+            last_conv, self._preact = torch.relu(last_conv), False
+        if self.pose_form and (labels_pose is None or pose_valid is None):
+            raise ValueError('FusedHeadStep: the cfg 003 form needs labels_pose [N,H,W,J] and pose_valid [N,J]')
+        if last_conv.requires_grad:
+            total = _FusedHeadFunction.apply(last_conv, self, labels_action, labels_pose, pose_valid)
+        else:       # nothing upstream to differentiate (head-only training): `total.backward()` stays legal, a no-op
+            total = self._run(last_conv, labels_action, labels_pose, pose_valid).requires_grad_(True)
+        st = self._step_obj
+        n, h, w = last_conv.shape[:3]
+        ep = {'Logits': st.logits, 'PosePrelogitsBasedAttention': st.att.view(n, h, w, -1),
+              'Losses': [l.detach() for l in self._losses]}
+        if self.pose_form:
+            ep['PoseLogits'] = st.Pl.view(n, h, w, -1)
+        return total, ep

@@ -898,6 +898,16 @@ def get_network_fn(name: str, num_classes: int, num_pose_keypoints: int, cfg,
             ws.append(temporal['weights'])
         return ws
 
+    def features(images: torch.Tensor):
+        """the backbone half of network_fn: images -> the conv5 map the head reads (the images themselves when no
+        backbone was given) and whether it is the block's PRE-activation sum (fuse_final_relu) -- for callers that
+        run the head themselves (deploy.FusedHeadStep: the head's forward, losses and backward as one host call)"""
+        last_conv = backbone(images) if backbone is not None else images
+        if isinstance(last_conv, dict):
+            last_conv = last_conv[last_conv_map[name][0]]
+        return last_conv, bool(fuse_final_relu)
+
+    network_fn.features = features
     network_fn.head = head
     network_fn.regularized_weights = regularized_weights
     network_fn.backbone = getattr(backbone, 'module', backbone)

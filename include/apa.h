@@ -486,6 +486,21 @@ int apa_momentum_sgd_step_shadow(int nseg, float* const* weights, const size_t* 
                                  float lr, float momentum, float grad_scale, void* const* bf16_shadow,
                                  void* stream);
 
+/* The other two optimisers src/train.py:84-100 can select (TRAIN.OPTIMIZER 'adam' / 'rmsprop'; no shipped YAML
+ * does), same flat layout, two slot buffers, one launch, optional bf16 shadows (may be NULL) as above:
+ *   apa_adam_step     tf.train.AdamOptimizer(lr, beta1, beta2, epsilon):  m += (g - m)(1 - beta1);
+ *                     v += (g^2 - v)(1 - beta2);  w -= lr_t m / (sqrt(v) + epsilon), where the CALLER passes
+ *                     lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t) for update number t = 1, 2, ...; slots start at 0.
+ *   apa_rmsprop_step  tf.train.RMSPropOptimizer(lr, decay, momentum, epsilon):  ms += (g^2 - ms)(1 - decay);
+ *                     mom = momentum mom + lr g / sqrt(ms + epsilon);  w -= mom;  `ms` starts at ONE, `mom` at 0.
+ * g = grad_scale * grad_flat[...] + weight_decay[i] * w_i in both. */
+int apa_adam_step(int nseg, float* const* weights, const size_t* sizes, const float* weight_decay,
+                  const float* grad_flat, float* m_flat, float* v_flat, float lr_t, float beta1, float beta2,
+                  float epsilon, float grad_scale, void* const* bf16_shadow, void* stream);
+int apa_rmsprop_step(int nseg, float* const* weights, const size_t* sizes, const float* weight_decay,
+                     const float* grad_flat, float* ms_flat, float* mom_flat, float lr, float decay, float momentum,
+                     float epsilon, float grad_scale, void* const* bf16_shadow, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * TRAIN.ITER_SIZE accumulation (src/train.py:529-566: `ref = grad` on the first micro-step, `ref += grad` on the
  * following ones, `apply_gradients(ref / ITER_SIZE)` on the last) for micro-batches whose gradients were written

@@ -896,6 +896,39 @@ def test_fused_momentum_sgd_matches_torch_sgd(gpu):
         assert _rel(params[k].cpu().numpy(), ref[k].detach().numpy()) < 1e-6, k
 
 
+@pytest.mark.parametrize('kind', ['adam', 'rmsprop'])
+def test_fused_adam_and_rmsprop_match_the_host_rule(gpu, kind):
+    """apa_adam_step / apa_rmsprop_step (TRAIN.OPTIMIZER 'adam' / 'rmsprop', src/train.py:84-100): the fused launch
+    against deploy's CPU-tensor path of the same TF 1.1 rule (held to a float64 restatement in
+    tests/test_deploy_gloo_cpu.py), odd sizes, L2 on the weights only, grad_scale, a bf16 shadow, the reference's
+    epsilon = 1.0 and a small one."""
+    from attentionalpoolingaction_amd import deploy
+    g = torch.Generator().manual_seed(6)
+    shapes = {'att_weights': (2048, 1), 'att_biases': (1,), 'td_weights': (2048, 51), 'odd': (1031,)}
+    for eps in (1.0, 1e-6):
+        cpu = {k: torch.randn(s_, generator=g) for k, s_ in shapes.items()}
+        dev = {k: v.clone().to(gpu) for k, v in cpu.items()}
+        shadow = {'odd': torch.zeros(1031, dtype=torch.bfloat16, device=gpu)}
+        bc, bd = deploy.GradientBucket(shapes, 'cpu'), deploy.GradientBucket(shapes, gpu)
+        kw = dict(weight_decay=5e-4, regularized=['att_weights', 'td_weights'])
+        if kind == 'adam':
+            oc = deploy.Adam(cpu, bc, lr=1e-2, epsilon=eps, **kw)
+            od = deploy.Adam(dev, bd, lr=1e-2, epsilon=eps, bf16_shadows=shadow, **kw)
+        else:
+            oc = deploy.RMSProp(cpu, bc, lr=1e-2, decay=0.9, momentum=0.9, epsilon=eps, **kw)
+            od = deploy.RMSProp(dev, bd, lr=1e-2, decay=0.9, momentum=0.9, epsilon=eps, bf16_shadows=shadow, **kw)
+        assert torch.equal(shadow['odd'], dev['odd'].to(torch.bfloat16))        # current from the start
+        for step in range(4):
+            grad = torch.randn(bc.flat.numel(), generator=g)
+            bc.flat.copy_(grad)
+            bd.flat.copy_(grad.to(gpu))
+            oc.step(grad_scale=0.5)
+            od.step(grad_scale=0.5)
+        for k in shapes:
+            assert _rel(dev[k].cpu().numpy(), cpu[k].numpy()) < 2e-6, (kind, eps, k)
+        assert torch.equal(shadow['odd'], dev['odd'].to(torch.bfloat16))
+
+
 def test_momentum_sgd_keeps_a_bf16_shadow_of_the_pose_head_weights_current(gpu):
     """apa_momentum_sgd_step_shadow (deploy.MomentumSGD(bf16_shadows=...)): the optimizer's own launch rewrites the bf16
     operand copy of chosen segments from the UPDATED weights -- bit-identical to rounding the updated fp32 weights, at odd

@@ -270,6 +270,77 @@ def test_one_call_train_steps_match_reference_at_the_benchmark_shape(gpu, path, 
         fx.check('grad/var/' + vn, full.reshape(shape), tol, dtype + ' ' + vn, tol_proj=tolp)
 
 
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('path', BIG_TRAIN, ids=rf.case_id)
+def test_fused_head_step_surface_matches_reference_at_the_benchmark_shape(gpu, path, dtype):
+    """deploy.FusedHeadStep -- the reference-shaped surface (get_network_fn from the fixture's config, the head's own
+    parameters, dropout seed / step) driving the one-call steps: total loss, end points, the conv5 gradient that
+    reaches autograd (`total.backward()` -> images.grad) and the head gradients in the flat bucket against the
+    reference-executed fixture; then ONE update of the optimiser `make_optimizer` configures (momentum-SGD from the
+    fixture's TRAIN table, L2 folded in, bf16 shadow of W1) against w - lr * (fixture gradient), whose gradient
+    already contains weight_decay * w."""
+    from attentionalpoolingaction_amd import config as apa_config, deploy
+    fx = _big(path)
+    bf = dtype == 'bf16'
+    network_fn, cfg = rf.build_head(fx, device=gpu)
+    try:
+        table = rf.module_tf_names(network_fn)
+        with torch.no_grad():
+            for vn, t in table.items():
+                t.copy_(torch.from_numpy(fx.var(vn).astype(np.float32)).to(gpu))
+        head = network_fn.head
+        head.seed, head._step = int(fx.meta['libmask'][0]), int(fx.meta['libmask'][1])
+        fused = deploy.FusedHeadStep(network_fn, cfg)
+        lr = 0.01
+        opt = fused.make_optimizer(lr)
+        if fused.pose_form:
+            assert torch.equal(fused.w1_shadow, head.pose_w1.data.to(torch.bfloat16))     # current from the start
+        images = torch.from_numpy(fx.arrays['in/images']).to(gpu).to(torch.bfloat16 if bf else torch.float32)
+        images.requires_grad_(True)
+        use_pose = bool(fx.meta['train_cfg']['LOSS_FN_POSE'])
+        total, ep = fused(images, torch.from_numpy(fx.arrays['in/labels_action']).to(gpu),
+                          torch.from_numpy(fx.arrays['in/labels_pose']).to(gpu) if use_pose else None,
+                          torch.from_numpy(fx.arrays['in/labels_pose_valid']).to(gpu) if use_pose else None)
+        (2.0 * total).backward()                  # a non-unit upstream coefficient: the node multiplies it through
+        assert head._step == int(fx.meta['libmask'][1]) + 1
+        exp_logits = fx.expected('out/logits').astype(np.float64)
+        got_logits = ep['Logits'].float().cpu().numpy().astype(np.float64)
+        err = np.abs(got_logits - exp_logits).max()
+        assert err <= (3e-3 if bf else 1e-3)
+        if not bf:
+            assert np.array_equal(got_logits.argmax(1), exp_logits.argmax(1))
+        tol, tolp = (1.2e-2, 8e-3) if bf else (5e-5, 5e-5)
+        exp_losses = fx.expected('out/losses')
+        assert len(ep['Losses']) == len(exp_losses)
+        for g_, e_ in zip(ep['Losses'], exp_losses):
+            assert abs(float(g_) - e_) <= (2e-3 if bf else 2e-5) * max(abs(e_), 1e-3)
+        assert abs(float(total) - exp_losses.sum()) <= (2e-3 if bf else 2e-5) * exp_losses.sum()
+        fx.check('grad/images', images.grad.float().cpu().numpy() / 2.0, tol, dtype + ' grad/images', tol_proj=tolp)
+        wd = fx.meta['weight_decay']
+        before = {n: p.detach().clone() for n, p in fused.params.items()}
+        names = head.tf_variable_names()
+        grads = {}
+        for n in fused._written:
+            full = fused.bucket.views[n].double().cpu().numpy() / 2.0 + \
+                (wd * before[n].double().cpu().numpy() if n in fused.regularized else 0.0)
+            fx.check('grad/var/' + names[n], full.reshape(fx.variables[names[n]].shape), tol, dtype + ' ' + n,
+                     tol_proj=tolp)
+            grads[n] = full
+        # one update: acc = g (+ wd w), w -= lr acc  (MomentumOptimizer from a zero accumulator, src/train.py:90-94)
+        fused.bucket.flat.mul_(0.5)
+        opt.step()
+        for n, p_ in fused.params.items():
+            g_ = grads.get(n)
+            if g_ is None:                    # pruned from the data path (cfg 002 forms): the L2 term alone
+                g_ = wd * before[n].double().cpu().numpy() if n in fused.regularized else 0.0 * before[n].double().cpu().numpy()
+            want = before[n].double().cpu().numpy() - lr * g_
+            assert np.abs(p_.detach().double().cpu().numpy() - want).max() <= 1e-6 * max(np.abs(want).max(), 1e-3), n
+        if fused.pose_form:
+            assert torch.equal(fused.w1_shadow, head.pose_w1.data.to(torch.bfloat16))     # rewritten by the update launch
+    finally:
+        apa_config.reset_cfg()
+
+
 @pytest.mark.parametrize('path', BIG_PATHS, ids=rf.case_id)
 def test_hip_topdown_endpoint_at_the_benchmark_shape(gpu, path):
     """end_points['TopDownAttention'] [32, 14, 14, 393] on request (nets_factory.py:309), against the reference's

@@ -8,9 +8,13 @@ replaces, these two say what share of a real step that part is and where its inp
 
   eval002   cfg 002 evaluation: fp32 backbone (eval-mode batch norm, no grad) -> attn-pool forward -> softmax +
             argmax (`eval_utils`), batch 32 x 448 x 448 x 3 -> conv5 32 x 14 x 14 x 2048.
-  train003  cfg 003 training: backbone under bf16 autocast -> pose head + attention head (bf16 kernels) -> pose L2
-            + softmax cross-entropy + L2 regulariser -> backward through head and backbone -> fused momentum-SGD
-            on the head, torch.optim.SGD(momentum) on the backbone (src/train.py:90-94).
+  train003  cfg 003 training: backbone under bf16 autocast -> `deploy.FusedHeadStep` (the head's forward, pose L2 +
+            softmax cross-entropy and backward as ONE host call, apa_pose_attn_train_step: 13 launches, conv5's
+            gradient handed to autograd) -> backward through the backbone -> the head's fused momentum-SGD launch
+            (deploy.MomentumSGD, which also rewrites the bf16 operand copy of W1; the L2 regulariser is its
+            weight-decay term), torch.optim.SGD(momentum) on the backbone (src/train.py:90-94).
+            `--module-path`: the same step through network_fn -> gen_losses -> autograd (the per-op calls) with
+            torch.optim.SGD on the head -- what round 4 timed.
 
 `build(...)` returns (step, info, probe): `step()` enqueues one step; `probe(n)` re-runs n steps with HIP events
 around the head (forward: around the module call; backward: from just before `.backward()` to the hook on the
@@ -37,7 +41,8 @@ CFG003 = {'MODEL_NAME': 'resnet_v1_101', 'NET': {'USE_POSE_PRELOGITS_BASED_ATTEN
           'TRAIN': {'LOSS_FN_POSE': 'l2', 'LOSS_FN_ACTION': 'softmax-xentropy'}}
 
 
-def build(which, dev, N=32, side=448, K=393, J=16, fuse_final_relu=False, backbone='resnet_v1_101'):
+def build(which, dev, N=32, side=448, K=393, J=16, fuse_final_relu=False, backbone='resnet_v1_101',
+          module_path=False):
     from attentionalpoolingaction_amd import config as apa_config, loss as apa_loss, nets_factory, deploy
     train = which == 'train003'
     cfg = apa_config.reset_cfg()
@@ -89,11 +94,23 @@ def build(which, dev, N=32, side=448, K=393, J=16, fuse_final_relu=False, backbo
                                  lr=lr, momentum=mom, foreach=True)
         hp = [p for p in head.parameters() if p.requires_grad]
         reg = {id(w) for w in fn.regularized_weights()}
+        if not module_path:
+            fused = deploy.FusedHeadStep(fn, cfg, assume_unit_upstream=True)
+            opt_fused = fused.make_optimizer(lr)
+
+            def step():
+                opt_bb.zero_grad(set_to_none=True)
+                fused.probe_events = ev['head_fwd']
+                total, _ = fused(images, labels, pose_lbl, valid)
+                total.backward()              # conv5's gradient -> backbone; the head's gradients are in the bucket
+                opt_fused.step()
+                opt_bb.step()
+                return total
         opt_head = torch.optim.SGD([{'params': [p for p in hp if id(p) in reg], 'weight_decay': wd},
                                     {'params': [p for p in hp if id(p) not in reg], 'weight_decay': 0.0}],
                                    lr=lr, momentum=mom, foreach=True)
 
-        def step():
+        def step_module():
             logits, ep = fn(images)
             losses = apa_loss.gen_losses(labels, logits, cfg.TRAIN.LOSS_FN_ACTION, K, cfg.TRAIN.LOSS_FN_ACTION_WT,
                                          pose_lbl, ep['PoseLogits'], cfg.TRAIN.LOSS_FN_POSE, valid,
@@ -108,6 +125,8 @@ def build(which, dev, N=32, side=448, K=393, J=16, fuse_final_relu=False, backbo
             opt_head.step()
             opt_bb.step()
             return total
+        if module_path:
+            step = step_module
         params = sum(p.numel() for p in bb_params)
 
     def probe(n=5):
@@ -115,28 +134,32 @@ def build(which, dev, N=32, side=448, K=393, J=16, fuse_final_relu=False, backbo
         pairs = lambda: [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         tf_, tb_, ts_ = [], [], []
         for _ in range(n):
-            ev['head_fwd'], ev['head_bwd'] = pairs(), (pairs() if train else None)
+            ev['head_fwd'], ev['head_bwd'] = pairs(), (pairs() if (train and module_path) else None)
             s0, s1 = pairs()
             s0.record()
             step()
             s1.record()
             torch.cuda.synchronize()
             tf_.append(ev['head_fwd'][0].elapsed_time(ev['head_fwd'][1]))
-            if train:
+            if train and module_path:
                 tb_.append(ev['head_bwd'][0].elapsed_time(ev['head_bwd'][1]))
             ts_.append(s0.elapsed_time(s1))
         ev['head_fwd'] = ev['head_bwd'] = None
         avg = lambda v: sum(v) / len(v) if v else 0.0
         return avg(tf_), avg(tb_), avg(ts_)
 
-    info = {'workload': ('cfg003 training step end to end: {bb} (bf16 autocast, channels-last, torch-ROCm/MIOpen) -> HIP '
-                         'pose head + attention head (bf16) -> pose L2 + softmax-xent -> backward through head and '
-                         'backbone -> momentum-SGD; batch {n} x {s}x{s}x3 -> conv5 {n} x {h}x{h}x2048, K={k}'
+    info = {'workload': (('cfg003 training step end to end: {bb} (bf16 autocast, channels-last, torch-ROCm/MIOpen) -> HIP '
+                          'pose head + attention head (bf16) -> pose L2 + softmax-xent -> backward through head and '
+                          'backbone -> momentum-SGD; batch {n} x {s}x{s}x3 -> conv5 {n} x {h}x{h}x2048, K={k}' +
+                          ('; head through the per-op module path' if module_path else
+                           '; head forward + losses + backward as ONE host call (deploy.FusedHeadStep), fused HIP '
+                           'momentum-SGD on the head'))
                          if train else
                          'cfg002 evaluation step end to end: {bb} (fp32, channels-last, torch-ROCm/MIOpen, no grad) -> HIP '
                          'attn-pool forward -> argmax; batch {n} x {s}x{s}x3 -> conv5 {n} x {h}x{h}x2048, K={k}'
                          ).format(bb=backbone, n=N, s=side, h=H, k=K) + ('; last ReLU folded into the op' if fuse_final_relu else ''),
-            'N': N, 'dtype': 'bf16' if train else 'f32', 'backbone_params': params}
+            'N': N, 'dtype': 'bf16' if train else 'f32', 'backbone_params': params,
+            'fused_head': bool(train and not module_path)}
     return step, info, probe
 
 
@@ -164,9 +187,11 @@ def run(which, dev, steps=6, warmup=3, **kw):
            'dtype': info['dtype'],
            'head_share': {'head_fwd_ms': round(hf, 4), 'head_bwd_ms': round(hb, 4), 'step_ms_under_probe': round(st, 3),
                           'fraction_of_step': round((hf + hb) / st, 5) if st > 0 else None,
-                          'how': 'HIP events on the compute stream: around the head module call (forward), and from '
-                                 'just before .backward() to the autograd hook on the conv5 gradient (backward: '
-                                 'loss kernels + head backward)'}}
+                          'how': ('HIP events on the compute stream around the ONE call that is the head\'s forward, '
+                                  'losses and backward (reported as head_fwd_ms; head_bwd_ms = 0)') if info['fused_head']
+                          else ('HIP events on the compute stream: around the head module call (forward), and from '
+                                'just before .backward() to the autograd hook on the conv5 gradient (backward: '
+                                'loss kernels + head backward)')}}
     from attentionalpoolingaction_amd import config as apa_config
     apa_config.reset_cfg()
     return out
@@ -181,12 +206,15 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--fuse-final-relu', action='store_true')
     ap.add_argument('--backbone', default='resnet_v1_101')
+    ap.add_argument('--module-path', action='store_true',
+                    help='train003: drive the head through network_fn -> gen_losses -> autograd (per-op calls)')
     args = ap.parse_args()
     from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
     cof.load_library()
     dev = torch.device('cuda:0')
     print(json.dumps(run(args.workload, dev, args.steps, args.warmup, N=args.batch, side=args.side,
-                         fuse_final_relu=args.fuse_final_relu, backbone=args.backbone)))
+                         fuse_final_relu=args.fuse_final_relu, backbone=args.backbone,
+                         module_path=args.module_path)))
 
 
 if __name__ == '__main__':
