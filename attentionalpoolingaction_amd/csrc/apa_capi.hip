@@ -205,6 +205,10 @@ static int attn_pool_fwd_impl(const Hooks& hk, const apa_concat_feat* catp, M1Xe
     set_error("apa_attn_pool_fwd: workspace too small (%zu < %zu)", ws_bytes, need);
     return APA_ERR_WORKSPACE;
   }
+  if ((flags & APA_FLAG_WEIGHT_IMAGES) && (reinterpret_cast<uintptr_t>(X) & 15)) {
+    set_error("apa_attn_pool_fwd: APA_FLAG_WEIGHT_IMAGES needs 16-byte aligned features (the images are laid out for them)");
+    return APA_ERR_INVALID_ARG;
+  }
   if (hk.td_ready) APA_HIP_CHECK(hipStreamWaitEvent(st, hk.td_ready, 0));
   return pc_forward(X, Xatt, Wa, ba, Wt, bt, logits, att, zsave, topdown, ws, N, P, C, Ca, K, flags,
                     keep_prob, seed, offset, dtype, st, topdown ? nullptr : xf);
@@ -294,6 +298,10 @@ static int attn_pool_bwd_impl(const Hooks& hk, const apa_concat_feat* catp, cons
   if (!ws || ws_bytes < need) {
     set_error("apa_attn_pool_bwd: workspace too small (%zu < %zu)", ws_bytes, need);
     return APA_ERR_WORKSPACE;
+  }
+  if ((flags & APA_FLAG_WEIGHT_IMAGES) && (reinterpret_cast<uintptr_t>(X) & 15)) {
+    set_error("apa_attn_pool_bwd: APA_FLAG_WEIGHT_IMAGES needs 16-byte aligned features (the images are laid out for them)");
+    return APA_ERR_INVALID_ARG;
   }
   rc = pc_backward(X, Xatt, Wa, Wt, att, zsave, G, dX, dXatt, dWa, dba, dWt, dbt, ws, N, P, C, Ca, K,
                    flags, keep_prob, seed, offset, dtype, st, xf);
@@ -509,6 +517,24 @@ extern "C" int apa_pose_attn_train_step(const apa_pose_attn_step_io* io, int N, 
   // (same workspace, same call: the bf16 copy of W1 the forward half built there -- when the caller keeps none -- is reused)
   return pose_bwd_fused(s.X, s.W1, s.W2, s.Ppre, s.dPl, s.dZ, s.Wa, s.dX, 1 | APA_POSE_WS_FROM_FWD, s.dW1, s.db1, s.dW2,
                         s.db2, s.dWa, s.dba, s.loss_pose, bump, s.ws_pose, s.ws_pose_bytes, N, P, C, Cp, J, dtype, a, st);
+}
+
+extern "C" int apa_per_class_weight_images(const float* Wa, const float* ba, const float* Wt, const float* bt, void* ws,
+                                           size_t ws_bytes, int N, int P, int C, int Ca, int K, int dtype,
+                                           apa_weight_image* maps, int* nmaps, void* stream) {
+  if (nmaps) *nmaps = 0;
+  if (!Wa || !ba || !Wt || !bt) {
+    set_error("apa_per_class_weight_images: null parameter pointer");
+    return APA_ERR_INVALID_ARG;
+  }
+  int rc = check_common("apa_per_class_weight_images", N, P, C, Ca, K, K, dtype);
+  if (rc != APA_OK) return rc;
+  const size_t need = pc_workspace_bytes(N, P, C, Ca, K, dtype);
+  if (!ws || ws_bytes < need) {
+    set_error("apa_per_class_weight_images: workspace too small (%zu < %zu)", ws_bytes, need);
+    return APA_ERR_WORKSPACE;
+  }
+  return pc_weight_images(Wa, ba, Wt, bt, ws, N, P, C, Ca, K, dtype, maps, nmaps, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int apa_attn_head_eval_step(const void* X, const void* Xatt, const float* Wa, const float* ba,

@@ -993,7 +993,7 @@ __global__ __launch_bounds__(256) void pc_pad_kernel(PcPadSegs sg, int K, int Kp
   const unsigned npad = gridDim.x - dr.nblocks;
   if (blockIdx.x >= npad) { pc_dropout_block(dr, blockIdx.x - npad, dr.nblocks); return; }
   const unsigned idx = blockIdx.x * 256u + threadIdx.x;       // vector index: 8 elements each
-  if (idx >= (unsigned)(sg.end[sg.n - 1] >> 3)) return;
+  if (sg.n == 0 || idx >= (unsigned)(sg.end[sg.n - 1] >> 3)) return;
   int s = 0;
   unsigned base = 0;
   if (sg.n > 1 && idx >= (unsigned)(sg.end[0] >> 3)) { s = 1; base = (unsigned)(sg.end[0] >> 3); }
@@ -1023,11 +1023,23 @@ struct PcPadList {
     sg.src[i] = W; sg.dst[i] = Wp; sg.bf16[i] = to_bf16 ? 1 : 0; sg.ld[i] = ld > 0 ? ld : Kp;
     sg.end[i] = (i ? sg.end[i - 1] : 0) + (long)rows * Kp;
   }
+  // (an empty list -- APA_FLAG_WEIGHT_IMAGES: the padded weights are kept by the caller -- launches the dropout
+  // blocks alone, or nothing)
   void launch(int K, int Kp, hipStream_t st, const PcDropArgs* drop = nullptr) const {
     PcDropArgs dr = {nullptr, nullptr, 0, 1.f, 0, 0, 0, nullptr, 0, nullptr};
     if (drop) dr = *drop;
-    hipLaunchKernelGGL(pc_pad_kernel, dim3((unsigned)(((sg.end[sg.n - 1] >> 3) + 255) / 256) + dr.nblocks), dim3(256), 0,
-                       st, sg, K, Kp, dr);
+    const unsigned npad = sg.n ? (unsigned)(((sg.end[sg.n - 1] >> 3) + 255) / 256) : 0u;
+    if (npad + dr.nblocks == 0) return;
+    hipLaunchKernelGGL(pc_pad_kernel, dim3(npad + dr.nblocks), dim3(256), 0, st, sg, K, Kp, dr);
+  }
+  // the images of this list as apa_weight_image maps: element (c, k) of segment i -> dst[c * ld + k]
+  int describe(const int* roles, int K, apa_weight_image* out) const {
+    for (int i = 0; i < sg.n; ++i) {
+      apa_weight_image& m = out[i];
+      m.dst = sg.dst[i]; m.role = roles[i]; m.is_f32 = sg.bf16[i] ? 0 : 1; m.cols = K; m.c_shift = 0;
+      m.a = sg.ld[i]; m.b = 0; m.d = 1; m.e = 0;
+    }
+    return sg.n;
   }
 };
 
@@ -1317,6 +1329,59 @@ static void set_dropout(GemmDesc& g, bool on_a, bool on_c, float keep_prob, uint
   g.thresh = k.thresh; g.seed = k.seed; g.offset = k.offset; g.offset_dev = k.offset_dev;
 }
 
+// APA_FLAG_WEIGHT_IMAGES: every image pc_forward / pc_backward would otherwise prepare per call, built once here
+// (for 16-byte aligned features: the [Wt | Wa] concatenation of pc_cat) and described for the optimiser's launch.
+// K <= 64 (bf16, Ca == C) builds BOTH sets -- the fused kernels' and the padded GEMM operands -- because which path a
+// call takes also depends on its Xatt (== X or not) and on its dropout source.
+int pc_weight_images(const float* Wa, const float* ba, const float* Wt, const float* bt, void* ws, int N, int P,
+                     int C, int Ca, int K, int dtype, apa_weight_image* maps, int* nmaps, hipStream_t st) {
+  const PcPlan pl = pc_plan(N, P, C, Ca, K, dtype);
+  char* w = static_cast<char*>(ws);
+  const int Kp = pl.Kp;
+  const bool wb16 = dtype == APA_DTYPE_BF16;
+  const bool cat = wb16 && Ca == C && C % 8 == 0 && knob("APA_PC_CAT", 1);
+  const int ldw = cat ? 2 * Kp : Kp;
+  void* WtP = w + pl.off_wtp;
+  void* WaP = cat ? static_cast<void*>(static_cast<bf16_t*>(WtP) + Kp) : static_cast<void*>(w + pl.off_wap);
+  float* baP = reinterpret_cast<float*>(w + pl.off_bap);
+  int n = 0;
+  {
+    PcPadList pads;
+    pads.add(Wa, WaP, Ca, Kp, wb16, ldw);
+    pads.add(ba, baP, 1, Kp, false);
+    pads.add(Wt, WtP, C, Kp, wb16, ldw);
+    pads.launch(K, Kp, st);
+    APA_LAUNCH_CHECK("pc_pad_kernel");
+    if (maps) {
+      const int roles[3] = {APA_WIMG_ROLE_WA, APA_WIMG_ROLE_BA, APA_WIMG_ROLE_WT};
+      n += pads.describe(roles, K, maps + n);
+    }
+  }
+  if (wb16 && Ca == C && K <= 64 && C % 256 == 0 && knob("APA_PC_FUSED", 1)) {   // pc_fused_supported, minus X
+    const PcFusedWs f = pc_fused_carve(w + pl.off_fused, N, P, C);
+    const int rc = pc_fused_prep(f, Wa, Wt, ba, bt, C, K, st, nullptr, true);
+    if (rc != APA_OK) return rc;
+    APA_HIP_CHECK(hipMemsetAsync(f.bits_tag, 0, 64, st));   // whatever the keep-bit map held: nobody may believe it
+    if (maps) {
+      auto put = [&](int role, void* dst, int f32, int sh, int a, int b, int d, int e) {
+        apa_weight_image& m = maps[n++];
+        m.dst = dst; m.role = role; m.is_f32 = f32; m.cols = K; m.c_shift = sh; m.a = a; m.b = b; m.d = d; m.e = e;
+      };
+      // WcatT [C/64][128][64]: tile c >> 6, row = column (Wa: k, Wt: 64 + k), position c & 63
+      put(APA_WIMG_ROLE_WA, f.WcatT, 0, 6, 128 * 64, 1, 64, 0);
+      put(APA_WIMG_ROLE_WT, f.WcatT, 0, 6, 128 * 64, 1, 64, 64 * 64);
+      // Wcat2 [C][128]: Wt | Wa
+      put(APA_WIMG_ROLE_WT, f.Wcat2, 0, 0, 128, 0, 1, 0);
+      put(APA_WIMG_ROLE_WA, f.Wcat2, 0, 0, 128, 0, 1, 64);
+      // bcat f32 [128]: ba | bt
+      put(APA_WIMG_ROLE_BA, f.bcat, 1, 0, 0, 0, 1, 0);
+      put(APA_WIMG_ROLE_BT, f.bcat, 1, 0, 0, 0, 1, 64);
+    }
+  }
+  if (nmaps) *nmaps = n;
+  return APA_OK;
+}
+
 int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba, const float* Wt,
                const float* bt, float* logits, float* att, float* Tsave, void* topdown, void* ws,
                int N, int P, int C, int Ca, int K, unsigned flags, float keep_prob, uint64_t seed,
@@ -1341,9 +1406,15 @@ int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
     const uint64_t* offd = devctr ? reinterpret_cast<const uint64_t*>(static_cast<uintptr_t>(offset)) : nullptr;
     // training: the weight-preparation launch also writes the step's keep bits (its 128 weight blocks leave half
     // the chip idle), and the product kernel DMAs them instead of hashing on its critical chain
-    const bool prebits = train;
+    // Round 5, the one-call train step with caller-kept weight images: NO preparation launch -- the keep bits of this
+    // step were written by the previous step's last launch (pc_dw_reduce_kernel's extra blocks) and are believed iff
+    // their tag says so; else the forward kernel hashes them itself (first step on a workspace, a jump of the offset)
+    static const int tagged_knob = knob("APA_PC_TAGGED_BITS", 1);
+    const bool tagged = tagged_knob && train && (flags & APA_FLAG_WEIGHT_IMAGES) && xf && xf->labels;
+    const bool prebits = train && !tagged;
     const PcPrepBits pb = {(size_t)R * C, keep_prob, seed, devctr ? 0 : offset, offd};
-    int rc = pc_fused_prep(f, Wa, Wt, ba, bt, C, K, st, prebits ? &pb : nullptr);
+    int rc = APA_OK;
+    if (!tagged) rc = pc_fused_prep(f, Wa, Wt, ba, bt, C, K, st, prebits ? &pb : nullptr, !(flags & APA_FLAG_WEIGHT_IMAGES));
     if (rc != APA_OK) return rc;
     static const int fold_xent = knob("APA_PC_XENT_FOLD", 1);
     static const int fold_act = knob("APA_PC_ACT_FOLD", 1);
@@ -1354,7 +1425,7 @@ int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
     const bool fold = fold_act && act != 2 && !topdown && P >= 32;
     const PcFwdFold ff = {att, act, P};
     rc = pc_fused_forward(f, X, Z, Tsave, R, C, K, train, keep_prob, seed, devctr ? 0 : offset, offd, st, prebits,
-                          fold ? &ff : nullptr);
+                          fold ? &ff : nullptr, tagged);
     if (rc != APA_OK) return rc;
     if (fold) {
       // one-call train step: pc_backward's first launch (pc_bwd_dx_kernel) finishes logits + cross-entropy
@@ -1379,9 +1450,11 @@ int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba
   }
   {
     PcPadList pads;
-    pads.add(Wa, WaP, Ca, Kp, wb16, ldw);
-    pads.add(ba, baP, 1, Kp, false);
-    if (fast) pads.add(Wt, WtP, C, Kp, true, ldw);
+    if (!(flags & APA_FLAG_WEIGHT_IMAGES)) {     // else: kept current by the caller (pc_weight_images' layout)
+      pads.add(Wa, WaP, Ca, Kp, wb16, ldw);
+      pads.add(ba, baP, 1, Kp, false);
+      if (fast) pads.add(Wt, WtP, C, Kp, true, ldw);
+    }
     if (fast && train) {   // + the materialised dropout(X) of the DMA-staged T product (and its keep bits), same launch
       const PcDropArgs dr = pc_drop_args(X, w + pl.off_xd, pl.R, C, keep_prob, seed, offset, flags,
                                          reinterpret_cast<uint8_t*>(w + pl.off_bits));
@@ -1471,7 +1544,8 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
     uint64_t* bump = (train && devctr) ? reinterpret_cast<uint64_t*>(static_cast<uintptr_t>(offset)) : nullptr;
     if (!(flags & APA_FLAG_WS_FROM_FWD)) {   // else the forward call left the operands and the mask bits in place
       const PcPrepBits pb = {(size_t)R * C, keep_prob, seed, off, offd};
-      rc = pc_fused_prep(f, Wa, Wt, nullptr, nullptr, C, K, st, train ? &pb : nullptr);
+      rc = pc_fused_prep(f, Wa, Wt, nullptr, nullptr, C, K, st, train ? &pb : nullptr,
+                         !(flags & APA_FLAG_WEIGHT_IMAGES));
       if (rc != APA_OK) return rc;
     }
     if (pc_fused_dx_supported(P, act_code(flags))) {
@@ -1483,6 +1557,13 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
       if (rc != APA_OK) return rc;
       PcDwTail tail = {pdbt, dbt, dba, rbs, bump, nullptr, 0, 0.f, nullptr};
       if (xf && xf->done) { tail.aux_src = xf->loss + 1; tail.aux_n = -N; tail.aux_scale = xf->lscale; tail.aux_dst = xf->loss; }
+      // the same condition as pc_forward's `tagged` (WS_FROM_FWD is set by the library's own train step only): this
+      // launch is the step's last -- it also leaves the NEXT step's keep bits behind, tagged (seed, offset + 1)
+      static const int tagged_knob = knob("APA_PC_TAGGED_BITS", 1);
+      if (tagged_knob && train && (flags & APA_FLAG_WEIGHT_IMAGES) && (flags & APA_FLAG_WS_FROM_FWD)) {
+        tail.next_bits = true;
+        tail.next_seed = seed;
+      }
       return pc_fused_dw(f, X, dWt, dWa, R, C, K, train, keep_prob, st, &tail);
     }
     bf16_t* dTc = static_cast<bf16_t*>(f.dTdZ);              // [R][dT (64) | dZ (64)]
@@ -1497,18 +1578,26 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
     PcDwTail tail = {pdbt, dbt, dba, N * ps, bump, nullptr, 0, 0.f, nullptr};
     // (aux_n < 0: the batch mean in apa_softmax_xent_fwd_bwd's own summation order -- bit-identical loss[0])
     if (xf && xf->done) { tail.aux_src = xf->loss + 1; tail.aux_n = -N; tail.aux_scale = xf->lscale; tail.aux_dst = xf->loss; }
-    rc = pc_fused_dw(f, X, dWt, dWa, R, C, K, train, keep_prob, st, &tail);
-    if (rc != APA_OK) return rc;
-    // dX = (dT . Wt^T) * mask/keep + dZ . Wa^T: one launch over the concatenated k = 128
+    static const int tagged_knob2 = knob("APA_PC_TAGGED_BITS", 1);
+    if (tagged_knob2 && train && (flags & APA_FLAG_WEIGHT_IMAGES) && (flags & APA_FLAG_WS_FROM_FWD)) {
+      tail.next_bits = true;      // (see the identity / relu branch above)
+      tail.next_seed = seed;
+    }
+    // dX = (dT . Wt^T) * mask/keep + dZ . Wa^T: one launch over the concatenated k = 128.  (Round 5: BEFORE the dW
+    // launches -- the reduce tail that ends them may overwrite the keep-bit map with the next step's.)
     static const int exp_mask = knob("APA_PC_EXP", 0);
-    if (train && !(exp_mask & 1))
-      return gemm_bf16_mid_dropout(f.dTdZ, 128, f.Wcat2, 128, dX, C, R, C, 128, 1.0f / keep_prob, f.maskbits, st);
-    GemmDesc g;
-    g.A = f.dTdZ; g.lda = 128; g.ta = 1; g.a_kc = true;
-    g.B = f.Wcat2; g.ldb = 128; g.tb = 1; g.b_kc = true;
-    g.C = dX; g.ldc = C; g.tc = 1;
-    g.M = R; g.N = C; g.K = 128;
-    return gemm_launch(g, st);
+    if (train && !(exp_mask & 1)) {
+      rc = gemm_bf16_mid_dropout(f.dTdZ, 128, f.Wcat2, 128, dX, C, R, C, 128, 1.0f / keep_prob, f.maskbits, st);
+    } else {
+      GemmDesc g;
+      g.A = f.dTdZ; g.lda = 128; g.ta = 1; g.a_kc = true;
+      g.B = f.Wcat2; g.ldb = 128; g.tb = 1; g.b_kc = true;
+      g.C = dX; g.ldc = C; g.tc = 1;
+      g.M = R; g.N = C; g.K = 128;
+      rc = gemm_launch(g, st);
+    }
+    if (rc != APA_OK) return rc;
+    return pc_fused_dw(f, X, dWt, dWa, R, C, K, train, keep_prob, st, &tail);
   }
   // APA_FLAG_WS_FROM_FWD (one-call train step): the forward call's padded bf16 weights and its materialised
   // dropout(X) are still in the workspace -- the second pc_pad / pc_dropout launch (7.9 + 8.4 us at K = 393) is
@@ -1517,8 +1606,10 @@ int pc_backward(const void* X, const void* Xatt, const float* Wa, const float* W
   const bool reuse_fwd = (flags & APA_FLAG_WS_FROM_FWD) && fast_bf16;
   if (!reuse_fwd) {
     PcPadList pads;
-    pads.add(Wa, WaP, Ca, Kp, wb16, ldw);
-    pads.add(Wt, WtP, C, Kp, wb16, ldw);
+    if (!(flags & APA_FLAG_WEIGHT_IMAGES)) {
+      pads.add(Wa, WaP, Ca, Kp, wb16, ldw);
+      pads.add(Wt, WtP, C, Kp, wb16, ldw);
+    }
     if (fast_bf16 && train) {   // + dropout(X) for the dWt product (and its keep bits), same launch
       const PcDropArgs dr = pc_drop_args(X, w + pl.off_xd, pl.R, C, keep_prob, seed, offset, flags,
                                          reinterpret_cast<uint8_t*>(w + pl.off_bits));

@@ -194,7 +194,7 @@ bool gemm_bf16_twin_ok(const GemmDesc& d, int splits, int k_per_split);   // can
 // Fused train step (apa_attn_head_train_step): softmax cross-entropy folded into the logits
 // reduction (forward sets `done` when it ran), batch-mean loss written by the backward head kernel.
 // Library-internal flag bits (never accepted from a caller: every extern "C" entry masks with APA_PUBLIC_FLAGS)
-constexpr unsigned APA_PUBLIC_FLAGS = 0xFFu;
+constexpr unsigned APA_PUBLIC_FLAGS = 0x1FFu;
 constexpr unsigned APA_IFLAG_ATT_READY = 1u << 24;      // M == 1, Xatt != X: `att` already holds Z (id / relu applied)
 constexpr unsigned APA_IFLAG_NO_ATT_WGRAD = 1u << 25;   // M == 1 + DXATT_RANK1: dWa / dba / RNG bump done by the caller
 constexpr unsigned APA_IFLAG_NO_DX = 1u << 26;          // M == 1, Xatt != X: dX is NOT written -- the caller forms the
@@ -354,6 +354,7 @@ struct PcFusedWs {
   float* partial;   // f32 [splits][C][128]
   uint8_t* maskbits;  // [R*C/8]: keep decisions of the dropout mask, bit (e & 7) of byte e >> 3
   float* lpart;       // f32 [ceil(R/32)][2][64]: per-block partial rows of sum_p A * T (folded activation pass)
+  uint64_t* bits_tag; // which mask `maskbits` holds: {seed, offset, thresh, n8} + the running step's offset (apa_pc_fused.hip)
 };
 bool pc_fused_supported(int N, int P, int C, int Ca, int K, int dtype, const void* X, const void* Xatt);
 size_t pc_fused_ws_bytes(int N, int P, int C);
@@ -365,13 +366,15 @@ struct PcDwTail {     // what the dW reduce launch's tail blocks also do (see pc
   const float* pdbt; float* dbt; float* dba; int nrows;         // dbt | dba from [nrows][2K] block partials
   uint64_t* rng_bump;                                            // device-side dropout counter to advance
   const float* aux_src; int aux_n; float aux_scale; float* aux_dst;   // aux_dst[0] = aux_scale * sum(aux_src)
+  bool next_bits = false; uint64_t next_seed = 0;                     // also prepare the NEXT step's keep bits (tagged)
 };
+// weights == false (APA_FLAG_WEIGHT_IMAGES: the images are the caller's business): the keep bits only
 int pc_fused_prep(const PcFusedWs& f, const float* Wa, const float* Wt, const float* ba, const float* bt, int C,
-                  int K, hipStream_t st, const PcPrepBits* bits = nullptr);
+                  int K, hipStream_t st, const PcPrepBits* bits = nullptr, bool weights = true);
 struct PcFwdFold { float* att; int act; int P; };   // identity (0) / relu (1) attention folded into the product's epilogue
 int pc_fused_forward(const PcFusedWs& f, const void* X, float* Z, float* T, int R, int C, int K, bool train,
                      float keep_prob, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, hipStream_t st,
-                     bool prebits = false, const PcFwdFold* fold = nullptr);
+                     bool prebits = false, const PcFwdFold* fold = nullptr, bool check_tag = false);
 bool pc_fused_dx_supported(int P, int act);
 int pc_fused_dx_rows(int R);
 int pc_fused_dx(const PcFusedWs& f, const float* G, const float* att, const float* Tm, void* dX, float* pd, int R,
@@ -382,6 +385,9 @@ int pc_fused_dw(const PcFusedWs& f, const void* X, float* dWt, float* dWa, int R
 
 // apa_dense.hip: per-class bottom-up maps (M == K); Tsave = fp32 [N,P,K] top-down map saved for bwd
 size_t pc_workspace_bytes(int N, int P, int C, int Ca, int K, int dtype);
+// every weight image the shape can need, built in `ws`; maps (optional, APA_WIMG_MAX entries) / nmaps describe them
+int pc_weight_images(const float* Wa, const float* ba, const float* Wt, const float* bt, void* ws, int N, int P,
+                     int C, int Ca, int K, int dtype, apa_weight_image* maps, int* nmaps, hipStream_t st);
 int pc_forward(const void* X, const void* Xatt, const float* Wa, const float* ba, const float* Wt,
                const float* bt, float* logits, float* att, float* Tsave, void* topdown, void* ws,
                int N, int P, int C, int Ca, int K, unsigned flags, float keep_prob, uint64_t seed,

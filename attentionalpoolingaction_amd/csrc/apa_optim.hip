@@ -20,11 +20,26 @@ struct SgdSegs {
   int nseg;
 };
 
+// apa_weight_image entries of a segment (apa_momentum_sgd_step_images): the updated weight of flat element i =
+// (c, k) = (i / cols, i % cols) is also stored at dst[(c >> sh) * a + (c & ((1 << sh) - 1)) * b + k * d + e]
+struct ImgMap { void* dst; int a, b, d, e, cols, sh, f32, pad_; };
+struct SgdImgs {
+  ImgMap m[APA_SGD_MAX_SEGMENTS][APA_WIMG_PER_SEGMENT];
+  unsigned char n[APA_SGD_MAX_SEGMENTS];
+};
+__device__ __forceinline__ void img_store(const ImgMap& m, unsigned i, float w) {
+  const unsigned c = i / (unsigned)m.cols, k = i - c * (unsigned)m.cols;
+  const long idx = (long)(c >> m.sh) * m.a + (long)(c & ((1u << m.sh) - 1u)) * m.b + (long)k * m.d + m.e;
+  if (m.f32) static_cast<float*>(m.dst)[idx] = w;
+  else static_cast<bf16_t*>(m.dst)[idx].v = (uint16_t)f32_to_bf16_bits(w);
+}
+
 // grid.y = segment; grid-stride over the segment in 4-element vectors (4-byte aligned: flat
 // offsets are arbitrary, gfx950 services unaligned dwordx4), scalar tail.
+template <bool IMG>
 __global__ __launch_bounds__(256) void momentum_sgd_kernel(SgdSegs s, const float* __restrict__ grad,
                                                            float* __restrict__ acc, float lr,
-                                                           float momentum, float gscale) {
+                                                           float momentum, float gscale, SgdImgs im) {
   typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
   const int sg = blockIdx.y;
   const size_t o = s.off[sg], n = s.off[sg + 1] - o;
@@ -49,6 +64,12 @@ __global__ __launch_bounds__(256) void momentum_sgd_kernel(SgdSegs s, const floa
       typedef unsigned u2u __attribute__((ext_vector_type(2), aligned(4)));
       *reinterpret_cast<u2u*>(sh + v * 4) = u2u{pack_bf16x2(wv[0], wv[1]), pack_bf16x2(wv[2], wv[3])};
     }
+    if constexpr (IMG) {   // the per-class head's operand images (uniform per segment)
+      const int ni = im.n[sg];
+      for (int q = 0; q < ni; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) img_store(im.m[sg][q], (unsigned)(v * 4 + e), wv[e]);
+    }
   }
   if (blockIdx.x == 0) {
     for (size_t i = nv * 4 + threadIdx.x; i < n; i += 256) {
@@ -57,6 +78,10 @@ __global__ __launch_bounds__(256) void momentum_sgd_kernel(SgdSegs s, const floa
       const float wn = fmaf(-lr, av, w[i]);
       w[i] = wn;
       if (sh) sh[i].v = (uint16_t)f32_to_bf16_bits(wn);
+      if constexpr (IMG) {
+        const int ni = im.n[sg];
+        for (int q = 0; q < ni; ++q) img_store(im.m[sg][q], (unsigned)i, wn);
+      }
     }
   }
 }
@@ -178,7 +203,8 @@ extern "C" int apa_accumulate_gradients_div(float* out, const float* const* part
 
 static int sgd_launch(const char* who, int nseg, float* const* weights, const size_t* sizes,
                       const float* weight_decay, const float* grad_flat, float* acc_flat, float lr, float momentum,
-                      float grad_scale, void* const* bf16_shadow, void* stream) {
+                      float grad_scale, void* const* bf16_shadow, void* stream,
+                      const apa_weight_image* images = nullptr, const int* image_segment = nullptr, int nimages = 0) {
   if (nseg <= 0 || nseg > APA_SGD_MAX_SEGMENTS || !weights || !sizes || !weight_decay || !grad_flat ||
       !acc_flat) {
     set_error("%s: bad arguments (nseg=%d, max %d)", who, nseg, APA_SGD_MAX_SEGMENTS);
@@ -208,10 +234,43 @@ static int sgd_launch(const char* who, int nseg, float* const* weights, const si
   size_t nbx = (biggest / 4 + 255) / 256;
   if (nbx < 1) nbx = 1;
   if (nbx > 1024) nbx = 1024;
-  hipLaunchKernelGGL(momentum_sgd_kernel, dim3((unsigned)nbx, (unsigned)nseg), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), s, grad_flat, acc_flat, lr, momentum, grad_scale);
+  SgdImgs im;
+  for (int i = 0; i < APA_SGD_MAX_SEGMENTS; ++i) im.n[i] = 0;
+  if (nimages > 0) {
+    if (!images || !image_segment) {
+      set_error("%s: nimages=%d without images / image_segment", who, nimages);
+      return APA_ERR_INVALID_ARG;
+    }
+    for (int q = 0; q < nimages; ++q) {
+      const int sgi = image_segment[q];
+      const apa_weight_image& w = images[q];
+      if (sgi < 0 || sgi >= nseg || !w.dst || w.cols <= 0 || w.c_shift < 0 || w.c_shift > 20 ||
+          im.n[sgi] >= APA_WIMG_PER_SEGMENT || sizes[sgi] % (size_t)w.cols != 0 || sizes[sgi] >= (1ull << 32)) {
+        set_error("%s: bad weight image %d (segment %d, cols %d; at most %d images per segment, whole rows)", who, q,
+                  sgi, w.cols, APA_WIMG_PER_SEGMENT);
+        return APA_ERR_INVALID_ARG;
+      }
+      ImgMap& m = im.m[sgi][im.n[sgi]++];
+      m.dst = w.dst; m.a = w.a; m.b = w.b; m.d = w.d; m.e = w.e; m.cols = w.cols; m.sh = w.c_shift;
+      m.f32 = w.is_f32 ? 1 : 0; m.pad_ = 0;
+    }
+    hipLaunchKernelGGL(momentum_sgd_kernel<true>, dim3((unsigned)nbx, (unsigned)nseg), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), s, grad_flat, acc_flat, lr, momentum, grad_scale, im);
+  } else {
+    hipLaunchKernelGGL(momentum_sgd_kernel<false>, dim3((unsigned)nbx, (unsigned)nseg), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), s, grad_flat, acc_flat, lr, momentum, grad_scale, im);
+  }
   APA_LAUNCH_CHECK("momentum_sgd_kernel");
   return APA_OK;
+}
+
+extern "C" int apa_momentum_sgd_step_images(int nseg, float* const* weights, const size_t* sizes,
+                                            const float* weight_decay, const float* grad_flat, float* acc_flat,
+                                            float lr, float momentum, float grad_scale, void* const* bf16_shadow,
+                                            const apa_weight_image* images, const int* image_segment, int nimages,
+                                            void* stream) {
+  return sgd_launch("apa_momentum_sgd_step_images", nseg, weights, sizes, weight_decay, grad_flat, acc_flat, lr,
+                    momentum, grad_scale, bf16_shadow, stream, images, image_segment, nimages);
 }
 
 static int adaptive_launch(const char* who, int mode, int nseg, float* const* weights, const size_t* sizes,

@@ -66,6 +66,45 @@ __device__ __forceinline__ uint4 apply_bits8(uint4 v, uint32_t bits) {
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// one 32-bit word of the bit map (bytes 4 v .. 4 v + 3 = elements 32 v ..): SMALL form -- fewer than 2^33 elements, so
+// the pair index fits 32 bits and the key's high-word term is zero (the same hashes on 32-bit arithmetic, 5 of ~21 VALU
+// operations per hash less) -- and the general form
+__device__ __forceinline__ bool keep_small_form(size_t n8) { return n8 <= (1ull << 30) && (n8 & 3) == 0; }
+__device__ __forceinline__ uint32_t keep_word32(uint32_t v, uint32_t k0, uint32_t k1, uint32_t thresh) {
+  uint32_t word = 0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    uint32_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t h = rng_hash((v * 4 + b) * 4 + i, k0, k1);     // pair index q = e / 2, e = 8 (4 v + b) + 2 i
+      bits |= ((h & 0xffffu) < thresh ? 1u : 0u) << (2 * i);
+      bits |= ((h >> 16) < thresh ? 1u : 0u) << (2 * i + 1);
+    }
+    word |= bits << (8 * b);
+  }
+  return word;
+}
+__device__ __forceinline__ uint32_t keep_word_any(size_t v, uint32_t k0, uint32_t k1, uint32_t thresh) {
+  uint32_t word = 0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) word |= keep_bits8((v * 4 + b) * 8, k0, k1, thresh) << (8 * b);
+  return word;
+}
+
+// WHICH mask the bit map in the workspace holds: tag = {seed, offset, thresh, n8} (four 64-bit words; word 4: the
+// running step's own offset, left by the forward kernel for the launch that prepares the NEXT step's bits).  Every
+// launch that rewrites the map states what it wrote (or zeroes the tag); the forward kernel of the one-call train step
+// believes the map only if the tag says it holds the mask of (seed, current offset).
+__device__ __forceinline__ void pc_tag_write(uint64_t* tag, uint64_t seed, uint64_t off, uint32_t thresh, size_t n8) {
+  tag[0] = seed; tag[1] = off; tag[2] = ((uint64_t)thresh << 32) | 0x6b656570u; tag[3] = (uint64_t)n8;
+}
+__device__ __forceinline__ bool pc_tag_match(const uint64_t* tag, uint64_t seed, uint64_t off, uint32_t thresh,
+                                             size_t n8) {
+  return tag[0] == seed && tag[1] == off && tag[2] == (((uint64_t)thresh << 32) | 0x6b656570u) &&
+         tag[3] == (uint64_t)n8;
+}
+
 // The keep-mask of the whole map as bits ([R*C/8] bytes, 1/16 of the bf16 map; bit (e & 7) of byte e >> 3 for flat
 // element e): written once per step by the extra blocks of pc_prep_kernel, read by the forward product (one LDS-DMA
 // instruction per stage) and by the two backward kernels (the mask-in-registers step of the dX product cost as much
@@ -83,42 +122,33 @@ __device__ __forceinline__ uint4 apply_bits8(uint4 v, uint32_t bits) {
 // hash the mask itself, on the barrier-to-barrier chain of every stage (3.9 us of hashing + 1 us of bit stores by
 // its own ablation); now it DMAs 512 bytes of bits per stage next to its operands.
 struct PcBitsArgs {
-  uint8_t* bits; size_t n8; uint32_t thresh; uint64_t seed, offset; const uint64_t* offset_dev;
+  uint8_t* bits; size_t n8; uint32_t thresh; uint64_t seed, offset; const uint64_t* offset_dev; uint64_t* tag;
 };
+// the whole bit map of (seed, off): block `bid` of `nb`, `nthr` threads each (a grid-stride loop over 32-bit words)
+__device__ __forceinline__ void pc_fill_bits(const PcBitsArgs& mb, uint64_t off, unsigned bid, unsigned nb,
+                                             unsigned nthr) {
+  uint32_t k0, k1;
+  rng_key_dev(mb.seed, off, k0, k1);
+  if (bid == 0 && threadIdx.x == 0 && mb.tag) pc_tag_write(mb.tag, mb.seed, off, mb.thresh, mb.n8);
+  if (keep_small_form(mb.n8)) {
+    uint32_t* bits4 = reinterpret_cast<uint32_t*>(mb.bits);
+    const uint32_t n4 = (uint32_t)(mb.n8 >> 2);
+    for (uint32_t v = bid * nthr + threadIdx.x; v < n4; v += nb * nthr) bits4[v] = keep_word32(v, k0, k1, mb.thresh);
+    return;
+  }
+  for (size_t v = (size_t)bid * nthr + threadIdx.x; v < mb.n8; v += (size_t)nb * nthr)
+    mb.bits[v] = (uint8_t)keep_bits8(v * 8, k0, k1, mb.thresh);
+}
 __global__ __launch_bounds__(256) void pc_prep_kernel(const float* __restrict__ Wa, const float* __restrict__ Wt,
                                                       const float* __restrict__ ba, const float* __restrict__ bt,
                                                       bf16_t* __restrict__ WcatT, bf16_t* __restrict__ Wcat2,
-                                                      float* __restrict__ bcat, int C, int K, PcBitsArgs mb) {
+                                                      float* __restrict__ bcat, int C, int K, PcBitsArgs mb,
+                                                      int nwblk) {
   // the keep-bit blocks come FIRST in dispatch order: they are VALU-bound (~3 us of hashing spread over the chip)
   // while the 128 weight blocks are one latency chain each -- started last, those chains overlap the hashing
-  const int nbits = (int)gridDim.x - C / 16;
-  if ((int)blockIdx.x < nbits) {       // 8 elements (one byte) per thread and round
-    uint32_t k0, k1;
-    rng_key_dev(mb.seed, mb.offset_dev ? *mb.offset_dev : mb.offset, k0, k1);
-    if (mb.n8 <= (1ull << 30) && (mb.n8 & 3) == 0) {
-      // fewer than 2^33 elements: the pair index fits 32 bits and the key's high-word term is zero -- the same
-      // hashes on 32-bit arithmetic (5 of ~21 VALU operations per hash less), four bytes per thread and store
-      uint32_t* bits4 = reinterpret_cast<uint32_t*>(mb.bits);
-      const uint32_t n4 = (uint32_t)(mb.n8 >> 2);
-      for (uint32_t v = blockIdx.x * 256u + threadIdx.x; v < n4; v += (uint32_t)nbits * 256u) {
-        uint32_t word = 0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          uint32_t bits = 0;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const uint32_t h = rng_hash((v * 4 + b) * 4 + i, k0, k1);     // pair index q = e / 2, e = 8 (4 v + b) + 2 i
-            bits |= ((h & 0xffffu) < mb.thresh ? 1u : 0u) << (2 * i);
-            bits |= ((h >> 16) < mb.thresh ? 1u : 0u) << (2 * i + 1);
-          }
-          word |= bits << (8 * b);
-        }
-        bits4[v] = word;
-      }
-      return;
-    }
-    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < mb.n8; v += (size_t)nbits * 256)
-      mb.bits[v] = (uint8_t)keep_bits8(v * 8, k0, k1, mb.thresh);
+  const int nbits = (int)gridDim.x - nwblk;      // nwblk = C / 16, or 0 when the images are kept by the caller
+  if ((int)blockIdx.x < nbits) {       // four bytes (32 elements, 16 hashes) per thread and round
+    pc_fill_bits(mb, mb.offset_dev ? *mb.offset_dev : mb.offset, blockIdx.x, (unsigned)nbits, 256u);
     return;
   }
   const int wblk = (int)blockIdx.x - nbits;
@@ -196,7 +226,9 @@ constexpr int ZB_A_EL = 32 * ZB_KT;                      // 4096 shorts (8 KB): 
 constexpr int ZB_B_EL = 128 * ZB_KT;                     // 16384 shorts (32 KB): two [128][64] tiles
 constexpr int ZB_STAGE_EL = ZB_A_EL + ZB_B_EL;           // 40 KB
 constexpr int ZB_NST = 3;
-constexpr size_t ZB_LDS_BYTES = (size_t)ZB_NST * ZB_STAGE_EL * 2 + ZB_NST * 512;
+constexpr int ZB_MAX_C = 8192;                           // 3 stages + the block's bits (4 C bytes) within 160 KB of LDS
+constexpr size_t ZB_LDS_MAX = (size_t)ZB_NST * ZB_STAGE_EL * 2 + 4 * ZB_MAX_C;
+static size_t zb_lds_bytes(int C) { return (size_t)ZB_NST * ZB_STAGE_EL * 2 + 4 * (size_t)C; }
 
 __device__ __forceinline__ void glds16_asm(const void* gsrc, uint32_t lds_dst) {
   unsigned keep;
@@ -209,10 +241,16 @@ __device__ __forceinline__ bf16x8 frag_sw64(const short* img, int rbase, int ks,
   return *reinterpret_cast<const bf16x8*>(img + row * 64 + chunk * 8);
 }
 
-// Dropout (round 4): the keep bits of the step already lie in `maskbits` (written by pc_prep_kernel's extra blocks):
-// a stage's 32 rows x 16 bytes of bits arrive by ONE more LDS-DMA instruction (wave 0, lanes 0-31: 16 bytes per
-// row) into a ring of three 512-byte slots, in natural [row][chunk] order; a T wave reads its row's 16 bytes once
-// per stage and picks the four bytes of its lane group.  No hashing, no bit stores, no DPP shuffles in this kernel.
+// Dropout (round 4): the keep bits of the step already lie in `maskbits` (written by pc_prep_kernel's extra blocks, or
+// -- round 5 -- by the tail of the PREVIOUS step's last launch).  Round 5: the block's whole share of the map (32 rows x
+// C / 8 bytes: one contiguous 8 KB run at C = 2048) arrives by ONE LDS-DMA instruction per wave in the prologue, ahead of
+// the first operand tile, instead of one more instruction per stage; 16-byte chunk `ch` of row r sits at slot
+// ch ^ (r & sw) so that the T waves' ds_read_b128 of 16 different rows do not meet on one bank.  A T wave reads its
+// row's 16 bytes once per stage and picks the four bytes of its lane group.
+// `tag` (the one-call train step with caller-kept weight images: NO preparation launch runs): the map is believed
+// only if its tag says it holds the mask of (seed, current offset); otherwise -- first step on a workspace, a jump of
+// the offset -- the block hashes its own 32 rows in the prologue, while its first two operand tiles are in flight
+// (the slow arm: +3 us), and stores them for the two backward kernels.  Block 0 leaves the step's offset in tag[4].
 // FOLD (round 4, identity / relu attention): the activation pass that used to follow is folded into this epilogue.  The
 // T waves hand their tile to the Z waves through LDS; a Z wave applies the activation, writes the attention map A = f(Z)
 // itself and sums A * T over its 16 rows -- split at the image boundary, a block's 32 rows may straddle two images --;
@@ -231,17 +269,18 @@ __global__ __launch_bounds__(512) void pc_fwd_zt_dma_kernel(
     const bf16_t* __restrict__ X, const bf16_t* __restrict__ WcatT, const float* __restrict__ bcat,
     float* __restrict__ Z, float* __restrict__ T, uint8_t* __restrict__ maskbits, int R, int C, int K,
     float inv_keep, uint32_t thresh, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev,
-    PcFoldArgs fo) {
+    PcFoldArgs fo, uint64_t* __restrict__ tag) {
   extern __shared__ __attribute__((aligned(16))) short smem[];
   typedef __attribute__((address_space(3))) void* lptr;
-  uint8_t* const s_bits = reinterpret_cast<uint8_t*>(smem + ZB_NST * ZB_STAGE_EL);   // [2][32 rows][4 kb][4]
+  uint8_t* const s_bits = reinterpret_cast<uint8_t*>(smem + ZB_NST * ZB_STAGE_EL);   // [32 rows][C / 8], chunks swizzled
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = wave >> 2, wn = (wave >> 1) & 1, mt = wave & 1;
   const int l16 = lane & 15, kb = lane >> 4;
   const int m0 = blockIdx.x * 32;
   const int nkt = C / ZB_KT;
-  (void)thresh; (void)seed; (void)offset; (void)offset_dev;   // the mask arrives as bits
+  const int rowb = C >> 3;                                               // bytes of bits per row = 16 nkt
+  const int sw = (nkt & (nkt - 1)) == 0 ? min(nkt, 16) - 1 : 0;          // chunk swizzle (power-of-two chunk counts)
 
   // per-lane DMA sources of this wave's five 1 KiB blocks of a stage: A block `wave` (sub-image wave >> 2,
   // rows 8 (wave & 3) ..), slab blocks 4 wave .. 4 wave + 3 (tile (4 wave + j) >> 4, rows 8 ((4 wave + j) & 15) ..)
@@ -258,8 +297,6 @@ __global__ __launch_bounds__(512) void pc_fwd_zt_dma_kernel(
     }
   }
   const uint32_t lds0 = (uint32_t)(size_t)(lptr)smem;
-  const uint8_t* msrc = nullptr;     // PREBITS: this lane's row of bits (lanes 0-31 of wave 0)
-  if (TRAIN) msrc = maskbits + (((size_t)min(m0 + (lane & 31), R - 1) * C) >> 3);
   const uint32_t lds_bits = lds0 + (uint32_t)(ZB_NST * ZB_STAGE_EL * 2);
   auto issue = [&](int t) {
     const uint32_t st = lds0 + (uint32_t)((t % ZB_NST) * ZB_STAGE_EL * 2);
@@ -267,25 +304,61 @@ __global__ __launch_bounds__(512) void pc_fwd_zt_dma_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       glds16_asm(bsrc[j] + (size_t)t * (2 * 128 * 64), st + (uint32_t)(ZB_A_EL * 2) + (uint32_t)(4 * wave + j) * 1024u);
-    if (TRAIN && wave == 0 && lane < 32)                  // 16 bytes per row: chunks 0..15 of stage t
-      glds16_asm(msrc + (size_t)t * (ZB_KT / 8), lds_bits + (uint32_t)((t % ZB_NST) * 512));
   };
   f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  if (TRAIN) {
+    // the block's bits: 32 nkt 16-byte units, lane-linear in LDS (unit u = row * nkt + slot), 64 units per instruction;
+    // issued BEFORE the first operand tile, so the counted waits below (which allow only younger pieces to be
+    // outstanding) cover them.  (With a tag to check this is speculative: a map that is not believed is overwritten.)
+    for (int u0 = wave * 64; u0 < 32 * nkt; u0 += 512) {
+      const int u = u0 + lane, row = u / nkt, slot = u - row * nkt;
+      glds16_asm(maskbits + (size_t)min(m0 + row, R - 1) * rowb + ((slot ^ (row & sw)) << 4),
+                 lds_bits + (uint32_t)u0 * 16u);
+    }
+  }
   issue(0);
   if (nkt > 1) issue(1);
+  bool have_bits = true;
+  if (TRAIN && tag) {
+    // uniform; the tag (and a device-side step counter) are read AFTER the first tiles were requested: the wait for
+    // them -- the compiler's, it does not count the DMA pieces -- then costs nothing the first stage would not wait
+    // for anyway
+    const uint64_t off_now = offset_dev ? *offset_dev : offset;
+    have_bits = pc_tag_match(tag, seed, off_now, thresh, (size_t)R * C / 8);
+    if (blockIdx.x == 0 && tid == 0) {
+      tag[4] = off_now;
+      if (!have_bits) tag[2] = 0;         // the map is being rewritten row block by row block: nobody may believe it
+    }
+  }
+  if (TRAIN && !have_bits) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // (the speculative bits have landed)
+    // the slow arm: hash this block's rows (one 32-bit word = 32 elements per thread and round) into LDS for the loop
+    // below and into the map for the backward kernels
+    uint32_t k0, k1;
+    rng_key_dev(seed, offset_dev ? *offset_dev : offset, k0, k1);
+    const bool small = keep_small_form((size_t)R * C / 8);
+    const int wpr = rowb >> 2;                                            // 32-bit words per row
+    for (int wi = tid; wi < 32 * wpr; wi += 512) {
+      const int row = wi / wpr, wc = wi - row * wpr;                      // word wc of the row: chunk wc >> 2
+      const size_t grow = (size_t)min(m0 + row, R - 1);
+      const size_t v = grow * wpr + wc;
+      const uint32_t word = small ? keep_word32((uint32_t)v, k0, k1, thresh) : keep_word_any(v, k0, k1, thresh);
+      *reinterpret_cast<uint32_t*>(s_bits + row * rowb + ((((wc >> 2) ^ (row & sw)) << 4) | ((wc & 3) << 2))) = word;
+      if (m0 + row < R) reinterpret_cast<uint32_t*>(maskbits)[v] = word;
+    }
+  }
   for (int t = 0; t < nkt; ++t) {
-    // tile t has landed once at most the five pieces of tile t+1 are outstanding (six for the wave that also
-    // moves the bits); the barrier publishes everybody's pieces and the bits, and says that stage (t+2) % 3 (read
-    // in iteration t-1) is free
+    // tile t has landed once at most the five pieces of tile t+1 are outstanding; the barrier publishes everybody's
+    // pieces (and, at t = 0, the bits), and says that stage (t+2) % 3 (read in iteration t-1) is free
     if (t + 1 >= nkt) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else if (TRAIN && wave == 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (t + 2 < nkt) issue(t + 2);
     const short* a_img = smem + (t % ZB_NST) * ZB_STAGE_EL;
     const short* b_img = a_img + ZB_A_EL;
     uint32_t mb = 0;
     if (TRAIN && half) {   // natural order: byte c = 4 sk + kb of the row -> byte kb of word sk
-      const uint4 rb = *reinterpret_cast<const uint4*>(s_bits + (t % ZB_NST) * 512 + (mt * 16 + l16) * 16);
+      const int brow = mt * 16 + l16;
+      const uint4 rb = *reinterpret_cast<const uint4*>(s_bits + brow * rowb + ((t ^ (brow & sw)) << 4));
       const int sh = 8 * kb;
       mb = ((rb.x >> sh) & 0xffu) | (((rb.y >> sh) & 0xffu) << 8) | (((rb.z >> sh) & 0xffu) << 16) |
            (((rb.w >> sh) & 0xffu) << 24);
@@ -771,13 +844,27 @@ __global__ __launch_bounds__(512) void pc_bwd_dx_kernel(PcDxArgs a) {
 struct PcTail {
   const float* pdbt; float* dbt; float* dba; int nrows, K;      // pdbt [nrows][2K]: dbt | dba partials
   uint64_t* rng_bump; ColsumExtra x;
-};
+  int ntail;                                                     // column-sum blocks (after the nmain reduce blocks)
+  PcBitsArgs next;                                               // next.bits != nullptr: the blocks after those write
+};                                                               //   the NEXT step's keep bits (offset tag[4] + 1)
+// Round 5: the last launch of the one-call train step also prepares the next step's dropout decisions -- the bit map
+// of (seed, offset + 1), 3 us of hashing spread over blocks that run beside the memory-bound reduce -- and tags the map
+// with what it holds; the next step's forward kernel believes it iff the tag matches its own (seed, offset), so that
+// a training loop with caller-kept weight images runs NO preparation launch at all (5 -> 4 launches per step).  Every
+// reader of this step's map (forward, dX, dW kernels) finished before this launch began.
 __global__ __launch_bounds__(1024) void pc_dw_reduce_kernel(const float* __restrict__ partial,
                                                             float* __restrict__ dWt, float* __restrict__ dWa,
                                                             int C, int K, int S, float inv_keep, int nmain,
                                                             PcTail tl) {
+  if ((int)blockIdx.x >= nmain + tl.ntail) {
+    // (tag[4]: this step's offset as the forward kernel read it -- the column-sum blocks of this very launch advance a
+    // device-side counter, so it must not be read here)
+    pc_fill_bits(tl.next, tl.next.tag[4] + 1, blockIdx.x - (unsigned)(nmain + tl.ntail),
+                 gridDim.x - (unsigned)(nmain + tl.ntail), 1024u);
+    return;
+  }
   if ((int)blockIdx.x >= nmain) {
-    colsum_block((int)blockIdx.x - nmain, (int)gridDim.x - nmain, tl.pdbt, nullptr, tl.dbt, nullptr, tl.nrows,
+    colsum_block((int)blockIdx.x - nmain, tl.ntail, tl.pdbt, nullptr, tl.dbt, nullptr, tl.nrows,
                  2 * tl.K, 2 * tl.K, tl.rng_bump, tl.dba, tl.K, nullptr, 2 * tl.K, 0, 0, tl.x);
     return;
   }
@@ -796,7 +883,7 @@ bool pc_fused_supported(int N, int P, int C, int Ca, int K, int dtype, const voi
   static const int enabled = knob("APA_PC_FUSED", 1);
   (void)N; (void)P;
   return enabled && dtype == APA_DTYPE_BF16 && Xatt == X && Ca == C && K >= 1 && K <= 64 && C % 256 == 0 &&
-         (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+         C <= ZB_MAX_C && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
 }
 
 size_t pc_fused_ws_bytes(int N, int P, int C) {
@@ -809,6 +896,7 @@ size_t pc_fused_ws_bytes(int N, int P, int C) {
   off += align_up((size_t)PC_DW_MAX_SPLITS * C * 128 * 4, 256);   // dW partials
   off += align_up(R * C / 8, 256);                    // keep-mask bits
   off += align_up(((R + 31) / 32) * 2 * 64 * 4, 256); // folded activation pass: [row blocks][2 segments][64] partials
+  off += 256;                                         // the bit map's tag
   return off;
 }
 
@@ -822,25 +910,28 @@ PcFusedWs pc_fused_carve(void* base, int N, int P, int C) {
   f.dTdZ = w;    w += align_up(R * 128 * 2, 256);
   f.partial = reinterpret_cast<float*>(w);  w += align_up((size_t)PC_DW_MAX_SPLITS * C * 128 * 4, 256);
   f.maskbits = reinterpret_cast<uint8_t*>(w);  w += align_up(R * C / 8, 256);
-  f.lpart = reinterpret_cast<float*>(w);
+  f.lpart = reinterpret_cast<float*>(w);  w += align_up(((R + 31) / 32) * 2 * 64 * 4, 256);
+  f.bits_tag = reinterpret_cast<uint64_t*>(w);
   return f;
 }
 
 // `bits` (training): the same launch also writes the step's keep bits (f.maskbits, n_elems / 8 bytes)
 int pc_fused_prep(const PcFusedWs& f, const float* Wa, const float* Wt, const float* ba, const float* bt, int C,
-                  int K, hipStream_t st, const PcPrepBits* bits) {
-  PcBitsArgs mb = {nullptr, 0, 0, 0, 0, nullptr};
+                  int K, hipStream_t st, const PcPrepBits* bits, bool weights) {
+  if (!weights && !bits) return APA_OK;            // evaluation with caller-kept images: nothing to prepare
+  PcBitsArgs mb = {nullptr, 0, 0, 0, 0, nullptr, nullptr};
   unsigned extra = 0;
   if (bits) {
     mb.bits = f.maskbits; mb.n8 = bits->n_elems / 8; mb.thresh = keep_thresh(bits->keep_prob);
-    mb.seed = bits->seed; mb.offset = bits->offset; mb.offset_dev = bits->offset_dev;
+    mb.seed = bits->seed; mb.offset = bits->offset; mb.offset_dev = bits->offset_dev; mb.tag = f.bits_tag;
     // 4 bytes of bits (16 hashes) per thread: the rest of the chip, but not more blocks than there is work for
     size_t nb = (mb.n8 + 256 * 4 - 1) / (256 * 4);
     if (nb > 2048) nb = 2048;
     extra = (unsigned)(nb < 1 ? 1 : nb);
   }
-  hipLaunchKernelGGL(pc_prep_kernel, dim3((unsigned)(C / 16) + extra), dim3(256), 0, st, Wa, Wt, ba,
-                     bt, static_cast<bf16_t*>(f.WcatT), static_cast<bf16_t*>(f.Wcat2), f.bcat, C, K, mb);
+  const int nwblk = weights ? C / 16 : 0;
+  hipLaunchKernelGGL(pc_prep_kernel, dim3((unsigned)nwblk + extra), dim3(256), 0, st, Wa, Wt, ba,
+                     bt, static_cast<bf16_t*>(f.WcatT), static_cast<bf16_t*>(f.Wcat2), f.bcat, C, K, mb, nwblk);
   APA_LAUNCH_CHECK("pc_prep_kernel");
   return APA_OK;
 }
@@ -853,7 +944,7 @@ int pc_fused_logits_finish(const PcFusedWs& f, float* logits, int N, int P, int 
 
 int pc_fused_forward(const PcFusedWs& f, const void* X, float* Z, float* T, int R, int C, int K, bool train,
                      float keep_prob, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, hipStream_t st,
-                     bool prebits, const PcFwdFold* fold) {
+                     bool prebits, const PcFwdFold* fold, bool check_tag) {
   if (C % ZB_KT != 0) {     // pc_fused_supported() admits multiples of 256 only
     set_error("pc_fused_forward: C=%d is not a multiple of %d", C, ZB_KT);
     return APA_ERR_UNSUPPORTED;
@@ -864,24 +955,25 @@ int pc_fused_forward(const PcFusedWs& f, const void* X, float* Z, float* T, int 
   static thread_local PerDevice<bool> attr_dev; bool& attr_set = attr_dev.here();
   if (!attr_set) {
     APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_fwd_zt_dma_kernel<true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_BYTES));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_MAX));
     APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_fwd_zt_dma_kernel<false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_BYTES));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_MAX));
     APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_fwd_zt_dma_kernel<true, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_BYTES));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_MAX));
     APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_fwd_zt_dma_kernel<false, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_BYTES));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_MAX));
     attr_set = true;
   }
-  if (train && !prebits) {
-    set_error("pc_fused_forward: training mode needs the keep bits of pc_fused_prep (internal)");
+  if (train && !prebits && !check_tag) {
+    set_error("pc_fused_forward: training mode needs the keep bits of pc_fused_prep, or a tagged map (internal)");
     return APA_ERR_INVALID_ARG;
   }
+  uint64_t* tag = (train && check_tag) ? f.bits_tag : nullptr;
   PcFoldArgs fo = {nullptr, nullptr, 0, 1};
   if (fold) { fo.att = fold->att; fo.lpart = f.lpart; fo.act = fold->act; fo.P = fold->P; }
 #define APA_ZT(TR, FO)                                                                                         \
-  hipLaunchKernelGGL((pc_fwd_zt_dma_kernel<TR, FO>), dim3((R + 31) / 32), dim3(512), ZB_LDS_BYTES, st, xx, ww,  \
-                     f.bcat, Z, T, f.maskbits, R, C, K, ik, keep_thresh(keep_prob), seed, offset, offset_dev, fo)
+  hipLaunchKernelGGL((pc_fwd_zt_dma_kernel<TR, FO>), dim3((R + 31) / 32), dim3(512), zb_lds_bytes(C), st, xx, ww, \
+                     f.bcat, Z, T, f.maskbits, R, C, K, ik, keep_thresh(keep_prob), seed, offset, offset_dev, fo, tag)
   if (fold) { if (train) APA_ZT(true, true); else APA_ZT(false, true); }
   else      { if (train) APA_ZT(true, false); else APA_ZT(false, false); }
 #undef APA_ZT
@@ -965,15 +1057,24 @@ int pc_fused_dw(const PcFusedWs& f, const void* X, float* dWt, float* dWa, int R
   const int nmain = (int)(((long)C * 128 + 1023) / 1024);
   PcTail tl;
   tl.pdbt = nullptr; tl.dbt = nullptr; tl.dba = nullptr; tl.nrows = 0; tl.K = K; tl.rng_bump = nullptr;
-  int ntail = 0;
+  tl.next = PcBitsArgs{nullptr, 0, 0, 0, 0, nullptr, nullptr};
+  int ntail = 0, nnext = 0;
   if (tail) {
     tl.pdbt = tail->pdbt; tl.dbt = tail->dbt; tl.dba = tail->dba; tl.nrows = tail->nrows; tl.rng_bump = tail->rng_bump;
     tl.x.aux_src = tail->aux_src; tl.x.aux_n = tail->aux_n; tl.x.aux_scale = tail->aux_scale; tl.x.aux_dst = tail->aux_dst;
     tl.x.C3 = 2 * K; tl.x.C4 = 2 * K;
     ntail = (2 * K + 31) / 32;
+    if (tail->next_bits && train) {
+      tl.next.bits = f.maskbits; tl.next.n8 = (size_t)R * C / 8; tl.next.thresh = keep_thresh(keep_prob);
+      tl.next.seed = tail->next_seed; tl.next.tag = f.bits_tag;
+      size_t nb = (tl.next.n8 / 4 + 1023) / 1024;                    // one 32-bit word per thread and round
+      if (nb > 1024) nb = 1024;
+      nnext = (int)(nb < 1 ? 1 : nb);
+    }
   }
-  hipLaunchKernelGGL(pc_dw_reduce_kernel, dim3((unsigned)(nmain + ntail)), dim3(1024), 0, st, f.partial, dWt, dWa,
-                     C, K, S, train ? 1.0f / keep_prob : 1.0f, nmain, tl);
+  tl.ntail = ntail;
+  hipLaunchKernelGGL(pc_dw_reduce_kernel, dim3((unsigned)(nmain + ntail + nnext)), dim3(1024), 0, st, f.partial, dWt,
+                     dWa, C, K, S, train ? 1.0f / keep_prob : 1.0f, nmain, tl);
   APA_LAUNCH_CHECK("pc_dw_reduce_kernel");
   return APA_OK;
 }

@@ -34,6 +34,9 @@ APA_FLAG_RNG_DEVICE = 8
 APA_FLAG_RELU_INPUT = 16  # X in memory is the pre-activation map: relu fused into both passes
 APA_FLAG_DXATT_RANK1 = 32  # attn_pool_bwd returns dZ [N*P] instead of dXatt = dZ (x) Wa
 APA_FLAG_RNG_EXTERNAL = 128  # `seed` is the address of a caller-supplied, bit-packed dropout keep mask
+APA_FLAG_WEIGHT_IMAGES = 256  # per-class maps: the operand images in the workspace are kept current by the caller
+APA_WIMG_MAX = 12
+APA_WIMG_ROLES = {0: 'Wa', 1: 'ba', 2: 'Wt', 3: 'bt'}
 
 # every symbol include/apa.h declares: name -> (restype, argtypes)
 _SIGNATURES = {
@@ -91,6 +94,11 @@ _SIGNATURES = {
     'apa_momentum_sgd_step_shadow': (c_int, [c_int, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_float),
                                              c_void_p, c_void_p, c_float, c_float, c_float, POINTER(c_void_p),
                                              c_void_p]),
+    'apa_per_class_weight_images': (c_int, [c_void_p] * 5 + [c_size_t] + [c_int] * 6 + [c_void_p, POINTER(c_int),
+                                                                                       c_void_p]),
+    'apa_momentum_sgd_step_images': (c_int, [c_int, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_float),
+                                             c_void_p, c_void_p, c_float, c_float, c_float, POINTER(c_void_p),
+                                             c_void_p, POINTER(c_int), c_int, c_void_p]),
     'apa_adam_step': (c_int, [c_int, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_float), c_void_p, c_void_p,
                               c_void_p, c_float, c_float, c_float, c_float, c_float, POINTER(c_void_p), c_void_p]),
     'apa_rmsprop_step': (c_int, [c_int, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_float), c_void_p, c_void_p,
@@ -770,7 +778,16 @@ class HeadTrainStep:
     pose_head_bwd(ext_rank1=(dZ, wa)) consumes."""
 
     def __init__(self, X, Xatt, Wa, ba, Wt, bt, labels, grads, *, flags=0, keep_prob=1.0, seed=0,
-                 offset=0, loss_wt=1.0, grad_scale=1.0, workspace=None, hooks=None, dxatt_rank1=False):
+                 offset=0, loss_wt=1.0, grad_scale=1.0, workspace=None, hooks=None, dxatt_rank1=False,
+                 weight_images=False, share_with=None):
+        """`weight_images=True` (per-class maps, M == K): the padded / concatenated operand images of the weights
+        are built ONCE in this step's workspace (`self.weight_image_maps` describes them) and every run() passes
+        APA_FLAG_WEIGHT_IMAGES: the caller keeps them current -- `momentum_sgd_step(..., images=...)` /
+        `deploy.MomentumSGD.attach_weight_images(step, ...)` in the optimiser's own launch, or
+        `refresh_weight_images()` after any other change of the weights.
+        `share_with` (another HeadTrainStep of the same shapes): this step is bound to ITS output tensors, workspace
+        and weight images -- a training loop has one set of them; only X / dX differ between the bound steps
+        (bench.py's rotating feature-map sets)."""
         self.lib = load_library()
         N, C = X.shape[0], X.shape[-1]
         P = X.numel() // (N * C)
@@ -785,17 +802,32 @@ class HeadTrainStep:
             flags |= APA_FLAG_DXATT_RANK1
         dX, dXatt, dWa, dba, dWt, dbt = grads
         self.hooks = hooks            # default apa_hooks of run(); kept alive here
-        self.logits = torch.empty((N, K), dtype=torch.float32, device=dev)
-        self.att = torch.empty((N, P, M), dtype=torch.float32, device=dev)
-        self.zsave = torch.empty((N, C) if M == 1 else (N, P, K), dtype=torch.float32, device=dev)
-        self.abar = torch.empty((N,), dtype=torch.float32, device=dev) if M == 1 else None
-        self.loss = torch.empty((1 + N,), dtype=torch.float32, device=dev)
-        self.G = torch.empty((N, K), dtype=torch.float32, device=dev)
+        if share_with is not None:
+            o = share_with
+            if tuple(o.logits.shape) != (N, K) or tuple(o.att.shape) != (N, P, M):
+                raise ApaError('HeadTrainStep: share_with needs a step of the same shapes')
+            self.logits, self.att, self.zsave, self.abar, self.loss, self.G = o.logits, o.att, o.zsave, o.abar, o.loss, o.G
+            workspace = o.workspace
+        else:
+            self.logits = torch.empty((N, K), dtype=torch.float32, device=dev)
+            self.att = torch.empty((N, P, M), dtype=torch.float32, device=dev)
+            self.zsave = torch.empty((N, C) if M == 1 else (N, P, K), dtype=torch.float32, device=dev)
+            self.abar = torch.empty((N,), dtype=torch.float32, device=dev) if M == 1 else None
+            self.loss = torch.empty((1 + N,), dtype=torch.float32, device=dev)
+            self.G = torch.empty((N, K), dtype=torch.float32, device=dev)
         need = int(self.lib.apa_attn_pool_workspace_bytes(N, P, C, Ca, K, M, flags))
         if workspace is None or workspace.numel() < need:
             workspace = torch.empty((max(need, 16),), dtype=torch.uint8, device=dev)
         self.workspace = workspace
         self._keep = (X, Xatt, Wa, ba, Wt, bt, labels, grads, offset, seed)
+        self.weight_image_maps = []
+        if share_with is not None and share_with.weight_image_maps:
+            self.weight_image_maps = share_with.weight_image_maps       # built there, in the shared workspace
+            flags |= APA_FLAG_WEIGHT_IMAGES
+        elif weight_images and M == K and M > 1:
+            self.weight_image_maps = per_class_weight_images(Wa, ba, Wt, bt, workspace, N, P, X.dtype)
+            if self.weight_image_maps:
+                flags |= APA_FLAG_WEIGHT_IMAGES
         seed, off, flags = _rng_key(seed, offset, flags)     # the pointers below stay valid
         self._args = [
             _dev_ptr(X, 'X'), _dev_ptr(X, 'X') if fused else _dev_ptr(Xatt, 'Xatt', X.dtype),
@@ -810,6 +842,14 @@ class HeadTrainStep:
             _dev_ptr(dbt, 'dbt', torch.float32), workspace.data_ptr(), workspace.numel(), N, P, C, Ca, K, M,
             flags, float(keep_prob), int(seed), off, _feat_dtype(X)]
         self._fn = self.lib.apa_attn_head_train_step_ex
+
+    def refresh_weight_images(self) -> None:
+        """Rebuild the operand images from the current weights (after load_state_dict, or an optimiser that does not
+        rewrite them in its own launch)."""
+        if self.weight_image_maps:
+            X, _, Wa, ba, Wt, bt = self._keep[:6]
+            N, C = X.shape[0], X.shape[-1]
+            per_class_weight_images(Wa, ba, Wt, bt, self.workspace, N, X.numel() // (N * C), X.dtype)
 
     def rebind(self, X=None, labels=None, offset=None) -> None:
         """Point the bound step at another feature map / label tensor of the SAME shape and dtype (a training loop
@@ -864,7 +904,9 @@ class PoseAttnTrainStep:
     Outputs as attributes: Ppre, Pl, att, logits, zsave, abar, loss_action [1+N], loss_pose [1], G, dPl, dZ."""
 
     def __init__(self, X, params, labels, pose_labels, pose_valid, grads, *, flags=0, keep_prob=1.0, seed=0,
-                 offset=0, action_wt=1.0, pose_wt=1.0, grad_scale=1.0, w1_bf16=None):
+                 offset=0, action_wt=1.0, pose_wt=1.0, grad_scale=1.0, w1_bf16=None, share_with=None):
+        """`share_with`: another PoseAttnTrainStep of the same shapes whose activation / loss buffers and workspaces
+        this step is bound to as well (see HeadTrainStep)."""
         self.lib = load_library()
         W1, b1, W2, b2, Wa, ba, Wt, bt = params
         dX, dW1, db1, dW2, db2, dWa, dba, dWt, dbt = grads
@@ -877,18 +919,29 @@ class PoseAttnTrainStep:
         if pose_valid.dtype == torch.bool:
             pose_valid = pose_valid.to(torch.uint8)
         new = lambda *shape, dt=f32: torch.empty(shape, dtype=dt, device=dev)
-        self.Ppre, self.Pl, self.att = new(N, P, Cp, dt=X.dtype), new(N, P, J), new(N, P, 1)
-        self.logits, self.zsave, self.abar = new(N, K), new(N, C), new(N)
-        self.loss_action, self.loss_pose = new(1 + N), new(1)
-        self.G, self.dPl, self.dZ = new(N, K), new(N, P, J), new(N * P)
+        _shared = ('Ppre', 'Pl', 'att', 'logits', 'zsave', 'abar', 'loss_action', 'loss_pose', 'G', 'dPl', 'dZ')
+        if share_with is not None:
+            if tuple(share_with.Ppre.shape) != (N, P, Cp) or share_with.Ppre.dtype != X.dtype or \
+                    tuple(share_with.logits.shape) != (N, K):
+                raise ApaError('PoseAttnTrainStep: share_with needs a step of the same shapes')
+            for name in _shared:
+                setattr(self, name, getattr(share_with, name))
+        else:
+            self.Ppre, self.Pl, self.att = new(N, P, Cp, dt=X.dtype), new(N, P, J), new(N, P, 1)
+            self.logits, self.zsave, self.abar = new(N, K), new(N, C), new(N)
+            self.loss_action, self.loss_pose = new(1 + N), new(1)
+            self.G, self.dPl, self.dZ = new(N, K), new(N, P, J), new(N * P)
         dt = _feat_dtype(X)
         seed, off, flags = _rng_key(seed, offset, flags)
         if flags & APA_FLAG_RNG_EXTERNAL:
             raise ApaError('PoseAttnTrainStep: an external keep mask is served by the per-op entry points')
-        self.ws_pool = torch.empty((max(int(self.lib.apa_attn_pool_workspace_bytes(N, P, C, Cp, K, 1, flags)), 16),),
-                                   dtype=torch.uint8, device=dev)
-        self.ws_pose = torch.empty((max(int(self.lib.apa_pose_head_workspace_bytes(N, P, C, Cp, J, dt)), 16),),
-                                   dtype=torch.uint8, device=dev)
+        if share_with is not None:
+            self.ws_pool, self.ws_pose = share_with.ws_pool, share_with.ws_pose
+        else:
+            self.ws_pool = torch.empty((max(int(self.lib.apa_attn_pool_workspace_bytes(N, P, C, Cp, K, 1, flags)), 16),),
+                                       dtype=torch.uint8, device=dev)
+            self.ws_pose = torch.empty((max(int(self.lib.apa_pose_head_workspace_bytes(N, P, C, Cp, J, dt)), 16),),
+                                       dtype=torch.uint8, device=dev)
         self._keep = (X, params, labels, pose_labels, pose_valid, grads, offset, w1_bf16)
         io = ApaPoseAttnStepIO()
         io.X = _dev_ptr(X, 'X')
@@ -988,7 +1041,41 @@ class HeadEvalStep:
             _check(rc, 'apa_attn_head_eval_step')
 
 
-def momentum_sgd_step(weights, weight_decay, grad_flat, acc_flat, lr, momentum=0.9, grad_scale=1.0, shadows=None):
+class ApaWeightImage(ctypes.Structure):
+    """`apa_weight_image` of include/apa.h (field order is the ABI): where the optimiser's launch stores the updated
+    element (c, k) of one head parameter inside a per-class workspace."""
+    _fields_ = [('dst', c_void_p), ('role', c_int), ('is_f32', c_int), ('cols', c_int), ('c_shift', c_int),
+                ('a', c_int), ('b', c_int), ('d', c_int), ('e', c_int)]
+
+
+def per_class_weight_images(Wa, ba, Wt, bt, workspace, N, P, dtype):
+    """apa_per_class_weight_images: build, inside `workspace`, every padded / concatenated operand image the
+    per-class head (M == K) would otherwise rebuild in each call, and return their descriptions
+    [(role 'Wa'|'ba'|'Wt'|'bt', ApaWeightImage), ...] for `momentum_sgd_step(..., images=...)`.  Calls that then
+    pass APA_FLAG_WEIGHT_IMAGES with this workspace skip the per-step weight preparation.  `dtype`: the FEATURE
+    dtype the images are for (torch.bfloat16 / torch.float32)."""
+    lib = load_library()
+    Ca, K = Wa.shape
+    C = Wt.shape[0]
+    if tuple(Wt.shape) != (C, K) or ba.numel() != K or bt.numel() != K:
+        raise ApaError('per_class_weight_images: Wa [Ca,K], ba [K], Wt [C,K], bt [K] expected (M == K)')
+    maps = (ApaWeightImage * APA_WIMG_MAX)()
+    n = c_int(0)
+    dt = APA_DTYPE_BF16 if dtype == torch.bfloat16 else APA_DTYPE_F32
+    _check(lib.apa_per_class_weight_images(
+        _dev_ptr(Wa, 'Wa', torch.float32), _dev_ptr(ba, 'ba', torch.float32), _dev_ptr(Wt, 'Wt', torch.float32),
+        _dev_ptr(bt, 'bt', torch.float32), workspace.data_ptr(), workspace.numel(), N, P, C, Ca, K, dt,
+        ctypes.addressof(maps), ctypes.byref(n), _stream_ptr()), 'apa_per_class_weight_images')
+    out = []
+    for i in range(n.value):
+        m = ApaWeightImage()
+        ctypes.memmove(ctypes.addressof(m), ctypes.addressof(maps[i]), ctypes.sizeof(ApaWeightImage))
+        out.append((APA_WIMG_ROLES[m.role], m))
+    return out
+
+
+def momentum_sgd_step(weights, weight_decay, grad_flat, acc_flat, lr, momentum=0.9, grad_scale=1.0, shadows=None,
+                      images=None):
     """One fused launch: acc = m*acc + (grad_scale*g + wd_i*w_i); w_i -= lr*acc for every parameter.
     `weights`: list of fp32 device tensors in bucket order; `weight_decay`: one float per tensor.
     `shadows`: optional list (one entry per tensor, None = no shadow) of bf16 device tensors that receive the
@@ -1002,6 +1089,22 @@ def momentum_sgd_step(weights, weight_decay, grad_flat, acc_flat, lr, momentum=0
     if grad_flat.numel() != total or acc_flat.numel() != total:
         raise ValueError('flat buffers hold {} / {} elements, parameters {}'.format(
             grad_flat.numel(), acc_flat.numel(), total))
+    if images:
+        # `images`: [(segment index, ApaWeightImage), ...] -- the per-class head's operand images, rewritten from the
+        # updated weights by this same launch (apa_momentum_sgd_step_images)
+        sh = None
+        if shadows is not None and any(t is not None for t in shadows):
+            sh = (c_void_p * n)(*[None if t is None else _dev_ptr(t, 'shadow', torch.bfloat16) for t in shadows])
+        ni = len(images)
+        arr = (ApaWeightImage * ni)()
+        seg = (c_int * ni)(*[int(i) for i, _ in images])
+        for q, (_, m) in enumerate(images):
+            ctypes.memmove(ctypes.addressof(arr[q]), ctypes.addressof(m), ctypes.sizeof(ApaWeightImage))
+        _check(lib.apa_momentum_sgd_step_images(
+            n, ptrs, sizes, wds, _dev_ptr(grad_flat, 'grad_flat', torch.float32),
+            _dev_ptr(acc_flat, 'acc_flat', torch.float32), lr, momentum, grad_scale, sh, ctypes.addressof(arr), seg, ni,
+            _stream_ptr()), 'apa_momentum_sgd_step_images')
+        return
     if shadows is not None and any(t is not None for t in shadows):
         for w_, t in zip(weights, shadows):
             if t is not None and (t.dtype != torch.bfloat16 or t.numel() != w_.numel() or not t.is_contiguous()):

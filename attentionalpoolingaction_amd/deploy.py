@@ -274,6 +274,30 @@ class MomentumSGD:
         reg = set(regularized)
         self.wd = [weight_decay if n in reg else 0.0 for n in bucket.names]
 
+    def attach_weight_images(self, step, names: Dict[str, str]) -> None:
+        """Keep the per-class head's operand images current in THIS optimiser's launch: `step` is a
+        cof.HeadTrainStep(..., weight_images=True) (or anything with `.weight_image_maps` and
+        `.refresh_weight_images()`), `names` maps the roles 'Wa' / 'ba' / 'Wt' / 'bt' to parameter names of the
+        bucket.  Several steps (micro-batch lanes, rotating buffer sets) may be attached; at most three images per
+        parameter fit the fused launch, further ones are rebuilt by their step's own refresh launch after the
+        update."""
+        if not hasattr(self, 'images'):
+            self.images, self._img_refresh = [], []
+        count = {}
+        for _, m in self.images:
+            count[_] = count.get(_, 0) + 1
+        fits = True
+        new = []
+        for role, m in step.weight_image_maps:
+            seg = self.bucket.names.index(names[role])
+            count[seg] = count.get(seg, 0) + 1
+            fits = fits and count[seg] <= 3
+            new.append((seg, m))
+        if fits:
+            self.images += new
+        else:
+            self._img_refresh.append(step)
+
     def refresh_shadows(self) -> None:
         """Rewrite every bf16 operand copy from its parameter: at construction, and after the weights were
         changed behind the optimiser's back (load_state_dict, a checkpoint restore)."""
@@ -287,7 +311,10 @@ class MomentumSGD:
         if self.bucket.flat.is_cuda:
             from .custom_ops import custom_ops_factory as cof
             sh = [self.shadows.get(n) for n in self.bucket.names] if self.shadows else None
-            cof.momentum_sgd_step(ws, self.wd, self.bucket.flat, self.acc, lr, self.momentum, grad_scale, shadows=sh)
+            cof.momentum_sgd_step(ws, self.wd, self.bucket.flat, self.acc, lr, self.momentum, grad_scale, shadows=sh,
+                                  images=getattr(self, 'images', None))
+            for st in getattr(self, '_img_refresh', ()):
+                st.refresh_weight_images()
             return
         o = 0
         for w, wd in zip(ws, self.wd):
@@ -307,6 +334,16 @@ class _AdaptiveOptimizer(MomentumSGD):
     def __init__(self, params, bucket, lr, weight_decay=0.0, regularized=(), bf16_shadows=None):
         super().__init__(params, bucket, lr, 0.0, weight_decay, regularized, bf16_shadows)
         self.slot2 = torch.zeros_like(bucket.flat)          # self.acc is the first slot
+
+    def attach_weight_images(self, step, names=None) -> None:
+        """the adaptive launches carry no image maps: an attached step rebuilds its images after each update"""
+        if not hasattr(self, '_img_refresh'):
+            self._img_refresh = []
+        self._img_refresh.append(step)
+
+    def _refresh_images(self) -> None:
+        for st in getattr(self, '_img_refresh', ()):
+            st.refresh_weight_images()
 
     def _segments(self, grad_scale):
         o = 0
@@ -338,6 +375,7 @@ class Adam(_AdaptiveOptimizer):
             sh = [self.shadows.get(n) for n in self.bucket.names] if self.shadows else None
             cof.adam_step(ws, self.wd, self.bucket.flat, self.acc, self.slot2, lr, self.t, self.beta1, self.beta2,
                           self.epsilon, grad_scale, shadows=sh)
+            self._refresh_images()
             return
         lr_t = lr * (1.0 - self.beta2 ** self.t) ** 0.5 / (1.0 - self.beta1 ** self.t)
         for w, g, m, v in self._segments(grad_scale):
@@ -366,6 +404,7 @@ class RMSProp(_AdaptiveOptimizer):
             sh = [self.shadows.get(n) for n in self.bucket.names] if self.shadows else None
             cof.rmsprop_step(ws, self.wd, self.bucket.flat, self.acc, self.slot2, lr, self.decay, self.momentum,
                              self.epsilon, grad_scale, shadows=sh)
+            self._refresh_images()
             return
         for w, g, ms, mom in self._segments(grad_scale):
             ms.add_((g * g - ms) * (1.0 - self.decay))
@@ -513,6 +552,7 @@ class FusedHeadStep:
         self._key = None
         self._dX = None
         self.w1_shadow = None
+        self._optimizer = None
         self.probe_events = None
 
     @staticmethod
@@ -544,9 +584,10 @@ class FusedHeadStep:
             w1 = self.params['pose_w1']
             self.w1_shadow = torch.empty(w1.shape, dtype=torch.bfloat16, device=w1.device)
             shadows = {'pose_w1': self.w1_shadow}
-        self._step_obj = None                        # re-bind with the shadow
-        return configure_optimizer(self.cfg, {n: p.data for n, p in self.params.items()}, self.bucket,
-                                   learning_rate, regularized=self.regularized, bf16_shadows=shadows)
+        self._step_obj = None                        # re-bind with the shadow / the weight images
+        self._optimizer = configure_optimizer(self.cfg, {n: p.data for n, p in self.params.items()}, self.bucket,
+                                              learning_rate, regularized=self.regularized, bf16_shadows=shadows)
+        return self._optimizer
 
     def _bind(self, X, labels_action, labels_pose, pose_valid):
         from .custom_ops import custom_ops_factory as cof
@@ -563,11 +604,16 @@ class FusedHeadStep:
                  v['td_weights'], v['td_biases']), flags=flags, keep_prob=head.keep_prob, seed=head.seed,
                 offset=head._step, action_wt=float(tr.LOSS_FN_ACTION_WT), pose_wt=float(tr.LOSS_FN_POSE_WT),
                 grad_scale=self.loss_scale, w1_bf16=shadow)
-        return cof.HeadTrainStep(
+        st = cof.HeadTrainStep(
             X, X, p['att_weights'], p['att_biases'], p['td_weights'], p['td_biases'], labels_action,
             (self._dX, None, v['att_weights'], v['att_biases'], v['td_weights'], v['td_biases']), flags=flags,
             keep_prob=head.keep_prob, seed=head.seed, offset=head._step, loss_wt=float(tr.LOSS_FN_ACTION_WT),
-            grad_scale=self.loss_scale, hooks=head.hooks)
+            grad_scale=self.loss_scale, hooks=head.hooks,
+            weight_images=bool(head.per_class and self._optimizer is not None))
+        if st.weight_image_maps:      # per-class maps: the operand images are rewritten by the optimiser's launch
+            self._optimizer.attach_weight_images(st, {'Wa': 'att_weights', 'ba': 'att_biases', 'Wt': 'td_weights',
+                                                      'bt': 'td_biases'})
+        return st
 
     def _run(self, last_conv, labels_action, labels_pose, pose_valid):
         head = self.head

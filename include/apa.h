@@ -85,6 +85,16 @@ typedef enum apa_status {
                                 /* is a whole number of 16-byte vectors; per-class maps take the GEMM route), */
                                 /* not by the hash-fused streaming kernels: a parity facility, not a fast path */
 
+#define APA_FLAG_WEIGHT_IMAGES 256u /* per-class maps (M == K): the caller vouches that the padded / concatenated   */
+                                /* operand images of Wa, ba, Wt, bt in `ws` are CURRENT -- built there by          */
+                                /* apa_per_class_weight_images() and rewritten after every weight change (by that  */
+                                /* function again, or by the optimiser's own launch, apa_momentum_sgd_step_images) */
+                                /* with nothing else using the workspace in between.  The per-step preparation     */
+                                /* launch then produces only what changes per step (the dropout decisions), or     */
+                                /* does not run at all (evaluation).  Needs 16-byte aligned features (else         */
+                                /* APA_ERR_INVALID_ARG); ignored for M == 1.  A stale image is the caller's bug,   */
+                                /* like a stale apa_pose_attn_step_io.W1_bf16.                                    */
+
 int apa_version(void);
 /* Thread-local, never NULL; describes the last failure on the calling thread. */
 const char* apa_last_error(void);
@@ -485,6 +495,43 @@ int apa_momentum_sgd_step_shadow(int nseg, float* const* weights, const size_t* 
                                  const float* weight_decay, const float* grad_flat, float* acc_flat,
                                  float lr, float momentum, float grad_scale, void* const* bf16_shadow,
                                  void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight images of the per-class head (M == K) kept current at WEIGHT-UPDATE time instead of being rebuilt by
+ * every step.  The per-class products read Wa | Wt (and ba | bt) as padded, concatenated bf16 images inside the
+ * workspace (K <= 64: `[C/64][128][64]` k-tile-major for the forward product and `[C][Wt | Wa]` for dX, biases as
+ * one f32 [128] row; any K: `[C][Wt (Kp) | Wa (Kp)]`, ba padded to f32 [Kp]); without APA_FLAG_WEIGHT_IMAGES each
+ * forward / train-step call rebuilds them from the fp32 parameters (5-6 us of a 58 us HMDB-51 step).
+ *
+ * apa_per_class_weight_images: builds every image the shape (N,P,C,Ca,K,dtype) can need in `ws` (>= apa_attn_pool_
+ *   workspace_bytes(..., M = K)) -- one or two launches, for initialisation and after a checkpoint restore -- and, when
+ *   `maps` is given, describes them: maps[i] says "element (c, k) of parameter `role` goes to
+ *   dst[(c >> c_shift) * a + (c & ((1 << c_shift) - 1)) * b + k * d + e]" (bf16, or f32 when is_f32).  *nmaps
+ *   receives the count (<= APA_WIMG_MAX; 0: this shape keeps no images and the flag changes nothing).
+ * apa_momentum_sgd_step_images: apa_momentum_sgd_step_shadow that ALSO rewrites those images from the updated
+ *   weights in the same launch: images[i] belongs to parameter segment image_segment[i].
+ */
+#define APA_WIMG_ROLE_WA 0
+#define APA_WIMG_ROLE_BA 1
+#define APA_WIMG_ROLE_WT 2
+#define APA_WIMG_ROLE_BT 3
+#define APA_WIMG_MAX 12
+#define APA_WIMG_PER_SEGMENT 3
+typedef struct apa_weight_image {
+  void* dst;          /* device pointer INTO the workspace                                   */
+  int role;           /* APA_WIMG_ROLE_*: the parameter this image is made from              */
+  int is_f32;         /* destination element type: 0 = bf16 (round to nearest even), 1 = f32 */
+  int cols;           /* columns of the parameter matrix: flat element i is (c, k) = (i / cols, i % cols) */
+  int c_shift;
+  int a, b, d, e;
+} apa_weight_image;
+int apa_per_class_weight_images(const float* Wa, const float* ba, const float* Wt, const float* bt, void* ws,
+                                size_t ws_bytes, int N, int P, int C, int Ca, int K, int dtype,
+                                apa_weight_image* maps, int* nmaps, void* stream);
+int apa_momentum_sgd_step_images(int nseg, float* const* weights, const size_t* sizes, const float* weight_decay,
+                                 const float* grad_flat, float* acc_flat, float lr, float momentum,
+                                 float grad_scale, void* const* bf16_shadow, const apa_weight_image* images,
+                                 const int* image_segment, int nimages, void* stream);
 
 /* The other two optimisers src/train.py:84-100 can select (TRAIN.OPTIMIZER 'adam' / 'rmsprop'; no shipped YAML
  * does), same flat layout, two slot buffers, one launch, optional bf16 shadows (may be NULL) as above:

@@ -287,6 +287,125 @@ def test_per_class_one_call_train_step_equals_the_separate_calls(gpu, K, dtype, 
     assert bool(torch.isfinite(ga[0].float()).all()) and float(ga[4].abs().max()) > 0
 
 
+@pytest.mark.parametrize('softmax', [False, True])
+@pytest.mark.parametrize('N,H,C', [(3, 7, 2048), (5, 6, 768)])
+def test_per_class_keep_bits_prepared_by_the_previous_step(gpu, N, H, C, softmax):
+    """K <= 64, bf16, caller-kept weight images: the one-call train step runs NO preparation launch -- its last launch
+    leaves the NEXT step's dropout decisions behind, tagged (seed, offset + 1), and the forward kernel believes the
+    map only if the tag matches its own (seed, offset); else (first step on a workspace, a jump of the offset) it hashes
+    its rows itself.  Four steps on a device-side counter (fallback, then three believed maps), one jump of the
+    counter (fallback again), a separately called forward / backward pair in between (its preparation launch rewrites
+    the map and says so): every output bit-identical to the step that prepares everything per call."""
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    K, P = 51, H * H
+    g = torch.Generator().manual_seed(77 + N)
+    Xs = [torch.relu(torch.randn(N, P, C, generator=g)).to(torch.bfloat16).to(gpu) for _ in range(2)]
+    mk = lambda *s_: (torch.randn(*s_, generator=g) / (C ** 0.5 if len(s_) == 2 else 10.0)).to(gpu)
+    Wa, ba, Wt, bt = mk(C, K), mk(K), mk(C, K), mk(K)
+    labels = torch.randint(0, K, (N,), generator=g).to(gpu)
+    flags = cof.attn_flags(softmax, False, True)
+    ca = torch.full((1,), 7, dtype=torch.int64, device=gpu)
+    cb = ca.clone()
+
+    def make(weight_images, ctr, X):
+        grads = (torch.full_like(X, float('nan')), None, torch.empty_like(Wa), torch.empty_like(ba), torch.empty_like(Wt),
+                 torch.empty_like(bt))
+        return cof.HeadTrainStep(X, X, Wa, ba, Wt, bt, labels, grads, flags=flags, keep_prob=0.2, seed=5, offset=ctr,
+                                 weight_images=weight_images), grads
+    a, ga = make(True, ca, Xs[0])
+    b, gb = make(False, cb, Xs[0])
+    assert a._args[-5] & cof.APA_FLAG_WEIGHT_IMAGES
+
+    def same(tag):
+        a.run(); b.run()
+        torch.cuda.synchronize()
+        assert int(ca) == int(cb)
+        for name in ('logits', 'att', 'zsave', 'loss', 'G'):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (tag, name)
+        for x, y in zip(ga, gb):
+            if x is not None:
+                assert torch.equal(x, y) and not torch.isnan(x.float()).any(), tag
+    for i in range(4):
+        if i == 2:                      # another feature map, same workspace: the mask does not depend on X
+            a.rebind(X=Xs[1]); b.rebind(X=Xs[1])
+        same('step %d' % i)
+    assert int(ca) == 11
+    ca.fill_(40); cb.fill_(40)          # the counter jumps: the prepared map is for offset 11
+    same('after the jump')
+    same('after the jump + 1')
+    # a separately called forward on the SAME workspace (its preparation launch writes the map of offset 99) ...
+    lg, att, zs, _, _, _ = cof.attn_pool_fwd(Xs[0], Xs[0], Wa, ba, Wt, bt, flags=flags | cof.APA_FLAG_WEIGHT_IMAGES,
+                                             keep_prob=0.2, seed=5, offset=99, workspace=a.workspace)
+    lg2, _, _, _, _, _ = cof.attn_pool_fwd(Xs[0], Xs[0], Wa, ba, Wt, bt, flags=flags, keep_prob=0.2, seed=5, offset=99)
+    assert torch.equal(lg, lg2)
+    same('after a foreign forward call')      # ... is noticed: the tag no longer says offset 42
+    same('and once more')
+
+
+@pytest.mark.parametrize('K,dtype,train', [(51, torch.bfloat16, True), (51, torch.bfloat16, False),
+                                           (130, torch.bfloat16, True), (70, torch.float32, True)])
+def test_per_class_weight_images_kept_by_the_optimizer_launch(gpu, K, dtype, train):
+    """APA_FLAG_WEIGHT_IMAGES (include/apa.h): the padded / concatenated operand images of the per-class head are
+    built once in the step's workspace (apa_per_class_weight_images) and rewritten by the OPTIMISER'S launch
+    (apa_momentum_sgd_step_images) -- the per-step preparation launch then writes only the keep bits.  Every output of
+    the one-call step must be BIT-identical to the step that rebuilds the images from the fp32 weights in every call:
+    right after construction, and again after two optimiser updates."""
+    from attentionalpoolingaction_amd import deploy
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    N, H, C = 3, 7, 2048
+    P = H * H
+    g = torch.Generator().manual_seed(1000 + K)
+    X = torch.relu(torch.randn(N, P, C, generator=g)).to(dtype).to(gpu)
+    shapes = {'att_weights': (C, K), 'att_biases': (K,), 'td_weights': (C, K), 'td_biases': (K,)}
+    params = {n: (torch.randn(s_, generator=g) / (C ** 0.5 if len(s_) == 2 else 10.0)).to(gpu) for n, s_ in shapes.items()}
+    labels = torch.randint(0, K, (N,), generator=g).to(gpu)
+    flags = cof.attn_flags(False, False, train)
+
+    def make(weight_images):
+        grads = (torch.full_like(X, float('nan')), None) + tuple(torch.full_like(params[n], float('nan')) for n in shapes)
+        st = cof.HeadTrainStep(X, X, params['att_weights'], params['att_biases'], params['td_weights'],
+                               params['td_biases'], labels, grads, flags=flags, keep_prob=0.5, seed=11, offset=3,
+                               weight_images=weight_images)
+        return st, grads
+    a, ga = make(True)
+    b, gb = make(False)
+    assert a.weight_image_maps and not b.weight_image_maps
+    roles = {r for r, _ in a.weight_image_maps}
+    assert roles >= {'Wa', 'ba', 'Wt'} and (K > 64 or dtype != torch.bfloat16 or 'bt' in roles)
+    bucket = deploy.GradientBucket(shapes, gpu)
+    opt = deploy.MomentumSGD(params, bucket, lr=0.05, momentum=0.9, weight_decay=5e-4,
+                             regularized=['att_weights', 'td_weights'])
+    opt.attach_weight_images(a, {'Wa': 'att_weights', 'ba': 'att_biases', 'Wt': 'td_weights', 'bt': 'td_biases'})
+    assert opt.images and not opt._img_refresh
+
+    def same():
+        a.run(); b.run()
+        torch.cuda.synchronize()
+        for name in ('logits', 'att', 'zsave', 'loss', 'G'):
+            assert torch.equal(getattr(a, name), getattr(b, name)), name
+        for x, y in zip(ga, gb):
+            if x is not None:
+                assert torch.equal(x, y) and not torch.isnan(x.float()).any()
+    same()
+    for _ in range(2):
+        bucket.flat.copy_(torch.randn(bucket.flat.numel(), generator=g).to(gpu))
+        opt.step()
+        same()
+    # evaluation on the same workspace: no preparation launch at all, same logits
+    ev_a = cof.HeadEvalStep(X, X, params['att_weights'], params['att_biases'], params['td_weights'], params['td_biases'],
+                            flags=cof.APA_FLAG_WEIGHT_IMAGES, workspace=a.workspace)
+    ev_b = cof.HeadEvalStep(X, X, params['att_weights'], params['att_biases'], params['td_weights'], params['td_biases'])
+    ev_a.run(); ev_b.run()
+    torch.cuda.synchronize()
+    assert torch.equal(ev_a.logits, ev_b.logits) and torch.equal(ev_a.pred, ev_b.pred)
+    # the images are laid out for 16-byte aligned features: an odd address is refused, not silently re-prepared
+    if dtype == torch.bfloat16:
+        Xo = torch.empty(N * P * C + 8, dtype=dtype, device=gpu)[1:1 + N * P * C].view(N, P, C)
+        with pytest.raises(cof.ApaError, match='16-byte'):
+            cof.attn_pool_fwd(Xo, Xo, params['att_weights'], params['att_biases'], params['td_weights'],
+                              params['td_biases'], flags=cof.APA_FLAG_WEIGHT_IMAGES, workspace=a.workspace)
+
+
 @pytest.mark.parametrize('K', [51, 130])
 def test_per_class_device_side_dropout_counter_is_advanced_by_the_backward_call(gpu, K):
     """APA_FLAG_RNG_DEVICE (include/apa.h): `offset` is the address of a step counter in HBM that apa_attn_pool_bwd

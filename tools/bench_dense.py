@@ -57,7 +57,7 @@ def _round_robin(runs):
 
 
 def _rot_note(R, per_set_bytes):
-    return '; X/dX rotated over {} sets ({:.0f} MB live)'.format(R, R * per_set_bytes / 1e6) if R > 1 else \
+    return '; X/dX rotated over {} sets ({:.0f} MB live; workspace and activations shared, as in a training loop)'.format(R, R * per_set_bytes / 1e6) if R > 1 else \
         '; ONE buffer set (features stay in the Infinity Cache between steps)'
 
 
@@ -96,11 +96,13 @@ def build_cfg003(cof, dev, N=32, H=14, K=393, dtype='bf16', rank1=True, one_call
         new = lambda t: torch.empty_like(t)
         pgrads = (new(W1), new(b1), new(W2), new(b2), new(Wa), new(ba), new(Wt), new(bt))
         sts = []
-        for r in range(R):        # one bound step per (X, dX) set; weights, parameter gradients, counter shared
+        for r in range(R):        # one bound step per (X, dX) set; everything else is shared, as in bench.py's headline:
+            #                       weights, parameter gradients, activations, workspaces, dropout counter
             Xr = X if r == 0 else _features(N, P, C, td, dev, seed=42 + r)
             sts.append(cof.PoseAttnTrainStep(Xr, (W1, b1, W2, b2, Wa, ba, Wt, bt), labels, lbl, valid,
                                              (dX if r == 0 else new(Xr),) + pgrads,
-                                             flags=flags, keep_prob=0.2, seed=42, offset=ctr, w1_bf16=w1_bf16))
+                                             flags=flags, keep_prob=0.2, seed=42, offset=ctr, w1_bf16=w1_bf16,
+                                             share_with=sts[0] if sts else None))
         info = {'workload': 'cfg003 pose-regularised attention head fwd+bwd (pose head 2048->768->16 + M=1 '
                             'pooling + pose L2 + softmax-xent), one host call; per-GPU batch {} x {}x{}x{} {}, K={}, '
                             'dropout keep=0.2'.format(N, H, H, C, dtype, K) + _rot_note(R, per_set),
@@ -158,7 +160,7 @@ def build_posebwd(cof, dev, N=32, H=14, dtype='bf16', accumulate=False):
     return step, info
 
 
-def build_perclass(cof, dev, N=32, H=14, K=51, dtype='bf16', rotate=0):
+def build_perclass(cof, dev, N=32, H=14, K=51, dtype='bf16', rotate=0, weight_images=True):
     C, P = 2048, H * H
     td = torch.bfloat16 if dtype == 'bf16' else torch.float32
     g = torch.Generator().manual_seed(42)
@@ -174,12 +176,16 @@ def build_perclass(cof, dev, N=32, H=14, K=51, dtype='bf16', rotate=0):
     sts = []
     for r in range(R):            # one host call per step, one bound step per (X, dX) set
         Xr = X if r == 0 else _features(N, P, C, td, dev, seed=42 + r)
+        # the padded / concatenated bf16 operand images of the weights live in the step's workspace and are kept
+        # current at weight-update time (APA_FLAG_WEIGHT_IMAGES: deploy.MomentumSGD.attach_weight_images rewrites them
+        # in the optimiser's own launch); here the weights do not change between steps
         sts.append(cof.HeadTrainStep(Xr, Xr, Wa, ba, Wt, bt, labels, (torch.empty_like(Xr), None) + pg, flags=flags,
-                                     keep_prob=0.2, seed=42, offset=ctr))
+                                     keep_prob=0.2, seed=42, offset=ctr, weight_images=weight_images,
+                                     share_with=sts[0] if sts else None))
     esz = X.element_size()
     info = {'workload': 'per-class bottom-up maps (M=K, HMDB-51 shape when K=51) attention head fwd+bwd; '
                         'per-GPU batch {} x {}x{}x{} {}, K={}, dropout keep=0.2'.format(N, H, H, C, dtype, K) +
-                        _rot_note(R, per_set),
+                        ('; weight images kept by the optimiser launch' if weight_images else '') + _rot_note(R, per_set),
             # K = 51: 0.25 GFLOP/img against 3*P*C*s bytes -> HBM-bound; K = 393: MFMA-bound
             'bound': 'hbm' if K <= 128 else 'mfma', 'dtype': dtype, 'N': N, 'rotate': R,
             'flops_per_image': 3 * (2 * 2.0 * P * C * K),              # Z and T products, fwd + 2x bwd
@@ -206,7 +212,7 @@ def build_rank1(cof, dev, N=32, H=14, K=51, dtype='bf16', rotate=0):
     for r in range(R):
         Xr = X if r == 0 else _features(N, P, C, td, dev, seed=42 + r)
         sts.append(cof.HeadTrainStep(Xr, Xr, Wa, ba, Wt, bt, labels, (torch.empty_like(Xr), None) + pg, flags=flags,
-                                     keep_prob=0.2, seed=42, offset=ctr))
+                                     keep_prob=0.2, seed=42, offset=ctr, share_with=sts[0] if sts else None))
     info = {'workload': 'class-agnostic map (M=1) attention head fwd + softmax-xent + bwd; per-GPU batch {} x {}x{}x{} '
                         '{}, K={}, dropout keep=0.2'.format(N, H, H, C, dtype, K) + _rot_note(R, per_set),
             'bound': 'hbm', 'dtype': dtype, 'N': N, 'rotate': R, 'flops_per_image': 0.0,
@@ -226,7 +232,7 @@ def build_eval002(cof, dev, N=32, H=14, K=393, dtype='f32', rotate=0):
     evs = []
     for r in range(R):
         Xr = X if r == 0 else _features(N, P, C, td, dev, seed=42 + r)
-        evs.append(cof.HeadEvalStep(Xr, Xr, Wa, ba, Wt, bt))
+        evs.append(cof.HeadEvalStep(Xr, Xr, Wa, ba, Wt, bt, workspace=evs[0].workspace if evs else None))
     info = {'workload': 'cfg002 eval step (attn-pool forward + softmax + argmax, one call); per-GPU batch '
                         '{} x {}x{}x{} {}, K={}'.format(N, H, H, C, dtype, K) + _rot_note(R, per_set).replace('X/dX', 'X'),
             'bound': 'hbm', 'dtype': dtype, 'N': N, 'rotate': R, 'bytes_per_image': 1.0 * P * C * X.element_size()}
@@ -284,6 +290,8 @@ def main():
                          'pose head bwd) instead of the one-call apa_pose_attn_train_step')
     ap.add_argument('--no-rank1', action='store_true',
                     help='cfg003: materialise the [N,P,768] attention-branch gradient between the two backward calls')
+    ap.add_argument('--no-weight-images', action='store_true',
+                    help='perclass: rebuild the padded bf16 weight images in every step (the round-4 form)')
     ap.add_argument('--rotate', type=int, default=0,
                     help='number of (X, dX) buffer sets cycled through; 0 = enough for 1.5 x the Infinity Cache')
     ap.add_argument('--steps', type=int, default=50)
@@ -305,7 +313,7 @@ def main():
                                    rotate=args.rotate)
     else:
         step, info = build_perclass(cof, dev, args.batch, args.hw, args.classes or 51, args.dtype or 'bf16',
-                                    rotate=args.rotate)
+                                    rotate=args.rotate, weight_images=not args.no_weight_images)
     sec, reps = timed(step, args.steps, args.warmup)
     print(json.dumps(report(info, sec, reps)))
 
