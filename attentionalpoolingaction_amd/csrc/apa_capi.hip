@@ -421,7 +421,7 @@ extern "C" int apa_pose_attn_train_step(const apa_pose_attn_step_io* io, int N, 
       !s.pose_labels || !s.pose_valid || !s.Ppre || !s.Pl || !s.att || !s.logits || !s.zsave || !s.abar ||
       !s.loss_action || !s.loss_pose || !s.G || !s.dPl || !s.dZ || !s.dX || !s.dW1 || !s.db1 || !s.dW2 || !s.db2 ||
       !s.dWa || !s.dba || !s.dWt || !s.dbt || !s.ws_pool || !s.ws_pose) {
-    set_error("apa_pose_attn_train_step: null pointer in apa_pose_attn_step_io (only W1_bf16 may be NULL)");
+    set_error("apa_pose_attn_train_step: null pointer in apa_pose_attn_step_io (only W1_bf16 / W2T_bf16 may be NULL)");
     return APA_ERR_INVALID_ARG;
   }
   int rc = check_common("apa_pose_attn_train_step", N, P, C, Cp, K, 1, dtype);
@@ -465,6 +465,7 @@ extern "C" int apa_pose_attn_train_step(const apa_pose_attn_step_io* io, int N, 
   // shadow (e.g. one carved out of a flat bf16 buffer), the DMA-staged products want 16-byte addressable rows -- an
   // operand they cannot read is ignored and W1 is converted inside the call, as if none had been given
   a.W1_bf16 = (reinterpret_cast<uintptr_t>(s.W1_bf16) & 15) == 0 ? s.W1_bf16 : nullptr;
+  a.W2T_bf16 = (reinterpret_cast<uintptr_t>(s.W2T_bf16) & 15) == 0 ? s.W2T_bf16 : nullptr;
   a.wa = s.Wa; a.ba = s.ba; a.att = s.att;
   a.relu_att = (flags & APA_FLAG_RELU_ATT) && !(flags & APA_FLAG_SOFTMAX_ATT);
   a.pose_labels = s.pose_labels; a.pose_valid = s.pose_valid; a.dPl = s.dPl;

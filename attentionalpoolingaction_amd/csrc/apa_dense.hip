@@ -395,23 +395,42 @@ static bool pose_bwd_rows_ok(const float* dPl, const void* Ppre, const void* ext
 // W2 staging: a thread converts the k pair (2kp, 2kp + 1) of four columns and writes four 32-bit words (2-way
 // bank aliasing at most, free for ds_write_b32; the 2-byte scatter it replaces showed an LDS conflict ratio of
 // 0.50 in the SQ counters), rows padded by 16 so that the ds_read_b128 fragment reads are conflict-free.
+// W2T (round 5): the LDS image of W2 -- [16][Cp + 16] bf16, rows padded for conflict-free fragment reads -- is a
+// verbatim copy of a caller-kept image of W2^T in the same layout, fetched by LDS-DMA (25 wave-instructions per block):
+// half the bytes of the fp32 W2, no conversion, no ds_write pass (the 2-byte-pair scatter had an LDS conflict ratio of
+// 0.29).  With the staging that cheap a block is TWO waves (32 rows, 196 blocks at the benchmark shape: every CU
+// ingests 49 + 25 KB instead of 98 + 49 KB; with the fp32 staging smaller blocks measured slower).  First try, B
+// fragments loaded straight from the global image by every lane: 10.2 us against 8.5 -- 24 KB per WAVE through the
+// CU's one memory pipe.
 struct PosePlExtra {
   const float* wa; const float* ba; float* att; int act;                                   // wa == nullptr: off
   const float* lbl; const uint8_t* valid; float* dPl; float* lpart; float gcoef; int P;    // lbl == nullptr: off
+  const bf16_t* w2t;                                                                        // W2T form only
 };
-template <int KS, bool FUSED>   // k steps of 32: Cp = 32 * KS
+template <int KS, bool FUSED, bool W2T = false>   // k steps of 32: Cp = 32 * KS
 __global__ __launch_bounds__(256) void pose_pl_kernel(const bf16_t* __restrict__ Ppre,
                                                       const float* __restrict__ W2,
                                                       const float* __restrict__ b2, float* __restrict__ Pl,
                                                       int R, int J, PosePlExtra x) {
   typedef short bf16x8 __attribute__((ext_vector_type(8)));
   constexpr int Cp = 32 * KS, LDW = Cp + 16;
-  __shared__ __attribute__((aligned(16))) short w2s[16 * LDW];   // [n][k] bf16, zero rows for n >= J
+  constexpr int WPB = W2T ? 2 : 4;                                   // waves per block (blockDim.x = 64 WPB)
+  constexpr int NCH = (16 * LDW * 2 + 1023) / 1024;                  // KiB chunks of the image (W2T: DMA instructions)
+  __shared__ __attribute__((aligned(16))) short w2s[W2T ? NCH * 512 : 16 * LDW];   // [n][k] bf16, zero rows for n >= J
   __shared__ __attribute__((aligned(16))) float was[FUSED ? Cp : 4];
   __shared__ float lred[4];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int l16 = lane & 15, kb = lane >> 4;
-  const int r0 = (blockIdx.x * 4 + wave) * 16;
+  const int r0 = (blockIdx.x * WPB + wave) * 16;
+  if constexpr (W2T) {   // first of all: the image is on its way while the A fragments are requested
+    typedef __attribute__((address_space(1))) const void* gptr;
+    typedef __attribute__((address_space(3))) void* lptr;
+    const char* img = reinterpret_cast<const char*>(x.w2t);
+    for (int ch = wave; ch < NCH; ch += WPB) {
+      const int off = min(ch * 1024 + lane * 16, 16 * LDW * 2 - 16);     // (the last chunk is ragged: clamped re-reads)
+      __builtin_amdgcn_global_load_lds((gptr)(img + off), (lptr)(w2s + ch * 512), 16, 0, 0);
+    }
+  }
   // A fragments first: they are the long-latency loads
   bf16x8 af[KS];
   const bf16_t* arow = Ppre + (size_t)min(r0 + l16, R - 1) * Cp + kb * 8;
@@ -420,6 +439,7 @@ __global__ __launch_bounds__(256) void pose_pl_kernel(const bf16_t* __restrict__
     const uint4 v = ld16(arow + ks * 32);
     af[ks] = __builtin_bit_cast(bf16x8, v);
   }
+
   // fused loss: this lane's four label values and validity flags are requested now, next to the A fragments (read after
   // the MFMA chain they were a second exposed round trip: the fused launch took 9.9 us against 6.0 us for Pl alone)
   float lblv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -432,7 +452,9 @@ __global__ __launch_bounds__(256) void pose_pl_kernel(const bf16_t* __restrict__
       vmv[r] = x.valid[(size_t)(row / x.P) * J + l16] ? 1.0f : 0.0f;
     }
   }
-  if (J == 16) {   // W2 rows are 64 B: task = (k pair, column quad), both float4 loads issued before the first use
+  if constexpr (W2T) {
+    // nothing to stage
+  } else if (J == 16) {   // W2 rows are 64 B: task = (k pair, column quad), both float4 loads issued before the first use
     constexpr int NT = Cp * 2 / 256;             // Cp/2 pairs x 4 quads over 256 threads
     float4 w0[NT], w1[NT];
 #pragma unroll
@@ -462,9 +484,9 @@ __global__ __launch_bounds__(256) void pose_pl_kernel(const bf16_t* __restrict__
     }
   }
   if (FUSED && x.wa)
-    for (int i = tid; i < Cp / 4; i += 256)
+    for (int i = tid; i < Cp / 4; i += 64 * WPB)
       *reinterpret_cast<float4*>(was + i * 4) = *reinterpret_cast<const float4*>(x.wa + i * 4);
-  __syncthreads();
+  __syncthreads();       // (W2T: the compiler waits for the DMA -- vmcnt(0) -- in front of this barrier)
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
@@ -510,7 +532,7 @@ __global__ __launch_bounds__(256) void pose_pl_kernel(const bf16_t* __restrict__
     lacc = wave_sum(lacc);
     if (lane == 0) lred[wave] = lacc;
     __syncthreads();
-    if (tid == 0) x.lpart[blockIdx.x] = (lred[0] + lred[1]) + (lred[2] + lred[3]);
+    if (tid == 0) x.lpart[blockIdx.x] = WPB == 4 ? (lred[0] + lred[1]) + (lred[2] + lred[3]) : lred[0] + lred[1];
   }
 }
 
@@ -523,11 +545,14 @@ static bool pose_pl_fast(int Cp, int J, int dtype, const void* Ppre) {
 // the skinny product's launch; `x` != nullptr: the fused form (attention logits column and / or pose L2 loss)
 static int pose_pl_launch(const bf16_t* pp, const float* W2, const float* b2, float* Pl, int R, int Cp, int J,
                           const PosePlExtra* x, hipStream_t st) {
-  const dim3 grid((R + 63) / 64);
-  const PosePlExtra none = {nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0.f, 1};
+  const bool w2t = x && x->w2t;
+  const dim3 grid(w2t ? (R + 31) / 32 : (R + 63) / 64);
+  const PosePlExtra none = {nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0.f, 1, nullptr};
 #define APA_PL(KSv)                                                                                              \
   do {                                                                                                           \
-    if (x) hipLaunchKernelGGL((pose_pl_kernel<KSv, true>), grid, dim3(256), 0, st, pp, W2, b2, Pl, R, J, *x);     \
+    if (w2t)                                                                                                     \
+      hipLaunchKernelGGL((pose_pl_kernel<KSv, true, true>), grid, dim3(128), 0, st, pp, W2, b2, Pl, R, J, *x);    \
+    else if (x) hipLaunchKernelGGL((pose_pl_kernel<KSv, true>), grid, dim3(256), 0, st, pp, W2, b2, Pl, R, J, *x); \
     else hipLaunchKernelGGL((pose_pl_kernel<KSv, false>), grid, dim3(256), 0, st, pp, W2, b2, Pl, R, J, none);    \
   } while (0)
   switch (Cp / 32) {
@@ -565,7 +590,7 @@ static PosePlan pose_plan(int N, int P, int C, int Cp, int J, int dtype) {
   pl.off_w1b = off;     off += align_up((size_t)C * Cp * 2, 256);
   // fused step: one pose-loss partial per block of the Pl kernel, alive from the forward to the last launch
   {                     // (its fallback runs apa_pose_l2_loss_fwd_bwd with the same region as scratch)
-    size_t lp = (size_t)((pl.R + 63) / 64) * 4;
+    size_t lp = (size_t)((pl.R + 31) / 32) * 4;         // (32-row blocks with the caller-kept W2^T image, else 64)
     const size_t l2 = apa_pose_l2_workspace_bytes(N, P, J);
     if (l2 > lp) lp = l2;
     pl.off_lpart = off; off += align_up(lp, 256);
@@ -894,6 +919,7 @@ int pose_fwd_fused(const void* X, const float* W1, const float* b1, const float*
   x.lbl = a.pose_labels; x.valid = a.pose_valid; x.dPl = a.dPl;
   x.lpart = reinterpret_cast<float*>(w + pl.off_lpart);
   x.gcoef = a.grad_scale * a.pose_wt / denom; x.P = P;
+  x.w2t = static_cast<const bf16_t*>(a.W2T_bf16);
   return pose_pl_launch(static_cast<const bf16_t*>(Ppre), W2, b2, Pl, R, Cp, J, &x, st);
 }
 
@@ -908,7 +934,7 @@ int pose_bwd_fused(const void* X, const float* W1, const float* W2, const void* 
   PoseBwdFuse f;
   f.dWa = dWa; f.dba = dba;
   f.aux_src = reinterpret_cast<const float*>(static_cast<char*>(ws) + pl.off_lpart);
-  f.aux_n = (int)((pl.R + 63) / 64);
+  f.aux_n = (int)(a.W2T_bf16 ? (pl.R + 31) / 32 : (pl.R + 63) / 64);     // loss partials: one per block of the Pl launch
   f.aux_scale = 0.5f * a.pose_wt / ((float)N * (float)N * (float)P);
   f.aux_dst = loss_pose;
   f.rng_bump = rng_bump;

@@ -310,6 +310,7 @@ int m1_logits2_xent(const float* z, const float* Wt, const float* abar, const fl
 // apa_dense.hip: the pose-head halves of the one-call cfg 003 step (apa_pose_attn_train_step)
 struct PoseStepArgs {
   const void* W1_bf16 = nullptr;        // caller-maintained bf16 copy of W1 (nullptr: converted per call)
+  const void* W2T_bf16 = nullptr;       // caller-maintained bf16 [16][Cp] transposed copy of W2 (nullptr: staged per block)
   const float* wa = nullptr; const float* ba = nullptr; float* att = nullptr; bool relu_att = false;
   const float* pose_labels = nullptr; const uint8_t* pose_valid = nullptr; float* dPl = nullptr;
   float pose_wt = 1.f, grad_scale = 1.f;

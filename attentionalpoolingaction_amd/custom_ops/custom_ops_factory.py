@@ -884,7 +884,7 @@ class HeadTrainStep:
 
 class ApaPoseAttnStepIO(ctypes.Structure):
     """`apa_pose_attn_step_io` of include/apa.h (field order is the ABI)."""
-    _fields_ = ([(n, c_void_p) for n in ('X', 'W1', 'b1', 'W2', 'b2', 'W1_bf16', 'Wa', 'ba', 'Wt', 'bt', 'labels',
+    _fields_ = ([(n, c_void_p) for n in ('X', 'W1', 'b1', 'W2', 'b2', 'W1_bf16', 'W2T_bf16', 'Wa', 'ba', 'Wt', 'bt', 'labels',
                                           'pose_labels', 'pose_valid')] +
                 [('action_wt', c_float), ('pose_wt', c_float), ('grad_scale', c_float)] +
                 [(n, c_void_p) for n in ('Ppre', 'Pl', 'att', 'logits', 'zsave', 'abar', 'loss_action', 'loss_pose',
@@ -904,9 +904,12 @@ class PoseAttnTrainStep:
     Outputs as attributes: Ppre, Pl, att, logits, zsave, abar, loss_action [1+N], loss_pose [1], G, dPl, dZ."""
 
     def __init__(self, X, params, labels, pose_labels, pose_valid, grads, *, flags=0, keep_prob=1.0, seed=0,
-                 offset=0, action_wt=1.0, pose_wt=1.0, grad_scale=1.0, w1_bf16=None, share_with=None):
+                 offset=0, action_wt=1.0, pose_wt=1.0, grad_scale=1.0, w1_bf16=None, share_with=None,
+                 w2t_bf16=None):
         """`share_with`: another PoseAttnTrainStep of the same shapes whose activation / loss buffers and workspaces
-        this step is bound to as well (see HeadTrainStep)."""
+        this step is bound to as well (see HeadTrainStep).  `w2t_bf16`: optional bf16 [16, Cp + 16] image of W2^T (rows
+        J.. and the pad columns zero) the caller keeps current -- `pose_w2t_image(W2)` builds it, `pose_w2t_image_map(image, W2)` describes
+        it for `momentum_sgd_step(..., images=...)`."""
         self.lib = load_library()
         W1, b1, W2, b2, Wa, ba, Wt, bt = params
         dX, dW1, db1, dW2, db2, dWa, dba, dWt, dbt = grads
@@ -942,7 +945,7 @@ class PoseAttnTrainStep:
                                        dtype=torch.uint8, device=dev)
             self.ws_pose = torch.empty((max(int(self.lib.apa_pose_head_workspace_bytes(N, P, C, Cp, J, dt)), 16),),
                                        dtype=torch.uint8, device=dev)
-        self._keep = (X, params, labels, pose_labels, pose_valid, grads, offset, w1_bf16)
+        self._keep = (X, params, labels, pose_labels, pose_valid, grads, offset, w1_bf16, w2t_bf16)
         io = ApaPoseAttnStepIO()
         io.X = _dev_ptr(X, 'X')
         for name, t in (('W1', W1), ('b1', b1), ('W2', W2), ('b2', b2), ('Wa', Wa), ('ba', ba), ('Wt', Wt), ('bt', bt),
@@ -950,6 +953,12 @@ class PoseAttnTrainStep:
                         ('dWa', dWa), ('dba', dba), ('dWt', dWt), ('dbt', dbt)):
             setattr(io, name, _dev_ptr(t, name, f32))
         io.W1_bf16 = None if w1_bf16 is None else _dev_ptr(w1_bf16, 'w1_bf16', torch.bfloat16)
+        io.W2T_bf16 = None
+        if w2t_bf16 is not None:
+            if tuple(w2t_bf16.shape) != (16, Cp + 16) or J > 16 or not w2t_bf16.is_contiguous():
+                raise ApaError('PoseAttnTrainStep: w2t_bf16 is a contiguous bf16 [16, Cp + 16] image of W2^T (J <= 16; '
+                               'pose_w2t_image)')
+            io.W2T_bf16 = _dev_ptr(w2t_bf16, 'w2t_bf16', torch.bfloat16)
         if w1_bf16 is not None and w1_bf16.numel() != W1.numel():
             raise ApaError('PoseAttnTrainStep: w1_bf16 must have W1\'s element count')
         io.labels = _dev_ptr(labels, 'labels', torch.int64)
@@ -1072,6 +1081,23 @@ def per_class_weight_images(Wa, ba, Wt, bt, workspace, N, P, dtype):
         ctypes.memmove(ctypes.addressof(m), ctypes.addressof(maps[i]), ctypes.sizeof(ApaWeightImage))
         out.append((APA_WIMG_ROLES[m.role], m))
     return out
+
+
+def pose_w2t_image(W2: torch.Tensor) -> torch.Tensor:
+    """bf16 [16, Cp + 16] image of W2^T (W2 [Cp, J <= 16]; rows J.. and the 16 pad columns zero) -- the LDS image of
+    the Pl product, which copies it verbatim: `PoseAttnTrainStep(w2t_bf16=...)`."""
+    Cp, J = W2.shape
+    img = torch.zeros((16, Cp + 16), dtype=torch.bfloat16, device=W2.device)
+    img[:J, :Cp].copy_(W2.t())
+    return img
+
+
+def pose_w2t_image_map(image: torch.Tensor, W2: torch.Tensor) -> ApaWeightImage:
+    """where the optimiser's launch stores the updated element (c, j) of W2 inside `image`: image[j, c]."""
+    m = ApaWeightImage()
+    m.dst, m.role, m.is_f32, m.cols, m.c_shift = image.data_ptr(), 0, 0, int(W2.shape[1]), 0
+    m.a, m.b, m.d, m.e = 1, 0, int(image.shape[1]), 0
+    return m
 
 
 def momentum_sgd_step(weights, weight_decay, grad_flat, acc_flat, lr, momentum=0.9, grad_scale=1.0, shadows=None,

@@ -298,6 +298,22 @@ class MomentumSGD:
         else:
             self._img_refresh.append(step)
 
+    def add_image(self, name: str, image_map, refresh=None) -> None:
+        """One more operand image of parameter `name` (a cof.ApaWeightImage, e.g. cof.pose_w2t_image_map: the bf16
+        transposed copy of the pose head's W2) to be rewritten by this optimiser's launch; `refresh()` rebuilds it
+        from the weights where the launch cannot (more than three images on one parameter; the adaptive optimisers,
+        whose launches carry no image maps)."""
+        if not hasattr(self, 'images'):
+            self.images, self._img_refresh = [], []
+        seg = self.bucket.names.index(name)
+        fused = isinstance(self, MomentumSGD) and not isinstance(self, _AdaptiveOptimizer)
+        if fused and sum(1 for s_, _ in self.images if s_ == seg) < 3:
+            self.images.append((seg, image_map))
+        elif refresh is not None:
+            self._img_refresh.append(type('ImageRefresh', (), {'refresh_weight_images': staticmethod(refresh)})())
+        else:
+            raise ValueError('add_image(%r): this optimiser cannot rewrite the image in its launch; pass refresh=' % name)
+
     def refresh_shadows(self) -> None:
         """Rewrite every bf16 operand copy from its parameter: at construction, and after the weights were
         changed behind the optimiser's back (load_state_dict, a checkpoint restore)."""
@@ -552,6 +568,7 @@ class FusedHeadStep:
         self._key = None
         self._dX = None
         self.w1_shadow = None
+        self.w2t_image = None
         self._optimizer = None
         self.probe_events = None
 
@@ -587,6 +604,14 @@ class FusedHeadStep:
         self._step_obj = None                        # re-bind with the shadow / the weight images
         self._optimizer = configure_optimizer(self.cfg, {n: p.data for n, p in self.params.items()}, self.bucket,
                                               learning_rate, regularized=self.regularized, bf16_shadows=shadows)
+        w2 = self.params['pose_w2'].data
+        if self.pose_form and w2.is_cuda and w2.shape[1] <= 16:
+            # the Pl product reads W2^T as a ready-made bf16 image, rewritten by the optimiser's launch as well
+            from .custom_ops import custom_ops_factory as cof
+            self.w2t_image = cof.pose_w2t_image(w2)
+            img = self.w2t_image
+            self._optimizer.add_image('pose_w2', cof.pose_w2t_image_map(img, w2),
+                                      refresh=lambda: img[:w2.shape[1], :w2.shape[0]].copy_(w2.t()))
         return self._optimizer
 
     def _bind(self, X, labels_action, labels_pose, pose_valid):
@@ -603,7 +628,8 @@ class FusedHeadStep:
                 (self._dX, v['pose_w1'], v['pose_b1'], v['pose_w2'], v['pose_b2'], v['att_weights'], v['att_biases'],
                  v['td_weights'], v['td_biases']), flags=flags, keep_prob=head.keep_prob, seed=head.seed,
                 offset=head._step, action_wt=float(tr.LOSS_FN_ACTION_WT), pose_wt=float(tr.LOSS_FN_POSE_WT),
-                grad_scale=self.loss_scale, w1_bf16=shadow)
+                grad_scale=self.loss_scale, w1_bf16=shadow,
+                w2t_bf16=self.w2t_image if X.dtype == torch.bfloat16 else None)
         st = cof.HeadTrainStep(
             X, X, p['att_weights'], p['att_biases'], p['td_weights'], p['td_biases'], labels_action,
             (self._dX, None, v['att_weights'], v['att_biases'], v['td_weights'], v['td_biases']), flags=flags,

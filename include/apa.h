@@ -238,6 +238,11 @@ int apa_attn_head_eval_step(const void* X, const void* Xatt, const float* Wa, co
  * pose loss and advances the dropout counter: 18 -> 13 launches at the benchmark shape.
  * io->W1_bf16 (optional): a bf16 copy of W1 [C,Cp] the caller keeps current (apa_momentum_sgd_step_shadow
  * rewrites it in the optimizer's own launch); NULL = converted inside the call.
+ * io->W2T_bf16 (optional, round 5): W2 TRANSPOSED and rounded to bf16, [16][Cp + 16] (rows J..15 and the 16 pad
+ * columns zero), 16-byte aligned, kept current the same way (apa_momentum_sgd_step_images with the map "element
+ * (c, j) of W2 -> dst[j * (Cp + 16) + c]": a = 1, d = Cp + 16, c_shift = b = e = 0): the Pl product copies this
+ * 24.5 KB image verbatim into LDS (LDS-DMA) instead of converting and transposing the fp32 W2 in every block;
+ * NULL = as before.  Same values.
  * All pointers device memory; X/Ppre/dX of `dtype`, everything else f32 (labels int64, pose_valid uint8).
  * flags: APA_FLAG_SOFTMAX_ATT / RELU_ATT / TRAIN / RNG_DEVICE as for apa_attn_pool_fwd.
  */
@@ -248,6 +253,7 @@ typedef struct apa_pose_attn_step_io {
   const float* W2;          /* [Cp,J]   PoseLogits/Conv2d_1c_1x1                         */
   const float* b2;          /* [J]                                                       */
   const void* W1_bf16;      /* optional bf16 [C,Cp] copy of W1, or NULL                  */
+  const void* W2T_bf16;     /* optional bf16 [16,Cp+16] transposed copy of W2, or NULL   */
   const float* Wa;          /* [Cp,1]   Conv2d_PrePose_Attn                              */
   const float* ba;          /* [1]                                                       */
   const float* Wt;          /* [C,K]    top-down conv                                    */

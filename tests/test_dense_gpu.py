@@ -220,12 +220,16 @@ def test_cfg003_whole_step_in_one_call_matches_the_per_op_sequence(gpu, dtype, N
     assert int(ctr_a) == 8
 
     # ---- one call (with and without the caller-maintained bf16 copy of W1)
-    for shadow in ((None, W1d.to(torch.bfloat16)) if dtype == torch.bfloat16 else (None,)):
+    # (the bf16 operand images a caller may keep: W1 as is, W2 transposed -- same values, so nothing may change)
+    variants = ((None, None), (W1d.to(torch.bfloat16), None), (W1d.to(torch.bfloat16), cof.pose_w2t_image(W2d))) \
+        if dtype == torch.bfloat16 else ((None, None),)
+    for shadow, w2t in variants:
         ctr_b.fill_(7)
         e = lambda t: torch.full_like(t, float('nan'))
         grads = (e(Xd), e(W1d), e(b1d), e(W2d), e(b2d), e(Wad), e(bad), e(Wtd), e(btd))
         st = cof.PoseAttnTrainStep(Xd, (W1d, b1d, W2d, b2d, Wad, bad, Wtd, btd), lab, lbl_d, valid_d, grads,
-                                   flags=flags, keep_prob=0.5, seed=9, offset=ctr_b, w1_bf16=shadow, **wts)
+                                   flags=flags, keep_prob=0.5, seed=9, offset=ctr_b, w1_bf16=shadow, w2t_bf16=w2t,
+                                   **wts)
         st.run()
         torch.cuda.synchronize()
         assert int(ctr_b) == 8                                  # the dropout counter advanced exactly once

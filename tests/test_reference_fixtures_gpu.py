@@ -337,6 +337,10 @@ def test_fused_head_step_surface_matches_reference_at_the_benchmark_shape(gpu, p
             assert np.abs(p_.detach().double().cpu().numpy() - want).max() <= 1e-6 * max(np.abs(want).max(), 1e-3), n
         if fused.pose_form:
             assert torch.equal(fused.w1_shadow, head.pose_w1.data.to(torch.bfloat16))     # rewritten by the update launch
+            J = head.pose_w2.shape[1]
+            Cp_ = head.pose_w2.shape[0]
+            assert torch.equal(fused.w2t_image[:J, :Cp_], head.pose_w2.data.t().to(torch.bfloat16))   # ... and so is W2^T
+            assert float(fused.w2t_image[:, Cp_:].abs().max()) == 0.0
     finally:
         apa_config.reset_cfg()
 

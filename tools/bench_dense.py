@@ -93,6 +93,7 @@ def build_cfg003(cof, dev, N=32, H=14, K=393, dtype='bf16', rank1=True, one_call
         # operand copy of W1 is the caller's -- in a training loop the optimizer's own launch keeps it current
         # (apa_momentum_sgd_step_shadow), here the weights do not change between steps
         w1_bf16 = W1.to(torch.bfloat16).contiguous()
+        w2t_bf16 = cof.pose_w2t_image(W2)      # ... and so is the bf16 image of W2^T the Pl product reads
         new = lambda t: torch.empty_like(t)
         pgrads = (new(W1), new(b1), new(W2), new(b2), new(Wa), new(ba), new(Wt), new(bt))
         sts = []
@@ -102,7 +103,7 @@ def build_cfg003(cof, dev, N=32, H=14, K=393, dtype='bf16', rank1=True, one_call
             sts.append(cof.PoseAttnTrainStep(Xr, (W1, b1, W2, b2, Wa, ba, Wt, bt), labels, lbl, valid,
                                              (dX if r == 0 else new(Xr),) + pgrads,
                                              flags=flags, keep_prob=0.2, seed=42, offset=ctr, w1_bf16=w1_bf16,
-                                             share_with=sts[0] if sts else None))
+                                             w2t_bf16=w2t_bf16, share_with=sts[0] if sts else None))
         info = {'workload': 'cfg003 pose-regularised attention head fwd+bwd (pose head 2048->768->16 + M=1 '
                             'pooling + pose L2 + softmax-xent), one host call; per-GPU batch {} x {}x{}x{} {}, K={}, '
                             'dropout keep=0.2'.format(N, H, H, C, dtype, K) + _rot_note(R, per_set),
