@@ -5,7 +5,7 @@ tag=${1:-r01}
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 mkdir -p $R/profiles
-for wl in cfg003 perclass "perclass --classes 393"; do
+for wl in cfg003 perclass "perclass --classes 393" eval002 rank1; do
   name=$(echo $wl | sed 's/ --classes //')
   O=$R/gpurun_out/prof_${tag}_$name; rm -rf $O; mkdir -p $O
   rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python $R/tools/bench_dense.py --workload $wl > $O/bench.log 2>&1
