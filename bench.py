@@ -45,7 +45,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-OVERLAP_COST_US = 12.6   # measured cost of the two-stream schedule itself on one rank (profiles/r02_overlap_1rank.md)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
 L3_BYTES = 256 << 20    # Infinity Cache
 
@@ -76,8 +75,8 @@ def parse_args():
                     help='N > 1: reduce dWt|dbt (99.7 %% of the bytes) on a communication stream with its own '
                          'RCCL communicator, between the grad-ready and td-weights-ready hooks (apa_hooks), '
                          'and only dWa|dba (8 KB) on the compute stream (deploy.OverlappedGradientSum).  auto (with '
-                         '--comm rccl) = decided from a MEASUREMENT at start-up: on iff one in-stream all-reduce of '
-                         'the bucket takes longer than the two-stream choreography costs (OVERLAP_COST_US)')
+                         '--comm rccl) = decided by a PROBE at start-up: a few steps are timed with each schedule on '
+                         'this node (max over ranks) and the faster one is kept')
     ap.add_argument('--comm', default='rccl', choices=['rccl', 'torch', 'gloo'],
                     help='N > 1 gradient sum: direct in-stream ncclAllReduce through librccl (default), '
                          'torch.distributed.all_reduce over RCCL, or over gloo (host-staged; lets two ranks '
@@ -433,13 +432,12 @@ def main():
             t_ar = torch.tensor([ar_us], dtype=torch.float64)
             dist.all_reduce(t_ar, op=dist.ReduceOp.MAX)
             ar_us = float(t_ar.item())
-            want_overlap = (args.overlap == 'on' or (args.overlap == 'auto' and ar_us > OVERLAP_COST_US)) and not args.graph
+            # --overlap auto: both schedules are built and a few steps of each are timed below (overlap_probe)
+            want_overlap = args.overlap in ('on', 'auto') and not args.graph
             comm_info = {'ranks': comm.count(), 'user_rank': comm.user_rank(),
                          'allreduce_bucket_bytes': bucket_numel * 4, 'allreduce_us': round(ar_us, 2),
                          'overlap': 'on' if want_overlap else 'off',
-                         'overlap_rule': '--overlap {}: on iff the measured in-stream all-reduce of the bucket (max over '
-                                         'ranks) exceeds the {} us the two-stream schedule itself costs'.format(
-                                             args.overlap, OVERLAP_COST_US)}
+                         'overlap_rule': '--overlap {}'.format(args.overlap)}
             if want_overlap:                                   # one communicator per stream
                 comm_td = rccl.RcclCommunicator(rank, max(world, 1), dev, group=None)
                 comm_td.all_reduce_(torch.zeros(8, device=dev))
@@ -527,6 +525,42 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    if overlap is not None and args.overlap == 'auto':
+        # Which schedule is faster on THIS node is measured, not assumed (round 5; rounds 3-4 compared the measured
+        # all-reduce with a constant from a one-rank run): 3 x 30 steps with the bucket reduced in-stream (no hooks)
+        # against 3 x 30 steps of the two-stream schedule, median each, max over ranks; the faster one is kept.
+        no_hooks = cof.make_hooks()
+
+        def probe(two_streams):
+            t = []
+            for _ in range(3):
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(30):
+                    if two_streams:
+                        work.compute(None)
+                        overlap.after_backward()
+                    else:
+                        work.compute(no_hooks)
+                        allreduce(bucket)
+                barrier()
+                t.append((time.perf_counter() - t0) / 30 * 1e6)
+            return reduce_max(sorted(t)[1])
+        probe(True), probe(False)                              # (both warm)
+        us_two, us_one = probe(True), probe(False)
+        keep = us_two < us_one
+        comm_info['overlap'] = 'on' if keep else 'off'
+        comm_info['overlap_rule'] = ('--overlap auto: probed at start-up, {:.1f} us/step with the two-stream schedule '
+                                     'against {:.1f} us/step with the bucket reduced in-stream (30-step loops, median of 3, '
+                                     'max over ranks); the faster one is kept'.format(us_two, us_one))
+        comm_info['overlap_probe_us'] = {'two_streams': round(us_two, 2), 'in_stream': round(us_one, 2)}
+        if not keep:
+            overlap.close()
+            overlap = None
+            work.hooks = None
+            for st in work.steppers:
+                if st is not None:
+                    st.hooks = None
     for _ in range(args.warmup):
         step()
     per, enq = timed_loops(step, barrier, args.steps, args.min_ms, args.repeats, reduce_max)

@@ -1404,7 +1404,9 @@ def test_bench_prints_one_json_line_with_the_contract_fields(gpu):
         if '--force-dist' in extra:      # a one-rank RCCL group: ncclCommCount and the measured bucket all-reduce
             cd = d['config']['comm_detail']
             assert cd['ranks'] == 1 and cd['allreduce_us'] > 0
-            assert cd['overlap'] == ('on' if cd['allreduce_us'] > 12.6 else 'off')
+            pr = cd['overlap_probe_us']          # --overlap auto: both schedules timed at start-up, the faster kept
+            assert pr['two_streams'] > 0 and pr['in_stream'] > 0
+            assert cd['overlap'] == ('on' if pr['two_streams'] < pr['in_stream'] else 'off')
         else:
             assert d['config']['comm_detail'] is None
         r = d['roofline']
