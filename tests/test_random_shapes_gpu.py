@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize('family,cases,seed', [('step', 25, 11), ('xent', 40, 11), ('perclass', 25, 11),
-                                               ('pose', 25, 11), ('bf16m1', 25, 11), ('losses', 40, 11)])
+                                               ('pose', 25, 11), ('bf16m1', 25, 11), ('losses', 40, 11),
+                                               ('wimg', 30, 11)])
 def test_entry_points_on_random_shapes(gpu, family, cases, seed):
     from tools import fuzz_all
     rnd = random.Random(seed * 131 + len(family))

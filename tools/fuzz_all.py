@@ -1,6 +1,7 @@
 """Random-shape sweeps of the entry points beyond tools/fuzz_attn_pool.py (tools, not tests: run through
 gpurun when kernels change).  python tools/fuzz_all.py [cases-per-family] [seed] [families]
-families: step (one-call train / eval step == per-op sequence, bit for bit), xent, perclass, pose, bf16m1"""
+families: step (one-call train / eval step == per-op sequence, bit for bit), xent, perclass, pose, bf16m1, catfeat,
+losses, wimg (the stateful per-class fast paths == the stateless step, bit for bit)"""
 import random
 import sys
 import time
@@ -335,7 +336,61 @@ def fam_losses(rnd, i):
     return desc
 
 
-FAMILIES = {'step': fam_step, 'xent': fam_xent, 'perclass': fam_perclass, 'pose': fam_pose, 'bf16m1': fam_bf16m1,
+def fam_wimg(rnd, i):
+    """round 5: the stateful per-class fast paths -- caller-kept weight images (APA_FLAG_WEIGHT_IMAGES, rewritten by the
+    optimiser's launch) and the tagged keep-bit map prepared by the previous step -- against the step that prepares
+    everything per call: identical bits over three steps with an optimiser update in between, random shapes."""
+    from attentionalpoolingaction_amd import deploy
+    C = rnd.choice([256, 512, 768, 1024, 1280, 2048])
+    K = rnd.choice([2, 3, 7, 16, 51, 64, 65, 101, 130])
+    N = rnd.choice([1, 2, 3, 8, 20, 33])
+    H = rnd.choice([2, 5, 6, 7, 14, 15])
+    softmax, relu = rnd.choice([(False, False), (True, False), (False, True)])
+    dtype = torch.bfloat16 if rnd.random() < 0.75 else torch.float32
+    train = rnd.random() < 0.8
+    devctr = rnd.random() < 0.6
+    global LAST
+    LAST = desc = dict(N=N, H=H, C=C, K=K, softmax=softmax, relu=relu, dtype=str(dtype), train=train, devctr=devctr)
+    P = H * H
+    g = torch.Generator().manual_seed(900 + i)
+    X = torch.relu(torch.randn(N, P, C, generator=g)).to(dtype).to(gpu)
+    shapes = {'att_weights': (C, K), 'att_biases': (K,), 'td_weights': (C, K), 'td_biases': (K,)}
+    pa = {n: (torch.randn(s_, generator=g) / (C ** 0.5 if len(s_) == 2 else 10.0)).to(gpu) for n, s_ in shapes.items()}
+    pb = {n: t.clone() for n, t in pa.items()}
+    labels = torch.randint(0, K, (N,), generator=g).to(gpu)
+    flags = cof.attn_flags(softmax, relu, train)
+
+    def make(p, wi):
+        off = torch.full((1,), 5, dtype=torch.int64, device=gpu) if devctr else 5
+        grads = (torch.full_like(X, float('nan')), None) + tuple(torch.empty_like(p[n]) for n in shapes)
+        st = cof.HeadTrainStep(X, X, p['att_weights'], p['att_biases'], p['td_weights'], p['td_biases'], labels, grads,
+                               flags=flags, keep_prob=0.5, seed=31 + i, offset=off, weight_images=wi)
+        return st, grads
+    a, ga = make(pa, True)
+    b, gb = make(pb, False)
+    ba_, bb_ = deploy.GradientBucket(shapes, gpu), deploy.GradientBucket(shapes, gpu)
+    oa = deploy.MomentumSGD(pa, ba_, lr=0.05, momentum=0.9, weight_decay=5e-4, regularized=['att_weights', 'td_weights'])
+    ob = deploy.MomentumSGD(pb, bb_, lr=0.05, momentum=0.9, weight_decay=5e-4, regularized=['att_weights', 'td_weights'])
+    oa.attach_weight_images(a, {'Wa': 'att_weights', 'ba': 'att_biases', 'Wt': 'td_weights', 'bt': 'td_biases'})
+    for step in range(3):
+        if not devctr:
+            a.rebind(offset=5 + step); b.rebind(offset=5 + step)
+        a.run(); b.run()
+        torch.cuda.synchronize()
+        for name in ('logits', 'att', 'zsave', 'loss', 'G'):
+            assert torch.equal(getattr(a, name), getattr(b, name)), 'step %d %s' % (step, name)
+        for x, y in zip(ga, gb):
+            if x is not None:
+                assert torch.equal(x, y) and not torch.isnan(x.float()).any(), 'step %d grads' % step
+        upd = torch.randn(ba_.flat.numel(), generator=g).to(gpu)
+        ba_.flat.copy_(upd); bb_.flat.copy_(upd)
+        oa.step(); ob.step()
+        for n in shapes:
+            assert torch.equal(pa[n], pb[n]), n
+    return desc
+
+
+FAMILIES = {'wimg': fam_wimg, 'step': fam_step, 'xent': fam_xent, 'perclass': fam_perclass, 'pose': fam_pose, 'bf16m1': fam_bf16m1,
             'catfeat': fam_catfeat, 'losses': fam_losses}
 
 
