@@ -346,6 +346,53 @@ def test_per_class_keep_bits_prepared_by_the_previous_step(gpu, N, H, C, softmax
     same('and once more')
 
 
+def test_per_class_tagged_step_replays_from_a_hipgraph(gpu):
+    """The stateful per-class step stays hipGraph-capturable: no host decision depends on the tag -- the forward kernel
+    checks it on the device against the HBM step counter -- so ONE captured step (caller-kept weight images, keep bits
+    from the previous replay's last launch) replayed four times draws four fresh masks and equals, bit for bit, the
+    eager stateless step at offsets 0, 1, 2, 3."""
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    N, H, C, K = 4, 7, 2048, 51
+    P = H * H
+    g = torch.Generator().manual_seed(5)
+    X = torch.relu(torch.randn(N, P, C, generator=g)).to(torch.bfloat16).to(gpu)
+    mk = lambda *s_: (torch.randn(*s_, generator=g) / (C ** 0.5 if len(s_) == 2 else 10.0)).to(gpu)
+    Wa, ba, Wt, bt = mk(C, K), mk(K), mk(C, K), mk(K)
+    labels = torch.randint(0, K, (N,), generator=g).to(gpu)
+    flags = cof.attn_flags(False, False, True)
+
+    def make(weight_images, offset):
+        grads = (torch.empty_like(X), None, torch.empty_like(Wa), torch.empty_like(ba), torch.empty_like(Wt),
+                 torch.empty_like(bt))
+        return cof.HeadTrainStep(X, X, Wa, ba, Wt, bt, labels, grads, flags=flags, keep_prob=0.2, seed=3, offset=offset,
+                                 weight_images=weight_images), grads
+    ref = []
+    for i in range(4):
+        st, gr = make(False, i)
+        st.run()
+        torch.cuda.synchronize()
+        ref.append((st.logits.clone(), st.loss.clone(), gr[0].clone(), gr[4].clone()))
+    assert not torch.equal(ref[0][0], ref[1][0])
+    ctr = torch.zeros(1, dtype=torch.int64, device=gpu)
+    a, ga = make(True, ctr)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        a.run(stream=side.cuda_stream)                   # warm-up outside the capture
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    ctr.zero_()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        a.run()
+    for i in range(4):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert int(ctr) == i + 1
+        for got, want in zip((a.logits, a.loss, ga[0], ga[4]), ref[i]):
+            assert torch.equal(got, want), 'replay %d' % i
+
+
 @pytest.mark.parametrize('K,dtype,train', [(51, torch.bfloat16, True), (51, torch.bfloat16, False),
                                            (130, torch.bfloat16, True), (70, torch.float32, True)])
 def test_per_class_weight_images_kept_by_the_optimizer_launch(gpu, K, dtype, train):
