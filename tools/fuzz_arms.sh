@@ -25,3 +25,9 @@ dense APA_PC_CAT=0
 dense APA_GEMM_GLDS=0
 dense APA_GEMM_FAST=0
 dense APA_POSE_BWD_ROWS=0 APA_POSE_PL_FAST=0
+# round 5: the caller-kept-state family (weight images + tagged keep bits) on the arms it crosses
+wimg() { echo "== wimg $*"; env "$@" timeout 300 python tools/fuzz_all.py 60 13 wimg 2>&1 | grep -E "^FAIL|cases," | cut -c1-260 | head -6; }
+wimg APA_PC_TAGGED_BITS=0
+wimg APA_PC_DX_FUSED=0
+wimg APA_PC_ACT_FOLD=0 APA_PC_XENT_FOLD=0
+wimg APA_PC_FUSED=0
