@@ -305,7 +305,18 @@ __global__ __launch_bounds__(512) void pc_fwd_zt_dma_kernel(
     for (int j = 0; j < 4; ++j)
       glds16_asm(bsrc[j] + (size_t)t * (2 * 128 * 64), st + (uint32_t)(ZB_A_EL * 2) + (uint32_t)(4 * wave + j) * 1024u);
   };
-  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  // Main loop roles (round 5, final): wave = (column half hq: Z | T) x (k-step kq of every stage).  A wave multiplies ALL
+  // 32 rows by its half's 64 columns for one 32-channel k-step per stage: 2 A + 4 B fragment reads for 8 MFMAs, where the
+  // (half x column group x row tile) split of rounds 3-4 read 4 + 8 for the same 8 -- the loop turned out to be bound by
+  // LDS bandwidth (40 KB of DMA writes + 96 KB of fragment reads per stage; with the reads halved for the measurement
+  // the kernel went from 18.6 to 15.3 us, with none 14.3), not by the operand bytes per CU.  The four k-step partials of
+  // a tile are summed through LDS after the loop (kq = 0..3 in order) into the epilogue's (half, wn, mt) layout.
+  const int hq = wave >> 2, kq = wave & 3;
+  f32x4 pacc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (TRAIN) {
     // the block's bits: 32 nkt 16-byte units, lane-linear in LDS (unit u = row * nkt + slot), 64 units per instruction;
     // issued BEFORE the first operand tile, so the counted waits below (which allow only younger pieces to be
@@ -355,26 +366,45 @@ __global__ __launch_bounds__(512) void pc_fwd_zt_dma_kernel(
     if (t + 2 < nkt) issue(t + 2);
     const short* a_img = smem + (t % ZB_NST) * ZB_STAGE_EL;
     const short* b_img = a_img + ZB_A_EL;
-    uint32_t mb = 0;
-    if (TRAIN && half) {   // natural order: byte c = 4 sk + kb of the row -> byte kb of word sk
-      const int brow = mt * 16 + l16;
-      const uint4 rb = *reinterpret_cast<const uint4*>(s_bits + brow * rowb + ((t ^ (brow & sw)) << 4));
-      const int sh = 8 * kb;
-      mb = ((rb.x >> sh) & 0xffu) | (((rb.y >> sh) & 0xffu) << 8) | (((rb.z >> sh) & 0xffu) << 16) |
-           (((rb.w >> sh) & 0xffu) << 24);
+    const short* a_sub = a_img + (kq >> 1) * (32 * 64);
+    const short* b_sub = b_img + (kq >> 1) * (128 * 64);
+    bf16x8 af[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      af[i] = frag_sw64(a_sub, i * 16, kq & 1, lane);
+      if (TRAIN && hq) {   // natural order: byte c = 4 kq + kb of the row's chunk -> byte kb of word kq
+        const int brow = i * 16 + l16;
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(s_bits + brow * rowb + ((t ^ (brow & sw)) << 4) + 4 * kq);
+        const uint4 m = apply_bits8(*reinterpret_cast<const uint4*>(&af[i]), (w >> (8 * kb)) & 0xffu);
+        af[i] = *reinterpret_cast<const bf16x8*>(&m);
+      }
     }
 #pragma unroll
-    for (int sk = 0; sk < 4; ++sk) {   // sk = 2 s + ks
-      bf16x8 af = frag_sw64(a_img + (sk >> 1) * (32 * 64), mt * 16, sk & 1, lane);
-      if (TRAIN && half) {
-        const uint4 m = apply_bits8(*reinterpret_cast<const uint4*>(&af), (mb >> (8 * sk)) & 0xffu);
-        af = *reinterpret_cast<const bf16x8*>(&m);
-      }
+    for (int j = 0; j < 4; ++j) {
+      const bf16x8 bf = frag_sw64(b_sub, hq * 64 + j * 16, kq & 1, lane);
+      pacc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf, pacc[0][j], 0, 0, 0);
+      pacc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf, pacc[1][j], 0, 0, 0);
+    }
+  }
+  // the k-step partials -> the epilogue's layout: wave (half, wn, mt) owns rows 16 mt .., columns 64 half + 32 wn + 16 j
+  f32x4 acc[2];
+  {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with the last stage
+    f32x4* red = reinterpret_cast<f32x4*>(smem);                       // [wave][row tile][column tile][lane]: 64 KB
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const bf16x8 bf = frag_sw64(b_img + (sk >> 1) * (128 * 64), half * 64 + wn * 32 + j * 16, sk & 1, lane);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[j], 0, 0, 0);
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[((wave * 2 + i) * 4 + j) * 64 + lane] = pacc[i][j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      f32x4 v = red[(((half * 4 + 0) * 2 + mt) * 4 + wn * 2 + j) * 64 + lane];
+#pragma unroll
+      for (int q = 1; q < 4; ++q) {
+        const f32x4 u = red[(((half * 4 + q) * 2 + mt) * 4 + wn * 2 + j) * 64 + lane];
+        v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
       }
+      acc[j] = v;
     }
   }
   // D layout of the 16x16 MFMA: row = 4 * (lane >> 4) + reg, col = lane & 15
