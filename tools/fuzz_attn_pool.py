@@ -49,8 +49,10 @@ def main():
             # tiny K makes dX tiny: a floor of 1e-6 x the scale of dWt keeps fp32 noise out of the verdict)
             floor = 1e-6 * float(ref['dWt'].abs().max())
             for k in ('dX', 'dWa', 'dba', 'dWt', 'dbt') + (() if fused else ('dXatt',)):
-                # (the softmax's d(ba) is a sum of dZ that cancels exactly: its noise scales with |dZ|, i.e. with dWa)
-                at = max(floor, 1e-5 * float(ref['dWa'].abs().max())) if (softmax and k == 'dba') else floor
+                # (d(ba) is ONE number, the sum of all dZ: with the softmax it cancels exactly, without it it may cancel
+                #  to a small value -- N=3, 3x14, C=1000, K=5000, seed 41: |d(ba)| = 0.004 from 126 terms -- so its noise
+                #  scales with |dZ|, i.e. with dWa, not with its own size)
+                at = max(floor, 1e-5 * float(ref['dWa'].abs().max())) if k == 'dba' else floor
                 T._close(got[k].reshape(ref[k].shape), ref[k], 5e-5, k, atol=at)
         except Exception as e:                                   # noqa: BLE001
             bad += 1
