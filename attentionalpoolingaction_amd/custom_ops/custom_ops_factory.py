@@ -1146,6 +1146,61 @@ def momentum_sgd_step(weights, weight_decay, grad_flat, acc_flat, lr, momentum=0
                                      grad_scale, _stream_ptr()), 'apa_momentum_sgd_step')
 
 
+class BoundMomentumSGD:
+    """`momentum_sgd_step` with the marshalling done ONCE (the optimiser's counterpart of HeadTrainStep): the pointer /
+    size / decay arrays, the shadow table and the image maps are built here, `run(lr, momentum, grad_scale)` is one
+    foreign call.  The per-update python cost of the unbound form (~40 us of ctypes array building for eight
+    parameters) is of the order of a whole HMDB-51 head step; a training loop pays it once per binding."""
+
+    def __init__(self, weights, weight_decay, grad_flat, acc_flat, shadows=None, images=None):
+        self.lib = load_library()
+        n = len(weights)
+        total = sum(w.numel() for w in weights)
+        if grad_flat.numel() != total or acc_flat.numel() != total:
+            raise ValueError('flat buffers hold {} / {} elements, parameters {}'.format(
+                grad_flat.numel(), acc_flat.numel(), total))
+        self._keep = (list(weights), grad_flat, acc_flat, list(shadows) if shadows else None,
+                      list(images) if images else None)
+        self._n = n
+        self._ptrs = (c_void_p * n)(*[_dev_ptr(w, 'weights[%d]' % i, torch.float32) for i, w in enumerate(weights)])
+        self._sizes = (c_size_t * n)(*[w.numel() for w in weights])
+        self._wds = (c_float * n)(*[float(x) for x in weight_decay])
+        self._g = _dev_ptr(grad_flat, 'grad_flat', torch.float32)
+        self._a = _dev_ptr(acc_flat, 'acc_flat', torch.float32)
+        self._sh = None
+        if shadows is not None and any(t is not None for t in shadows):
+            for w_, t in zip(weights, shadows):
+                if t is not None and (t.dtype != torch.bfloat16 or t.numel() != w_.numel() or not t.is_contiguous()):
+                    raise ApaError('momentum_sgd_step: a shadow must be a contiguous bf16 tensor of its weight\'s size')
+            self._sh = (c_void_p * n)(*[None if t is None else _dev_ptr(t, 'shadow', torch.bfloat16) for t in shadows])
+        self._ni = 0
+        if images:
+            ni = len(images)
+            self._arr = (ApaWeightImage * ni)()
+            self._seg = (c_int * ni)(*[int(i) for i, _ in images])
+            for q, (_, m) in enumerate(images):
+                ctypes.memmove(ctypes.addressof(self._arr[q]), ctypes.addressof(m), ctypes.sizeof(ApaWeightImage))
+            self._ni = ni
+
+    def run(self, lr, momentum=0.9, grad_scale=1.0, stream: Optional[int] = None) -> None:
+        st = _stream_ptr() if stream is None else stream
+        if self._ni:
+            rc = self.lib.apa_momentum_sgd_step_images(self._n, self._ptrs, self._sizes, self._wds, self._g, self._a, lr,
+                                                       momentum, grad_scale, self._sh, ctypes.addressof(self._arr),
+                                                       self._seg, self._ni, st)
+            who = 'apa_momentum_sgd_step_images'
+        elif self._sh is not None:
+            rc = self.lib.apa_momentum_sgd_step_shadow(self._n, self._ptrs, self._sizes, self._wds, self._g, self._a, lr,
+                                                       momentum, grad_scale, self._sh, st)
+            who = 'apa_momentum_sgd_step_shadow'
+        else:
+            rc = self.lib.apa_momentum_sgd_step(self._n, self._ptrs, self._sizes, self._wds, self._g, self._a, lr,
+                                                momentum, grad_scale, st)
+            who = 'apa_momentum_sgd_step'
+        if rc != 0:
+            _check(rc, who)
+
+
 def _optim_segments(weights, weight_decay, flats, shadows, who):
     n = len(weights)
     ptrs = (c_void_p * n)(*[_dev_ptr(w, 'weights[%d]' % i, torch.float32) for i, w in enumerate(weights)])

@@ -78,10 +78,18 @@ def exchange_unique_id(raw: bytes, rank: int, world_size: int, group=None, devic
 
 class RcclCommunicator:
     """One communicator per process (= per GPU).  `group`: an initialised torch.distributed group
-    used only to ship the unique id (None when world_size == 1)."""
+    used only to ship the unique id (None when world_size == 1).
 
-    def __init__(self, rank: int, world_size: int, device: torch.device, group=None):
-        self.lib = load_rccl()
+    `lib` / `current_stream` (round 6): the library object and the stream source are injectable so that the CALL
+    SEQUENCE of this class -- unique id on rank 0, the 128-byte broadcast, ncclCommInitRank on every rank, one
+    ncclAllReduce per call on the given stream -- can be driven on two CPU ranks against a stand-in whose
+    ncclAllReduce is a gloo all-reduce (tests/test_multi_rank_dryrun_cpu.py).  No GPU node with more than one rank
+    was available to any round; the product always runs with the defaults (librccl, torch's current HIP stream)."""
+
+    def __init__(self, rank: int, world_size: int, device: torch.device, group=None, lib=None, current_stream=None):
+        self._stub = lib is not None
+        self.lib = load_rccl() if lib is None else lib
+        self._current_stream = current_stream
         self.rank, self.world_size, self.device = rank, world_size, torch.device(device)
         uid = _UniqueId()
         if rank == 0:
@@ -91,15 +99,22 @@ class RcclCommunicator:
         assert len(raw) == NCCL_UNIQUE_ID_BYTES
         ctypes.memmove(ctypes.byref(uid), raw, NCCL_UNIQUE_ID_BYTES)
         self.comm = ctypes.c_void_p()
-        with torch.cuda.device(self.device):
+        if self._stub:
             _check(self.lib, self.lib.ncclCommInitRank(ctypes.byref(self.comm), world_size, uid, rank),
                    'ncclCommInitRank')
+        else:
+            with torch.cuda.device(self.device):
+                _check(self.lib, self.lib.ncclCommInitRank(ctypes.byref(self.comm), world_size, uid, rank),
+                       'ncclCommInitRank')
 
     def all_reduce_(self, t: torch.Tensor, stream: Optional[torch.cuda.Stream] = None) -> torch.Tensor:
         """In-place SUM over all ranks, enqueued on `stream` (default: the current stream)."""
-        if not t.is_cuda or not t.is_contiguous():
+        if not (t.is_cuda or self._stub) or not t.is_contiguous():
             raise ValueError('all_reduce_ needs a contiguous device tensor')
-        st = (stream or torch.cuda.current_stream(self.device)).cuda_stream
+        if stream is None:
+            stream = self._current_stream() if self._current_stream is not None else \
+                torch.cuda.current_stream(self.device)
+        st = stream.cuda_stream
         _check(self.lib, self.lib.ncclAllReduce(ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(t.data_ptr()),
                                                 t.numel(), _DTYPES[t.dtype], _NCCL_SUM, self.comm,
                                                 ctypes.c_void_p(st)), 'ncclAllReduce')

@@ -428,6 +428,13 @@ def main():
         else:
             # What RCCL itself reports, and what the bucket's all-reduce costs on THIS node: the overlap decision is
             # taken from this measurement (every rank uses the slowest rank's figure), not from an estimate.
+            if comm.count() != max(world, 1) or comm.user_rank() != rank:
+                # fail fast and loudly: a communicator that does not span the launcher's ranks would time N private
+                # one-rank "all-reduces" and print a scaling line that means nothing
+                raise SystemExit('bench.py --gpus {}: RCCL reports {} rank(s) in the communicator and user rank {} for '
+                                 'launcher rank {} -- ncclCommCount must equal WORLD_SIZE (one process per GPU, one '
+                                 'communicator over all of them)'.format(args.gpus, comm.count(), comm.user_rank(),
+                                                                         rank))
             ar_us = comm.measure_all_reduce_us(bucket_numel)
             t_ar = torch.tensor([ar_us], dtype=torch.float64)
             dist.all_reduce(t_ar, op=dist.ReduceOp.MAX)
@@ -530,25 +537,16 @@ def main():
         # all-reduce with a constant from a one-rank run): 3 x 30 steps with the bucket reduced in-stream (no hooks)
         # against 3 x 30 steps of the two-stream schedule, median each, max over ranks; the faster one is kept.
         no_hooks = cof.make_hooks()
+        from attentionalpoolingaction_amd import deploy as _deploy
 
-        def probe(two_streams):
-            t = []
-            for _ in range(3):
-                barrier()
-                t0 = time.perf_counter()
-                for _ in range(30):
-                    if two_streams:
-                        work.compute(None)
-                        overlap.after_backward()
-                    else:
-                        work.compute(no_hooks)
-                        allreduce(bucket)
-                barrier()
-                t.append((time.perf_counter() - t0) / 30 * 1e6)
-            return reduce_max(sorted(t)[1])
-        probe(True), probe(False)                              # (both warm)
-        us_two, us_one = probe(True), probe(False)
-        keep = us_two < us_one
+        def _two():
+            work.compute(None)
+            overlap.after_backward()
+
+        def _one():
+            work.compute(no_hooks)
+            allreduce(bucket)
+        keep, us_two, us_one = _deploy.probe_overlap_schedule(_two, _one, barrier, reduce_max)
         comm_info['overlap'] = 'on' if keep else 'off'
         comm_info['overlap_rule'] = ('--overlap auto: probed at start-up, {:.1f} us/step with the two-stream schedule '
                                      'against {:.1f} us/step with the bucket reduced in-stream (30-step loops, median of 3, '
@@ -709,6 +707,16 @@ def main():
         run_extra('cfg003_bf16_train', bd.build_cfg003, N=32, H=14, K=393, dtype='bf16')
         run_extra('hmdb51_perclass_bf16_train', bd.build_perclass, N=32, H=14, K=51, dtype='bf16')
         run_extra('hmdb51_rank1_bf16_train', bd.build_rank1, N=32, H=14, K=51, dtype='bf16')
+        # step + UPDATE: the optimiser launch that carries the relocated operand preparation, next to the plain launch
+        # with per-step preparation, at TRAIN.ITER_SIZE 1 and 2 (src/train.py:90-94,529-566)
+        for key, which in (('cfg003_bf16_update', 'cfg003'), ('hmdb51_perclass_update', 'perclass')):
+            if only and key not in only:
+                continue
+            try:
+                extra[key] = bd.run_update_pair(cof, dev, which, min_ms=args.min_ms, repeats=args.repeats)
+            except Exception as e:                             # noqa: BLE001
+                extra[key] = {'error': '{}: {}'.format(type(e).__name__, e)}
+            torch.cuda.empty_cache()
         # the headline step far outside every cache: N = 512 (1.6 GB of features per pass, no rotation needed)
         try:
             if only and 'cfg002_train_n512' not in only:

@@ -241,3 +241,74 @@ def test_exponential_decay_staircase():
     assert f(0) == f(4999) == 1e-3
     assert f(5000) == 1e-3 * 0.33 and abs(f(11999) - 1e-3 * 0.33 ** 2) < 1e-18
     assert deploy.exponential_decay_lr(1.0, 2500, 5000, 0.25, staircase=False) == 0.5
+
+
+class _FakeImageOwner:
+    """stands in for a cof.HeadTrainStep(weight_images=True): two image maps and a refresh counter"""
+
+    def __init__(self):
+        self.weight_image_maps = [('Wa', object()), ('Wt', object())]
+        self.refreshed = 0
+
+    def refresh_weight_images(self):
+        self.refreshed += 1
+
+
+def test_stale_operand_guard_and_image_ownership():
+    """VERDICT r05 Weak #1 / ADVICE r05: a weight written behind the optimiser's back (load_state_dict, a no_grad
+    copy_) while a bf16 shadow / operand image of it is in use is caught by a host-side `Parameter._version` compare
+    -- StaleOperandError by default, a rebuild of every copy with stale='refresh'; the optimiser's own updates never
+    trip it.  Image entries carry their owner (kept alive, dropped by detach_weight_images), the list never grows
+    when steps are re-bound, and add_image after attach_weight_images keeps the attached owners on every optimiser."""
+    w1 = torch.nn.Parameter(torch.randn(6, 4))
+    wt = torch.nn.Parameter(torch.randn(6, 3))
+    params = {'pose_w1': w1, 'att_weights': torch.nn.Parameter(torch.randn(6, 3)), 'td_weights': wt}
+    bucket = deploy.GradientBucket({n: p.shape for n, p in params.items()}, 'cpu')
+    shadow = torch.empty(6, 4, dtype=torch.bfloat16)
+    opt = deploy.MomentumSGD(params, bucket, lr=0.1, bf16_shadows={'pose_w1': shadow})
+    assert torch.equal(shadow, w1.data.to(torch.bfloat16))
+    for _ in range(3):                                   # the optimiser's own writes do not look stale
+        bucket.flat.normal_()
+        opt.step()
+        assert torch.equal(shadow, w1.data.to(torch.bfloat16)) and not opt.stale_names()
+    with torch.no_grad():
+        w1.copy_(torch.randn(6, 4))                      # what load_state_dict does
+    assert opt.stale_names() == ['pose_w1']
+    with pytest.raises(deploy.StaleOperandError, match='pose_w1'):
+        opt.check_fresh()
+    with pytest.raises(deploy.StaleOperandError):
+        opt.step()
+    opt.refresh_shadows()
+    assert torch.equal(shadow, w1.data.to(torch.bfloat16)) and not opt.stale_names()
+    opt.step()
+    # ownership: attach two owners, detach one -- nothing of it is left, the other one's entries stay
+    a, b = _FakeImageOwner(), _FakeImageOwner()
+    roles = {'Wa': 'att_weights', 'Wt': 'td_weights'}
+    opt.attach_weight_images(a, roles)
+    opt.attach_weight_images(b, roles)
+    assert len(opt.images) == 4 and all(e[2] in (a, b) for e in opt.images)
+    opt.detach_weight_images(a)
+    assert len(opt.images) == 2 and all(e[2] is b for e in opt.images) and not opt._img_refresh
+    for _ in range(10):                                  # re-binding does not accumulate entries
+        c = _FakeImageOwner()
+        opt.attach_weight_images(c, roles)
+        opt.detach_weight_images(c)
+    assert len(opt.images) == 2 and not opt._img_refresh
+    # a written weight that has an image: refresh_shadows() rebuilds the images too (ADVICE r05, low #2)
+    with torch.no_grad():
+        wt.mul_(2.0)
+    assert opt.stale_names() == ['td_weights']
+    opt.stale = 'refresh'
+    opt.check_fresh()
+    assert b.refreshed == 1 and not opt.stale_names()
+    # the adaptive optimisers: attach then add_image -- both owners survive and are rebuilt after the update
+    adam = deploy.Adam(params, bucket, lr=0.01)
+    adam.attach_weight_images(a, roles)
+    hits = []
+    adam.add_image('td_weights', object(), refresh=lambda: hits.append(1))
+    assert len(adam._img_refresh) == 2 and not adam.images
+    n0 = a.refreshed
+    adam.refresh_images()
+    assert a.refreshed == n0 + 1 and hits == [1]
+    with pytest.raises(ValueError):
+        adam.add_image('td_weights', object())           # no launch-side rewrite and no refresh: refused

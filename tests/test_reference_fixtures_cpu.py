@@ -186,7 +186,7 @@ def test_oracle_gen_losses_match_reference(case):
 @pytest.mark.regen
 def test_generator_reproduces_the_committed_fixtures():
     """tests/golden/make_head_reference.py is deterministic: re-running it on the reference tree gives the
-    committed arrays AND meta tables back bit for bit (two small head cases + one benchmark-shape case)."""
+    committed arrays AND meta tables back bit for bit (two small head cases + two benchmark-shape cases)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location('make_head_reference',
                                                   os.path.join(rf.GOLD, 'make_head_reference.py'))
@@ -198,8 +198,10 @@ def test_generator_reproduces_the_committed_fixtures():
         cfgmod, nf, lossmod = gen.load_reference()
         import copy
         defaults = copy.deepcopy(cfgmod.cfg)
-        # two small head cases + one benchmark-shape case (32 x 14 x 14 x 2048, stored by seed / digest)
-        for name in ('cfg003_train', 'posefeat_softmax_train', 'perclass_k51_train_baseline_libmask'):
+        # two small head cases + two benchmark-shape cases (32 x 14 x 14 x 2048 per-class, and round 6's
+        # 32 x 15 x 15 x 2048 at the reference's native map; stored by seed / digest)
+        for name in ('cfg003_train', 'posefeat_softmax_train', 'perclass_k51_train_baseline_libmask',
+                     'cfg002_train_15x15_libmask'):
             case = [c for c in gen.HEAD_CASES + gen.BIG_CASES if c['name'] == name][0]
             out = gen.run_head_case(cfgmod, nf, lossmod, defaults, case)
             d = np.load(os.path.join(rf.GOLD, ('refbig_%s.npz' if case.get('big') else 'ref_head_%s.npz') % name))
@@ -226,7 +228,7 @@ def test_oracle_matches_reference_at_the_benchmark_shape(path):
     seeds, the dropout mask from the library stream's numpy twin; tensors above the storage limit are held as
     whole-tensor projections + 4096 exact samples (tests/golden/apa_digest.py)."""
     fx = rf.HeadFixture(path)
-    assert fx.meta['big'] and fx.arrays['in/images'].shape == (32, 14, 14, 2048)
+    assert fx.meta['big'] and fx.arrays['in/images'].shape in ((32, 14, 14, 2048), (32, 15, 15, 2048))
     assert fx.meta['num_classes'] == (51 if fx.flag('_PER_CLASS') else 393)          # HMDB-51 per class / MPII
     got = rf.run_oracle(fx)
     keys = fx.output_keys()

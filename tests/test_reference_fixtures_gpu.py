@@ -109,6 +109,21 @@ BIG_PATHS = rf.big_fixture_paths()
 _BIG_CACHE = {}
 
 
+def _bf16_logit_tol(exp_logits):
+    """tests/test_bf16_parity_gpu.py's LOGIT_TOL_BF16 = 3e-3 is an absolute figure for logits of order one; where the
+    reference's logits are small (spatial-softmax attention: the map sums to one, max |logit| ~ 1e-2) it scales down
+    with them, so that 'within tolerance' and 'argmax on rows whose margin exceeds twice the tolerance' keep meaning"""
+    return min(3e-3, 0.03 * float(np.abs(exp_logits).max()))
+
+
+def _grad_floor(fx, vn):
+    """a spatial softmax is shift invariant: the gradient of its bias is exactly 0 and both sides hold round-off
+    (1e-11 against 1e-21): measured against the size of the attention WEIGHT gradient instead"""
+    if fx.flag('_SOFTMAX_ATT') and 'Conv2d_PrePose_Attn' in vn and vn.endswith('biases'):
+        return float(np.abs(fx.expected('grad/var/' + vn[:-len('biases')] + 'weights')).max())
+    return 1e-30
+
+
 def _big(path):
     if path not in _BIG_CACHE:               # regenerating 12.8 M normals + the bf16 rounding takes a second or two
         _BIG_CACHE[path] = rf.HeadFixture(path)
@@ -141,9 +156,10 @@ def test_hip_head_matches_reference_at_the_benchmark_shape(gpu, path, dtype):
     err = np.abs(got_logits - exp_logits).max()
     print('%s %s: logits max abs err %.3e (max |logit| %.3f)' % (fx.name, dtype, err, np.abs(exp_logits).max()))
     if bf:
-        assert err <= 3e-3
+        ltol = _bf16_logit_tol(exp_logits)
+        assert err <= ltol
         top2 = np.sort(exp_logits, axis=1)[:, -2:]
-        sure = (top2[:, 1] - top2[:, 0]) > 6e-3
+        sure = (top2[:, 1] - top2[:, 0]) > 2 * ltol
         assert sure.sum() >= 20 and np.array_equal(got_logits.argmax(1)[sure], exp_logits.argmax(1)[sure])
     else:
         assert err <= 1e-3 and _rel(got_logits, exp_logits) < 2e-5
@@ -168,7 +184,8 @@ def test_hip_head_matches_reference_at_the_benchmark_shape(gpu, path, dtype):
         if t.grad is None:
             assert float(np.abs(fx.expected('grad/var/' + vn)).max()) == 0.0, vn
             continue
-        fx.check('grad/var/' + vn, t.grad.float().cpu().numpy(), tol, dtype + ' ' + vn, tol_proj=tolp)
+        fx.check('grad/var/' + vn, t.grad.float().cpu().numpy(), tol, dtype + ' ' + vn, tol_proj=tolp,
+                 floor=_grad_floor(fx, vn))
 
 
 BIG_TRAIN = [p for p in BIG_PATHS if 'train' in os.path.basename(p)]
@@ -247,9 +264,10 @@ def test_one_call_train_steps_match_reference_at_the_benchmark_shape(gpu, path, 
     err = np.abs(got_logits - exp_logits).max()
     print('%s %s one call: logits max abs err %.3e' % (fx.name, dtype, err))
     if bf:
-        assert err <= 3e-3
+        ltol = _bf16_logit_tol(exp_logits)
+        assert err <= ltol
         top2 = np.sort(exp_logits, axis=1)[:, -2:]
-        sure = (top2[:, 1] - top2[:, 0]) > 6e-3
+        sure = (top2[:, 1] - top2[:, 0]) > 2 * ltol
         assert sure.sum() >= 20 and np.array_equal(got_logits.argmax(1)[sure], exp_logits.argmax(1)[sure])
     else:
         assert err <= 1e-3 and _rel(got_logits, exp_logits) < 2e-5
@@ -267,7 +285,7 @@ def test_one_call_train_steps_match_reference_at_the_benchmark_shape(gpu, path, 
         assert vn in fx.meta['trainable'] and vn not in fx.meta['reg_only_grad']
         full = g.double().cpu().numpy() + (wd * p_.double().cpu().numpy() if vn.endswith('/weights') else 0.0)
         shape = fx.variables[vn].shape
-        fx.check('grad/var/' + vn, full.reshape(shape), tol, dtype + ' ' + vn, tol_proj=tolp)
+        fx.check('grad/var/' + vn, full.reshape(shape), tol, dtype + ' ' + vn, tol_proj=tolp, floor=_grad_floor(fx, vn))
 
 
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
@@ -306,7 +324,7 @@ def test_fused_head_step_surface_matches_reference_at_the_benchmark_shape(gpu, p
         exp_logits = fx.expected('out/logits').astype(np.float64)
         got_logits = ep['Logits'].float().cpu().numpy().astype(np.float64)
         err = np.abs(got_logits - exp_logits).max()
-        assert err <= (3e-3 if bf else 1e-3)
+        assert err <= (_bf16_logit_tol(exp_logits) if bf else 1e-3)
         if not bf:
             assert np.array_equal(got_logits.argmax(1), exp_logits.argmax(1))
         tol, tolp = (1.2e-2, 8e-3) if bf else (5e-5, 5e-5)
@@ -324,7 +342,7 @@ def test_fused_head_step_surface_matches_reference_at_the_benchmark_shape(gpu, p
             full = fused.bucket.views[n].double().cpu().numpy() / 2.0 + \
                 (wd * before[n].double().cpu().numpy() if n in fused.regularized else 0.0)
             fx.check('grad/var/' + names[n], full.reshape(fx.variables[names[n]].shape), tol, dtype + ' ' + n,
-                     tol_proj=tolp)
+                     tol_proj=tolp, floor=_grad_floor(fx, names[n]))
             grads[n] = full
         # one update: acc = g (+ wd w), w -= lr acc  (MomentumOptimizer from a zero accumulator, src/train.py:90-94)
         fused.bucket.flat.mul_(0.5)

@@ -194,6 +194,119 @@ def build_perclass(cof, dev, N=32, H=14, K=51, dtype='bf16', rotate=0, weight_im
     return _round_robin([st.run for st in sts]), info
 
 
+def _bucket_and_optimizer(dev, params, regularized, shadows=None):
+    """flat gradient bucket + the momentum-SGD of the shipped configs (src/train.py:90-94; lr small enough that the
+    synthetic weights stay put over thousands of timed updates, WEIGHT_DECAY as in experiments/*.yaml)"""
+    from attentionalpoolingaction_amd import deploy
+    bucket = deploy.GradientBucket({n: p.shape for n, p in params.items()}, dev)
+    opt = deploy.MomentumSGD(params, bucket, lr=1e-7, momentum=0.9, weight_decay=5e-4, regularized=regularized,
+                             bf16_shadows=shadows)
+    return bucket, opt
+
+
+def build_update(cof, dev, which='cfg003', prepared=True, iter_size=1, N=32, H=14, K=None, rotate=0):
+    """One parameter UPDATE of a training loop, i.e. what a driver-timed `step` line leaves out (VERDICT r05 Weak #5):
+    ITER_SIZE head steps (src/train.py:529-566) + the fused momentum-SGD launch.
+
+      prepared=True   the bf16 operand copies the steps read (cfg 003: W1 shadow, W2^T image; per-class head: the
+                      padded / concatenated weight images) are rewritten by the OPTIMISER'S launch
+                      (apa_momentum_sgd_step_shadow / _images) -- the shipped arrangement (deploy.FusedHeadStep)
+      prepared=False  the steps convert / build them from the fp32 weights in every call, the optimiser launch is the
+                      plain apa_momentum_sgd_step -- the arrangement of rounds 1-3
+    Both arms do the same arithmetic on the same buffers; the difference is where the preparation runs."""
+    C, P = 2048, H * H
+    td = torch.bfloat16
+    g = torch.Generator().manual_seed(42)
+    per_set = 2 * N * P * C * 2
+    R = _n_sets(per_set, rotate)
+    X = _features(N, P, C, td, dev)
+    flags = cof.attn_flags(False, False, True)
+    ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+    new = lambda t: torch.empty_like(t)
+    if which == 'cfg003':
+        K = K or 393
+        Cp, J = 768, 16
+        W1 = (torch.randn(C, Cp, generator=g) / C ** 0.5).to(dev); b1 = torch.zeros(Cp, device=dev)
+        W2 = (torch.randn(Cp, J, generator=g) / Cp ** 0.5).to(dev); b2 = torch.zeros(J, device=dev)
+        Wa = (torch.randn(Cp, 1, generator=g) / Cp ** 0.5).to(dev); ba = torch.zeros(1, device=dev)
+        Wt = (torch.randn(C, K, generator=g) / C ** 0.5).to(dev); bt = torch.zeros(K, device=dev)
+        labels = torch.randint(0, K, (N,), generator=g).to(dev)
+        lbl = torch.rand(N, P, J, generator=g).to(dev)
+        valid = (torch.rand(N, J, generator=g) > 0.3).to(dev)
+        params = {'pose_w1': W1, 'pose_b1': b1, 'pose_w2': W2, 'pose_b2': b2, 'att_weights': Wa, 'att_biases': ba,
+                  'td_weights': Wt, 'td_biases': bt}
+        w1_bf16 = torch.empty(W1.shape, dtype=torch.bfloat16, device=dev) if prepared else None
+        bucket, opt = _bucket_and_optimizer(dev, params, ['pose_w1', 'pose_w2', 'att_weights', 'td_weights'],
+                                            {'pose_w1': w1_bf16} if prepared else None)
+        w2t = None
+        if prepared:
+            w2t = cof.pose_w2t_image(W2)
+            opt.add_image('pose_w2', cof.pose_w2t_image_map(w2t, W2), owner=w2t,
+                          refresh=lambda: w2t[:J, :Cp].copy_(W2.t()))
+        v = bucket.views
+        sts = []
+        for r in range(R):
+            Xr = X if r == 0 else _features(N, P, C, td, dev, seed=42 + r)
+            sts.append(cof.PoseAttnTrainStep(
+                Xr, (W1, b1, W2, b2, Wa, ba, Wt, bt), labels, lbl, valid,
+                (new(Xr), v['pose_w1'], v['pose_b1'], v['pose_w2'], v['pose_b2'], v['att_weights'], v['att_biases'],
+                 v['td_weights'], v['td_biases']), flags=flags, keep_prob=0.2, seed=42, offset=ctr, w1_bf16=w1_bf16,
+                w2t_bf16=w2t, share_with=sts[0] if sts else None))
+        name = 'cfg003 head step (one host call)'
+    else:
+        K = K or 51
+        Wa = (torch.randn(C, K, generator=g) / C ** 0.5).to(dev); ba = torch.zeros(K, device=dev)
+        Wt = (torch.randn(C, K, generator=g) / C ** 0.5).to(dev); bt = torch.zeros(K, device=dev)
+        labels = torch.randint(0, K, (N,), generator=g).to(dev)
+        params = {'att_weights': Wa, 'att_biases': ba, 'td_weights': Wt, 'td_biases': bt}
+        bucket, opt = _bucket_and_optimizer(dev, params, ['att_weights', 'td_weights'])
+        v = bucket.views
+        sts = []
+        for r in range(R):
+            Xr = X if r == 0 else _features(N, P, C, td, dev, seed=42 + r)
+            sts.append(cof.HeadTrainStep(Xr, Xr, Wa, ba, Wt, bt, labels,
+                                         (new(Xr), None, v['att_weights'], v['att_biases'], v['td_weights'],
+                                          v['td_biases']), flags=flags, keep_prob=0.2, seed=42, offset=ctr,
+                                         weight_images=prepared, share_with=sts[0] if sts else None))
+        if prepared:       # the R bound steps share ONE workspace, hence one set of images
+            opt.attach_weight_images(sts[0], {'Wa': 'att_weights', 'ba': 'att_biases', 'Wt': 'td_weights',
+                                              'bt': 'td_biases'})
+        name = 'HMDB-51 per-class head step (K={}, one host call)'.format(K)
+    rr = _round_robin([st.run for st in sts])
+    scale = 1.0 / iter_size
+
+    def update():
+        for _ in range(iter_size):
+            rr()
+        opt.step(grad_scale=scale)
+    info = {'workload': 'one UPDATE = {} x {} + the fused momentum-SGD launch ({}); per-GPU batch {} x {}x{}x{} bf16'
+                        .format(iter_size, name,
+                                'operand copies rewritten by the optimiser launch' if prepared else
+                                'plain launch; the steps prepare their bf16 operands themselves',
+                                N, H, H, C) + _rot_note(R, per_set),
+            'dtype': 'bf16', 'N': N * iter_size, 'rotate': R, 'iter_size': iter_size, 'prepared': bool(prepared)}
+    return update, info
+
+
+def run_update_pair(cof, dev, which, min_ms=50.0, repeats=5, rotate=0):
+    """the four driver-timed numbers VERDICT r05 asks for: us per update with the preparation in the optimiser's
+    launch vs in every step, at TRAIN.ITER_SIZE 1 and 2"""
+    out = {}
+    for it in (1, 2):
+        row = {}
+        for prepared in (True, False):
+            fn, info = build_update(cof, dev, which, prepared=prepared, iter_size=it, rotate=rotate)
+            sec, reps = timed(fn, 50, 5, min_ms=min_ms, repeats=repeats)
+            row['prepared_by_optimizer_us' if prepared else 'prepared_per_step_us'] = round(sec * 1e6, 2)
+            row['repeats'] = reps
+            row.setdefault('workload', info['workload'] if prepared else None)
+            del fn
+            torch.cuda.empty_cache()
+        row['saving_us_per_update'] = round(row['prepared_per_step_us'] - row['prepared_by_optimizer_us'], 2)
+        out['iter_size_%d' % it] = row
+    return out
+
+
 def build_rank1(cof, dev, N=32, H=14, K=51, dtype='bf16', rotate=0):
     """class-agnostic bottom-up map (M = 1, the shipped HMDB / MPII attention configs) on bf16 features:
     the headline op, one host call per step."""
@@ -281,7 +394,8 @@ def report(info, sec, repeats):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--workload', default='cfg003', choices=['cfg003', 'perclass', 'eval002', 'rank1', 'posebwd', 'posebwd_acc'])
+    ap.add_argument('--workload', default='cfg003', choices=['cfg003', 'perclass', 'eval002', 'rank1', 'posebwd', 'posebwd_acc', 'update003',
+                                                         'update_perclass'])
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--hw', type=int, default=14)
     ap.add_argument('--classes', type=int, default=None)
@@ -300,6 +414,10 @@ def main():
     args = ap.parse_args()
     from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
     dev = torch.device('cuda:0')
+    if args.workload in ('update003', 'update_perclass'):
+        print(json.dumps(run_update_pair(cof, dev, 'cfg003' if args.workload == 'update003' else 'perclass',
+                                         rotate=args.rotate)))
+        return
     if args.workload == 'cfg003':
         step, info = build_cfg003(cof, dev, args.batch, args.hw, args.classes or 393, args.dtype or 'bf16',
                                   rank1=not args.no_rank1, one_call=not args.per_op, rotate=args.rotate)
