@@ -723,8 +723,8 @@ static bool use_stream_kernels(int C, int dtype) {
 // inside a one-call step (the forward half left the bits in the workspace)
 bool m1_no_dx_supported(int C, int dtype, bool train) {
   static const int use_bits = knob("APA_M1_KEEP_BITS", 1);
-  static const int pix = knob("APA_M1S_PIX", 2);
-  return train && dtype == APA_DTYPE_BF16 && use_bits && pix == 2 && use_stream_kernels(C, dtype);
+  static const int pix = knob("APA_M1S_PIX", 0);     // 0 = the dtype's default (bf16: 2, apa_m1_stream.hip)
+  return train && dtype == APA_DTYPE_BF16 && use_bits && (pix == 0 || pix == 2) && use_stream_kernels(C, dtype);
 }
 
 template <typename T, int VEC>
