@@ -351,6 +351,241 @@ __global__ __launch_bounds__(512) void pose_bwd_rows_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// MFMA form of the rows pass (round 6; bf16 features, J == 16, Cp a multiple of 128, rank-1 or no external
+// gradient).  The VALU form above spends 16 us at the benchmark shape on 2 x 17 fp32 FMAs per element of the
+// [6272 x 768] map (SQ: MFMA 0.000, `active` 0.46); both contractions are 16 deep, i.e. ONE k step of the matrix
+// pipe each once the fp32 operand is split into a bf16 head and a bf16 remainder (x = hi + lo exactly to 2^-17):
+//     dPpre^T tile [16 c x 16 r] = [W2hi | W2hi] . [dPlhi ; dPllo]  +  [W2lo | 0] . [dPlhi ; 0]        (k = 32)
+//     dW2^T tile   [16 q x 16 c] = dPlhi^T . Ppre + dPllo^T . Ppre                                     (k = 32 rows)
+// so what is dropped is lo x lo (2^-18 relative): the result is the fp32 kernel's to ~1e-5, far inside the bf16
+// store of dPpre.  Block = 32 rows x all Cp columns, parked once in LDS ([32][Cp + 8] bf16, 16-byte vectors);
+// wave w owns channels [128 w, 128 w + 128):
+//   * dW2 / dWa first (the tile is the k-major B operand: ds_read_b64_tr_b16), written TRANSPOSED -- D[q][c] puts a
+//     lane's four registers on four consecutive q of one channel: one float4 per lane, 1 KB per wave-store, in the
+//     natural [c][q] order (the permuted layout of the VALU form is not needed);
+//   * then dPpre, also transposed (M = channels): a lane holds four CONSECUTIVE channels of one row, reads the four
+//     Ppre values it gates with (8 bytes of the tile), adds the rank-1 term dZ[r] wa[c] in fp32, writes the bf16
+//     result back IN PLACE; db1 leaves through a 16-lane DPP row sum;
+//   * the finished tile is streamed out as 16-byte row segments.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split_bf16x8(const float (&x)[8], short (&hi)[8], short (&lo)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    const uint32_t h = pack_bf16x2(x[e], x[e + 1]);
+    const uint32_t l = pack_bf16x2(x[e] - bf16_lo(h), x[e + 1] - bf16_hi(h));
+    hi[e] = (short)(h & 0xffffu); hi[e + 1] = (short)(h >> 16);
+    lo[e] = (short)(l & 0xffffu); lo[e + 1] = (short)(l >> 16);
+  }
+}
+
+template <bool R1, bool WA>
+__global__ __launch_bounds__(512) void pose_bwd_rows_mfma_kernel(
+    const float* __restrict__ dPl, const float* __restrict__ W2, const float* __restrict__ ext_row,
+    const float* __restrict__ ext_col, const bf16_t* __restrict__ Ppre, bf16_t* __restrict__ dPpre,
+    float* __restrict__ partial, long R, int Cp, size_t ldp, int G) {
+  typedef short bf16x8 __attribute__((ext_vector_type(8)));
+  typedef short bf16x4 __attribute__((ext_vector_type(4)));
+  typedef bf16x4 __attribute__((address_space(3))) * lds_v4;
+  constexpr int RPB = 32, DLD = 20;
+  constexpr int CT = 4;             // 16-channel tiles per wave (8 spilled: 64 + 64 + 32 fragment / accumulator registers)
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  // blockIdx.y = channel group: the block's waves own channels [gbase, gbase + 16 CT blockDim.x / 64).  blockIdx.x = row
+  // block of G groups of 32 rows, taken one after the other with the weight-gradient accumulators kept in registers:
+  // ONE partial row per 32 G rows (with a partial row per 32 rows -- 55 KB each -- a third of the kernel's traffic was
+  // partials, and the column sum behind it read 196 of them).
+  const int CB = (blockDim.x >> 6) * (16 * CT), gbase = blockIdx.y * CB;
+  const int LDT = CB + 8;
+  short* tile = reinterpret_cast<short*>(s_raw);                  // [32][CB + 8] bf16
+  float* s_dpl = reinterpret_cast<float*>(tile + RPB * LDT);      // [32][20]
+  float* s_er = s_dpl + RPB * DLD;                                // [32]
+  const int tid = threadIdx.x, nthr = blockDim.x, wave = tid >> 6, lane = tid & 63, l16 = lane & 15, kb = lane >> 4;
+  const int vpr = CB / 8;                                         // 16-byte vectors per row; 32 vpr == CT nthr
+  const int cbase = wave * (16 * CT), q0 = 8 * (kb & 1);   // cbase: within the tile; + gbase: within the map
+
+  // this lane's W2 rows as MFMA A fragments, once: channel gbase + cbase + 16 ct + l16, k blocks [hi | hi] and [lo | 0]
+  bf16x8 a1[CT], a2v[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const float4* wsrc = reinterpret_cast<const float4*>(W2 + (size_t)(gbase + cbase + ct * 16 + l16) * 16 + q0);
+    const float4 w0 = wsrc[0], w1 = wsrc[1];
+    const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    short hi[8], lo[8];
+    split_bf16x8(wv, hi, lo);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      a1[ct][e] = hi[e];
+      a2v[ct][e] = kb < 2 ? lo[e] : (short)0;
+    }
+  }
+  f32x4 accw[CT], acca[WA ? CT : 1];
+  float osum[CT][4];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    accw[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (WA) acca[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) osum[ct][g] = 0.f;
+  }
+  float sdb = 0.f, sdz = 0.f;                 // db2 (threads < 16 of channel group 0) / dba (its last thread)
+
+  // one group ahead through registers: group g + 1's rows (and its dPl / dZ values) are requested between the two
+  // MFMA phases of group g and parked in LDS when g's finished tile has left
+  uint4 buf[CT];
+  float4 dplv = make_float4(0.f, 0.f, 0.f, 0.f);
+  float erv = 0.f;
+  auto request = [&](int grp) {
+    const long r0 = ((long)blockIdx.x * G + grp) * RPB;
+    const int nrows = (int)max(0L, min((long)RPB, R - r0));
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+      const int vi = tid + i * nthr, row = vi / vpr, v = vi - row * vpr;
+      buf[i] = ld16(Ppre + (size_t)max(0L, min(r0 + row, R - 1)) * Cp + gbase + v * 8);   // surplus rows re-read row R - 1 (dPl = 0 there)
+    }
+    dplv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 128 && (tid >> 2) < nrows) dplv = *reinterpret_cast<const float4*>(dPl + (size_t)(r0 + (tid >> 2)) * 16 + (tid & 3) * 4);
+    erv = 0.f;
+    if (R1 && tid >= nthr - 32 && tid - (nthr - 32) < nrows) erv = ext_row[r0 + tid - (nthr - 32)];
+  };
+  request(0);
+  for (int grp = 0; grp < G; ++grp) {
+    const long r0 = ((long)blockIdx.x * G + grp) * RPB;
+    if (r0 >= R) break;                       // (block-uniform)
+    const int nrows = (int)min((long)RPB, R - r0);
+    // ---- phase 0: park the group's operands in LDS ----
+    if (grp > 0) __syncthreads();             // the previous group's tile has been streamed out
+    if (tid < 128) *reinterpret_cast<float4*>(s_dpl + (tid >> 2) * DLD + (tid & 3) * 4) = dplv;
+    if (tid >= nthr - 32) s_er[tid - (nthr - 32)] = erv;
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+      const int vi = tid + i * nthr, row = vi / vpr, v = vi - row * vpr;
+      *reinterpret_cast<uint4*>(tile + row * LDT + v * 8) = buf[i];
+    }
+    __syncthreads();
+
+    // ---- phase 1: dW2^T (and dWa) tiles: A = dPl^T (m = q = l16, k = row 8 kb + i), B = the tile, k-major ----
+    {
+      float dv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dv[i] = s_dpl[(8 * kb + i) * DLD + l16];
+      short hi[8], lo[8];
+      split_bf16x8(dv, hi, lo);
+      const bf16x8 ahi = {hi[0], hi[1], hi[2], hi[3], hi[4], hi[5], hi[6], hi[7]};
+      const bf16x8 alo = {lo[0], lo[1], lo[2], lo[3], lo[4], lo[5], lo[6], lo[7]};
+      bf16x8 az = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (WA) {                               // row m = 0: head of dZ, row m = 1: remainder; the two result rows are added
+        float ev[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ev[i] = s_er[8 * kb + i];
+        short eh[8], el[8];
+        split_bf16x8(ev, eh, el);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) az[i] = l16 == 0 ? eh[i] : (l16 == 1 ? el[i] : (short)0);
+      }
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const short* s0 = tile + (kb * 8 + (l16 >> 2)) * LDT + cbase + ct * 16 + 4 * (l16 & 3);
+        const bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(s0));
+        const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(s0 + 4 * LDT));
+        const bf16x8 bfr = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+        accw[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, bfr, accw[ct], 0, 0, 0);
+        accw[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, bfr, accw[ct], 0, 0, 0);
+        if (WA) acca[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(az, bfr, acca[ct], 0, 0, 0);
+      }
+    }
+    if (blockIdx.y == 0) {
+      if (tid < 16) {                         // db2[q] += sum_r dPl[r][q] (fixed order)
+        for (int rr = 0; rr < nrows; ++rr) sdb += s_dpl[rr * DLD + tid];
+      } else if (WA && tid == nthr - 1) {     // dba += sum_r dZ[r]
+        for (int rr = 0; rr < nrows; ++rr) sdz += s_er[rr];
+      }
+    }
+    __syncthreads();                          // every wave is done reading the tile as an operand
+    if (grp + 1 < G) request(grp + 1);        // (flies under phase 2 and the stores of phase 3)
+
+    // ---- phase 2: dPpre^T tiles: A = W2 (m = channel), B = dPl^T (n = row), gate + rank-1 term, in place ----
+    {
+      bf16x8 b1[2], b2[2];
+      float er2[2];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const float* dsrc = s_dpl + (rt * 16 + l16) * DLD + q0;
+        const float4 d0 = *reinterpret_cast<const float4*>(dsrc), d1 = *reinterpret_cast<const float4*>(dsrc + 4);
+        const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        short hi[8], lo[8];
+        split_bf16x8(dv, hi, lo);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          b1[rt][e] = kb < 2 ? hi[e] : lo[e];
+          b2[rt][e] = kb < 2 ? hi[e] : (short)0;
+        }
+        er2[rt] = s_er[rt * 16 + l16];
+      }
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        float4 wa4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (R1) wa4 = *reinterpret_cast<const float4*>(ext_col + gbase + cbase + ct * 16 + 4 * kb);
+        const float wa[4] = {wa4.x, wa4.y, wa4.z, wa4.w};
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[ct], b1[rt], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2v[ct], b2[rt], acc, 0, 0, 0);
+          // D[channel 4 kb + reg][row l16]
+          short* tp = tile + (rt * 16 + l16) * LDT + cbase + ct * 16 + 4 * kb;
+          const uint2 pv = *reinterpret_cast<const uint2*>(tp);
+          const float pp[4] = {bf16_lo(pv.x), bf16_hi(pv.x), bf16_lo(pv.y), bf16_hi(pv.y)};
+          float o[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float x = R1 ? fmaf(er2[rt], wa[g], acc[g]) : acc[g];
+            o[g] = pp[g] > 0.f ? x : 0.f;
+            osum[ct][g] += o[g];
+          }
+          *reinterpret_cast<uint2*>(tp) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+        }
+      }
+    }
+    __syncthreads();
+    // ---- phase 3: the finished dPpre tile leaves as 16-byte row segments ----
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+      const int vi = tid + i * nthr, row = vi / vpr, v = vi - row * vpr;
+      if (row < nrows)
+        st16(dPpre + (size_t)(r0 + row) * Cp + gbase + v * 8, *reinterpret_cast<const uint4*>(tile + row * LDT + v * 8));
+    }
+  }
+
+  // ---- the block's partial row: [dW2 (natural [c][q]) | db1 | db2 (| dWa | dba)] ----
+  float* prow = partial + (size_t)blockIdx.x * ldp;
+  const size_t dw2_cols = (size_t)Cp * 16;
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    // D[q = 4 kb + reg][c = l16]  ->  dW2[c][q]: four consecutive floats per lane, 1 KB per wave-store
+    *reinterpret_cast<float4*>(prow + (size_t)(gbase + cbase + ct * 16 + l16) * 16 + 4 * kb) =
+        make_float4(accw[ct][0], accw[ct][1], accw[ct][2], accw[ct][3]);
+    if (WA && kb == 0) prow[dw2_cols + Cp + 16 + gbase + cbase + ct * 16 + l16] = acca[ct][0] + acca[ct][1];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float s2 = row_sum16(osum[ct][g]);
+      if (l16 == 0) prow[dw2_cols + gbase + cbase + ct * 16 + 4 * kb + g] = s2;
+    }
+  }
+  if (blockIdx.y == 0) {
+    if (tid < 16) prow[dw2_cols + Cp + tid] = sdb;
+    else if (WA && tid == nthr - 1) prow[dw2_cols + Cp + 16 + Cp] = sdz;
+  }
+}
+
+static bool pose_rows_mfma_ok(const float* dPl, const void* dPpre_ext, const float* ext_row, const float* ext_col,
+                              const float* W2, const void* Ppre, int Cp, int J, int dtype) {
+  static const int enabled = knob("APA_POSE_ROWS_MFMA", 1);
+  const uintptr_t al = reinterpret_cast<uintptr_t>(dPl) | reinterpret_cast<uintptr_t>(W2) | reinterpret_cast<uintptr_t>(Ppre) |
+                       reinterpret_cast<uintptr_t>(ext_col);
+  return enabled && dtype == APA_DTYPE_BF16 && dPl && J == 16 && Cp % 128 == 0 && Cp >= 256 && Cp <= 1024 &&
+         (al & 15) == 0 && (!dPpre_ext || ext_row);
+}
+
 // LDS bytes of one block: dPl rows + ext_row + the [rpb][nthr] tile(s)
 static size_t pose_rows_lds(int rpb, int nthr, int dtype, bool ext) {
   return (size_t)rpb * 17 * 4 + (size_t)rpb * nthr * (dtype == APA_DTYPE_BF16 ? 4 : 8) * (ext ? 2 : 1);
@@ -779,6 +1014,51 @@ static int pose_head_bwd_impl(const void* X, const float* W1, const float* W2, c
   if (Cp % 4 != 0) {
     set_error("apa_pose_head_bwd: Cp=%d must be a multiple of 4", Cp);
     return APA_ERR_UNSUPPORTED;
+  }
+  if (pose_bwd_rows_ok(dPl, Ppre, dPpre_ext, W2, Cp, J, dtype) &&
+      pose_rows_mfma_ok(dPl, dPpre_ext, ext_row, ext_col, W2, Ppre, Cp, J, dtype)) {
+    // round 6: the same pass on the matrix pipe (bf16 features); partial rows in NATURAL [dW2 | db1 | db2 (| dWa | dba)] order
+    const int nthr2 = Cp / 2;
+    // waves per block (a wave owns 64 channels) and 32-row groups per block.  Fewer partial rows mean less traffic
+    // here and in the column sum behind (G), small blocks let a CU overlap one block's loads with another's MFMAs
+    // and stores (wpb); measured at the benchmark shape (rows kernel + column sum, us): wpb 6 G 1 14.7 + 5.8,
+    // 6/2 12.3 + 4.8, 4/2 11.8 + 4.9, 3/2 11.5 + 4.8, 3/4 15.1 + 4.8, 2/4 15.7 + 4.8 (the VALU form: 16.3 + 5.5)
+    static const int wpb_knob = knob("APA_POSE_ROWS_WPB", 0), grp_knob = knob("APA_POSE_ROWS_GRP", 0);
+    const int nw = Cp / 64;                           // waves a whole row takes
+    int wpb = nw % 3 == 0 ? 3 : (nw % 4 == 0 ? 4 : 2);
+    if (wpb_knob >= 2 && wpb_knob <= 8 && nw % wpb_knob == 0) wpb = wpb_knob;   // (>= 128 threads: the dPl loaders)
+    const int ngrp = nw / wpb;
+    const int G = grp_knob > 0 ? grp_knob : (pl.R >= 2048 ? 2 : 1);
+    const int nblk = (int)((pl.R + 32L * G - 1) / (32L * G));
+    const size_t lds = (size_t)32 * (wpb * 64 + 8) * 2 + 32 * 20 * 4 + 32 * 4;
+    const size_t ldp = pose_rows_ld(Cp, J, nthr2);
+    const bool want_wa = fuse && fuse->dWa;
+    if (want_wa && !ext_row) {
+      set_error("apa_pose_head_bwd: the fused dWa / dba outputs need the rank-1 external gradient (internal)");
+      return APA_ERR_INVALID_ARG;
+    }
+#define APA_ROWSM(R1v, WAv)                                                                                      \
+  hipLaunchKernelGGL((pose_bwd_rows_mfma_kernel<R1v, WAv>), dim3(nblk, ngrp), dim3(64 * wpb), lds, st, dPl, W2, ext_row, \
+                     ext_col, static_cast<const bf16_t*>(Ppre), static_cast<bf16_t*>(dPpre), partial, pl.R, Cp, ldp, G)
+    if (ext_row && want_wa) APA_ROWSM(true, true);
+    else if (ext_row) APA_ROWSM(true, false);
+    else APA_ROWSM(false, false);
+#undef APA_ROWSM
+    APA_LAUNCH_CHECK("pose_bwd_rows_mfma_kernel");
+    const int c1 = Cp * J;
+    ColsumMore more;
+    int ncol = c1 + Cp + J;
+    if (want_wa) {
+      more.dwa4 = fuse->dWa; more.C3 = c1 + Cp + J;
+      more.dwa5 = fuse->dba; more.C4 = c1 + Cp + J + Cp;
+      ncol = c1 + Cp + J + Cp + 1;
+    }
+    if (fuse) { more.aux_src = fuse->aux_src; more.aux_n = fuse->aux_n; more.aux_scale = fuse->aux_scale; more.aux_dst = fuse->aux_dst; }
+    int rc = m1_colsum(partial, nullptr, dW2, nullptr, nblk, ncol, (int)ldp, fuse ? fuse->rng_bump : nullptr, st, db1, c1,
+                       db2, c1 + Cp, 0, Cp, fuse ? &more : nullptr);
+    if (rc != APA_OK) return rc;
+    return pose_head_bwd_big(X, W1, dPpre, dX, accumulate_dX, dW1, w, pl, gws, R, C, Cp, dtype, st,
+                             fuse ? fuse->W1_bf16 : nullptr, fuse);
   }
   if (pose_bwd_rows_ok(dPl, Ppre, dPpre_ext, W2, Cp, J, dtype)) {
     // one pass: dPpre + partial rows [dW2 | db1 | db2], one fixed-order column sum for all three

@@ -718,6 +718,33 @@ static int gemm_cu_count() {
   return cus;
 }
 
+// ---- 32 x 32 x 16 MFMA fragments on the same swizzled images (development build) ----
+// A / B operand of v_mfma_f32_32x32x16_bf16: lane l holds row (l & 31), k = 8 (l >> 5) .. + 7 of a 32-row x 16-k
+// slab.  [row][k] image: one ds_read_b128 (the (row >> 1) & 7 chunk swizzle stays conflict-free for the instruction's
+// four 16-lane service groups: their rows differ in parity or in the swizzled slot).  [k][row] image: the transposing
+// read works per 16-lane group, so group g = l >> 4 fetches columns 16 (g & 1) .. of k block g >> 1.
+#ifdef APA_ABLATION
+template <bool KM>
+__device__ __forceinline__ bf16x8 fragment32_sw(const short* img, int rbase, int ks16, int lane) {
+  if (!KM) {
+    const int row = rbase + (lane & 31);
+    const int chunk = (ks16 * 2 + (lane >> 5)) ^ ((row >> 1) & 7);
+    return *reinterpret_cast<const bf16x8*>(img + row * TK + chunk * 8);
+  } else {
+    typedef bf16x4 __attribute__((address_space(3))) * lds_v4;
+    const int l16 = lane & 15, g = lane >> 4;
+    const int k = ks16 * 16 + 8 * (g >> 1) + (l16 >> 2);
+    const int r = rbase + 16 * (g & 1) + 4 * (l16 & 3);
+    const int sw = 8 * ((k >> 3) & 1);
+    const short* s0 = img + k * TM + (((r >> 3) ^ (2 * (k & 3)) ^ sw) * 8) + (r & 7);
+    const short* s1 = img + (k + 4) * TM + (((r >> 3) ^ (2 * ((k + 4) & 3)) ^ sw) * 8) + (r & 7);
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(s0));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(s1));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  }
+}
+#endif
+
 template <int MT> struct RingCfg {
   static constexpr int TMR = 2 * MT * 16;                    // rows of the block tile
   static constexpr int A_EL = TMR * TK;                      // shorts
@@ -898,6 +925,146 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_ring_kernel(FastParams p) {
       }
   }
 }
+
+#ifdef APA_ABLATION
+// The ring kernel with 32 x 32 x 16 MFMAs (MT even): wave tile (16 MT) x 32 = MT/2 tiles of 32 x 32; per 16-wide k step
+// MT/2 + 1 fragment reads (1 KB each) for MT/2 MFMAs of 32 768 flop -- the SAME LDS bytes per flop as the 16 x 16 x 32 form
+// ((MT + 2) reads per 2 MT MFMAs of 16 384 flop), half the MFMA instructions.  Same ring, same hand-over, the
+// software pipeline over the four k steps of a tile (fragments of step s + 1 read under the MFMAs of step s).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <typename TC, bool B_KM, int MT>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_ring32_kernel(FastParams p) {
+  typedef RingCfg<MT> R;
+  static_assert(MT % 2 == 0, "32-row tiles");
+  constexpr int MH = MT / 2;
+  extern __shared__ __attribute__((aligned(16))) short smem[];
+  typedef __attribute__((address_space(3))) void* lptr;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int ntm = (p.M + R::TMR - 1) / R::TMR, ntn = (p.N + TN - 1) / TN;
+  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (tile / ntn) * R::TMR, n0 = (tile % ntn) * TN;
+  const int nk = p.K / TK;
+  constexpr int NMINE = R::C_LO + (R::N_HI ? 1 : 0);
+  const bf16_t* src[NMINE];
+  uint32_t dst[NMINE];
+  long step[NMINE];
+#pragma unroll
+  for (int j = 0; j < NMINE; ++j) {
+    const int b = wave + 8 * j;
+    if (b < R::TMR / 8) {
+      src[j] = static_cast<const bf16_t*>(p.A) + glds_src_offset<false>(b, lane, p.lda, m0, p.M);
+      dst[j] = (uint32_t)b * 1024u;
+      step[j] = TK;
+    } else {
+      const int g = min(b - R::TMR / 8, 15);
+      src[j] = static_cast<const bf16_t*>(p.B) + glds_src_offset<B_KM>(g, lane, p.ldb, n0, p.N);
+      dst[j] = (uint32_t)(R::A_EL * 2) + (uint32_t)g * 1024u;
+      step[j] = B_KM ? (long)TK * p.ldb : (long)TK;
+    }
+  }
+  const bool extra = wave < R::N_HI;
+  const uint32_t lds0 = (uint32_t)(size_t)(lptr)smem;
+  auto issue = [&](int t) {
+    const uint32_t st = lds0 + (uint32_t)((t % R::NST) * R::STAGE_EL * 2);
+#pragma unroll
+    for (int j = 0; j < R::C_LO; ++j) glds16_ring(src[j] + (long)t * step[j], st + dst[j]);
+    if (R::N_HI && extra) glds16_ring(src[NMINE - 1] + (long)t * step[NMINE - 1], st + dst[NMINE - 1]);
+  };
+  f32x16 acc[MH];
+#pragma unroll
+  for (int i = 0; i < MH; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  auto load_frags = [&](int t, int ks16, bf16x8 (&af)[MH], bf16x8& bf) {
+    const short* a_img = smem + (t % R::NST) * R::STAGE_EL;
+    const short* b_img = a_img + R::A_EL;
+#pragma unroll
+    for (int i = 0; i < MH; ++i) af[i] = fragment32_sw<false>(a_img, (wm * MH + i) * 32, ks16, lane);
+    bf = fragment32_sw<B_KM>(b_img, wn * 32, ks16, lane);
+  };
+  auto mma = [&](const bf16x8 (&af)[MH], const bf16x8& bf) {
+#pragma unroll
+    for (int i = 0; i < MH; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf, acc[i], 0, 0, 0);
+  };
+  auto hand_over = [&](int younger) {
+    if (extra) {
+      if (younger >= 2) ring_wait_barrier<2 * (R::C_LO + 1)>();
+      else if (younger == 1) ring_wait_barrier<R::C_LO + 1>();
+      else ring_wait_barrier<0>();
+    } else {
+      if (younger >= 2) ring_wait_barrier<2 * R::C_LO>();
+      else if (younger == 1) ring_wait_barrier<R::C_LO>();
+      else ring_wait_barrier<0>();
+    }
+  };
+  auto settle = [&](bf16x8 (&af)[MH], bf16x8& bf) {
+#pragma unroll
+    for (int i = 0; i < MH; ++i) asm volatile("" : "+v"(af[i]));
+    asm volatile("" : "+v"(bf));
+  };
+  bf16x8 afa[MH], afb[MH], bfa, bfb;
+#pragma unroll
+  for (int t = 0; t < R::NST - 1; ++t)
+    if (t < nk) issue(t);
+  hand_over(min(R::NST - 2, nk - 1));
+  if (R::NST - 1 < nk) issue(R::NST - 1);
+  load_frags(0, 0, afa, bfa);
+  for (int t = 0; t + 1 < nk; ++t) {     // k16 steps 0..3 of tile t; the hand-over sits between steps 2 and 3
+    settle(afa, bfa); load_frags(t, 1, afb, bfb); __builtin_amdgcn_sched_barrier(0); mma(afa, bfa); __builtin_amdgcn_sched_barrier(0);
+    settle(afb, bfb); load_frags(t, 2, afa, bfa); __builtin_amdgcn_sched_barrier(0); mma(afb, bfb); __builtin_amdgcn_sched_barrier(0);
+    settle(afa, bfa); load_frags(t, 3, afb, bfb); __builtin_amdgcn_sched_barrier(0); mma(afa, bfa); __builtin_amdgcn_sched_barrier(0);
+    hand_over(min(R::NST - 2, nk - 2 - t));
+    if (t + R::NST < nk) issue(t + R::NST);
+    load_frags(t + 1, 0, afa, bfa);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(afb, bfb);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  settle(afa, bfa); load_frags(nk - 1, 1, afb, bfb); __builtin_amdgcn_sched_barrier(0); mma(afa, bfa);
+  settle(afb, bfb); load_frags(nk - 1, 2, afa, bfa); __builtin_amdgcn_sched_barrier(0); mma(afb, bfb);
+  settle(afa, bfa); load_frags(nk - 1, 3, afb, bfb); __builtin_amdgcn_sched_barrier(0); mma(afa, bfa);
+  mma(afb, bfb);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  // epilogue.  D layout of the 32 x 32 MFMA: col = lane & 31, row = 8 (reg >> 2) + 4 (lane >> 5) + (reg & 3)
+  TC* C = static_cast<TC*>(p.C);
+  uint32_t h0 = 0, h1 = 0;
+  if (p.drop_c) rng_key_dev_x(p.seed, p.offset_dev ? *p.offset_dev : p.offset, p.thresh, h0, h1);
+  float* stage = reinterpret_cast<float*>(smem);
+  constexpr int LDS_C = TN + 4;
+#pragma unroll
+  for (int i = 0; i < MH; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      stage[((wm * MH + i) * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3)) * LDS_C + wn * 32 + (lane & 31)] = acc[i][e];
+  __syncthreads();
+  for (int v = tid; v < R::TMR * 16; v += 512) {
+    const int row = v >> 4, c8 = (v & 15) * 8;
+    const int grow = m0 + row, gcol = n0 + c8;
+    if (grow >= p.M || gcol >= p.Nout) continue;
+    const float4 x0 = *reinterpret_cast<const float4*>(stage + row * LDS_C + c8);
+    const float4 x1 = *reinterpret_cast<const float4*>(stage + row * LDS_C + c8 + 4);
+    store8<TC>(p, C, grow, gcol, x0, x1, h0, h1);
+  }
+}
+
+template <typename TC, bool B_KM, int MT>
+int launch_ring32(const FastParams& p, hipStream_t st) {
+  typedef RingCfg<MT> R;
+  static thread_local PerDevice<bool> attr_dev; bool& attr_set = attr_dev.here();
+  if (!attr_set) {
+    APA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring32_kernel<TC, B_KM, MT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)R::LDS_BYTES));
+    attr_set = true;
+  }
+  const int tiles = ((p.M + R::TMR - 1) / R::TMR) * ((p.N + TN - 1) / TN);
+  hipLaunchKernelGGL((gemm_bf16_ring32_kernel<TC, B_KM, MT>), dim3(tiles), dim3(512), R::LDS_BYTES, st, p);
+  APA_LAUNCH_CHECK("gemm_bf16_ring32_kernel");
+  return APA_OK;
+}
+#endif
 
 template <typename TC, bool B_KM, int MT>
 int launch_ring(const FastParams& p, hipStream_t st) {
@@ -1504,6 +1671,15 @@ int gemm_bf16_launch(const GemmDesc& d, int splits, int k_per_split, hipStream_t
       return APA_ERR_UNSUPPORTED;
     }
     if (kind == KIND_RING) {
+#ifdef APA_ABLATION
+      static const int m32 = knob("APA_GEMM_M32", 0);      // 6: 192 x 128 tiles, 4: 128 x 128, 8: 256 x 128; 16: MT 6 with 16x16x32
+      if ((m32 == 4 || m32 == 6 || m32 == 8) && d.tc == 1 && p.vec_epi && !d.twin) {
+        if (m32 == 4) return d.b_kc ? launch_ring32<bf16_t, false, 4>(p, st) : launch_ring32<bf16_t, true, 4>(p, st);
+        if (m32 == 6) return d.b_kc ? launch_ring32<bf16_t, false, 6>(p, st) : launch_ring32<bf16_t, true, 6>(p, st);
+        return d.b_kc ? launch_ring32<bf16_t, false, 8>(p, st) : launch_ring32<bf16_t, true, 8>(p, st);
+      }
+      if (m32 == 16 && d.tc == 1) return d.b_kc ? launch_ring_mt<bf16_t, false>(p, 6, st) : launch_ring_mt<bf16_t, true>(p, 6, st);
+#endif
       const int mt = ring_pick_mt(d.M, d.N, gemm_cu_count());
       if (d.tc == 1) return d.b_kc ? launch_ring_mt<bf16_t, false>(p, mt, st) : launch_ring_mt<bf16_t, true>(p, mt, st);
       return d.b_kc ? launch_ring_mt<float, false>(p, mt, st) : launch_ring_mt<float, true>(p, mt, st);

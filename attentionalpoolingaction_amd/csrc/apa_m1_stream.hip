@@ -183,7 +183,7 @@ __device__ __forceinline__ void fwd_chunk(FwdState<T, VW, PIX, FUSED, TRAIN>& st
                                           float* __restrict__ att_im, int n, int P, int C, int cbase,
                                           int wave, int lane, int act, float inv_keep,
                                           uint32_t thresh, uint32_t k0, uint32_t k1,
-                                          uint8_t* __restrict__ bits_im) {
+                                          uint8_t* __restrict__ bits_im, float av_pre) {
   constexpr int EPV = Vec<T>::EPV;
   constexpr int EPL = VW * EPV;
   const int l16 = lane & 15;
@@ -224,7 +224,9 @@ __device__ __forceinline__ void fwd_chunk(FwdState<T, VW, PIX, FUSED, TRAIN>& st
       if (wave == 0 && lane < np) att_im[q0 + lane] = av;
     }
   } else {
-    av = l16 < np ? att_im[q0 + l16] : 0.f;
+    // the pre-computed map's values travel with the chunk's prefetch (round 6: loaded here, on the spot, this was the
+    // YOUNGEST outstanding load -- its s_waitcnt vmcnt(0) also waited for the next chunk's features, every chunk)
+    av = l16 < np ? av_pre : 0.f;
   }
 #pragma unroll
   for (int i = 0; i < PIX; ++i) {
@@ -301,6 +303,10 @@ __global__ __launch_bounds__(256, 2) void m1s_pool_fwd_kernel(
 
   const int p_last = p_end - 1;
   uint4 xa[PIX][VW], xb[PIX][VW];
+  const int l16 = lane & 15;
+  const float* att_rd = opaque_global(static_cast<const float*>(att_im));   // (!FUSED: read-only here)
+  float av_a = 0.f, av_b = 0.f;
+  if (!FUSED) av_a = att_rd[min(p_begin + l16, p_last)];
   load_chunk<T, VW, PIX>(xa, xim, p_begin, p_last, C, cbase);
   FwdState<T, VW, PIX, FUSED, TRAIN> st;
 #pragma unroll
@@ -321,15 +327,17 @@ __global__ __launch_bounds__(256, 2) void m1s_pool_fwd_kernel(
 
   // chunk k+1 is always fetched (clamped to the block's last pixel past the end: L1/L2 hits)
   for (int ch = 0; ch < nchunk; ch += 2) {
+    if (!FUSED) av_b = att_rd[min(p_begin + (ch + 1) * PIX + l16, p_last)];
     load_chunk<T, VW, PIX>(xb, xim, p_begin + (ch + 1) * PIX, p_last, C, cbase);
     fwd_chunk<T, VW, PIX, FUSED, TRAIN, RIN>(st, xa, chunk_range<PIX>(p_begin, p_end, ch), sm_x[0],
                                         att_im, n, P, C, cbase, wave, lane, act, inv_keep, thresh,
-                                        k0, k1, bits_im);
+                                        k0, k1, bits_im, av_a);
     if (ch + 1 >= nchunk) break;
+    if (!FUSED) av_a = att_rd[min(p_begin + (ch + 2) * PIX + l16, p_last)];
     load_chunk<T, VW, PIX>(xa, xim, p_begin + (ch + 2) * PIX, p_last, C, cbase);
     fwd_chunk<T, VW, PIX, FUSED, TRAIN, RIN>(st, xb, chunk_range<PIX>(p_begin, p_end, ch + 1), sm_x[1],
                                         att_im, n, P, C, cbase, wave, lane, act, inv_keep, thresh,
-                                        k0, k1, bits_im);
+                                        k0, k1, bits_im, av_b);
   }
 
   float* pa = pacc + (size_t)blk * C + cbase;
