@@ -95,6 +95,9 @@ __device__ __forceinline__ void relu_in(float (&x)[EPV]) {
 #ifndef APA_M1S_OPAQUE_X
 #define APA_M1S_OPAQUE_X 1
 #endif
+#ifndef APA_M1S_NB
+#define APA_M1S_NB 2      // depth of the register ring of chunks (chunk in work + NB - 1 in flight)
+#endif
 template <typename T>
 __device__ __forceinline__ const T* opaque_global(const T* p) {
 #if APA_M1S_OPAQUE_X
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void m1s_pool_fwd_kernel(
   constexpr int EPL = VW * EPV;   // channels per lane
   constexpr int CW = EPL * 64;    // channels per wave
   constexpr int C = CW * 4;
-  __shared__ __attribute__((aligned(16))) float sm_x[2][256];
+  __shared__ __attribute__((aligned(16))) float sm_x[APA_M1S_NB][256];   // one exchange buffer per ring slot
   uint32_t k0 = 0, k1 = 0;
   if (TRAIN) rng_key_dev(seed, offset_dev ? *offset_dev : offset, k0, k1);
 
@@ -302,12 +305,18 @@ __global__ __launch_bounds__(256, 2) void m1s_pool_fwd_kernel(
   uint8_t* bits_im = TRAIN ? maskbits + (size_t)n * P * MaskBytes<EPL>::BPP : nullptr;
 
   const int p_last = p_end - 1;
-  uint4 xa[PIX][VW], xb[PIX][VW];
+  constexpr int NB = APA_M1S_NB;                 // register ring: NB - 1 chunks in flight beside the one in work
+  uint4 xr[NB][PIX][VW];
   const int l16 = lane & 15;
   const float* att_rd = opaque_global(static_cast<const float*>(att_im));   // (!FUSED: read-only here)
-  float av_a = 0.f, av_b = 0.f;
-  if (!FUSED) av_a = att_rd[min(p_begin + l16, p_last)];
-  load_chunk<T, VW, PIX>(xa, xim, p_begin, p_last, C, cbase);
+  float av_r[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) av_r[b] = 0.f;
+#pragma unroll
+  for (int b = 0; b < NB - 1; ++b) {
+    if (!FUSED) av_r[b] = att_rd[min(p_begin + b * PIX + l16, p_last)];
+    load_chunk<T, VW, PIX>(xr[b], xim, p_begin + b * PIX, p_last, C, cbase);
+  }
   FwdState<T, VW, PIX, FUSED, TRAIN> st;
 #pragma unroll
   for (int i = 0; i < EPL; ++i) st.acc[i] = 0.f;
@@ -325,19 +334,19 @@ __global__ __launch_bounds__(256, 2) void m1s_pool_fwd_kernel(
     st.bias = ba[0];
   }
 
-  // chunk k+1 is always fetched (clamped to the block's last pixel past the end: L1/L2 hits)
-  for (int ch = 0; ch < nchunk; ch += 2) {
-    if (!FUSED) av_b = att_rd[min(p_begin + (ch + 1) * PIX + l16, p_last)];
-    load_chunk<T, VW, PIX>(xb, xim, p_begin + (ch + 1) * PIX, p_last, C, cbase);
-    fwd_chunk<T, VW, PIX, FUSED, TRAIN, RIN>(st, xa, chunk_range<PIX>(p_begin, p_end, ch), sm_x[0],
-                                        att_im, n, P, C, cbase, wave, lane, act, inv_keep, thresh,
-                                        k0, k1, bits_im, av_a);
-    if (ch + 1 >= nchunk) break;
-    if (!FUSED) av_a = att_rd[min(p_begin + (ch + 2) * PIX + l16, p_last)];
-    load_chunk<T, VW, PIX>(xa, xim, p_begin + (ch + 2) * PIX, p_last, C, cbase);
-    fwd_chunk<T, VW, PIX, FUSED, TRAIN, RIN>(st, xb, chunk_range<PIX>(p_begin, p_end, ch + 1), sm_x[1],
-                                        att_im, n, P, C, cbase, wave, lane, act, inv_keep, thresh,
-                                        k0, k1, bits_im, av_b);
+  // chunk k + NB - 1 is always fetched (clamped to the block's last pixel past the end: L1/L2 hits)
+  for (int ch = 0; ch < nchunk; ch += NB) {
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      if (u > 0 && ch + u >= nchunk) break;
+      constexpr int NBm1 = NB - 1;
+      const int slot = (u + NBm1) % NB;
+      if (!FUSED) av_r[slot] = att_rd[min(p_begin + (ch + u + NBm1) * PIX + l16, p_last)];
+      load_chunk<T, VW, PIX>(xr[slot], xim, p_begin + (ch + u + NBm1) * PIX, p_last, C, cbase);
+      fwd_chunk<T, VW, PIX, FUSED, TRAIN, RIN>(st, xr[u], chunk_range<PIX>(p_begin, p_end, ch + u), sm_x[u],
+                                               att_im, n, P, C, cbase, wave, lane, act, inv_keep, thresh,
+                                               k0, k1, bits_im, av_r[u]);
+    }
   }
 
   float* pa = pacc + (size_t)blk * C + cbase;
@@ -490,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void m1s_bwd_main_kernel(
   constexpr int EPL = VW * EPV;
   constexpr int CW = EPL * 64;
   constexpr int C = CW * 4;
-  __shared__ __attribute__((aligned(16))) float sm_x[2][256];
+  __shared__ __attribute__((aligned(16))) float sm_x[APA_M1S_NB][256];
   __shared__ float sm_aux[4];
   uint32_t k0 = 0, k1 = 0;
   if (TRAIN) rng_key_dev(seed, offset_dev ? *offset_dev : offset, k0, k1);
@@ -507,25 +516,35 @@ __global__ __launch_bounds__(256, 2) void m1s_bwd_main_kernel(
 
   const T* xim = opaque_global(X + (size_t)n * P * C);
   T* dxim = dX + (size_t)n * P * C;
-  const float* att_im = att + (size_t)n * P;
+  const float* att_im = opaque_global(att + (size_t)n * P);     // (prefetched with the chunk: keep the loads chained)
   float* dZout_im = FUSED ? nullptr : dZout + (size_t)n * P;
 
   const int p_last = p_end - 1;
-  uint4 xa[PIX][VW], xb[PIX][VW];
-  load_chunk<T, VW, PIX, APA_BWD_NT_LOAD>(xa, xim, p_begin, p_last, C, cbase);
-  const float* ex_im = dA_extra + (size_t)n * P;
-  float a_a = att_im[min(p_begin + l16, p_last)], a_b = 0.f;
-  float e_a = ex_im[min(p_begin + l16, p_last)] * extra_scale, e_b = 0.f;
+  constexpr int NB = APA_M1S_NB;
+  uint4 xr[NB][PIX][VW];
+  const float* ex_im = opaque_global(dA_extra + (size_t)n * P);
   // BITS: the forward pass left the keep decisions of this lane's channels behind, BPL bytes per pixel
   constexpr int BPL = MaskBytes<EPL>::BPL;
   constexpr int BPP = MaskBytes<EPL>::BPP;
-  const uint8_t* kb_im = BITS ? maskbits + (size_t)n * P * BPP + (size_t)(wave * 64 + lane) * BPL : nullptr;
-  uint32_t kb_a[PIX], kb_b[PIX];
+  const uint8_t* kb_im = BITS ? opaque_global(maskbits + (size_t)n * P * BPP) + (size_t)(wave * 64 + lane) * BPL : nullptr;
+  float a_r[NB], e_r[NB];
+  uint32_t kb_r[NB][PIX];
+  auto fetch = [&](int slot_, int ch_) {      // everything of chunk ch_ that comes from memory, into ring slot slot_
+    load_chunk<T, VW, PIX, APA_BWD_NT_LOAD>(xr[slot_], xim, p_begin + ch_ * PIX, p_last, C, cbase);
+    a_r[slot_] = att_im[min(p_begin + ch_ * PIX + l16, p_last)];
+    e_r[slot_] = ex_im[min(p_begin + ch_ * PIX + l16, p_last)] * extra_scale;
 #pragma unroll
-  for (int i = 0; i < PIX; ++i) {
-    kb_a[i] = BITS ? ld_keep_bits<BPL>(kb_im + (size_t)min(p_begin + i, p_last) * BPP) : 0u;
-    kb_b[i] = 0u;
+    for (int i = 0; i < PIX; ++i)
+      kb_r[slot_][i] = BITS ? ld_keep_bits<BPL>(kb_im + (size_t)min(p_begin + ch_ * PIX + i, p_last) * BPP) : 0u;
+  };
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    a_r[b] = 0.f; e_r[b] = 0.f;
+#pragma unroll
+    for (int i = 0; i < PIX; ++i) kb_r[b][i] = 0u;
   }
+#pragma unroll
+  for (int b = 0; b < NB - 1; ++b) fetch(b, b);
 
   // per-image constants: L2 hits issued behind the first chunk's HBM loads
   BwdState<T, VW, PIX, FUSED, TRAIN> st;
@@ -567,30 +586,16 @@ __global__ __launch_bounds__(256, 2) void m1s_bwd_main_kernel(
     }
   }
 
-  for (int ch = 0; ch < nchunk; ch += 2) {
-    load_chunk<T, VW, PIX, APA_BWD_NT_LOAD>(xb, xim, p_begin + (ch + 1) * PIX, p_last, C, cbase);
-    a_b = att_im[min(p_begin + (ch + 1) * PIX + l16, p_last)];
-    e_b = ex_im[min(p_begin + (ch + 1) * PIX + l16, p_last)] * extra_scale;
-    if (BITS) {
+  for (int ch = 0; ch < nchunk; ch += NB) {
 #pragma unroll
-      for (int i = 0; i < PIX; ++i)
-        kb_b[i] = ld_keep_bits<BPL>(kb_im + (size_t)min(p_begin + (ch + 1) * PIX + i, p_last) * BPP);
+    for (int u = 0; u < NB; ++u) {
+      if (u > 0 && ch + u >= nchunk) break;
+      constexpr int NBm1 = NB - 1;
+      fetch((u + NBm1) % NB, ch + u + NBm1);
+      bwd_chunk<T, VW, PIX, FUSED, TRAIN, RIN, BITS, NODX>(st, xr[u], a_r[u], e_r[u], kb_r[u], chunk_range<PIX>(p_begin, p_end, ch + u),
+                                                           sm_x[u], dxim, dZout_im, n, P, C, cbase, wave, lane, act, invP,
+                                                           inv_keep, thresh, k0, k1);
     }
-    bwd_chunk<T, VW, PIX, FUSED, TRAIN, RIN, BITS, NODX>(st, xa, a_a, e_a, kb_a, chunk_range<PIX>(p_begin, p_end, ch), sm_x[0],
-                                        dxim, dZout_im, n, P, C, cbase, wave, lane, act, invP,
-                                        inv_keep, thresh, k0, k1);
-    if (ch + 1 >= nchunk) break;
-    load_chunk<T, VW, PIX, APA_BWD_NT_LOAD>(xa, xim, p_begin + (ch + 2) * PIX, p_last, C, cbase);
-    a_a = att_im[min(p_begin + (ch + 2) * PIX + l16, p_last)];
-    e_a = ex_im[min(p_begin + (ch + 2) * PIX + l16, p_last)] * extra_scale;
-    if (BITS) {
-#pragma unroll
-      for (int i = 0; i < PIX; ++i)
-        kb_a[i] = ld_keep_bits<BPL>(kb_im + (size_t)min(p_begin + (ch + 2) * PIX + i, p_last) * BPP);
-    }
-    bwd_chunk<T, VW, PIX, FUSED, TRAIN, RIN, BITS, NODX>(st, xb, a_b, e_b, kb_b, chunk_range<PIX>(p_begin, p_end, ch + 1),
-                                        sm_x[1], dxim, dZout_im, n, P, C, cbase, wave, lane, act,
-                                        invP, inv_keep, thresh, k0, k1);
   }
 
   if (FUSED) {
