@@ -902,8 +902,16 @@ __global__ __launch_bounds__(1024) void pc_dw_reduce_kernel(const float* __restr
   if (idx >= (long)C * 128) return;
   const int c = (int)(idx >> 7), col = (int)(idx & 127), k = col & 63;
   if (k >= K) return;
+  // sixteen splits' loads in flight at once (round 6: the plain loop compiled to load / s_waitcnt vmcnt(0) / add per
+  // split -- sixteen dependent round trips per thread); same ascending order of the sum
   float acc = 0.f;
-  for (int s = 0; s < S; ++s) acc += partial[((size_t)s * C + c) * 128 + col];
+  for (int s0 = 0; s0 < S; s0 += 16) {
+    float t[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t[u] = partial[((size_t)min(s0 + u, S - 1) * C + c) * 128 + col];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += (s0 + u < S) ? t[u] : 0.f;
+  }
   if (col < 64) dWt[(size_t)c * K + k] = acc * inv_keep;
   else dWa[(size_t)c * K + k] = acc;
 }
