@@ -945,7 +945,7 @@ struct PoseBwdFuse {
 static int pose_head_bwd_big(const void* X, const float* W1, const void* dPpre, void* dX, int accumulate_dX,
                              float* dW1, char* w, const PosePlan& pl, float* gws, int R, int C, int Cp,
                              int dtype, hipStream_t st, const void* W1_shadow = nullptr,
-                             const PoseBwdFuse* fuse = nullptr) {
+                             const PoseBwdFuse* fuse = nullptr, ColsumJob* job = nullptr) {
   const int tdt = dt_code(dtype);
   int rc;
   {  // dW1[c,j] = sum_r X[r,c] dPpre[r,j]
@@ -955,8 +955,18 @@ static int pose_head_bwd_big(const void* X, const float* W1, const void* dPpre, 
     g.C = dW1; g.ldc = Cp; g.tc = 0;
     g.M = C; g.N = Cp; g.K = R;
     g.splits = pose_dw1_splits(C, Cp, R, dtype); g.ws = gws;
+    g.tail = job;
     rc = gemm_launch(g, st);
     if (rc != APA_OK) return rc;
+    if (job && !job->done) {     // no split-K reduce launch to ride on: the column sum as a launch of its own
+      ColsumMore more;
+      more.dwa4 = job->dwa4; more.C3 = job->C3; more.dwa5 = job->dwa5; more.C4 = job->C4;
+      more.aux_src = job->aux_src; more.aux_n = job->aux_n; more.aux_scale = job->aux_scale; more.aux_dst = job->aux_dst;
+      rc = m1_colsum(job->pdwa, nullptr, job->dwa, nullptr, job->nblk, job->C, job->ld, job->rng_bump, st, job->dwa2,
+                     job->C1, job->dwa3, job->C2, job->perm_nthr, job->perm_cp, &more);
+      if (rc != APA_OK) return rc;
+      job->done = true;
+    }
   }
   {  // dX (+)= dPpre . W1^T
     GemmDesc g;
@@ -1046,19 +1056,21 @@ static int pose_head_bwd_impl(const void* X, const float* W1, const float* W2, c
 #undef APA_ROWSM
     APA_LAUNCH_CHECK("pose_bwd_rows_mfma_kernel");
     const int c1 = Cp * J;
-    ColsumMore more;
-    int ncol = c1 + Cp + J;
+    // [dW2 | db1 | db2 (| dWa | dba)]: one fixed-order column sum for all of them (+ the pose loss and the dropout
+    // counter in the fused step).  Nothing behind it reads its outputs: it rides on the tail blocks of dW1's split-K
+    // reduce launch when there is one (round 6), else it is a launch of its own
+    ColsumJob job;
+    job.pdwa = partial; job.dwa = dW2; job.nblk = nblk; job.ld = (int)ldp; job.rng_bump = fuse ? fuse->rng_bump : nullptr;
+    job.dwa2 = db1; job.C1 = c1; job.dwa3 = db2; job.C2 = c1 + Cp; job.perm_nthr = 0; job.perm_cp = Cp;
+    job.C = c1 + Cp + J;
     if (want_wa) {
-      more.dwa4 = fuse->dWa; more.C3 = c1 + Cp + J;
-      more.dwa5 = fuse->dba; more.C4 = c1 + Cp + J + Cp;
-      ncol = c1 + Cp + J + Cp + 1;
+      job.dwa4 = fuse->dWa; job.C3 = c1 + Cp + J;
+      job.dwa5 = fuse->dba; job.C4 = c1 + Cp + J + Cp;
+      job.C = c1 + Cp + J + Cp + 1;
     }
-    if (fuse) { more.aux_src = fuse->aux_src; more.aux_n = fuse->aux_n; more.aux_scale = fuse->aux_scale; more.aux_dst = fuse->aux_dst; }
-    int rc = m1_colsum(partial, nullptr, dW2, nullptr, nblk, ncol, (int)ldp, fuse ? fuse->rng_bump : nullptr, st, db1, c1,
-                       db2, c1 + Cp, 0, Cp, fuse ? &more : nullptr);
-    if (rc != APA_OK) return rc;
+    if (fuse) { job.aux_src = fuse->aux_src; job.aux_n = fuse->aux_n; job.aux_scale = fuse->aux_scale; job.aux_dst = fuse->aux_dst; }
     return pose_head_bwd_big(X, W1, dPpre, dX, accumulate_dX, dW1, w, pl, gws, R, C, Cp, dtype, st,
-                             fuse ? fuse->W1_bf16 : nullptr, fuse);
+                             fuse ? fuse->W1_bf16 : nullptr, fuse, &job);
   }
   if (pose_bwd_rows_ok(dPl, Ppre, dPpre_ext, W2, Cp, J, dtype)) {
     // one pass: dPpre + partial rows [dW2 | db1 | db2], one fixed-order column sum for all three

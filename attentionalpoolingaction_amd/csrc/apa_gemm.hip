@@ -332,6 +332,54 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
   }
 }
 
+// The vector form of the reduce with a column-sum job on its tail blocks (GemmDesc::tail): blocks < nmain run the
+// reduce (1024 threads, one float4 each: same per-element order of the sum as above), blocks >= nmain are literally
+// m1_colsum_kernel's blocks (colsum_block: same sums bit for bit).
+struct ColsumJobDev {
+  const float* pdwa; float* dwa; int nblk, C, ld; uint64_t* rng_bump; float* dwa2; int C1; float* dwa3; int C2;
+  int perm_nthr, perm_cp, ntail; ColsumExtra x;
+};
+template <typename TC>
+__global__ __launch_bounds__(1024) void gemm_splitk_reduce_tail_kernel(const float* __restrict__ partial,
+                                                                       TC* __restrict__ C, long ldc, int M, int N,
+                                                                       int pN, int splits,
+                                                                       const float* __restrict__ bias, float beta,
+                                                                       int act, int nmain, ColsumJobDev j) {
+  // (the column-sum blocks at the END of the grid: 9.2 us for the launch; in front of the reduce blocks 9.8 us --
+  //  either way ~2 us less than the two launches, 6.6 + 4.8 us)
+  if ((int)blockIdx.x >= nmain) {
+    colsum_block((int)blockIdx.x - nmain, j.ntail, j.pdwa, nullptr, j.dwa, nullptr, j.nblk, j.C, j.ld, j.rng_bump,
+                 j.dwa2, j.C1, j.dwa3, j.C2, j.perm_nthr, j.perm_cp, j.x);
+    return;
+  }
+  const long idx = ((long)blockIdx.x * 1024 + threadIdx.x) * 4;
+  if (idx >= (long)M * pN) return;
+  const int row = (int)(idx / pN), col = (int)(idx % pN);
+  if (col >= N) return;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  const size_t stride = (size_t)M * pN;
+  for (int s0 = 0; s0 < splits; s0 += 8) {
+    float t[8][4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float4 q = *reinterpret_cast<const float4*>(partial + (size_t)min(s0 + u, splits - 1) * stride + idx);
+      t[u][0] = q.x; t[u][1] = q.y; t[u][2] = q.z; t[u][3] = q.w;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += (s0 + u < splits) ? t[u][e] : 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (col + e >= N) break;
+    if (bias) v[e] += bias[col + e];
+    if (act == 1) v[e] = fmaxf(v[e], 0.f);
+    if (beta != 0.f) v[e] += Elem<TC>::get(C, (long)row * ldc + col + e);
+    Elem<TC>::put(C, (long)row * ldc + col + e, v[e]);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host dispatch
 // ---------------------------------------------------------------------------------------------
@@ -418,6 +466,24 @@ static int gemm_launch_t(const GemmDesc& d, hipStream_t st) {
       tw.N = d.twin->n_valid > 0 ? d.twin->n_valid : d.twin->N;
     }
     const bool vec = pN % 4 == 0 && aligned16(d.ws) && (!twin || aligned16(d.twin->ws));
+    static const int ride = knob("APA_GEMM_REDUCE_TAIL", 1);
+    if (vec && !twin && d.tail && !d.tail->done && ride) {
+      const ColsumJob& c = *d.tail;
+      ColsumJobDev j;
+      j.pdwa = c.pdwa; j.dwa = c.dwa; j.nblk = c.nblk; j.C = c.C; j.ld = c.ld; j.rng_bump = c.rng_bump;
+      j.dwa2 = c.dwa2; j.C1 = c.dwa2 ? c.C1 : c.C; j.dwa3 = c.dwa3; j.C2 = c.dwa3 ? c.C2 : c.C;
+      j.perm_nthr = c.perm_nthr; j.perm_cp = c.perm_cp; j.ntail = (c.C + 31) / 32;
+      j.x.C3 = c.C; j.x.C4 = c.C;
+      if (c.dwa4) { j.x.dwa4 = c.dwa4; j.x.C3 = c.C3; }
+      if (c.dwa5) { j.x.dwa5 = c.dwa5; j.x.C4 = c.C4; }
+      j.x.aux_src = c.aux_src; j.x.aux_n = c.aux_n; j.x.aux_scale = c.aux_scale; j.x.aux_dst = c.aux_dst;
+      const int nmain = (int)((tot / 4 + 1023) / 1024);
+      hipLaunchKernelGGL((gemm_splitk_reduce_tail_kernel<TC>), dim3((unsigned)(nmain + j.ntail)), dim3(1024), 0, st, d.ws,
+                         static_cast<TC*>(d.C), d.ldc, d.M, Nst, pN, splits, d.bias, d.beta, d.act, nmain, j);
+      APA_LAUNCH_CHECK("gemm_splitk_reduce_tail_kernel");
+      d.tail->done = true;
+      return APA_OK;
+    }
     if (vec) {
       hipLaunchKernelGGL((gemm_splitk_reduce_kernel<TC, true>), dim3((unsigned)((tot / 4 + 255) / 256), twin ? 2 : 1),
                          dim3(256), 0, st, d.ws, static_cast<TC*>(d.C), d.ldc, d.M, Nst, pN, splits, d.bias,

@@ -147,6 +147,17 @@ int sgemm_small(const float* A, long a_si, long a_sk, const float* B, long b_sk,
 //   a_kc: A stored [M][K] (k contiguous) else [K][M];  b_kc: B stored [N][K] else [K][N].
 //   ta/tb/tc: 0 = f32, 1 = bf16.  f32 x f32 runs on the exact f32 MFMA, anything else on bf16 MFMA.
 // ------------------------------------------------------------------------------------------
+// A fixed-order column sum (m1_colsum's arguments) that may ride on the tail blocks of a split-K reduce launch
+// (GemmDesc::tail, round 6): the reduce is memory-bound on its partial tiles, the column sum is a handful of blocks
+// that nothing behind the product waits for -- as a launch of its own it cost 4.9 us of the cfg 003 step.  `done` is
+// set by gemm_launch when the job was taken; otherwise the caller launches m1_colsum itself.
+struct ColsumJob {
+  const float* pdwa = nullptr; float* dwa = nullptr; int nblk = 0, C = 0, ld = 0; uint64_t* rng_bump = nullptr;
+  float* dwa2 = nullptr; int C1 = 0; float* dwa3 = nullptr; int C2 = 0; int perm_nthr = 0, perm_cp = 0;
+  float* dwa4 = nullptr; int C3 = 0; float* dwa5 = nullptr; int C4 = 0;
+  const float* aux_src = nullptr; int aux_n = 0; float aux_scale = 0.f; float* aux_dst = nullptr;
+  bool done = false;
+};
 struct GemmDesc {
   const void* A = nullptr; long lda = 0; int ta = 0; bool a_kc = true;
   const void* B = nullptr; long ldb = 0; int tb = 0; bool b_kc = false;
@@ -177,6 +188,8 @@ struct GemmDesc {
   // mid-contraction mask (wide kernel only, bf16 C): C = (A[:, :mid_k] . B[:, :mid_k]^T) * keepbit / keep + the rest of
   // the contraction; mid_bits = keep bits of C's elements, natural layout (bit (e & 7) of byte e >> 3, e = m * N + n)
   const uint8_t* mid_bits = nullptr; int mid_k = 0; float mid_inv_keep = 1.f;
+  // a column sum to run on the tail blocks of this product's split-K reduce launch (taken only if there is one)
+  ColsumJob* tail = nullptr;
 };
 bool gemm_bf16_wide_serves(int M, int N, int K);   // would this all-bf16, k-contiguous, unsplit product take the wide kernel?
 int gemm_bf16_wide_tile_rows(int M, int N, int K);  // ... and with how many rows per tile (0 = not served)
