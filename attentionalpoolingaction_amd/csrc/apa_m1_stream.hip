@@ -29,6 +29,16 @@
 #ifndef APA_BWD_NT_LOAD
 #define APA_BWD_NT_LOAD false
 #endif
+// Direction of the backward walk (round 6).  Both passes give block b the same pixels of the same image
+// (xcd_remap() puts it on the same XCD), and the forward pass walks them upwards: what it read LAST is what this
+// XCD's L2 and the Infinity Cache still hold when the backward pass starts.  Walking DOWNWARDS meets those lines
+// first, before the pass's own traffic has pushed them out; walking upwards again evicts them unread.  Measured
+// on one box, physically contiguous X / dX, fp32 (up / down, us): N = 32: 18.55 / 17.65, N = 64: 32.6 / 32.2,
+// N = 256: 164 / 144.5, N = 512: 320 / 298, 512 x 15x15: 384 / 354; bf16 N = 512: 149.5 / 146.5.
+// (docs/DESIGN_HISTORY.md, round 6: how the "two kinds of box" of the N = 512 line turned out to be this.)
+#ifndef APA_M1S_BWD_DOWN
+#define APA_M1S_BWD_DOWN 1
+#endif
 
 namespace apa {
 
@@ -543,8 +553,10 @@ __global__ __launch_bounds__(256, 2) void m1s_bwd_main_kernel(
 #pragma unroll
     for (int i = 0; i < PIX; ++i) kb_r[b][i] = 0u;
   }
+  // i-th chunk of the walk (slots past the end re-read the walk's last chunk: L1/L2 hits)
+  auto walk = [&](int i_) { return APA_M1S_BWD_DOWN ? max(nchunk - 1 - i_, 0) : i_; };
 #pragma unroll
-  for (int b = 0; b < NB - 1; ++b) fetch(b, b);
+  for (int b = 0; b < NB - 1; ++b) fetch(b, walk(b));
 
   // per-image constants: L2 hits issued behind the first chunk's HBM loads
   BwdState<T, VW, PIX, FUSED, TRAIN> st;
@@ -591,8 +603,8 @@ __global__ __launch_bounds__(256, 2) void m1s_bwd_main_kernel(
     for (int u = 0; u < NB; ++u) {
       if (u > 0 && ch + u >= nchunk) break;
       constexpr int NBm1 = NB - 1;
-      fetch((u + NBm1) % NB, ch + u + NBm1);
-      bwd_chunk<T, VW, PIX, FUSED, TRAIN, RIN, BITS, NODX>(st, xr[u], a_r[u], e_r[u], kb_r[u], chunk_range<PIX>(p_begin, p_end, ch + u),
+      fetch((u + NBm1) % NB, walk(ch + u + NBm1));
+      bwd_chunk<T, VW, PIX, FUSED, TRAIN, RIN, BITS, NODX>(st, xr[u], a_r[u], e_r[u], kb_r[u], chunk_range<PIX>(p_begin, p_end, walk(ch + u)),
                                                            sm_x[u], dxim, dZout_im, n, P, C, cbase, wave, lane, act, invP,
                                                            inv_keep, thresh, k0, k1);
     }

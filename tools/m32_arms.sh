@@ -14,7 +14,7 @@ echo "== SQ counters"
 cd /tmp; export TMPDIR=/tmp
 for m in 0 16 6 8; do
   O=$R/gpurun_out/pmc_m32_$m; rm -rf $O; mkdir -p $O
-  APA_LIB_PATH=$L APA_GEMM_M32=$m rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY \
+  APA_LIB_PATH=$L APA_GEMM_M32=$m timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY \
      --output-format csv -d $O -- python $R/tools/bench_dense.py --workload cfg003 --steps 10 --warmup 2 > $O/bench.log 2>&1
   python3 - "$O" "$m" <<'PY'
 import csv, glob, os, sys

@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 O=$R/gpurun_out/prof_n512_$1; rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 shift
-env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python $R/bench.py --batch 512 --rotate 1 --steps 40 --warmup 5 --no-extra --no-cpu-baseline > $O/bench.log 2>&1
+env "$@" timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python $R/bench.py --batch 512 --rotate 2 --steps 40 --warmup 5 --no-extra --no-cpu-baseline > $O/bench.log 2>&1
 python3 - "$O" <<'PY'
 import csv, glob, json, os, sys
 O = sys.argv[1]

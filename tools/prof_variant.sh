@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 O=$R/gpurun_out/var_$name; rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 env APA_LIB_PATH=$R/attentionalpoolingaction_amd/custom_ops/libapa_hip_ablate.so "$@" \
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python $R/tools/bench_dense.py $args > $O/bench.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python $R/tools/bench_dense.py $args > $O/bench.log 2>&1
 python - "$O" "$name" <<'PY'
 import csv, glob, json, os, sys
 O, name = sys.argv[1:3]

@@ -8,7 +8,7 @@ mkdir -p $R/profiles
 for wl in cfg003 perclass "perclass --classes 393" eval002 rank1; do
   name=$(echo $wl | sed 's/ --classes //')
   O=$R/gpurun_out/prof_${tag}_$name; rm -rf $O; mkdir -p $O
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python $R/tools/bench_dense.py --workload $wl > $O/bench.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python $R/tools/bench_dense.py --workload $wl > $O/bench.log 2>&1
   python - "$O" "$R/profiles/${tag}_${name}" "$wl" <<'PY'
 import csv, glob, json, os, sys
 out_dir, prefix, wl = sys.argv[1:4]

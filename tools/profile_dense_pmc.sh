@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 mkdir -p $R/gpurun_out/profiles_out
 for wl in cfg003 perclass; do
 O=$R/gpurun_out/pmc_${tag}_$wl; rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY \
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY \
   --output-format csv -d $O -- python $R/tools/bench_dense.py --workload $wl --steps 10 --warmup 2 > $O/bench.log 2>&1
 f=$(find $O -name "*counter_collection.csv" | head -1)
 python - "$f" "$R/gpurun_out/profiles_out/${tag}_${wl}_pmc.md" "$wl" <<'PY'

@@ -15,8 +15,8 @@ O=$R/gpurun_out/prof_${tag}_e2e; rm -rf $O; mkdir -p $O
 cd $R
 for wl in eval002 train003; do
   python tools/bench_e2e.py --workload $wl > $O/$wl.json 2> $O/$wl.err
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$wl -- python tools/bench_e2e.py --workload $wl --steps 3 --warmup 2 > $O/stats_$wl.log 2>&1
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "apa::" --output-format csv -d $O/pmc_$wl -- python tools/bench_e2e.py --workload $wl --steps 2 --warmup 1 > $O/pmc_$wl.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$wl -- python tools/bench_e2e.py --workload $wl --steps 3 --warmup 2 > $O/stats_$wl.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "apa::" --output-format csv -d $O/pmc_$wl -- python tools/bench_e2e.py --workload $wl --steps 2 --warmup 1 > $O/pmc_$wl.log 2>&1
 done
 python tools/bench_e2e.py --workload eval002 --fuse-final-relu > $O/eval002_fused_relu.json 2> $O/eval002_fused_relu.err
 python - "$O" "$R/gpurun_out/profiles_out/${tag}_e2e_summary.md" <<'PY'

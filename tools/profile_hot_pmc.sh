@@ -6,7 +6,7 @@ cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 mkdir -p $R/gpurun_out/profiles_out
 O=$R/gpurun_out/pmc_${tag}_hot; rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY \
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY \
   --output-format csv -d $O -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extra --repeats 2 --min-ms 1 > $O/bench.log 2>&1
 f=$(find $O -name "*counter_collection.csv" | head -1)
 python - "$f" "$R/gpurun_out/profiles_out/${tag}_hot_pmc.md" <<'PY'

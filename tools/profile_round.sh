@@ -10,7 +10,7 @@ cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 O=$R/gpurun_out/prof_$tag; rm -rf $O; mkdir -p $O
 cd $R
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extra "$@" > $O/bench_under_rocprof.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extra --repeats 2 --min-ms 1 "$@" > $O/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extra --repeats 2 --min-ms 1 "$@" > $O/pmc_write.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extra "$@" > $O/bench_under_rocprof.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extra --repeats 2 --min-ms 1 "$@" > $O/pmc_fetch.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extra --repeats 2 --min-ms 1 "$@" > $O/pmc_write.log 2>&1
 python tools/profile_summarise.py $O $tag "$@"
