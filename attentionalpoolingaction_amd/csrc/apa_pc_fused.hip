@@ -29,6 +29,10 @@
 #include "apa_device.h"
 #include "apa_internal.h"
 
+#ifndef APA_PC_XCD_MATCH
+#define APA_PC_XCD_MATCH 1
+#endif
+
 namespace apa {
 
 // timing-experiment switches of the development build (make ABLATE=1: pieces of a kernel switched off to price them --
@@ -277,7 +281,10 @@ __global__ __launch_bounds__(512) void pc_fwd_zt_dma_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = wave >> 2, wn = (wave >> 1) & 1, mt = wave & 1;
   const int l16 = lane & 15, kb = lane >> 4;
-  const int m0 = blockIdx.x * 32;
+  // row block through the XCD-aware remap: XCD x reads one contiguous eighth of the rows here, and pc_bwd_dw_kernel
+  // gives the same XCD the row splits that cover it (APA_PC_XCD_MATCH)
+  const int bx = APA_PC_XCD_MATCH ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int m0 = bx * 32;
   const int nkt = C / ZB_KT;
   const int rowb = C >> 3;                                               // bytes of bits per row = 16 nkt
   const int sw = (nkt & (nkt - 1)) == 0 ? min(nkt, 16) - 1 : 0;          // chunk swizzle (power-of-two chunk counts)
@@ -336,7 +343,7 @@ __global__ __launch_bounds__(512) void pc_fwd_zt_dma_kernel(
     // for anyway
     const uint64_t off_now = offset_dev ? *offset_dev : offset;
     have_bits = pc_tag_match(tag, seed, off_now, thresh, (size_t)R * C / 8);
-    if (blockIdx.x == 0 && tid == 0) {
+    if (bx == 0 && tid == 0) {
       tag[4] = off_now;
       if (!have_bits) tag[2] = 0;         // the map is being rewritten row block by row block: nobody may believe it
     }
@@ -458,7 +465,7 @@ __global__ __launch_bounds__(512) void pc_fwd_zt_dma_kernel(
     __syncthreads();
     if (tid < 128) {
       const int seg = tid >> 6, c = tid & 63;
-      fo.lpart[((size_t)blockIdx.x * 2 + seg) * 64 + c] = psum[(0 * 2 + seg) * 64 + c] + psum[(1 * 2 + seg) * 64 + c];
+      fo.lpart[((size_t)bx * 2 + seg) * 64 + c] = psum[(0 * 2 + seg) * 64 + c] + psum[(1 * 2 + seg) * 64 + c];
     }
     return;
   }
@@ -515,8 +522,11 @@ __global__ __launch_bounds__(512) void pc_bwd_dw_kernel(
   // row half x 32-column quarter; 64 x 32 outputs per wave
   const int half = wave >> 2, wm = (wave >> 1) & 1, wq = wave & 1;
   const int l16 = lane & 15, kb = lane >> 4;
-  const int c0 = blockIdx.x * 128;
-  const int rbeg = blockIdx.y * rows_per_split, rend = min(R, rbeg + rows_per_split);
+  const int lg = APA_PC_XCD_MATCH ? xcd_remap((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y))
+                                  : (int)(blockIdx.y * gridDim.x + blockIdx.x);
+  const int cx = lg % (int)gridDim.x, sy = lg / (int)gridDim.x;     // (channel tile, row split)
+  const int c0 = cx * 128;
+  const int rbeg = sy * rows_per_split, rend = min(R, rbeg + rows_per_split);
   const int nk = APA_EXPBIT(exp, 16) ? 0 : (APA_EXPBIT(exp, 32) ? 1 : (rend - rbeg + FK - 1) / FK);
 
   // Two tiles ahead through registers: a tile's 5 loads per thread are requested two iterations before they are
@@ -611,7 +621,7 @@ __global__ __launch_bounds__(512) void pc_bwd_dw_kernel(
     iteration(t, SB, SA);
     if (t + 1 < nk) iteration(t + 1, SA, SB);
   }
-  float* out = partial + ((size_t)blockIdx.y * C + c0) * 128;
+  float* out = partial + ((size_t)sy * C + c0) * 128;
   if (APA_EXPBIT(exp, 1)) return;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
