@@ -329,6 +329,10 @@ BIG_CASES = [
     dict(name='cfg002_train_softmax_libmask', yaml='002_MPII_ResNet_withAttention.yaml', train=True,
          net={P + '_SOFTMAX_ATT': True}, shape=(32, 14, 14, 2048), K=393, libmask=(42, 17), big=True, quant='bf16',
          full_limit=1 << 16),
+    # ... and the ReLU-attention variant (nets_factory.py:284-285)
+    dict(name='cfg002_train_relu_libmask', yaml='002_MPII_ResNet_withAttention.yaml', train=True,
+         net={P + '_RELU_ATT': True}, shape=(32, 14, 14, 2048), K=393, libmask=(42, 25), big=True, quant='bf16',
+         full_limit=1 << 16),
 ]
 BIG_FULL = 1 << 20       # big cases: tensors up to this many elements are stored in full (float32)
 
