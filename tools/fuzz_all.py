@@ -288,6 +288,16 @@ def fam_catfeat(rnd, i):
                                      head.pose_b2.detach())
     if int(((Ppre_k.cpu().double() > 0) != (pre.detach() > 0)).sum()) > 0:
         return desc     # a ReLU gate within rounding of 0 (see fam_pose)
+    if two_layer:
+        # ... and the ReLU behind the _2LAYER conv + batch-norm (oracle/attn_pool_oracle.py:170-175): with 450 pixels of
+        # random sign in every gradient sum, ONE gate that fp32 rounds the other way is 5-10 % of max |grad|
+        # (seed 606 case 12: a pre-activation of 3.4e-7 against a typical 0.75)
+        with torch.no_grad():
+            y = pl.detach() @ p['pose_feat_weights'].detach().reshape(J, J)
+            z = (y - y.mean(dim=(0, 1, 2))) / torch.sqrt(y.var(dim=(0, 1, 2), unbiased=False) + 1e-5)
+            z = z * p['pose_feat_bn_gamma'].detach() + p['pose_feat_bn_beta'].detach()
+            if float(z.abs().min()) < 2e-5 * float(z.abs().mean()):
+                return desc
     assert rel(logits, lr) < 5e-5, 'logits'
     assert rel(ep['PoseLogits'], pl) < 5e-5, 'PoseLogits'
     floor = 1e-5 * float(p['td_weights'].grad.abs().max())
