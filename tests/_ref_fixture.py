@@ -53,6 +53,9 @@ class HeadFixture(object):
             if spec[1]:
                 x = np.maximum(x, 0)
             x = apa_digest.bf16_round(x) if spec[2] else x.astype(np.float32).astype(np.float64)
+            if 'inpatch/images_idx' in self.arrays:       # make_head_reference.gate_safe_inputs: a few features moved
+                x = np.array(x, dtype=np.float64)
+                x.reshape(-1)[self.arrays['inpatch/images_idx']] = self.arrays['inpatch/images_val'].astype(np.float64)
             chk = self.arrays['insum/images']
             assert abs(x.sum() - chk[0]) <= 1e-9 * abs(chk[0]) and abs((x ** 2).sum() - chk[1]) <= 1e-12 * chk[1]
             self.arrays['in/images'] = x.astype(np.float32)

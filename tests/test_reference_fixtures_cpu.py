@@ -186,7 +186,7 @@ def test_oracle_gen_losses_match_reference(case):
 @pytest.mark.regen
 def test_generator_reproduces_the_committed_fixtures():
     """tests/golden/make_head_reference.py is deterministic: re-running it on the reference tree gives the
-    committed arrays AND meta tables back bit for bit (two small head cases + two benchmark-shape cases)."""
+    committed arrays AND meta tables back bit for bit (two small head cases + three benchmark-shape cases)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location('make_head_reference',
                                                   os.path.join(rf.GOLD, 'make_head_reference.py'))
@@ -201,7 +201,7 @@ def test_generator_reproduces_the_committed_fixtures():
         # two small head cases + two benchmark-shape cases (32 x 14 x 14 x 2048 per-class, and round 6's
         # 32 x 15 x 15 x 2048 at the reference's native map; stored by seed / digest)
         for name in ('cfg003_train', 'posefeat_softmax_train', 'perclass_k51_train_baseline_libmask',
-                     'cfg002_train_15x15_libmask'):
+                     'cfg002_train_15x15_libmask', 'cfg003_train_15x15_libmask'):    # (the last one: gate-safe inputs)
             case = [c for c in gen.HEAD_CASES + gen.BIG_CASES if c['name'] == name][0]
             out = gen.run_head_case(cfgmod, nf, lossmod, defaults, case)
             d = np.load(os.path.join(rf.GOLD, ('refbig_%s.npz' if case.get('big') else 'ref_head_%s.npz') % name))
