@@ -333,6 +333,10 @@ BIG_CASES = [
     # rank-1 dX epilogue at P = 225, R = 7200 rows)
     dict(name='cfg003_train_15x15_libmask', yaml='003_MPII_ResNet_withPoseAttention.yaml', train=True,
          shape=(32, 15, 15, 2048), K=393, libmask=(42, 29), big=True, quant='bf16', full_limit=1 << 17, gate_safe=True),
+    # ... the HMDB-51 per-class head at the native map: 7200 rows = 225 row blocks of the fused forward product (not a
+    # multiple of the 8 XCDs its row ownership is spread over since round 6)
+    dict(name='perclass_k51_train_15x15_libmask', train=True, shape=(32, 15, 15, 2048), K=51, train_cfg=NOPOSE,
+         net=dict(SL, **{P + '_PER_CLASS': True}), libmask=(42, 33), big=True, quant='bf16', full_limit=1 << 16),
     # ... and the ReLU-attention variant (nets_factory.py:284-285)
     dict(name='cfg002_train_relu_libmask', yaml='002_MPII_ResNet_withAttention.yaml', train=True,
          net={P + '_RELU_ATT': True}, shape=(32, 14, 14, 2048), K=393, libmask=(42, 25), big=True, quant='bf16',
