@@ -338,11 +338,29 @@ def fam_losses(rnd, i):
     (pooled_ref * dpo.double()).sum().backward()
     wd, bd = (w.to(gpu), b.to(gpu)) if use_att else (None, None)
     pooled, tatt = cof.frame_pool_fwd(lg.to(gpu), F, wd, bd)
-    assert rel(pooled, pooled_ref) < 2e-5, 'frame pool fwd'
+    if use_att:
+        # the frame weight t_f = w . logits_f + b is a K-term sum that can cancel (seed 777 case 241: t = -1.1e-3 from
+        # terms summing to 25 in magnitude; torch's own fp32 dot is 1.4e-4 off there): every output scales with t, so a
+        # relative tolerance means nothing on such a draw -- the bound is the fp32 error of that sum (3e-6 of the
+        # magnitude of its terms) times the largest logit
+        mag = float(((lg.double() * w.double()).abs().sum(1) + b.double().abs()).max())
+        slack = 3e-6 * mag * float(lg.abs().max())
+    else:
+        slack = 0.0
+    aerr = float((pooled.detach().cpu().double() - pooled_ref.detach()).abs().max())
+    assert rel(pooled, pooled_ref) < 2e-5 or aerr <= slack, 'frame pool fwd'
     dlg, dw, db = cof.frame_pool_bwd(lg.to(gpu), F, wd, tatt, dpo.to(gpu))
     assert rel(dlg, lgr.grad) < 5e-5, 'frame pool dlogits'
     if use_att:
-        assert rel(dw, wr.grad) < 5e-5 and rel(db, br.grad) < 5e-5, 'frame pool dw/db'
+        # db is ONE sum of B F K products of random sign (seed 779 case 442): measured against the magnitude of its terms
+        db_mag = float((dpo.double().repeat_interleave(F, dim=0) * lg.double()).abs().sum()) / F
+        db_err = abs(float(db.detach().cpu().double().reshape(-1)[0]) - float(br.grad.reshape(-1)[0]))
+        # ... and so is dw when K is small (seed 780 case 920, K = 1): dw_k = sum_bf logits_bf,k * (dpo_b . logits_bf) / F
+        rowmag = (dpo.double().repeat_interleave(F, dim=0) * lg.double()).abs().sum(1) / F
+        dw_mag = float((lg.double().abs() * rowmag[:, None]).sum(0).max())
+        dw_err = float((dw.detach().cpu().double().reshape(-1) - wr.grad.reshape(-1)).abs().max())
+        assert (rel(dw, wr.grad) < 5e-5 or dw_err <= 3e-6 * dw_mag) and \
+            (rel(db, br.grad) < 5e-5 or db_err <= 3e-6 * db_mag), 'frame pool dw/db'
     return desc
 
 
