@@ -288,6 +288,60 @@ def test_one_call_train_steps_match_reference_at_the_benchmark_shape(gpu, path, 
         fx.check('grad/var/' + vn, full.reshape(shape), tol, dtype + ' ' + vn, tol_proj=tolp, floor=_grad_floor(fx, vn))
 
 
+BIG_PERCLASS = [p for p in BIG_TRAIN if 'perclass' in os.path.basename(p)]
+
+
+@pytest.mark.parametrize('path', BIG_PERCLASS, ids=rf.case_id)
+def test_per_class_fast_arm_meets_the_reference_directly(gpu, path):
+    """VERDICT r05 Weak #2, second half: the STATEFUL arm of the per-class step -- caller-kept weight images and the
+    keep-bit map the previous step's last launch left behind, believed by its (seed, offset) tag -- against the
+    reference-executed fixture itself, not via the stateless step.  The counter starts one step early: step 1 (the
+    fallback arm, results ignored) prepares the map of the fixture's offset; step 2 believes it and is the one compared."""
+    from attentionalpoolingaction_amd.custom_ops import custom_ops_factory as cof
+    fx = _big(path)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(gpu)
+    N, H, W_, C = fx.arrays['in/images'].shape
+    P, K = H * W_, fx.meta['num_classes']
+    X = t(fx.arrays['in/images']).view(N, P, C).to(torch.bfloat16)
+    Wa, ba = t(fx.var(rf.PRE + 'Conv2d_PrePose_Attn/weights')), t(fx.var(rf.PRE + 'Conv2d_PrePose_Attn/biases'))
+    Wt, bt = t(fx.var(rf.PRE + 'Conv/weights')), t(fx.var(rf.PRE + 'Conv/biases'))
+    assert Wa.shape[1] == K
+    labels = torch.from_numpy(fx.arrays['in/labels_action']).to(gpu)
+    seed, offset = fx.meta['libmask']
+    tc, wd = fx.meta['train_cfg'], fx.meta['weight_decay']
+    flags = cof.attn_flags(bool(fx.flag('_SOFTMAX_ATT')), bool(fx.flag('_RELU_ATT')), True)
+    ctr = torch.full((1,), offset - 1, dtype=torch.int64, device=gpu)
+    grads = (torch.full_like(X, float('nan')), None, torch.empty_like(Wa), torch.empty_like(ba), torch.empty_like(Wt),
+             torch.empty_like(bt))
+    st = cof.HeadTrainStep(X, X, Wa, ba, Wt, bt, labels, grads, flags=flags, keep_prob=fx.keep_prob, seed=seed,
+                           offset=ctr, loss_wt=tc['LOSS_FN_ACTION_WT'], weight_images=True)
+    assert st._args[-5] & cof.APA_FLAG_WEIGHT_IMAGES
+    st.run()                                  # offset - 1: hashes its own rows, leaves the map of `offset` behind
+    torch.cuda.synchronize()
+    assert int(ctr) == offset
+    grads[0].fill_(float('nan'))
+    st.run()                                  # offset: the believed map + the kept weight images
+    torch.cuda.synchronize()
+    assert int(ctr) == offset + 1
+    exp_logits = fx.expected('out/logits').astype(np.float64)
+    got_logits = st.logits.float().cpu().numpy().astype(np.float64)
+    ltol = _bf16_logit_tol(exp_logits)
+    assert np.abs(got_logits - exp_logits).max() <= ltol
+    top2 = np.sort(exp_logits, axis=1)[:, -2:]
+    sure = (top2[:, 1] - top2[:, 0]) > 2 * ltol
+    assert sure.sum() >= 20 and np.array_equal(got_logits.argmax(1)[sure], exp_logits.argmax(1)[sure])
+    exp_losses = fx.expected('out/losses')
+    assert len(exp_losses) == 1 and abs(float(st.loss[0]) - exp_losses[0]) <= 2e-3 * max(abs(exp_losses[0]), 1e-3)
+    tol, tolp = 1.2e-2, 8e-3
+    assert not torch.isnan(grads[0].float()).any()
+    fx.check('grad/images', grads[0].float().cpu().numpy().reshape(N, H, W_, C), tol, 'fast arm grad/images', tol_proj=tolp)
+    for vn, g, p_ in ((rf.PRE + 'Conv2d_PrePose_Attn/weights', grads[2], Wa), (rf.PRE + 'Conv2d_PrePose_Attn/biases', grads[3], ba),
+                      (rf.PRE + 'Conv/weights', grads[4], Wt), (rf.PRE + 'Conv/biases', grads[5], bt)):
+        full = g.double().cpu().numpy() + (wd * p_.double().cpu().numpy() if vn.endswith('/weights') else 0.0)
+        fx.check('grad/var/' + vn, full.reshape(fx.variables[vn].shape), tol, 'fast arm ' + vn, tol_proj=tolp,
+                 floor=_grad_floor(fx, vn))
+
+
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
 @pytest.mark.parametrize('path', BIG_TRAIN, ids=rf.case_id)
 def test_fused_head_step_surface_matches_reference_at_the_benchmark_shape(gpu, path, dtype):
